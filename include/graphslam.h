@@ -1,0 +1,254 @@
+/*
+ * graphslam.h — C-ABI of the MI355X-native GraphSLAM back-end.
+ *
+ * Drop-in boundary for the ONE hot path of cfsd/opendlv-logic-cfsd18-sensation-slam:
+ * every call `Slam` makes on its private `g2o::SparseOptimizer m_optimizer`
+ * (reference src/slam.hpp:98) plus the batched front-end arithmetic that feeds
+ * it (polar->XY, cone->map association).  The reference has no FFI of its own;
+ * each entry point below cites the reference call site it replaces.
+ *
+ * Conventions
+ *  - plain C, opaque handles, caller-owned buffers, all inputs copied (g2o takes
+ *    ownership of new-ed vertices/edges, we copy instead: src/slam.cpp:434-438).
+ *  - every function returns an int status (GS_OK == 0, negative == error) except
+ *    gs_optimize / gs_iterate which follow g2o's convention of returning the
+ *    number of iterations performed (0 == factorisation failed) or a negative
+ *    error code.  Nothing throws, nothing aborts.
+ *  - all arithmetic is IEEE fp64, all indices int32.
+ *  - pose ids and landmark ids live in SEPARATE id spaces (the reference's
+ *    single namespace, cones 0.., poses 1000.., collides beyond 1000 cones:
+ *    src/slam.hpp:118, src/slam.cpp:556,610).
+ *  - a handle is externally synchronised (the reference holds m_optimizerMutex
+ *    around every optimiser call: src/slam.cpp:324,372,402,560,586,614,627).
+ *  - the compute path is HIP on gfx950 only.  There is no CPU fallback: without
+ *    a usable device gs_create fails with GS_ERR_NO_DEVICE.
+ */
+#ifndef GRAPHSLAM_H
+#define GRAPHSLAM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_VERSION_MAJOR 0
+#define GS_VERSION_MINOR 1
+
+/* ---- status codes ------------------------------------------------------- */
+#define GS_OK                    0
+#define GS_ERR_INVALID          -1  /* null pointer / bad argument              */
+#define GS_ERR_DUPLICATE_ID     -2  /* g2o addVertex returns false on dup id    */
+#define GS_ERR_UNKNOWN_ID       -3  /* g2o vertex(id) returns nullptr           */
+#define GS_ERR_NO_DEVICE        -4  /* no gfx950 device / HIP runtime unusable  */
+#define GS_ERR_HIP              -5  /* a HIP call failed (see gs_last_error)    */
+#define GS_ERR_NOT_INITIALIZED  -6  /* gs_iterate before gs_initialize_optimization */
+#define GS_ERR_EMPTY            -7  /* nothing to optimise (no free vertex)     */
+#define GS_ERR_NUMERIC          -8  /* non-positive pivot: H not SPD            */
+#define GS_ERR_CAPACITY         -9  /* output buffer too small                  */
+
+typedef struct gs_graph gs_graph;   /* replaces g2o::SparseOptimizer (src/slam.hpp:98) */
+typedef struct gs_slam  gs_slam;    /* replaces the graph-side state of class Slam     */
+
+/* ---- configuration ------------------------------------------------------ */
+typedef struct gs_config {
+    int32_t struct_size;        /* sizeof(gs_config), for ABI evolution                     */
+    int32_t device;             /* HIP device ordinal; -1 = current device                  */
+    int32_t verbose;            /* 1: print g2o-style "iteration= i chi2= ..." to stderr
+                                   (reference: setVerbose(true), src/slam.cpp:63)          */
+    int32_t leaf_poses;         /* nested-dissection leaf size in poses; 0 = default        */
+    int32_t use_hip_graph;      /* 1: replay one Gauss-Newton iteration as a hipGraph       */
+    int32_t reserved0;
+    /* Slam-level constants, defaults are the reference's hard-coded values */
+    double  odometry_information;   /* 5.0   (src/slam.cpp:456)                             */
+    double  cone_information;       /* 0.01  (src/slam.cpp:546)                             */
+    double  same_cone_threshold;    /* --sameConeThreshold, m_newConeThreshold (slam.cpp:740) */
+    double  cone_mapping_threshold; /* --coneMappingThreshold (slam.cpp:744)                */
+    double  lidar_to_cog;           /* 1.5 m (src/slam.cpp:514)                             */
+    double  loop_closing_radius;    /* 1.0 m (src/slam.cpp:702)                             */
+    int32_t loop_closing_min_index; /* 20    (src/slam.cpp:702)                             */
+    int32_t optimize_iterations;    /* 10    (src/slam.cpp:481)                             */
+    int32_t reference_quirks;       /* 1: keep SURVEY §8-B quirks 1-2 (duplicate first edge,
+                                       re-optimise per remaining observation)              */
+    int32_t reserved1;
+} gs_config;
+
+/* per-call statistics of gs_optimize / gs_iterate (all times from HIP events on
+ * the handle's stream, milliseconds, summed over the iterations of the call) */
+typedef struct gs_stats {
+    int32_t struct_size;
+    int32_t iterations;         /* iterations actually performed                            */
+    int32_t n_free_poses, n_free_landmarks;
+    int32_t n_odometry_edges, n_observation_edges;
+    int32_t n_fronts, n_levels, max_front;   /* multifrontal plan                          */
+    int32_t numeric_failure;    /* 1 if a non-positive pivot was met                        */
+    double  chi2_initial;       /* chi2 at the linearisation point of the first iteration   */
+    double  chi2_final;         /* chi2 at the linearisation point of the last iteration    */
+    double  ms_structure;       /* host: ordering + symbolic + upload (iteration-0 work)   */
+    double  ms_linearize;       /* A5+A6+A7 kernel(s)                                       */
+    double  ms_factor;          /* multifrontal numeric factorisation + forward solve       */
+    double  ms_backsolve;       /* backward solve                                           */
+    double  ms_update;          /* A9                                                       */
+    double  ms_total;           /* whole call, events                                       */
+    int64_t factor_flops;       /* model flops of one factorisation                         */
+    int64_t factor_bytes;       /* L + update-matrix storage, bytes                         */
+} gs_stats;
+
+int  gs_version(void);                               /* major*100+minor */
+const char *gs_last_error(void);                      /* thread-local message of the last failure */
+int  gs_config_default(gs_config *cfg);
+int  gs_device_count(void);                           /* number of usable gfx950 devices, 0 if none */
+
+/* ---- lifetime: replaces Slam::setupOptimizer (src/slam.cpp:53-65) -------- */
+int  gs_create(const gs_config *cfg, gs_graph **out);
+int  gs_destroy(gs_graph *g);
+int  gs_clear(gs_graph *g);                           /* drop all vertices and edges */
+/* use an externally owned hipStream_t (e.g. torch's current stream); NULL = own stream */
+int  gs_set_stream(gs_graph *g, void *hip_stream);
+
+/* ---- graph construction (A2) --------------------------------------------
+ * gs_add_pose             <- new VertexSE2; setId; setEstimate; addVertex        (src/slam.cpp:434-438)
+ * gs_add_landmark         <- new VertexPointXY; setId; setEstimate; addVertex    (src/slam.cpp:527-531)
+ * gs_add_odometry_edge    <- new EdgeSE2; vertices; setMeasurement; setInformation; addEdge (src/slam.cpp:447-457)
+ * gs_add_observation_edge <- new EdgeSE2PointXY; ...                              (src/slam.cpp:538-547)
+ * information matrices are row-major full (9 resp. 4 doubles) and must be symmetric. */
+int  gs_add_pose(gs_graph *g, int32_t pose_id, const double est_xytheta[3]);
+int  gs_add_landmark(gs_graph *g, int32_t lm_id, const double est_xy[2]);
+int  gs_add_odometry_edge(gs_graph *g, int32_t pose_id_i, int32_t pose_id_j,
+                          const double z_xytheta[3], const double information[9]);
+int  gs_add_observation_edge(gs_graph *g, int32_t pose_id, int32_t lm_id,
+                             const double z_xy[2], const double information[4]);
+/* bulk SoA/AoS variants (count records, arrays tightly packed, row-major per record) */
+int  gs_add_poses(gs_graph *g, int32_t count, const int32_t *pose_ids, const double *est_xytheta);
+int  gs_add_landmarks(gs_graph *g, int32_t count, const int32_t *lm_ids, const double *est_xy);
+int  gs_add_odometry_edges(gs_graph *g, int32_t count, const int32_t *pose_ids_i,
+                           const int32_t *pose_ids_j, const double *z_xytheta,
+                           const double *information /* count*9, or NULL -> cfg.odometry_information*I */);
+int  gs_add_observation_edges(gs_graph *g, int32_t count, const int32_t *pose_ids,
+                              const int32_t *lm_ids, const double *z_xy,
+                              const double *information /* count*4, or NULL -> cfg.cone_information*I */);
+
+/* gs_set_fixed_* <- dynamic_cast<...>(vertex(id))->setFixed(true)                 (src/slam.cpp:464-474) */
+int  gs_set_fixed_pose(gs_graph *g, int32_t pose_id, int32_t fixed);
+int  gs_set_fixed_landmark(gs_graph *g, int32_t lm_id, int32_t fixed);
+int  gs_set_pose_estimate(gs_graph *g, int32_t pose_id, const double est_xytheta[3]);
+int  gs_set_landmark_estimate(gs_graph *g, int32_t lm_id, const double est_xy[2]);
+
+/* ---- read-back (A11) -----------------------------------------------------
+ * gs_get_pose     <- static_cast<VertexSE2*>(vertex(id))->estimate().toVector()   (src/slam.cpp:418-420,451-452)
+ * gs_get_landmark <- static_cast<VertexPointXY*>(vertex(j))->estimate()           (src/slam.cpp:719-720) */
+int  gs_get_pose(gs_graph *g, int32_t pose_id, double out_xytheta[3]);
+int  gs_get_landmark(gs_graph *g, int32_t lm_id, double out_xy[2]);
+int  gs_num_poses(gs_graph *g);
+int  gs_num_landmarks(gs_graph *g);
+int  gs_num_odometry_edges(gs_graph *g);
+int  gs_num_observation_edges(gs_graph *g);
+/* all vertices in insertion order; ids may be NULL */
+int  gs_get_poses(gs_graph *g, int32_t capacity, int32_t *out_ids, double *out_xytheta);
+int  gs_get_landmarks(gs_graph *g, int32_t capacity, int32_t *out_ids, double *out_xy);
+
+/* ---- optimisation (A3-A10) ------------------------------------------------
+ * gs_initialize_optimization <- m_optimizer.initializeOptimization()              (src/slam.cpp:480)
+ *      + g2o BlockSolver::buildStructure: index maps, ordering, symbolic plan, upload to HBM.
+ * gs_optimize                <- m_optimizer.optimize(10)                          (src/slam.cpp:481)
+ *      runs `iterations` x (computeActiveErrors, buildSystem, solve, update) on the device,
+ *      no damping, no line search, no convergence test; returns iterations done, 0 if the
+ *      factorisation met a non-positive pivot (g2o returns 0 when the solver fails).
+ * gs_iterate                 one Gauss-Newton iteration, asynchronous on the handle's stream
+ *      (the bench's "step"); estimates stay in HBM until gs_sync_estimates / gs_optimize. */
+int  gs_initialize_optimization(gs_graph *g);
+int  gs_optimize(gs_graph *g, int32_t iterations, gs_stats *stats /* may be NULL */);
+int  gs_iterate(gs_graph *g);
+int  gs_sync_estimates(gs_graph *g);      /* device -> host estimates, waits for the stream   */
+int  gs_stream_synchronize(gs_graph *g);
+/* computeActiveErrors + activeChi2 at the current estimates (device) */
+int  gs_chi2(gs_graph *g, double *out_chi2);
+int  gs_get_stats(gs_graph *g, gs_stats *stats);      /* plan statistics after initialize */
+
+/* ---- measurement / parity hooks ------------------------------------------
+ * gs_linearize: one A5+A6+A7 pass (the roofline kernel) on the stream, nothing else.
+ * gs_time_linearize: `reps` back-to-back passes bracketed by HIP events on the handle's
+ *      stream; returns the mean milliseconds per pass in *out_ms_per_pass.
+ * gs_linearize_bytes: algorithmic bytes of one pass, SURVEY §8(d):
+ *      E_pp*152 + E_pl*96 + N*120 + M*64.
+ * gs_export_system: copy the block-sparse H and b of the last linearisation to the host
+ *      (vertex arrays in insertion order, edge arrays in the order reported by *_edge_order):
+ *      Hpp_diag [N*9], Hll_diag [M*4], Hpp_off [Epp*9] (= A^T Omega B), Hpl [Epl*6] (= A^T Omega B,
+ *      3x2 row-major), b_pose [N*3], b_lm [M*2].  Any pointer may be NULL.
+ * gs_export_delta: the last solve's increment, per vertex in insertion order
+ *      (zeros for fixed vertices): dpose [N*3], dlm [M*2]. */
+int  gs_linearize(gs_graph *g);
+int  gs_time_linearize(gs_graph *g, int32_t reps, double *out_ms_per_pass);
+int64_t gs_linearize_bytes(gs_graph *g);
+int  gs_export_system(gs_graph *g, double *Hpp_diag, double *Hll_diag, double *Hpp_off,
+                      double *Hpl, double *b_pose, double *b_lm,
+                      int32_t *odometry_edge_order, int32_t *observation_edge_order);
+int  gs_export_delta(gs_graph *g, double *dpose, double *dlm);
+/* per-phase timing of `reps` full iterations (events on the stream); fills stats->ms_* with
+ * per-iteration means.  Estimates are restored afterwards. */
+int  gs_time_iterations(gs_graph *g, int32_t reps, gs_stats *stats);
+
+/* ---- plan export (host logic, no device work; for tests of the symbolic phase) ---- */
+typedef struct gs_plan_info {
+    int32_t n_scalar;        /* free scalar unknowns                                          */
+    int32_t n_fronts;
+    int32_t n_levels;
+    int32_t max_front;
+    int64_t l_doubles;       /* factor storage                                                */
+    int64_t u_doubles;       /* update-matrix storage                                         */
+    int64_t n_asm_blocks;    /* original-entry assembly records                               */
+    int64_t n_child_map;     /* extend-add map entries                                        */
+} gs_plan_info;
+/* builds the plan on the host only (no HIP), usable without a device */
+int  gs_plan_build_host(gs_graph *g, gs_plan_info *info);
+/* flat int32 dump of the plan, see csrc/gs_plan.hpp for the layout; call with out==NULL
+ * to get the required length in *out_len. */
+int  gs_plan_export(gs_graph *g, int32_t *out, int64_t *out_len);
+
+/* ---- front end (A0, A1) ----------------------------------------------------
+ * gs_polar_to_xy_batch  <- Slam::Spherical2Cartesian + transformConeToCoG    (src/slam.cpp:637-654, 513-523)
+ *      in : az_deg[n], zen_deg[n], dist[n]   out: xy[n*2] (CoG-frame x,y)
+ * gs_cone_to_global_batch <- Slam::coneToGlobal                               (src/slam.cpp:499-510)
+ *      in : pose_of_obs[n] index into poses[npose*3]; out: xy_global[n*2]
+ * gs_associate_batch    <- association loop of Slam::addConesToMap against a FIXED map
+ *      (src/slam.cpp:570-607; localizer variant :350-382): for each observation the LOWEST map
+ *      index j with |type_j - type_i| < type_tol and Euclidean distance < threshold, else -1.
+ *      obs is the reference's m_coneCollector layout, column-major 4 x n: (az, zen, dist, type).
+ * All three run on the device of `g`. */
+int  gs_polar_to_xy_batch(gs_graph *g, int32_t n, const double *az_deg, const double *zen_deg,
+                          const double *dist, double *out_xy);
+int  gs_cone_to_global_batch(gs_graph *g, int32_t n, const double *poses_xytheta, int32_t n_poses,
+                             const int32_t *pose_of_obs, const double *obs_4xn, double *out_xy_global);
+int  gs_associate_batch(gs_graph *g, int32_t n, const double *poses_xytheta, int32_t n_poses,
+                        const int32_t *pose_of_obs, const double *obs_4xn,
+                        int32_t n_map, const double *map_xy, const int32_t *map_type,
+                        double threshold, double type_tol, int32_t *out_index);
+
+/* ---- multi-GPU: pose-window shards -----------------------------
+ * Each rank owns a contiguous pose window and builds the SAME global plan; it linearises and
+ * factorises only its own subtrees, exports the update contributions to the shared top of the
+ * assembly tree into a dense exchange buffer (device memory), the caller all-reduces that
+ * buffer (RCCL sum, fp64), and every rank finishes the top of the tree redundantly. */
+int  gs_dist_configure(gs_graph *g, int32_t rank, int32_t world_size);
+int64_t gs_dist_exchange_doubles(gs_graph *g);         /* length of the exchange buffer   */
+int  gs_dist_set_exchange_buffer(gs_graph *g, void *device_ptr);
+int  gs_dist_iterate_local(gs_graph *g);               /* linearise + local subtrees      */
+int  gs_dist_iterate_finish(gs_graph *g);              /* top of tree + solve + update    */
+
+/* ---- Slam-level host mirror (rows f-1/f-2 of SURVEY §8f) ----------------------
+ * gs_slam_perform <- Slam::performSLAM graph part (src/slam.cpp:298-338): addPoseToGraph,
+ *      addConesToMap / localizer, loop-closure trigger, optimizeGraph, updateMap. */
+int  gs_slam_create(const gs_config *cfg, gs_slam **out);
+int  gs_slam_destroy(gs_slam *s);
+int  gs_slam_perform(gs_slam *s, const double pose_xytheta[3], const double *cones_4xk, int32_t k);
+int  gs_slam_map_size(gs_slam *s);
+int  gs_slam_get_map(gs_slam *s, int32_t capacity, double *out_xy, int32_t *out_type);
+int  gs_slam_loop_closed(gs_slam *s);
+int  gs_slam_current_cone_index(gs_slam *s);
+int  gs_slam_get_send_pose(gs_slam *s, double out_xytheta[3]);
+gs_graph *gs_slam_graph(gs_slam *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHSLAM_H */
