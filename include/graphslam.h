@@ -53,7 +53,9 @@ typedef struct gs_slam  gs_slam;    /* replaces the graph-side state of class Sl
 /* ---- configuration ------------------------------------------------------ */
 typedef struct gs_config {
     int32_t struct_size;        /* sizeof(gs_config), for ABI evolution                     */
-    int32_t device;             /* HIP device ordinal; -1 = current device                  */
+    int32_t device;             /* HIP device ordinal; -1 = current device; -2 = host-only
+                                   handle (graph container + plan inspection, every compute
+                                   entry point returns GS_ERR_NO_DEVICE)                    */
     int32_t verbose;            /* 1: print g2o-style "iteration= i chi2= ..." to stderr
                                    (reference: setVerbose(true), src/slam.cpp:63)          */
     int32_t leaf_poses;         /* nested-dissection leaf size in poses; 0 = default        */

@@ -1,0 +1,418 @@
+"""ctypes binding of include/graphslam.h (libgraphslam_hip.so).
+
+This is plumbing above the C-ABI: the product is the HIP library.  There is no CPU fallback: if the
+shared library is missing or no gfx950 device is usable, calls raise.
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libgraphslam_hip.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "graphslam.h")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+GS_OK = 0
+ERRORS = {-1: "GS_ERR_INVALID", -2: "GS_ERR_DUPLICATE_ID", -3: "GS_ERR_UNKNOWN_ID", -4: "GS_ERR_NO_DEVICE",
+          -5: "GS_ERR_HIP", -6: "GS_ERR_NOT_INITIALIZED", -7: "GS_ERR_EMPTY", -8: "GS_ERR_NUMERIC",
+          -9: "GS_ERR_CAPACITY"}
+
+
+class GsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERRORS.get(code, "GS_ERR"), code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("verbose", C.c_int32),
+                ("leaf_poses", C.c_int32), ("use_hip_graph", C.c_int32), ("reserved0", C.c_int32),
+                ("odometry_information", C.c_double), ("cone_information", C.c_double),
+                ("same_cone_threshold", C.c_double), ("cone_mapping_threshold", C.c_double),
+                ("lidar_to_cog", C.c_double), ("loop_closing_radius", C.c_double),
+                ("loop_closing_min_index", C.c_int32), ("optimize_iterations", C.c_int32),
+                ("reference_quirks", C.c_int32), ("reserved1", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("iterations", C.c_int32),
+                ("n_free_poses", C.c_int32), ("n_free_landmarks", C.c_int32),
+                ("n_odometry_edges", C.c_int32), ("n_observation_edges", C.c_int32),
+                ("n_fronts", C.c_int32), ("n_levels", C.c_int32), ("max_front", C.c_int32),
+                ("numeric_failure", C.c_int32),
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double),
+                ("ms_structure", C.c_double), ("ms_linearize", C.c_double), ("ms_factor", C.c_double),
+                ("ms_backsolve", C.c_double), ("ms_update", C.c_double), ("ms_total", C.c_double),
+                ("factor_flops", C.c_int64), ("factor_bytes", C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("n_scalar", C.c_int32), ("n_fronts", C.c_int32), ("n_levels", C.c_int32),
+                ("max_front", C.c_int32), ("l_doubles", C.c_int64), ("u_doubles", C.c_int64),
+                ("n_asm_blocks", C.c_int64), ("n_child_map", C.c_int64)]
+
+
+def declared_symbols():
+    """Every function name include/graphslam.h declares."""
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", txt)))
+
+
+def build(force=False):
+    """Compile libgraphslam_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j4"]
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library.  Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libgraphslam_hip.so is missing (run __graft_entry__.build()); "
+                           "the GraphSLAM back-end has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    L.gs_last_error.restype = C.c_char_p
+    L.gs_linearize_bytes.restype = C.c_int64
+    L.gs_dist_exchange_doubles.restype = C.c_int64
+    L.gs_slam_graph.restype = C.c_void_p
+    vp = C.c_void_p
+    L.gs_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.gs_slam_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    for name in ("gs_destroy", "gs_clear", "gs_initialize_optimization", "gs_iterate", "gs_sync_estimates",
+                 "gs_stream_synchronize", "gs_linearize", "gs_num_poses", "gs_num_landmarks",
+                 "gs_num_odometry_edges", "gs_num_observation_edges", "gs_dist_iterate_local",
+                 "gs_dist_iterate_finish", "gs_slam_destroy", "gs_slam_map_size", "gs_slam_loop_closed",
+                 "gs_slam_current_cone_index"):
+        getattr(L, name).argtypes = [vp]
+    L.gs_linearize_bytes.argtypes = [vp]
+    L.gs_dist_exchange_doubles.argtypes = [vp]
+    L.gs_slam_graph.argtypes = [vp]
+    L.gs_set_stream.argtypes = [vp, vp]
+    L.gs_dist_set_exchange_buffer.argtypes = [vp, vp]
+    L.gs_dist_configure.argtypes = [vp, C.c_int32, C.c_int32]
+    L.gs_add_pose.argtypes = [vp, C.c_int32, _dp]
+    L.gs_add_landmark.argtypes = [vp, C.c_int32, _dp]
+    L.gs_add_odometry_edge.argtypes = [vp, C.c_int32, C.c_int32, _dp, _dp]
+    L.gs_add_observation_edge.argtypes = [vp, C.c_int32, C.c_int32, _dp, _dp]
+    L.gs_add_poses.argtypes = [vp, C.c_int32, _ip, _dp]
+    L.gs_add_landmarks.argtypes = [vp, C.c_int32, _ip, _dp]
+    L.gs_add_odometry_edges.argtypes = [vp, C.c_int32, _ip, _ip, _dp, _dp]
+    L.gs_add_observation_edges.argtypes = [vp, C.c_int32, _ip, _ip, _dp, _dp]
+    L.gs_set_fixed_pose.argtypes = [vp, C.c_int32, C.c_int32]
+    L.gs_set_fixed_landmark.argtypes = [vp, C.c_int32, C.c_int32]
+    L.gs_set_pose_estimate.argtypes = [vp, C.c_int32, _dp]
+    L.gs_set_landmark_estimate.argtypes = [vp, C.c_int32, _dp]
+    L.gs_get_pose.argtypes = [vp, C.c_int32, _dp]
+    L.gs_get_landmark.argtypes = [vp, C.c_int32, _dp]
+    L.gs_get_poses.argtypes = [vp, C.c_int32, _ip, _dp]
+    L.gs_get_landmarks.argtypes = [vp, C.c_int32, _ip, _dp]
+    L.gs_optimize.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
+    L.gs_chi2.argtypes = [vp, _dp]
+    L.gs_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.gs_time_linearize.argtypes = [vp, C.c_int32, _dp]
+    L.gs_export_system.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip]
+    L.gs_export_delta.argtypes = [vp, _dp, _dp]
+    L.gs_time_iterations.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
+    L.gs_plan_build_host.argtypes = [vp, C.POINTER(PlanInfo)]
+    L.gs_plan_export.argtypes = [vp, _ip, C.POINTER(C.c_int64)]
+    L.gs_polar_to_xy_batch.argtypes = [vp, C.c_int32, _dp, _dp, _dp, _dp]
+    L.gs_cone_to_global_batch.argtypes = [vp, C.c_int32, _dp, C.c_int32, _ip, _dp, _dp]
+    L.gs_associate_batch.argtypes = [vp, C.c_int32, _dp, C.c_int32, _ip, _dp, C.c_int32, _dp, _ip,
+                                     C.c_double, C.c_double, _ip]
+    L.gs_slam_perform.argtypes = [vp, _dp, _dp, C.c_int32]
+    L.gs_slam_get_map.argtypes = [vp, C.c_int32, _dp, _ip]
+    L.gs_slam_get_send_pose.argtypes = [vp, _dp]
+    _lib = L
+    return L
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a if shape is None else a.reshape(shape)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def default_config(**kw):
+    cfg = Config()
+    lib().gs_config_default(C.byref(cfg))
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def device_count():
+    return int(lib().gs_device_count())
+
+
+class Graph:
+    """Mirror of the calls Slam makes on g2o::SparseOptimizer (reference src/slam.cpp:53-65,433-484,525-550)."""
+
+    def __init__(self, cfg=None, _handle=None, **kw):
+        self.L = lib()
+        self._owned = _handle is None
+        if _handle is not None:
+            self.h = C.c_void_p(_handle)
+            return
+        if cfg is None:
+            cfg = default_config(**kw)
+        h = C.c_void_p()
+        self._check(self.L.gs_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def _check(self, rc):
+        if rc < 0:
+            raise GsError(rc, (self.L.gs_last_error() or b"").decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None) and self._owned:
+            self.L.gs_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- construction
+    def add_pose(self, pid, est):
+        e = _f64(est); self._check(self.L.gs_add_pose(self.h, int(pid), _d(e)))
+
+    def add_landmark(self, lid, est):
+        e = _f64(est); self._check(self.L.gs_add_landmark(self.h, int(lid), _d(e)))
+
+    def add_odometry_edge(self, i, j, z, info):
+        z = _f64(z); info = _f64(info); self._check(self.L.gs_add_odometry_edge(self.h, int(i), int(j), _d(z), _d(info)))
+
+    def add_observation_edge(self, p, l, z, info):
+        z = _f64(z); info = _f64(info); self._check(self.L.gs_add_observation_edge(self.h, int(p), int(l), _d(z), _d(info)))
+
+    def add_poses(self, ids, est):
+        ids = _i32(ids); est = _f64(est); self._check(self.L.gs_add_poses(self.h, len(ids), _i(ids), _d(est)))
+
+    def add_landmarks(self, ids, est):
+        ids = _i32(ids); est = _f64(est); self._check(self.L.gs_add_landmarks(self.h, len(ids), _i(ids), _d(est)))
+
+    def add_odometry_edges(self, i, j, z, info=None):
+        i = _i32(i); j = _i32(j); z = _f64(z)
+        ip = _d(_f64(info)) if info is not None else None
+        if info is not None:
+            info = _f64(info); ip = _d(info)
+        self._check(self.L.gs_add_odometry_edges(self.h, len(i), _i(i), _i(j), _d(z), ip))
+
+    def add_observation_edges(self, p, l, z, info=None):
+        p = _i32(p); l = _i32(l); z = _f64(z); ip = None
+        if info is not None:
+            info = _f64(info); ip = _d(info)
+        self._check(self.L.gs_add_observation_edges(self.h, len(p), _i(p), _i(l), _d(z), ip))
+
+    def set_fixed_pose(self, pid, fixed=True):
+        self._check(self.L.gs_set_fixed_pose(self.h, int(pid), int(fixed)))
+
+    def set_fixed_landmark(self, lid, fixed=True):
+        self._check(self.L.gs_set_fixed_landmark(self.h, int(lid), int(fixed)))
+
+    def set_pose_estimate(self, pid, est):
+        e = _f64(est); self._check(self.L.gs_set_pose_estimate(self.h, int(pid), _d(e)))
+
+    def set_landmark_estimate(self, lid, est):
+        e = _f64(est); self._check(self.L.gs_set_landmark_estimate(self.h, int(lid), _d(e)))
+
+    def clear(self):
+        self._check(self.L.gs_clear(self.h))
+
+    # ---- read-back
+    @property
+    def n_poses(self): return self._check(self.L.gs_num_poses(self.h))
+    @property
+    def n_landmarks(self): return self._check(self.L.gs_num_landmarks(self.h))
+    @property
+    def n_pp(self): return self._check(self.L.gs_num_odometry_edges(self.h))
+    @property
+    def n_pl(self): return self._check(self.L.gs_num_observation_edges(self.h))
+
+    def get_pose(self, pid):
+        o = np.zeros(3); self._check(self.L.gs_get_pose(self.h, int(pid), _d(o))); return o
+
+    def get_landmark(self, lid):
+        o = np.zeros(2); self._check(self.L.gs_get_landmark(self.h, int(lid), _d(o))); return o
+
+    def poses(self):
+        n = self.n_poses; o = np.zeros((n, 3)); self._check(self.L.gs_get_poses(self.h, n, None, _d(o))); return o
+
+    def landmarks(self):
+        n = self.n_landmarks; o = np.zeros((n, 2)); self._check(self.L.gs_get_landmarks(self.h, n, None, _d(o))); return o
+
+    # ---- optimisation
+    def initialize_optimization(self):
+        self._check(self.L.gs_initialize_optimization(self.h))
+
+    def optimize(self, iterations=10):
+        st = Stats(); st.struct_size = C.sizeof(Stats)
+        done = self._check(self.L.gs_optimize(self.h, int(iterations), C.byref(st)))
+        return done, st
+
+    def iterate(self):
+        return self._check(self.L.gs_iterate(self.h))
+
+    def synchronize(self):
+        self._check(self.L.gs_stream_synchronize(self.h))
+
+    def sync_estimates(self):
+        self._check(self.L.gs_sync_estimates(self.h))
+
+    def chi2(self):
+        o = C.c_double(); self._check(self.L.gs_chi2(self.h, C.byref(o))); return o.value
+
+    def stats(self):
+        st = Stats(); self._check(self.L.gs_get_stats(self.h, C.byref(st))); return st
+
+    def set_stream(self, stream_ptr):
+        self._check(self.L.gs_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    # ---- measurement / parity hooks
+    def linearize(self):
+        self._check(self.L.gs_linearize(self.h))
+
+    def time_linearize(self, reps):
+        o = C.c_double(); self._check(self.L.gs_time_linearize(self.h, int(reps), C.byref(o))); return o.value
+
+    def linearize_bytes(self):
+        return int(self.L.gs_linearize_bytes(self.h))
+
+    def time_iterations(self, reps):
+        st = Stats(); self._check(self.L.gs_time_iterations(self.h, int(reps), C.byref(st))); return st
+
+    def export_system(self):
+        """Block-sparse H and b of the last linearisation, edge arrays re-ordered to INSERTION order."""
+        N, M, Epp, Epl = self.n_poses, self.n_landmarks, self.n_pp, self.n_pl
+        o = dict(Hpp_diag=np.zeros((N, 9)), Hll_diag=np.zeros((M, 4)), Hpp_off=np.zeros((Epp, 9)),
+                 Hpl=np.zeros((Epl, 6)), b_pose=np.zeros((N, 3)), b_lm=np.zeros((M, 2)))
+        ppo = np.zeros(Epp, dtype=np.int32); plo = np.zeros(Epl, dtype=np.int32)
+        self._check(self.L.gs_export_system(self.h, _d(o["Hpp_diag"]), _d(o["Hll_diag"]), _d(o["Hpp_off"]),
+                                            _d(o["Hpl"]), _d(o["b_pose"]), _d(o["b_lm"]), _i(ppo), _i(plo)))
+        hpp = np.zeros_like(o["Hpp_off"]); hpp[ppo] = o["Hpp_off"]; o["Hpp_off"] = hpp
+        hpl = np.zeros_like(o["Hpl"]); hpl[plo] = o["Hpl"]; o["Hpl"] = hpl
+        return o
+
+    def export_delta(self):
+        dp = np.zeros((self.n_poses, 3)); dl = np.zeros((self.n_landmarks, 2))
+        self._check(self.L.gs_export_delta(self.h, _d(dp), _d(dl))); return dp, dl
+
+    # ---- host-only plan (no device work)
+    def plan_build_host(self):
+        info = PlanInfo(); self._check(self.L.gs_plan_build_host(self.h, C.byref(info))); return info
+
+    def plan_export(self):
+        n = C.c_int64(0)
+        self._check(self.L.gs_plan_export(self.h, None, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.int32)
+        self._check(self.L.gs_plan_export(self.h, _i(out), C.byref(n)))
+        return out
+
+    # ---- front end
+    def polar_to_xy(self, az, zen, dist):
+        az = _f64(az); zen = _f64(zen); dist = _f64(dist); out = np.zeros((len(az), 2))
+        self._check(self.L.gs_polar_to_xy_batch(self.h, len(az), _d(az), _d(zen), _d(dist), _d(out))); return out
+
+    def cone_to_global(self, poses, pose_of_obs, obs):
+        poses = _f64(poses, (-1, 3)); obs = _f64(obs, (-1, 4)); po = _i32(pose_of_obs); out = np.zeros((len(obs), 2))
+        self._check(self.L.gs_cone_to_global_batch(self.h, len(obs), _d(poses), len(poses), _i(po), _d(obs), _d(out)))
+        return out
+
+    def associate(self, poses, pose_of_obs, obs, map_xy, map_type, thr, type_tol=1e-4):
+        poses = _f64(poses, (-1, 3)); obs = _f64(obs, (-1, 4)); po = _i32(pose_of_obs)
+        map_xy = _f64(map_xy, (-1, 2)); map_type = _i32(map_type); out = np.zeros(len(obs), dtype=np.int32)
+        self._check(self.L.gs_associate_batch(self.h, len(obs), _d(poses), len(poses), _i(po), _d(obs), len(map_xy),
+                                              _d(map_xy), _i(map_type), float(thr), float(type_tol), _i(out)))
+        return out
+
+    # ---- convenience: load the arrays of track.bench_graph (ids = indices)
+    def load_bench_graph(self, g):
+        N, M = len(g["pose_est"]), len(g["lm_est"])
+        self.add_poses(np.arange(N), g["pose_est"]); self.add_landmarks(np.arange(M), g["lm_est"])
+        self.add_odometry_edges(g["pp_i"], g["pp_j"], g["pp_z"], g["pp_info"])
+        self.add_observation_edges(g["pl_p"], g["pl_l"], g["pl_z"], g["pl_info"])
+        for i in g["fixed_poses"]:
+            self.set_fixed_pose(int(i))
+        for l in g["fixed_landmarks"]:
+            self.set_fixed_landmark(int(l))
+
+
+class Slam:
+    """Mirror of the graph side of class Slam (reference src/slam.cpp:298-338 performSLAM and what it calls)."""
+
+    def __init__(self, cfg=None, **kw):
+        self.L = lib()
+        if cfg is None:
+            cfg = default_config(**kw)
+        h = C.c_void_p()
+        rc = self.L.gs_slam_create(C.byref(cfg), C.byref(h))
+        if rc < 0:
+            raise GsError(rc, (self.L.gs_last_error() or b"").decode())
+        self.h = h
+        self.graph = Graph(_handle=self.L.gs_slam_graph(self.h))
+
+    def _check(self, rc):
+        if rc < 0:
+            raise GsError(rc, (self.L.gs_last_error() or b"").decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gs_slam_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def perform_slam(self, pose, cones_4xk):
+        """cones: [K,4] rows (az deg, zen deg, dist m, type) = columns of the reference's collector matrix."""
+        pose = _f64(pose); cones = _f64(cones_4xk, (-1, 4))
+        self._check(self.L.gs_slam_perform(self.h, _d(pose), _d(cones), len(cones)))
+
+    @property
+    def map_size(self): return self._check(self.L.gs_slam_map_size(self.h))
+    @property
+    def loop_closed(self): return bool(self._check(self.L.gs_slam_loop_closed(self.h)))
+    @property
+    def current_cone_index(self): return self._check(self.L.gs_slam_current_cone_index(self.h))
+
+    def map(self):
+        n = self.map_size; xy = np.zeros((n, 2)); ty = np.zeros(n, dtype=np.int32)
+        self._check(self.L.gs_slam_get_map(self.h, n, _d(xy), _i(ty))); return xy, ty
+
+    def send_pose(self):
+        o = np.zeros(3); self._check(self.L.gs_slam_get_send_pose(self.h, _d(o))); return o

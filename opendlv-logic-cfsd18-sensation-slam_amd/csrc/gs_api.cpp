@@ -1,0 +1,673 @@
+// gs_api.cpp — C-ABI of the GraphSLAM back-end (include/graphslam.h) over the HIP kernels.
+// Host side of the drop-in boundary: everything Slam calls on g2o::SparseOptimizer
+// (reference src/slam.cpp:53-65, 433-484, 525-550, 713-732) lands here.
+#include "../../include/graphslam.h"
+#include "gs_device.hpp"
+#include "gs_host.hpp"
+#include "gs_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace gs;
+
+namespace gs {
+thread_local std::string g_last_error;
+int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
+}  // namespace gs
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    return fail(GS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+// ------------------------------------------------------------------ helpers
+static int usable_devices() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+template <class T> static int dev_alloc(gs_graph *g, T **ptr, size_t count) {
+    *ptr = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    g->allocs.push_back(p);
+    *ptr = (T *)p;
+    return GS_OK;
+}
+template <class T> static int dev_upload(gs_graph *g, T **ptr, const std::vector<T> &v) {
+    int rc = dev_alloc(g, ptr, v.size());
+    if (rc != GS_OK) return rc;
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(*ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, g->stream));
+    return GS_OK;
+}
+static void dev_free_all(gs_graph *g) {
+    for (void *p : g->allocs) hipFree(p);
+    g->allocs.clear();
+    g->d = DevGraph();
+    g->dev_valid = false;
+}
+
+static int ensure_device(gs_graph *g) {
+    if (g->host_only) return fail(GS_ERR_NO_DEVICE, "host-only handle (device = -2): no compute without a gfx950 device");
+    HIP_TRY(hipSetDevice(g->device));
+    return GS_OK;
+}
+
+// ------------------------------------------------------------------ misc
+extern "C" int gs_version(void) { return GS_VERSION_MAJOR * 100 + GS_VERSION_MINOR; }
+extern "C" const char *gs_last_error(void) { return g_last_error.c_str(); }
+extern "C" int gs_device_count(void) { return usable_devices(); }
+
+extern "C" int gs_config_default(gs_config *c) {
+    if (!c) return fail(GS_ERR_INVALID, "null config");
+    std::memset(c, 0, sizeof(*c));
+    c->struct_size = (int32_t)sizeof(gs_config);
+    c->device = -1; c->verbose = 0; c->leaf_poses = 0; c->use_hip_graph = 0;
+    c->odometry_information = 5.0;       // reference src/slam.cpp:456
+    c->cone_information = 0.01;          // reference src/slam.cpp:546
+    c->same_cone_threshold = 1.0;        // m_newConeThreshold default, reference src/slam.hpp:114
+    c->cone_mapping_threshold = 67.0;    // reference src/slam.hpp:117
+    c->lidar_to_cog = 1.5;               // reference src/slam.cpp:514
+    c->loop_closing_radius = 1.0;        // reference src/slam.cpp:702
+    c->loop_closing_min_index = 20;      // reference src/slam.cpp:702
+    c->optimize_iterations = 10;         // reference src/slam.cpp:481
+    c->reference_quirks = 0;
+    return GS_OK;
+}
+
+extern "C" int gs_create(const gs_config *cfg, gs_graph **out) {
+    if (!out) return fail(GS_ERR_INVALID, "null out");
+    *out = nullptr;
+    gs_config c;
+    gs_config_default(&c);
+    if (cfg) { size_t n = std::min<size_t>(sizeof(c), (size_t)std::max(cfg->struct_size, 0)); std::memcpy(&c, cfg, n); c.struct_size = (int32_t)sizeof(c); }
+    if (c.device == -2) {   // host-only handle: graph container + plan inspection, never any arithmetic
+        gs_graph *g = new gs_graph(); g->cfg = c; g->device = -2; g->host_only = true; *out = g; return GS_OK; }
+    int ndev = usable_devices();
+    if (ndev <= 0) return fail(GS_ERR_NO_DEVICE, "no HIP device: this back-end has no CPU fallback");
+    int dev = c.device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= ndev) return fail(GS_ERR_NO_DEVICE, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(GS_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    gs_graph *g = new gs_graph();
+    g->cfg = c; g->device = dev;
+    HIP_TRY(hipSetDevice(dev));
+    if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) { delete g; return fail(GS_ERR_HIP, "hipStreamCreate failed"); }
+    g->own_stream = true;
+    for (auto &e : g->ev) hipEventCreate(&e);
+    *out = g;
+    return GS_OK;
+}
+
+extern "C" int gs_destroy(gs_graph *g) {
+    if (!g) return GS_OK;
+    if (g->host_only) { delete g; return GS_OK; }
+    hipSetDevice(g->device);
+    hipStreamSynchronize(g->stream);
+    dev_free_all(g);
+    for (auto &e : g->ev) hipEventDestroy(e);
+    if (g->own_stream) hipStreamDestroy(g->stream);
+    delete g;
+    return GS_OK;
+}
+
+extern "C" int gs_clear(gs_graph *g) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    if (!g->host_only) { hipSetDevice(g->device); hipStreamSynchronize(g->stream); dev_free_all(g); }
+    g->h.clear(); g->plan = Plan(); g->plan_version = ~0ull;
+    return GS_OK;
+}
+
+extern "C" int gs_set_stream(gs_graph *g, void *s) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    { int rc = ensure_device(g); if (rc != GS_OK) return rc; }
+    hipStreamSynchronize(g->stream);
+    if (g->own_stream) { hipStreamDestroy(g->stream); g->own_stream = false; }
+    if (s) g->stream = (hipStream_t)s;
+    else { HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking)); g->own_stream = true; }
+    return GS_OK;
+}
+
+// ------------------------------------------------------------------ construction (A2)
+static int pull_estimates_if_needed(gs_graph *g);
+
+extern "C" int gs_add_pose(gs_graph *g, int32_t id, const double est[3]) {
+    if (!g || !est) return fail(GS_ERR_INVALID, "null argument");
+    if (g->h.pose_index.count(id)) return fail(GS_ERR_DUPLICATE_ID, "pose id already present");
+    int rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
+    g->h.pose_index[id] = g->h.n_poses();
+    g->h.pose_id.push_back(id); g->h.pose_est.insert(g->h.pose_est.end(), est, est + 3); g->h.pose_fixed.push_back(0);
+    ++g->h.structure_version;
+    return GS_OK;
+}
+extern "C" int gs_add_landmark(gs_graph *g, int32_t id, const double est[2]) {
+    if (!g || !est) return fail(GS_ERR_INVALID, "null argument");
+    if (g->h.lm_index.count(id)) return fail(GS_ERR_DUPLICATE_ID, "landmark id already present");
+    int rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
+    g->h.lm_index[id] = g->h.n_lms();
+    g->h.lm_id.push_back(id); g->h.lm_est.insert(g->h.lm_est.end(), est, est + 2); g->h.lm_fixed.push_back(0);
+    ++g->h.structure_version;
+    return GS_OK;
+}
+static bool sym_ok(const double *m, int n) {
+    for (int r = 0; r < n; ++r) for (int c = 0; c < r; ++c) {
+        double a = m[r * n + c], b = m[c * n + r];
+        if (!(std::fabs(a - b) <= 1e-12 * (std::fabs(a) + std::fabs(b)) + 1e-300)) return false;
+    }
+    return true;
+}
+extern "C" int gs_add_odometry_edge(gs_graph *g, int32_t idi, int32_t idj, const double z[3], const double info[9]) {
+    if (!g || !z || !info) return fail(GS_ERR_INVALID, "null argument");
+    auto a = g->h.pose_index.find(idi), b = g->h.pose_index.find(idj);
+    if (a == g->h.pose_index.end() || b == g->h.pose_index.end()) return fail(GS_ERR_UNKNOWN_ID, "odometry edge references an unknown pose");
+    if (a->second == b->second) return fail(GS_ERR_INVALID, "odometry edge joins a pose to itself");
+    if (!sym_ok(info, 3)) return fail(GS_ERR_INVALID, "information matrix not symmetric");
+    g->h.pp_i.push_back(a->second); g->h.pp_j.push_back(b->second);
+    g->h.pp_z.insert(g->h.pp_z.end(), z, z + 3);
+    const double s[6] = {info[0], info[1], info[2], info[4], info[5], info[8]};
+    g->h.pp_info.insert(g->h.pp_info.end(), s, s + 6);
+    ++g->h.structure_version;
+    return GS_OK;
+}
+extern "C" int gs_add_observation_edge(gs_graph *g, int32_t idp, int32_t idl, const double z[2], const double info[4]) {
+    if (!g || !z || !info) return fail(GS_ERR_INVALID, "null argument");
+    auto a = g->h.pose_index.find(idp); auto b = g->h.lm_index.find(idl);
+    if (a == g->h.pose_index.end() || b == g->h.lm_index.end()) return fail(GS_ERR_UNKNOWN_ID, "observation edge references an unknown vertex");
+    if (!sym_ok(info, 2)) return fail(GS_ERR_INVALID, "information matrix not symmetric");
+    g->h.pl_p.push_back(a->second); g->h.pl_l.push_back(b->second);
+    g->h.pl_z.insert(g->h.pl_z.end(), z, z + 2);
+    const double s[3] = {info[0], info[1], info[3]};
+    g->h.pl_info.insert(g->h.pl_info.end(), s, s + 3);
+    ++g->h.structure_version;
+    return GS_OK;
+}
+extern "C" int gs_add_poses(gs_graph *g, int32_t n, const int32_t *ids, const double *est) {
+    if (!g || (n > 0 && (!ids || !est))) return fail(GS_ERR_INVALID, "null argument");
+    for (int k = 0; k < n; ++k) { int rc = gs_add_pose(g, ids[k], est + 3 * (size_t)k); if (rc != GS_OK) return rc; }
+    return GS_OK;
+}
+extern "C" int gs_add_landmarks(gs_graph *g, int32_t n, const int32_t *ids, const double *est) {
+    if (!g || (n > 0 && (!ids || !est))) return fail(GS_ERR_INVALID, "null argument");
+    for (int k = 0; k < n; ++k) { int rc = gs_add_landmark(g, ids[k], est + 2 * (size_t)k); if (rc != GS_OK) return rc; }
+    return GS_OK;
+}
+extern "C" int gs_add_odometry_edges(gs_graph *g, int32_t n, const int32_t *idi, const int32_t *idj, const double *z, const double *info) {
+    if (!g || (n > 0 && (!idi || !idj || !z))) return fail(GS_ERR_INVALID, "null argument");
+    const double w = g->cfg.odometry_information;
+    const double def[9] = {w, 0, 0, 0, w, 0, 0, 0, w};
+    for (int k = 0; k < n; ++k) { int rc = gs_add_odometry_edge(g, idi[k], idj[k], z + 3 * (size_t)k, info ? info + 9 * (size_t)k : def); if (rc != GS_OK) return rc; }
+    return GS_OK;
+}
+extern "C" int gs_add_observation_edges(gs_graph *g, int32_t n, const int32_t *idp, const int32_t *idl, const double *z, const double *info) {
+    if (!g || (n > 0 && (!idp || !idl || !z))) return fail(GS_ERR_INVALID, "null argument");
+    const double w = g->cfg.cone_information;
+    const double def[4] = {w, 0, 0, w};
+    for (int k = 0; k < n; ++k) { int rc = gs_add_observation_edge(g, idp[k], idl[k], z + 2 * (size_t)k, info ? info + 4 * (size_t)k : def); if (rc != GS_OK) return rc; }
+    return GS_OK;
+}
+extern "C" int gs_set_fixed_pose(gs_graph *g, int32_t id, int32_t fixed) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    auto a = g->h.pose_index.find(id);
+    if (a == g->h.pose_index.end()) return fail(GS_ERR_UNKNOWN_ID, "unknown pose id");
+    uint8_t f = fixed != 0;
+    if (g->h.pose_fixed[a->second] != f) { g->h.pose_fixed[a->second] = f; ++g->h.structure_version; }
+    return GS_OK;
+}
+extern "C" int gs_set_fixed_landmark(gs_graph *g, int32_t id, int32_t fixed) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    auto a = g->h.lm_index.find(id);
+    if (a == g->h.lm_index.end()) return fail(GS_ERR_UNKNOWN_ID, "unknown landmark id");
+    uint8_t f = fixed != 0;
+    if (g->h.lm_fixed[a->second] != f) { g->h.lm_fixed[a->second] = f; ++g->h.structure_version; }
+    return GS_OK;
+}
+extern "C" int gs_set_pose_estimate(gs_graph *g, int32_t id, const double est[3]) {
+    if (!g || !est) return fail(GS_ERR_INVALID, "null argument");
+    auto a = g->h.pose_index.find(id);
+    if (a == g->h.pose_index.end()) return fail(GS_ERR_UNKNOWN_ID, "unknown pose id");
+    int rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
+    std::memcpy(&g->h.pose_est[3 * (size_t)a->second], est, 3 * sizeof(double));
+    ++g->h.estimate_version;
+    return GS_OK;
+}
+extern "C" int gs_set_landmark_estimate(gs_graph *g, int32_t id, const double est[2]) {
+    if (!g || !est) return fail(GS_ERR_INVALID, "null argument");
+    auto a = g->h.lm_index.find(id);
+    if (a == g->h.lm_index.end()) return fail(GS_ERR_UNKNOWN_ID, "unknown landmark id");
+    int rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
+    std::memcpy(&g->h.lm_est[2 * (size_t)a->second], est, 2 * sizeof(double));
+    ++g->h.estimate_version;
+    return GS_OK;
+}
+
+// ------------------------------------------------------------------ read-back (A11)
+static int pull_estimates_if_needed(gs_graph *g) {
+    if (!g->dev_valid || !g->dev_estimates_newer) return GS_OK;
+    int rc = ensure_device(g); if (rc != GS_OK) return rc;
+    const int N = g->d.N, M = g->d.M;
+    if (N > 0) HIP_TRY(hipMemcpyAsync(g->h.pose_est.data(), g->d.pose_est, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    if (M > 0) HIP_TRY(hipMemcpyAsync(g->h.lm_est.data(), g->d.lm_est, (size_t)M * 2 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    g->dev_estimates_newer = false;
+    return GS_OK;
+}
+extern "C" int gs_sync_estimates(gs_graph *g) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    return pull_estimates_if_needed(g);
+}
+extern "C" int gs_stream_synchronize(gs_graph *g) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    int rc = ensure_device(g); if (rc != GS_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return GS_OK;
+}
+extern "C" int gs_get_pose(gs_graph *g, int32_t id, double out[3]) {
+    if (!g || !out) return fail(GS_ERR_INVALID, "null argument");
+    auto a = g->h.pose_index.find(id);
+    if (a == g->h.pose_index.end()) return fail(GS_ERR_UNKNOWN_ID, "unknown pose id");
+    int rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
+    std::memcpy(out, &g->h.pose_est[3 * (size_t)a->second], 3 * sizeof(double));
+    return GS_OK;
+}
+extern "C" int gs_get_landmark(gs_graph *g, int32_t id, double out[2]) {
+    if (!g || !out) return fail(GS_ERR_INVALID, "null argument");
+    auto a = g->h.lm_index.find(id);
+    if (a == g->h.lm_index.end()) return fail(GS_ERR_UNKNOWN_ID, "unknown landmark id");
+    int rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
+    std::memcpy(out, &g->h.lm_est[2 * (size_t)a->second], 2 * sizeof(double));
+    return GS_OK;
+}
+extern "C" int gs_num_poses(gs_graph *g) { return g ? g->h.n_poses() : fail(GS_ERR_INVALID, "null graph"); }
+extern "C" int gs_num_landmarks(gs_graph *g) { return g ? g->h.n_lms() : fail(GS_ERR_INVALID, "null graph"); }
+extern "C" int gs_num_odometry_edges(gs_graph *g) { return g ? g->h.n_pp() : fail(GS_ERR_INVALID, "null graph"); }
+extern "C" int gs_num_observation_edges(gs_graph *g) { return g ? g->h.n_pl() : fail(GS_ERR_INVALID, "null graph"); }
+extern "C" int gs_get_poses(gs_graph *g, int32_t cap, int32_t *ids, double *out) {
+    if (!g || !out) return fail(GS_ERR_INVALID, "null argument");
+    if (cap < g->h.n_poses()) return fail(GS_ERR_CAPACITY, "buffer too small");
+    int rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
+    if (ids) std::memcpy(ids, g->h.pose_id.data(), g->h.pose_id.size() * sizeof(int32_t));
+    std::memcpy(out, g->h.pose_est.data(), g->h.pose_est.size() * sizeof(double));
+    return g->h.n_poses();
+}
+extern "C" int gs_get_landmarks(gs_graph *g, int32_t cap, int32_t *ids, double *out) {
+    if (!g || !out) return fail(GS_ERR_INVALID, "null argument");
+    if (cap < g->h.n_lms()) return fail(GS_ERR_CAPACITY, "buffer too small");
+    int rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
+    if (ids) std::memcpy(ids, g->h.lm_id.data(), g->h.lm_id.size() * sizeof(int32_t));
+    std::memcpy(out, g->h.lm_est.data(), g->h.lm_est.size() * sizeof(double));
+    return g->h.n_lms();
+}
+
+// ------------------------------------------------------------------ structure phase (A3/A4) + upload
+static void se2_inverse_host(const double *a, double *out) {
+    auto norm = [](double th) { if (th >= -M_PI && th < M_PI) return th; double m = std::floor(th / (2 * M_PI)); th -= m * 2 * M_PI;
+                                if (th >= M_PI) th -= 2 * M_PI; if (th < -M_PI) th += 2 * M_PI; return th; };
+    double th = norm(-a[2]); double c = std::cos(th), s = std::sin(th);
+    out[0] = c * (-a[0]) - s * (-a[1]); out[1] = s * (-a[0]) + c * (-a[1]); out[2] = th;
+}
+
+static int upload_graph(gs_graph *g) {
+    const HostGraph &h = g->h; const Plan &P = g->plan; DevGraph &d = g->d;
+    const int N = h.n_poses(), M = h.n_lms(), Epp = h.n_pp(), Epl = h.n_pl();
+    d.N = N; d.M = M; d.Epp = Epp; d.Epl = Epl; d.n_scalar = P.n_scalar;
+    int rc;
+#define UP(dst, vec) if ((rc = dev_upload(g, &d.dst, vec)) != GS_OK) return rc
+    UP(pose_est, h.pose_est); UP(lm_est, h.lm_est); UP(pose_fixed, h.pose_fixed); UP(lm_fixed, h.lm_fixed);
+    UP(pose_gidx, P.pose_gidx); UP(lm_gidx, P.lm_gidx);
+    { std::vector<int32_t> p(Epl), l(Epl); std::vector<double> z((size_t)Epl * 2), w((size_t)Epl * 3);
+      for (int pos = 0; pos < Epl; ++pos) { int k = P.pl_order[pos]; p[pos] = h.pl_p[k]; l[pos] = h.pl_l[k];
+          z[2 * (size_t)pos] = h.pl_z[2 * (size_t)k]; z[2 * (size_t)pos + 1] = h.pl_z[2 * (size_t)k + 1];
+          for (int t = 0; t < 3; ++t) w[3 * (size_t)pos + t] = h.pl_info[3 * (size_t)k + t]; }
+      UP(pl_p, p); UP(pl_l, l); UP(pl_z, z); UP(pl_info, w); }
+    { std::vector<int32_t> a(Epp), b(Epp); std::vector<double> zi((size_t)Epp * 3), w((size_t)Epp * 6);
+      for (int pos = 0; pos < Epp; ++pos) { int k = P.pp_order[pos]; a[pos] = h.pp_i[k]; b[pos] = h.pp_j[k];
+          se2_inverse_host(&h.pp_z[3 * (size_t)k], &zi[3 * (size_t)pos]);
+          for (int t = 0; t < 6; ++t) w[6 * (size_t)pos + t] = h.pp_info[6 * (size_t)k + t]; }
+      UP(pp_i, a); UP(pp_j, b); UP(pp_zinv, zi); UP(pp_info, w); }
+    UP(pl_start, P.pl_start); UP(lm_start, P.lm_start); UP(lm_edges, P.lm_edges); UP(ppadj_start, P.ppadj_start); UP(ppadj, P.ppadj);
+#define AL(dst, cnt) if ((rc = dev_alloc(g, &d.dst, (size_t)(cnt))) != GS_OK) return rc
+    AL(Hpp_diag, (size_t)N * 9); AL(Hll_diag, (size_t)M * 4); AL(Hpp_off, (size_t)Epp * 9); AL(Hpl, (size_t)Epl * 6);
+    AL(b_pose, (size_t)N * 3); AL(b_lm, (size_t)M * 2);
+    d.n_chi2_partial = (N + 255) / 256;
+    AL(chi2_partial, d.n_chi2_partial); AL(chi2, 80);
+    // plan
+    { std::vector<DevFront> df(P.fronts.size());
+      for (size_t s = 0; s < P.fronts.size(); ++s) { const Front &F = P.fronts[s]; DevFront &o = df[s];
+          o.npiv = F.npiv; o.nbnd = F.nbnd; o.piv0 = F.piv0; o.parent = F.parent; o.asm_off = F.asm_off; o.asm_cnt = F.asm_cnt;
+          o.asm_dup = F.asm_dup; o.child_off = F.child_off; o.child_cnt = F.child_cnt; o.owner = F.owner; o.level = F.level; o.pad0 = 0;
+          o.bnd_off = F.bnd_off; o.map_off = F.map_off; o.L_off = F.L_off; o.U_off = F.U_off; }
+      UP(fronts, df); d.n_fronts = (int32_t)df.size(); }
+    UP(bnd_rows, P.bnd_rows); UP(child_map, P.child_map); UP(children, P.children); UP(level_fronts, P.level_fronts);
+    { std::vector<int32_t> recs(P.asm_recs.size() * 4);
+      for (size_t t = 0; t < P.asm_recs.size(); ++t) { recs[4 * t] = P.asm_recs[t].kind; recs[4 * t + 1] = P.asm_recs[t].src;
+          recs[4 * t + 2] = P.asm_recs[t].r0; recs[4 * t + 3] = P.asm_recs[t].c0; }
+      UP(asm_recs, recs); }
+    AL(Lbuf, P.l_doubles); AL(Ubuf, P.u_doubles); AL(xe, P.n_scalar); AL(dpose, (size_t)N * 3); AL(dlm, (size_t)M * 2); AL(fail, 4);
+    HIP_TRY(hipMemsetAsync(d.fail, 0, 4 * sizeof(int32_t), g->stream));
+    HIP_TRY(hipMemsetAsync(d.chi2, 0, 80 * sizeof(double), g->stream));
+    HIP_TRY(hipMemsetAsync(d.dpose, 0, std::max<size_t>((size_t)N * 3, 1) * sizeof(double), g->stream));
+    HIP_TRY(hipMemsetAsync(d.dlm, 0, std::max<size_t>((size_t)M * 2, 1) * sizeof(double), g->stream));
+    // per-level launch parameters and the global workspace for fronts beyond the LDS limit
+    const int nlev = (int)P.level_start.size() - 1;
+    g->lvl_max_f.assign(nlev, 0); g->lvl_max_npiv.assign(nlev, 0); g->lvl_max_nbnd.assign(nlev, 0);
+    int64_t ws = 0; const int lim = factor_lds_limit_f();
+    for (int l = 0; l < nlev; ++l) {
+        for (int q = P.level_start[l]; q < P.level_start[l + 1]; ++q) { const Front &F = P.fronts[P.level_fronts[q]];
+            g->lvl_max_f[l] = std::max(g->lvl_max_f[l], F.npiv + F.nbnd);
+            g->lvl_max_npiv[l] = std::max(g->lvl_max_npiv[l], F.npiv); g->lvl_max_nbnd[l] = std::max(g->lvl_max_nbnd[l], F.nbnd); }
+        if (g->lvl_max_f[l] > lim) { int64_t f = g->lvl_max_f[l]; int64_t stride = ((f + 1) | 1) * f;
+            d.front_ws_stride = std::max(d.front_ws_stride, stride); ws = std::max(ws, stride * (int64_t)(P.level_start[l + 1] - P.level_start[l])); }
+    }
+    if (ws > 0) { // every oversize level uses the same stride
+        int64_t need = 0;
+        for (int l = 0; l < nlev; ++l) if (g->lvl_max_f[l] > lim) need = std::max(need, d.front_ws_stride * (int64_t)(P.level_start[l + 1] - P.level_start[l]));
+        AL(front_ws, need);
+    }
+#undef UP
+#undef AL
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    g->dev_valid = true; g->dev_estimates_newer = false;
+    g->dev_estimate_version = h.estimate_version;
+    return GS_OK;
+}
+
+static int build_plan_host(gs_graph *g) {
+    PlanOptions o; o.leaf_poses = g->cfg.leaf_poses; o.world = g->world; o.rank = g->rank;
+    std::string err;
+    if (!build_plan(g->h, o, g->plan, err)) { g->plan_version = ~0ull; return fail(GS_ERR_EMPTY, "plan: " + err); }
+    g->plan_version = g->h.structure_version;
+    return GS_OK;
+}
+
+extern "C" int gs_plan_build_host(gs_graph *g, gs_plan_info *info) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    int rc = build_plan_host(g); if (rc != GS_OK) return rc;
+    if (info) { const Plan &P = g->plan; info->n_scalar = P.n_scalar; info->n_fronts = (int32_t)P.fronts.size();
+        info->n_levels = (int32_t)P.level_start.size() - 1; info->max_front = P.max_front; info->l_doubles = P.l_doubles;
+        info->u_doubles = P.u_doubles; info->n_asm_blocks = (int64_t)P.asm_recs.size(); info->n_child_map = (int64_t)P.child_map.size(); }
+    // a host-only plan must not be mistaken for an uploaded one
+    if (g->dev_valid && !g->host_only) { hipSetDevice(g->device); hipStreamSynchronize(g->stream); pull_estimates_if_needed(g); dev_free_all(g); }
+    return GS_OK;
+}
+extern "C" int gs_plan_export(gs_graph *g, int32_t *out, int64_t *out_len) {
+    if (!g || !out_len) return fail(GS_ERR_INVALID, "null argument");
+    if (!g->plan.valid) return fail(GS_ERR_NOT_INITIALIZED, "no plan built");
+    std::vector<int32_t> v; export_plan(g->plan, v);
+    if (!out) { *out_len = (int64_t)v.size(); return GS_OK; }
+    if (*out_len < (int64_t)v.size()) return fail(GS_ERR_CAPACITY, "buffer too small");
+    std::memcpy(out, v.data(), v.size() * sizeof(int32_t)); *out_len = (int64_t)v.size();
+    return GS_OK;
+}
+
+extern "C" int gs_initialize_optimization(gs_graph *g) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    int rc = ensure_device(g); if (rc != GS_OK) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    dev_free_all(g);
+    rc = build_plan_host(g); if (rc != GS_OK) return rc;
+    rc = upload_graph(g); if (rc != GS_OK) { dev_free_all(g); return rc; }
+    g->ms_structure = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return GS_OK;
+}
+
+static int ensure_ready(gs_graph *g) {
+    int rc = ensure_device(g); if (rc != GS_OK) return rc;
+    if (!g->dev_valid || g->plan_version != g->h.structure_version) return gs_initialize_optimization(g);
+    if (g->dev_estimate_version != g->h.estimate_version) {      // host-side setEstimate since the upload
+        const int N = g->d.N, M = g->d.M;
+        if (N > 0) HIP_TRY(hipMemcpyAsync(g->d.pose_est, g->h.pose_est.data(), (size_t)N * 3 * sizeof(double), hipMemcpyHostToDevice, g->stream));
+        if (M > 0) HIP_TRY(hipMemcpyAsync(g->d.lm_est, g->h.lm_est.data(), (size_t)M * 2 * sizeof(double), hipMemcpyHostToDevice, g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        g->dev_estimate_version = g->h.estimate_version; g->dev_estimates_newer = false;
+    }
+    return GS_OK;
+}
+
+// ------------------------------------------------------------------ one Gauss-Newton iteration (A5-A9)
+static void enqueue_factor(gs_graph *g) {
+    const Plan &P = g->plan; const int nlev = (int)P.level_start.size() - 1;
+    for (int l = 0; l < nlev; ++l)
+        launch_factor_level(g->d, P.level_start[l], P.level_start[l + 1] - P.level_start[l], g->lvl_max_f[l], g->stream);
+}
+static void enqueue_backsolve(gs_graph *g) {
+    const Plan &P = g->plan; const int nlev = (int)P.level_start.size() - 1;
+    for (int l = nlev - 1; l >= 0; --l)
+        launch_backsolve_level(g->d, P.level_start[l], P.level_start[l + 1] - P.level_start[l], g->lvl_max_npiv[l], g->lvl_max_nbnd[l], g->stream);
+}
+static void enqueue_iteration(gs_graph *g, bool timed) {
+    if (timed) hipEventRecord(g->ev[0], g->stream);
+    launch_linearize(g->d, g->stream);
+    if (timed) hipEventRecord(g->ev[1], g->stream);
+    enqueue_factor(g);
+    if (timed) hipEventRecord(g->ev[2], g->stream);
+    enqueue_backsolve(g);
+    if (timed) hipEventRecord(g->ev[3], g->stream);
+    launch_update(g->d, g->stream);
+    if (timed) hipEventRecord(g->ev[4], g->stream);
+    g->dev_estimates_newer = true;
+}
+
+extern "C" int gs_iterate(gs_graph *g) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    if (!g->dev_valid || g->plan_version != g->h.structure_version) return fail(GS_ERR_NOT_INITIALIZED, "call gs_initialize_optimization first");
+    int rc = ensure_device(g); if (rc != GS_OK) return rc;
+    enqueue_iteration(g, false);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return 1;
+}
+
+static void fill_plan_stats(gs_graph *g, gs_stats *s) {
+    const Plan &P = g->plan;
+    s->n_free_poses = 0; s->n_free_landmarks = 0;
+    for (auto v : P.pose_gidx) s->n_free_poses += v >= 0;
+    for (auto v : P.lm_gidx) s->n_free_landmarks += v >= 0;
+    s->n_odometry_edges = g->h.n_pp(); s->n_observation_edges = g->h.n_pl();
+    s->n_fronts = (int32_t)P.fronts.size(); s->n_levels = (int32_t)P.level_start.size() - 1; s->max_front = P.max_front;
+    s->factor_flops = P.factor_flops; s->factor_bytes = (P.l_doubles + P.u_doubles) * 8; s->ms_structure = g->ms_structure;
+}
+
+extern "C" int gs_get_stats(gs_graph *g, gs_stats *s) {
+    if (!g || !s) return fail(GS_ERR_INVALID, "null argument");
+    if (!g->plan.valid) return fail(GS_ERR_NOT_INITIALIZED, "no plan built");
+    std::memset(s, 0, sizeof(*s)); s->struct_size = (int32_t)sizeof(*s);
+    fill_plan_stats(g, s);
+    return GS_OK;
+}
+
+extern "C" int gs_optimize(gs_graph *g, int32_t iterations, gs_stats *stats) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    if (iterations < 0) return fail(GS_ERR_INVALID, "negative iteration count");
+    // g2o: optimize() is always preceded by initializeOptimization() (reference src/slam.cpp:480-481);
+    // the plan is rebuilt only when the structure changed since the last call.
+    int rc = ensure_ready(g); if (rc != GS_OK) return rc;
+    HIP_TRY(hipMemsetAsync(g->d.fail, 0, 4 * sizeof(int32_t), g->stream));
+    hipEventRecord(g->ev[5], g->stream);
+    const int nh = std::min(iterations, 64);
+    for (int it = 0; it < iterations; ++it) {
+        enqueue_iteration(g, false);
+        if (it < nh) hipMemcpyAsync(g->d.chi2 + 1 + it, g->d.chi2, sizeof(double), hipMemcpyDeviceToDevice, g->stream);
+    }
+    if (g->cfg.verbose || stats) { launch_chi2_only(g->d, g->stream);
+        hipMemcpyAsync(g->d.chi2 + 1 + nh, g->d.chi2, sizeof(double), hipMemcpyDeviceToDevice, g->stream); }
+    hipEventRecord(g->ev[6], g->stream);
+    int32_t failflag[4] = {0, 0, 0, 0}; double hist[80];
+    HIP_TRY(hipMemcpyAsync(failflag, g->d.fail, sizeof(failflag), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipMemcpyAsync(hist, g->d.chi2, sizeof(hist), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("iteration: ") + hipGetErrorString(e));
+    rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
+    float ms = 0; hipEventElapsedTime(&ms, g->ev[5], g->ev[6]);
+    if (g->cfg.verbose) for (int it = 0; it < nh; ++it)     // g2o prints the chi2 AFTER the update of iteration it
+        std::fprintf(stderr, "iteration= %d\t chi2= %.6f\t edges= %d\t schur= 0\n", it, hist[2 + it], g->h.n_pp() + g->h.n_pl());
+    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->struct_size = (int32_t)sizeof(*stats);
+        fill_plan_stats(g, stats); stats->iterations = failflag[0] ? 0 : iterations; stats->numeric_failure = failflag[0];
+        stats->chi2_initial = iterations > 0 ? hist[1] : hist[1 + nh]; stats->chi2_final = hist[1 + nh]; stats->ms_total = ms; }
+    if (failflag[0]) { g_last_error = "non-positive pivot: H is not positive definite"; return 0; }
+    return iterations;
+}
+
+extern "C" int gs_chi2(gs_graph *g, double *out) {
+    if (!g || !out) return fail(GS_ERR_INVALID, "null argument");
+    int rc = ensure_ready(g); if (rc != GS_OK) return rc;
+    launch_chi2_only(g->d, g->stream);
+    HIP_TRY(hipMemcpyAsync(out, g->d.chi2, sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return GS_OK;
+}
+
+// ------------------------------------------------------------------ measurement / parity hooks
+extern "C" int gs_linearize(gs_graph *g) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    int rc = ensure_ready(g); if (rc != GS_OK) return rc;
+    launch_linearize(g->d, g->stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("linearize: ") + hipGetErrorString(e));
+    return GS_OK;
+}
+extern "C" int gs_time_linearize(gs_graph *g, int32_t reps, double *out_ms) {
+    if (!g || !out_ms || reps <= 0) return fail(GS_ERR_INVALID, "bad argument");
+    int rc = ensure_ready(g); if (rc != GS_OK) return rc;
+    launch_linearize(g->d, g->stream);                       // warm
+    hipEventRecord(g->ev[0], g->stream);
+    for (int r = 0; r < reps; ++r) launch_linearize(g->d, g->stream);
+    hipEventRecord(g->ev[1], g->stream);
+    HIP_TRY(hipEventSynchronize(g->ev[1]));
+    float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, g->ev[0], g->ev[1]));
+    *out_ms = (double)ms / reps;
+    return GS_OK;
+}
+extern "C" int64_t gs_linearize_bytes(gs_graph *g) {
+    if (!g) return 0;
+    return (int64_t)g->h.n_pp() * 152 + (int64_t)g->h.n_pl() * 96 + (int64_t)g->h.n_poses() * 120 + (int64_t)g->h.n_lms() * 64;
+}
+extern "C" int gs_export_system(gs_graph *g, double *Hpp_diag, double *Hll_diag, double *Hpp_off, double *Hpl,
+                                double *b_pose, double *b_lm, int32_t *pp_order, int32_t *pl_order) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    if (!g->dev_valid) return fail(GS_ERR_NOT_INITIALIZED, "nothing linearised yet");
+    int rc = ensure_device(g); if (rc != GS_OK) return rc;
+    const DevGraph &d = g->d;
+    auto dl = [&](double *dst, const double *src, size_t n) -> hipError_t {
+        return (dst && n) ? hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, g->stream) : hipSuccess; };
+    HIP_TRY(dl(Hpp_diag, d.Hpp_diag, (size_t)d.N * 9)); HIP_TRY(dl(Hll_diag, d.Hll_diag, (size_t)d.M * 4));
+    HIP_TRY(dl(Hpp_off, d.Hpp_off, (size_t)d.Epp * 9)); HIP_TRY(dl(Hpl, d.Hpl, (size_t)d.Epl * 6));
+    HIP_TRY(dl(b_pose, d.b_pose, (size_t)d.N * 3)); HIP_TRY(dl(b_lm, d.b_lm, (size_t)d.M * 2));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    if (pp_order) std::memcpy(pp_order, g->plan.pp_order.data(), g->plan.pp_order.size() * sizeof(int32_t));
+    if (pl_order) std::memcpy(pl_order, g->plan.pl_order.data(), g->plan.pl_order.size() * sizeof(int32_t));
+    return GS_OK;
+}
+extern "C" int gs_export_delta(gs_graph *g, double *dpose, double *dlm) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    if (!g->dev_valid) return fail(GS_ERR_NOT_INITIALIZED, "no iteration run yet");
+    int rc = ensure_device(g); if (rc != GS_OK) return rc;
+    if (dpose && g->d.N) HIP_TRY(hipMemcpyAsync(dpose, g->d.dpose, (size_t)g->d.N * 3 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    if (dlm && g->d.M) HIP_TRY(hipMemcpyAsync(dlm, g->d.dlm, (size_t)g->d.M * 2 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return GS_OK;
+}
+extern "C" int gs_time_iterations(gs_graph *g, int32_t reps, gs_stats *s) {
+    if (!g || !s || reps <= 0) return fail(GS_ERR_INVALID, "bad argument");
+    int rc = ensure_ready(g); if (rc != GS_OK) return rc;
+    const int N = g->d.N, M = g->d.M;
+    double *sp = nullptr, *sl = nullptr;                        // save estimates
+    HIP_TRY(hipMalloc((void **)&sp, std::max<size_t>((size_t)N * 3, 1) * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&sl, std::max<size_t>((size_t)M * 2, 1) * sizeof(double)));
+    hipMemcpyAsync(sp, g->d.pose_est, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToDevice, g->stream);
+    hipMemcpyAsync(sl, g->d.lm_est, (size_t)M * 2 * sizeof(double), hipMemcpyDeviceToDevice, g->stream);
+    const bool newer = g->dev_estimates_newer;
+    std::memset(s, 0, sizeof(*s)); s->struct_size = (int32_t)sizeof(*s); fill_plan_stats(g, s);
+    enqueue_iteration(g, false);                                 // warm
+    for (int r = 0; r < reps; ++r) {
+        enqueue_iteration(g, true);
+        hipEventSynchronize(g->ev[4]);
+        float a = 0, b = 0, c = 0, dd = 0;
+        hipEventElapsedTime(&a, g->ev[0], g->ev[1]); hipEventElapsedTime(&b, g->ev[1], g->ev[2]);
+        hipEventElapsedTime(&c, g->ev[2], g->ev[3]); hipEventElapsedTime(&dd, g->ev[3], g->ev[4]);
+        s->ms_linearize += a; s->ms_factor += b; s->ms_backsolve += c; s->ms_update += dd;
+    }
+    s->ms_linearize /= reps; s->ms_factor /= reps; s->ms_backsolve /= reps; s->ms_update /= reps;
+    s->ms_total = s->ms_linearize + s->ms_factor + s->ms_backsolve + s->ms_update; s->iterations = reps;
+    hipMemcpyAsync(g->d.pose_est, sp, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToDevice, g->stream);
+    hipMemcpyAsync(g->d.lm_est, sl, (size_t)M * 2 * sizeof(double), hipMemcpyDeviceToDevice, g->stream);
+    int32_t failflag = 0;
+    hipMemcpyAsync(&failflag, g->d.fail, sizeof(int32_t), hipMemcpyDeviceToHost, g->stream);
+    hipMemsetAsync(g->d.fail, 0, sizeof(int32_t), g->stream);
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    hipFree(sp); hipFree(sl);
+    g->dev_estimates_newer = newer; s->numeric_failure = failflag;
+    return GS_OK;
+}
+
+// ------------------------------------------------------------------ front end (A0, A1)
+namespace {
+struct Scratch {   // device scratch freed on scope exit
+    std::vector<void *> p;
+    ~Scratch() { for (void *q : p) hipFree(q); }
+    template <class T> T *up(const T *h, size_t n, hipStream_t st) { void *d = nullptr; if (hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+        p.push_back(d); if (h && n) hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, st); return (T *)d; }
+};
+}
+extern "C" int gs_polar_to_xy_batch(gs_graph *g, int32_t n, const double *az, const double *zen, const double *dist, double *out) {
+    if (!g || n < 0 || (n > 0 && (!az || !zen || !dist || !out))) return fail(GS_ERR_INVALID, "bad argument");
+    int rc = ensure_device(g); if (rc != GS_OK) return rc;
+    if (n == 0) return GS_OK;
+    Scratch s; double *a = s.up(az, n, g->stream), *z = s.up(zen, n, g->stream), *d = s.up(dist, n, g->stream), *o = s.up<double>(nullptr, 2 * (size_t)n, g->stream);
+    if (!a || !z || !d || !o) return fail(GS_ERR_HIP, "hipMalloc failed");
+    launch_polar_to_xy(n, a, z, d, g->cfg.lidar_to_cog, o, g->stream);
+    HIP_TRY(hipMemcpyAsync(out, o, 2 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return GS_OK;
+}
+extern "C" int gs_cone_to_global_batch(gs_graph *g, int32_t n, const double *poses, int32_t npose, const int32_t *pose_of_obs,
+                                       const double *obs, double *out) {
+    if (!g || n < 0 || npose < 0 || (n > 0 && (!poses || !pose_of_obs || !obs || !out))) return fail(GS_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n; ++i) if (pose_of_obs[i] < 0 || pose_of_obs[i] >= npose) return fail(GS_ERR_INVALID, "pose_of_obs out of range");
+    int rc = ensure_device(g); if (rc != GS_OK) return rc;
+    if (n == 0) return GS_OK;
+    Scratch s; double *p = s.up(poses, 3 * (size_t)npose, g->stream); int32_t *po = s.up(pose_of_obs, n, g->stream);
+    double *ob = s.up(obs, 4 * (size_t)n, g->stream), *o = s.up<double>(nullptr, 2 * (size_t)n, g->stream);
+    if (!p || !po || !ob || !o) return fail(GS_ERR_HIP, "hipMalloc failed");
+    launch_cone_to_global(n, p, po, ob, g->cfg.lidar_to_cog, o, g->stream);
+    HIP_TRY(hipMemcpyAsync(out, o, 2 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return GS_OK;
+}
+extern "C" int gs_associate_batch(gs_graph *g, int32_t n, const double *poses, int32_t npose, const int32_t *pose_of_obs, const double *obs,
+                                  int32_t n_map, const double *map_xy, const int32_t *map_type, double thr, double type_tol, int32_t *out) {
+    if (!g || n < 0 || npose < 0 || n_map < 0 || (n > 0 && (!poses || !pose_of_obs || !obs || !out)) || (n_map > 0 && (!map_xy || !map_type)))
+        return fail(GS_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n; ++i) if (pose_of_obs[i] < 0 || pose_of_obs[i] >= npose) return fail(GS_ERR_INVALID, "pose_of_obs out of range");
+    int rc = ensure_device(g); if (rc != GS_OK) return rc;
+    if (n == 0) return GS_OK;
+    Scratch s; double *p = s.up(poses, 3 * (size_t)npose, g->stream); int32_t *po = s.up(pose_of_obs, n, g->stream);
+    double *ob = s.up(obs, 4 * (size_t)n, g->stream); double *mx = s.up(map_xy, 2 * (size_t)n_map, g->stream);
+    int32_t *mt = s.up(map_type, n_map, g->stream), *o = s.up<int32_t>(nullptr, n, g->stream);
+    if (!p || !po || !ob || !mx || !mt || !o) return fail(GS_ERR_HIP, "hipMalloc failed");
+    launch_associate(n, p, po, ob, g->cfg.lidar_to_cog, n_map, mx, mt, thr, type_tol, o, g->stream);
+    HIP_TRY(hipMemcpyAsync(out, o, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return GS_OK;
+}
+
+// ------------------------------------------------------------------ multi-GPU
+extern "C" int gs_dist_configure(gs_graph *g, int32_t rank, int32_t world) {
+    if (!g || world < 1 || rank < 0 || rank >= world) return fail(GS_ERR_INVALID, "bad rank/world");
+    g->rank = rank; g->world = world; ++g->h.structure_version;
+    return GS_OK;
+}
+extern "C" int64_t gs_dist_exchange_doubles(gs_graph *g) { return (g && g->plan.valid) ? g->plan.exchange_doubles : 0; }
+extern "C" int gs_dist_set_exchange_buffer(gs_graph *g, void *p) { if (!g) return fail(GS_ERR_INVALID, "null graph"); g->exchange = (double *)p; return GS_OK; }
+extern "C" int gs_dist_iterate_local(gs_graph *g) { (void)g; return fail(GS_ERR_NOT_INITIALIZED, "pose-window sharding not configured"); }
+extern "C" int gs_dist_iterate_finish(gs_graph *g) { (void)g; return fail(GS_ERR_NOT_INITIALIZED, "pose-window sharding not configured"); }

@@ -1,0 +1,56 @@
+// gs_device.hpp — device-resident state of one graph (all pointers are HBM) and kernel launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace gs {
+
+// Mirror of Front for the device (POD, 64 bytes)
+struct DevFront {
+    int32_t npiv, nbnd, piv0, parent;
+    int32_t asm_off, asm_cnt, asm_dup, child_off;
+    int32_t child_cnt, owner, level, pad0;
+    int64_t bnd_off, map_off, L_off, U_off;
+};
+
+struct DevGraph {
+    int32_t N = 0, M = 0, Epp = 0, Epl = 0, n_scalar = 0;
+    // state
+    double *pose_est = nullptr, *lm_est = nullptr;             // [N*3], [M*2]
+    uint8_t *pose_fixed = nullptr, *lm_fixed = nullptr;
+    int32_t *pose_gidx = nullptr, *lm_gidx = nullptr;          // first scalar in elimination order, -1 fixed
+    // observation edges sorted by pose
+    int32_t *pl_p = nullptr, *pl_l = nullptr; double *pl_z = nullptr, *pl_info = nullptr;   // z [E*2], info [E*3]
+    // odometry edges; z stored as the inverse measurement (g2o keeps _inverseMeasurement)
+    int32_t *pp_i = nullptr, *pp_j = nullptr; double *pp_zinv = nullptr, *pp_info = nullptr; // zinv [E*3], info [E*6]
+    // adjacency
+    int32_t *pl_start = nullptr, *lm_start = nullptr, *lm_edges = nullptr, *ppadj_start = nullptr, *ppadj = nullptr;
+    // block-sparse H and b (A6/A7 output)
+    double *Hpp_diag = nullptr, *Hll_diag = nullptr, *Hpp_off = nullptr, *Hpl = nullptr, *b_pose = nullptr, *b_lm = nullptr;
+    double *chi2_partial = nullptr; int32_t n_chi2_partial = 0; double *chi2 = nullptr;     // chi2[0] = last value
+    // multifrontal plan
+    DevFront *fronts = nullptr; int32_t n_fronts = 0;
+    int32_t *bnd_rows = nullptr, *child_map = nullptr, *children = nullptr, *asm_recs = nullptr /* [n*4] */;
+    int32_t *level_fronts = nullptr;
+    double *Lbuf = nullptr, *Ubuf = nullptr;                   // factor and update-matrix arenas
+    double *xe = nullptr;                                       // solution in elimination order [n_scalar]
+    double *dpose = nullptr, *dlm = nullptr;                    // last increment per vertex
+    int32_t *fail = nullptr;                                    // [0] != 0 : non-positive pivot met
+    double *front_ws = nullptr; int64_t front_ws_stride = 0;    // global workspace for fronts too big for LDS
+};
+
+// launchers (gs_kernels.hip); all asynchronous on `st`
+void launch_linearize(const DevGraph &d, hipStream_t st);
+void launch_chi2_only(const DevGraph &d, hipStream_t st);
+void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f, hipStream_t st);
+void launch_backsolve_level(const DevGraph &d, int level_off, int count, int max_npiv, int max_nbnd, hipStream_t st);
+void launch_update(const DevGraph &d, hipStream_t st);
+void launch_polar_to_xy(int n, const double *az, const double *zen, const double *dist, double lidar, double *out, hipStream_t st);
+void launch_cone_to_global(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar,
+                           double *out, hipStream_t st);
+void launch_associate(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar,
+                      int n_map, const double *map_xy, const int32_t *map_type, double thr, double type_tol,
+                      int32_t *out, hipStream_t st);
+int  factor_lds_limit_f();      // largest front dimension that fits the LDS variant
+
+}  // namespace gs

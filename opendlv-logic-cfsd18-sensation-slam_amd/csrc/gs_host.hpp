@@ -1,0 +1,95 @@
+// gs_host.hpp — host-side graph container and multifrontal plan of the GraphSLAM back-end.
+//
+// HostGraph is the SoA replacement of what g2o keeps as heap-allocated vertex/edge objects behind
+// Slam::m_optimizer (reference src/slam.hpp:98; insertions src/slam.cpp:433-459, 525-550).
+// Plan is the product of the structure phase that g2o runs in initializeOptimization() +
+// BlockSolver::buildStructure() + Eigen analyzePattern (reference src/slam.cpp:480-481,
+// SURVEY.md §8 row A4): index maps, elimination order, symbolic factorisation — here a
+// nested-dissection multifrontal plan instead of AMD + simplicial column counts.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace gs {
+
+struct HostGraph {
+    // vertices, insertion order
+    std::vector<int32_t> pose_id;  std::vector<double> pose_est;  std::vector<uint8_t> pose_fixed;   // [N*3]
+    std::vector<int32_t> lm_id;    std::vector<double> lm_est;    std::vector<uint8_t> lm_fixed;     // [M*2]
+    std::unordered_map<int32_t, int32_t> pose_index, lm_index;                                      // id -> index
+    // edges, insertion order; information stored packed symmetric
+    std::vector<int32_t> pp_i, pp_j; std::vector<double> pp_z /*[E*3]*/, pp_info /*[E*6] xx xy xt yy yt tt*/;
+    std::vector<int32_t> pl_p, pl_l; std::vector<double> pl_z /*[E*2]*/, pl_info /*[E*3] xx xy yy*/;
+    uint64_t structure_version = 0;     // bumped by every change that invalidates the plan
+    uint64_t estimate_version = 0;      // bumped by host-side estimate writes
+
+    int n_poses() const { return (int)pose_id.size(); }
+    int n_lms() const { return (int)lm_id.size(); }
+    int n_pp() const { return (int)pp_i.size(); }
+    int n_pl() const { return (int)pl_p.size(); }
+    void clear();
+};
+
+// One assembly record = one original H block (or diagonal block + rhs) landing in a front.
+enum AsmKind : int32_t {
+    ASM_POSE_DIAG = 0,   // src = pose index      : 3x3 at (r0,r0) lower part, rhs row gets b_pose
+    ASM_LM_DIAG = 1,     // src = landmark index  : 2x2 at (r0,r0) lower part, rhs row gets b_lm
+    ASM_PP = 2,          // src = sorted pp edge  : F[r0+a][c0+b] = Hpp_off[a][b]   (i-vertex rows later)
+    ASM_PP_T = 3,        //                         F[r0+a][c0+b] = Hpp_off[b][a]   (j-vertex rows later)
+    ASM_PL = 4,          // src = sorted pl edge  : F[r0+a][c0+b] = Hpl[a][b]  3x2  (pose rows later)
+    ASM_PL_T = 5,        //                         F[r0+a][c0+b] = Hpl[b][a]  2x3  (landmark rows later)
+};
+struct AsmRec { int32_t kind, src, r0, c0; };
+
+struct Front {
+    int32_t npiv = 0, nbnd = 0;     // pivot / boundary scalars, f = npiv + nbnd
+    int32_t piv0 = 0;               // first pivot's index in the elimination order (pivots contiguous)
+    int32_t parent = -1, level = 0;
+    int32_t owner = 0;              // rank that factorises it (multi-GPU); -1 = shared top of the tree
+    int64_t bnd_off = 0;            // into Plan::bnd_rows  (elimination indices of boundary rows, ascending)
+    int64_t map_off = 0;            // into Plan::child_map (this front's boundary rows -> rows of parent's front)
+    int64_t L_off = 0;              // doubles: (f+1) x npiv column-major, ld = f+1 (last row = forward-solved rhs)
+    int64_t U_off = 0;              // doubles: (nbnd+1) x nbnd column-major, ld = nbnd+1 (last row = rhs update)
+    int32_t asm_off = 0, asm_cnt = 0, asm_dup = 0;   // records [asm_off, +asm_cnt): first asm_cnt-asm_dup unique, rest duplicates
+    int32_t child_off = 0, child_cnt = 0;            // into Plan::children
+};
+
+struct Plan {
+    bool valid = false;
+    int32_t n_scalar = 0;                   // free scalar unknowns
+    // vertex -> first scalar in elimination order (-1 fixed)
+    std::vector<int32_t> pose_gidx, lm_gidx;
+    // sorted edge orders (position -> insertion index) used on the device
+    std::vector<int32_t> pl_order, pp_order;
+    // CSR: pose -> its pl edges are [pl_start[p], pl_start[p+1]) in sorted order
+    std::vector<int32_t> pl_start;
+    // CSR: landmark -> sorted pl edge positions
+    std::vector<int32_t> lm_start, lm_edges;
+    // CSR: pose -> incident pp edges (sorted position * 2 + role; role 0 = i endpoint)
+    std::vector<int32_t> ppadj_start, ppadj;
+    // fronts in elimination (post)order
+    std::vector<Front> fronts;
+    std::vector<int32_t> bnd_rows, child_map, children;
+    std::vector<AsmRec> asm_recs;
+    // levels: fronts of level l are level_fronts[level_start[l] .. level_start[l+1])
+    std::vector<int32_t> level_start, level_fronts;
+    int32_t max_front = 0;
+    int64_t l_doubles = 0, u_doubles = 0, factor_flops = 0;
+    // multi-GPU
+    int32_t world = 1, rank = 0;
+    int32_t n_shared_fronts = 0;            // fronts with owner == -1
+    int64_t exchange_doubles = 0;           // total size of the update matrices feeding shared fronts
+    double ms_build = 0;
+};
+
+struct PlanOptions { int leaf_poses = 8; int world = 1; int rank = 0; };
+
+// Builds the plan on the host (no device work).  Returns false (and sets err) on failure.
+bool build_plan(const HostGraph &g, const PlanOptions &opt, Plan &plan, std::string &err);
+
+// flat int32 dump for tests (layout documented in gs_plan.cpp)
+void export_plan(const Plan &plan, std::vector<int32_t> &out);
+
+}  // namespace gs

@@ -1,0 +1,35 @@
+// gs_internal.hpp — the opaque handle behind gs_graph (shared by gs_api.cpp and gs_slam.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "../../include/graphslam.h"
+#include "gs_device.hpp"
+#include "gs_host.hpp"
+
+struct gs_graph {
+    gs_config cfg{};
+    int device = 0;
+    bool host_only = false;                 // cfg.device == -2: no HIP calls, no arithmetic
+    gs::HostGraph h;
+    gs::Plan plan;
+    uint64_t plan_version = ~0ull;          // h.structure_version the plan was built for
+    gs::DevGraph d;
+    std::vector<void *> allocs;             // every device allocation of this handle
+    bool dev_valid = false;                 // device mirrors the host graph + plan
+    bool dev_estimates_newer = false;       // estimates in HBM are ahead of the host copy
+    uint64_t dev_estimate_version = 0;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    hipEvent_t ev[8]{};
+    std::vector<int> lvl_max_f, lvl_max_npiv, lvl_max_nbnd;
+    double ms_structure = 0;
+    int rank = 0, world = 1; double *exchange = nullptr;
+};
+
+namespace gs {
+extern thread_local std::string g_last_error;
+int fail(int code, const std::string &msg);
+}

@@ -1,0 +1,498 @@
+// gs_kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) of the GraphSLAM hot path.
+//
+//   A0  k_polar_to_xy, k_cone_to_global    Slam::transformConeToCoG / Spherical2Cartesian / coneToGlobal
+//                                          (reference src/slam.cpp:513-523, 637-654, 499-510)
+//   A1  k_associate                        association loop of Slam::addConesToMap vs a fixed map
+//                                          (reference src/slam.cpp:570-607, 708-711)
+//   A5-A7 k_linearize_pose / k_linearize_lm   g2o computeError + linearizeOplus + constructQuadraticForm of
+//                                          EdgeSE2 / EdgeSE2PointXY, summed per vertex (SURVEY.md §8-A.2-4;
+//                                          driven from reference src/slam.cpp:481)
+//   A8  k_factor_level / k_backsolve_level  multifrontal Cholesky of the joint system (replaces Eigen
+//                                          SimplicialLDLT, reference thirdparty/Eigen/src/SparseCholesky/
+//                                          SimplicialCholesky_impl.h:101-190), forward solve fused as an extra row
+//   A9  k_update                           VertexSE2::oplusImpl / VertexPointXY::oplusImpl (§8-A.5)
+//
+// All fp64; every sum has a fixed order (no floating-point atomics) so results are bitwise reproducible.
+#include "gs_device.hpp"
+
+namespace gs {
+
+static constexpr int WAVE = 64;
+
+// constants exactly as the reference declares them (src/slam.hpp:134-136; PI is a FLOAT literal)
+__device__ static constexpr double kDeg2Rad = 0.017453292522222;
+__device__ static constexpr double kRad2Deg = 57.295779513082325;
+__device__ static constexpr double kPiF = (double)3.14159265f;
+__device__ static constexpr double kPi = 3.14159265358979323846;
+
+// g2o normalize_theta
+__device__ __forceinline__ double normalize_theta(double th) {
+    if (th >= -kPi && th < kPi) return th;
+    double m = floor(th / (2.0 * kPi));
+    th = th - m * 2.0 * kPi;
+    if (th >= kPi) th -= 2.0 * kPi;
+    if (th < -kPi) th += 2.0 * kPi;
+    return th;
+}
+
+// ------------------------------------------------------------------ A0
+__device__ __forceinline__ void polar_to_xy(double az, double zen, double dist, double lidar, double &x, double &y) {
+    // transformConeToCoG: sign is NaN at az == 0 (kept)
+    double sign = az / fabs(az);
+    double ang = kPiF - fabs(az * kDeg2Rad);
+    double dnew = sqrt(lidar * lidar + dist * dist - 2.0 * lidar * dist * cos(ang));
+    double anew = asin((sin(ang) * dist) / dnew) * kRad2Deg;
+    double az2 = anew * sign;
+    // Spherical2Cartesian
+    double cz = cos(zen * kDeg2Rad);
+    x = dnew * cz * cos(az2 * kDeg2Rad);
+    y = dnew * cz * sin(az2 * kDeg2Rad);
+}
+
+__global__ void k_polar_to_xy(int n, const double *__restrict__ az, const double *__restrict__ zen,
+                              const double *__restrict__ dist, double lidar, double *__restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x, y; polar_to_xy(az[i], zen[i], dist[i], lidar, x, y);
+    out[2 * i] = x; out[2 * i + 1] = y;
+}
+
+__device__ __forceinline__ void cone_to_global(const double *pose, const double *obs, double lidar, double &gx, double &gy) {
+    double x, y; polar_to_xy(obs[0], obs[1], obs[2], lidar, x, y);
+    double c = cos(pose[2]), s = sin(pose[2]);
+    gx = (x * c - y * s) + pose[0];
+    gy = (x * s + y * c) + pose[1];
+}
+
+__global__ void k_cone_to_global(int n, const double *__restrict__ poses, const int32_t *__restrict__ pose_of_obs,
+                                 const double *__restrict__ obs, double lidar, double *__restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double gx, gy; cone_to_global(poses + 3 * pose_of_obs[i], obs + 4 * i, lidar, gx, gy);
+    out[2 * i] = gx; out[2 * i + 1] = gy;
+}
+
+// ------------------------------------------------------------------ A1
+// One thread per observation; the map is streamed through LDS in tiles and every thread keeps the LOWEST
+// matching index, which equals the reference's first-match-in-insertion-order scan.
+static constexpr int ASSOC_TILE = 1024;
+__global__ void __launch_bounds__(256) k_associate(int n, const double *__restrict__ poses,
+        const int32_t *__restrict__ pose_of_obs, const double *__restrict__ obs, double lidar, int n_map,
+        const double *__restrict__ map_xy, const int32_t *__restrict__ map_type, double thr, double type_tol,
+        int32_t *__restrict__ out) {
+    __shared__ double sx[ASSOC_TILE], sy[ASSOC_TILE];
+    __shared__ int32_t st[ASSOC_TILE];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double gx = 0, gy = 0, ty = 0; bool live = i < n;
+    if (live) { cone_to_global(poses + 3 * pose_of_obs[i], obs + 4 * i, lidar, gx, gy); ty = obs[4 * i + 3]; }
+    int found = -1;
+    for (int base = 0; base < n_map; base += ASSOC_TILE) {
+        int cnt = min(ASSOC_TILE, n_map - base);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt; t += blockDim.x) { sx[t] = map_xy[2 * (base + t)]; sy[t] = map_xy[2 * (base + t) + 1]; st[t] = map_type[base + t]; }
+        __syncthreads();
+        if (live && found < 0) {
+            for (int t = 0; t < cnt; ++t) {
+                if (fabs((double)st[t] - ty) < type_tol) {
+                    double dx = sx[t] - gx, dy = sy[t] - gy;
+                    if (sqrt(dx * dx + dy * dy) < thr) { found = base + t; break; }
+                }
+            }
+        }
+    }
+    if (live) out[i] = found;
+}
+
+// ------------------------------------------------------------------ A5-A7
+struct Sym3 { double xx, xy, xt, yy, yt, tt; };
+
+// EdgeSE2PointXY: error, Jacobian rows A0/A1 (2x3), B = R(theta)^T
+__device__ __forceinline__ void edge_pl(const double *__restrict__ xp, double lx, double ly, double zx, double zy,
+                                        double &ex, double &ey, double A0[3], double A1[3], double &c, double &s) {
+    sincos(xp[2], &s, &c);
+    double dx = lx - xp[0], dy = ly - xp[1];
+    ex = (c * dx + s * dy) - zx;
+    ey = (-s * dx + c * dy) - zy;
+    A0[0] = -c; A0[1] = -s; A0[2] = c * dy - s * dx;
+    A1[0] = s;  A1[1] = -c; A1[2] = -s * dy - c * dx;
+}
+
+// EdgeSE2: e = vec(zinv * (xi^-1 * xj)), A = Z*Ji, B = Z*Jj (rows)
+__device__ __forceinline__ void edge_pp(const double *__restrict__ xi, const double *__restrict__ xj,
+                                        const double *__restrict__ zinv, double e[3], double A[3][3], double B[3][3]) {
+    double si, ci; sincos(xi[2], &si, &ci);
+    double dx = xj[0] - xi[0], dy = xj[1] - xi[1];
+    // rel = xi^-1 * xj
+    double rx = ci * dx + si * dy, ry = -si * dx + ci * dy;
+    double rth = normalize_theta(normalize_theta(-xi[2]) + xj[2]);
+    double sz, cz; sincos(zinv[2], &sz, &cz);
+    e[0] = zinv[0] + (cz * rx - sz * ry);
+    e[1] = zinv[1] + (sz * rx + cz * ry);
+    e[2] = normalize_theta(zinv[2] + rth);
+    double Ji[3][3] = {{-ci, -si, -si * dx + ci * dy}, {si, -ci, -ci * dx - si * dy}, {0.0, 0.0, -1.0}};
+    double Jj[3][3] = {{ci, si, 0.0}, {-si, ci, 0.0}, {0.0, 0.0, 1.0}};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        A[0][c] = cz * Ji[0][c] - sz * Ji[1][c]; A[1][c] = sz * Ji[0][c] + cz * Ji[1][c]; A[2][c] = Ji[2][c];
+        B[0][c] = cz * Jj[0][c] - sz * Jj[1][c]; B[1][c] = sz * Jj[0][c] + cz * Jj[1][c]; B[2][c] = Jj[2][c];
+    }
+}
+
+__device__ __forceinline__ double block_sum_256(double v, double *red) {
+    // fixed-order tree: wave shuffle then 4 partials
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    double r = 0;
+    if (threadIdx.x == 0) { for (int k = 0; k < (int)(blockDim.x >> 6); ++k) r += red[k]; }
+    return r;
+}
+
+// thread per pose: diagonal block + b of the pose, off-diagonal blocks of the edges it owns, chi2
+template <bool WRITE_H>
+__global__ void __launch_bounds__(256) k_linearize_pose(DevGraph d) {
+    __shared__ double red[4];
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    double chi = 0.0;
+    if (p < d.N) {
+        const double xp[3] = {d.pose_est[3 * p], d.pose_est[3 * p + 1], d.pose_est[3 * p + 2]};
+        const bool fp = d.pose_fixed[p];
+        double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, b[3] = {0, 0, 0};
+        for (int e = d.pl_start[p]; e < d.pl_start[p + 1]; ++e) {
+            int l = d.pl_l[e];
+            double ex, ey, A0[3], A1[3], c, s;
+            edge_pl(xp, d.lm_est[2 * l], d.lm_est[2 * l + 1], d.pl_z[2 * e], d.pl_z[2 * e + 1], ex, ey, A0, A1, c, s);
+            double w00 = d.pl_info[3 * e], w01 = d.pl_info[3 * e + 1], w11 = d.pl_info[3 * e + 2];
+            double We0 = w00 * ex + w01 * ey, We1 = w01 * ex + w11 * ey;
+            const bool fl = d.lm_fixed[l];
+            if (!(fp && fl)) chi += ex * We0 + ey * We1;
+            if (WRITE_H) {
+                double WA0[3], WA1[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { WA0[k] = w00 * A0[k] + w01 * A1[k]; WA1[k] = w01 * A0[k] + w11 * A1[k]; }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) H[r][k] += A0[r] * WA0[k] + A1[r] * WA1[k];
+                    b[r] -= A0[r] * We0 + A1[r] * We1;
+                }
+                // Hpl = A^T W B, B rows (c, s), (-s, c)
+                double WB0[2] = {w00 * c - w01 * s, w00 * s + w01 * c};
+                double WB1[2] = {w01 * c - w11 * s, w01 * s + w11 * c};
+                const bool both = !fp && !fl;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    d.Hpl[6 * e + 2 * r]     = both ? A0[r] * WB0[0] + A1[r] * WB1[0] : 0.0;
+                    d.Hpl[6 * e + 2 * r + 1] = both ? A0[r] * WB0[1] + A1[r] * WB1[1] : 0.0;
+                }
+            }
+        }
+        for (int q = d.ppadj_start[p]; q < d.ppadj_start[p + 1]; ++q) {
+            int code = d.ppadj[q], k = code >> 1, role = code & 1;
+            int i = d.pp_i[k], j = d.pp_j[k];
+            double e[3], A[3][3], B[3][3];
+            edge_pp(d.pose_est + 3 * i, d.pose_est + 3 * j, d.pp_zinv + 3 * k, e, A, B);
+            const double *w = d.pp_info + 6 * k;
+            double W[3][3] = {{w[0], w[1], w[2]}, {w[1], w[3], w[4]}, {w[2], w[4], w[5]}};
+            double We[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) We[r] = W[r][0] * e[0] + W[r][1] * e[1] + W[r][2] * e[2];
+            const bool fi = d.pose_fixed[i], fj = d.pose_fixed[j];
+            if (role == 0 && !(fi && fj)) chi += e[0] * We[0] + e[1] * We[1] + e[2] * We[2];
+            if (WRITE_H) {
+                double WA[3][3], WB[3][3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        WA[r][c] = W[r][0] * A[0][c] + W[r][1] * A[1][c] + W[r][2] * A[2][c];
+                        WB[r][c] = W[r][0] * B[0][c] + W[r][1] * B[1][c] + W[r][2] * B[2][c];
+                    }
+                if (role == 0) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            H[r][c] += A[0][r] * WA[0][c] + A[1][r] * WA[1][c] + A[2][r] * WA[2][c];
+                            double off = A[0][r] * WB[0][c] + A[1][r] * WB[1][c] + A[2][r] * WB[2][c];
+                            d.Hpp_off[9 * k + 3 * r + c] = (!fi && !fj) ? off : 0.0;
+                        }
+                        b[r] -= A[0][r] * We[0] + A[1][r] * We[1] + A[2][r] * We[2];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) H[r][c] += B[0][r] * WB[0][c] + B[1][r] * WB[1][c] + B[2][r] * WB[2][c];
+                        b[r] -= B[0][r] * We[0] + B[1][r] * We[1] + B[2][r] * We[2];
+                    }
+                }
+            }
+        }
+        if (WRITE_H) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d.Hpp_diag[9 * p + 3 * r + c] = fp ? 0.0 : H[r][c];
+                d.b_pose[3 * p + r] = fp ? 0.0 : b[r];
+            }
+        }
+    }
+    double tot = block_sum_256(chi, red);
+    if (threadIdx.x == 0) d.chi2_partial[blockIdx.x] = tot;
+}
+
+// thread per landmark: diagonal block + b of the landmark (recomputes B and e of its edges)
+__global__ void __launch_bounds__(256) k_linearize_lm(DevGraph d) {
+    int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= d.M) return;
+    double h00 = 0, h01 = 0, h11 = 0, b0 = 0, b1 = 0;
+    if (!d.lm_fixed[l]) {
+        double lx = d.lm_est[2 * l], ly = d.lm_est[2 * l + 1];
+        for (int q = d.lm_start[l]; q < d.lm_start[l + 1]; ++q) {
+            int e = d.lm_edges[q], p = d.pl_p[e];
+            double s, c; sincos(d.pose_est[3 * p + 2], &s, &c);
+            double dx = lx - d.pose_est[3 * p], dy = ly - d.pose_est[3 * p + 1];
+            double ex = (c * dx + s * dy) - d.pl_z[2 * e], ey = (-s * dx + c * dy) - d.pl_z[2 * e + 1];
+            double w00 = d.pl_info[3 * e], w01 = d.pl_info[3 * e + 1], w11 = d.pl_info[3 * e + 2];
+            double We0 = w00 * ex + w01 * ey, We1 = w01 * ex + w11 * ey;
+            double WB0[2] = {w00 * c - w01 * s, w00 * s + w01 * c};
+            double WB1[2] = {w01 * c - w11 * s, w01 * s + w11 * c};
+            // B rows: B0 = (c, s), B1 = (-s, c);  Hll[r][k] = B0[r]*WB0[k] + B1[r]*WB1[k]
+            h00 += c * WB0[0] - s * WB1[0];
+            h01 += c * WB0[1] - s * WB1[1];
+            h11 += s * WB0[1] + c * WB1[1];
+            b0 -= c * We0 - s * We1;
+            b1 -= s * We0 + c * We1;
+        }
+    }
+    d.Hll_diag[4 * l] = h00; d.Hll_diag[4 * l + 1] = h01; d.Hll_diag[4 * l + 2] = h01; d.Hll_diag[4 * l + 3] = h11;
+    d.b_lm[2 * l] = b0; d.b_lm[2 * l + 1] = b1;
+}
+
+__global__ void k_reduce_chi2(DevGraph d) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0; for (int k = 0; k < d.n_chi2_partial; ++k) s += d.chi2_partial[k];
+        d.chi2[0] = s;
+    }
+}
+
+void launch_linearize(const DevGraph &d, hipStream_t st) {
+    int gp = (d.N + 255) / 256, gl = (d.M + 255) / 256;
+    if (gp > 0) hipLaunchKernelGGL(k_linearize_pose<true>, dim3(gp), dim3(256), 0, st, d);
+    if (gl > 0) hipLaunchKernelGGL(k_linearize_lm, dim3(gl), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_reduce_chi2, dim3(1), dim3(64), 0, st, d);
+}
+void launch_chi2_only(const DevGraph &d, hipStream_t st) {
+    int gp = (d.N + 255) / 256;
+    if (gp > 0) hipLaunchKernelGGL(k_linearize_pose<false>, dim3(gp), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_reduce_chi2, dim3(1), dim3(64), 0, st, d);
+}
+
+// ------------------------------------------------------------------ A8 factorisation
+// One workgroup per front.  The (f+1) x f frontal matrix (last row = rhs) lives in LDS, column-major with
+// an odd leading dimension; lower triangle only.  assemble originals -> extend-add children -> partial
+// Cholesky of the npiv pivot columns -> L panel and update matrix to HBM.
+__device__ __forceinline__ void apply_asm(const DevGraph &d, const int32_t *rec, double *F, int ld, int f) {
+    int kind = rec[0], src = rec[1], r0 = rec[2], c0 = rec[3];
+    switch (kind) {
+        case 0: {   // pose diagonal + rhs
+            const double *H = d.Hpp_diag + 9 * (int64_t)src;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int r = c; r < 3; ++r) F[(c0 + c) * ld + r0 + r] += H[3 * r + c];
+                F[(c0 + c) * ld + f] += d.b_pose[3 * (int64_t)src + c];
+            }
+        } break;
+        case 1: {
+            const double *H = d.Hll_diag + 4 * (int64_t)src;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int r = c; r < 2; ++r) F[(c0 + c) * ld + r0 + r] += H[2 * r + c];
+                F[(c0 + c) * ld + f] += d.b_lm[2 * (int64_t)src + c];
+            }
+        } break;
+        case 2: case 3: {
+            const double *H = d.Hpp_off + 9 * (int64_t)src;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) F[(c0 + b) * ld + r0 + a] += (kind == 2) ? H[3 * a + b] : H[3 * b + a];
+        } break;
+        case 4: {   // 3x2 as is
+            const double *H = d.Hpl + 6 * (int64_t)src;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) F[(c0 + b) * ld + r0 + a] += H[2 * a + b];
+        } break;
+        default: {  // 2x3 transposed
+            const double *H = d.Hpl + 6 * (int64_t)src;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) F[(c0 + b) * ld + r0 + a] += H[2 * b + a];
+        } break;
+    }
+}
+
+template <bool USE_LDS>
+__global__ void __launch_bounds__(256) k_factor_level(DevGraph d, int level_off) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int s = d.level_fronts[level_off + blockIdx.x];
+    const DevFront fr = d.fronts[s];
+    const int npiv = fr.npiv, nbnd = fr.nbnd, f = npiv + nbnd, ld = (f + 1) | 1;
+    double *F = USE_LDS ? smem : d.front_ws + (int64_t)blockIdx.x * d.front_ws_stride;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < ld * f; idx += 256) F[idx] = 0.0;
+    __syncthreads();
+    const int nuniq = fr.asm_cnt - fr.asm_dup;
+    for (int t = tid; t < nuniq; t += 256) apply_asm(d, d.asm_recs + 4 * (int64_t)(fr.asm_off + t), F, ld, f);
+    __syncthreads();
+    if (fr.asm_dup > 0) {
+        if (tid == 0) for (int t = nuniq; t < fr.asm_cnt; ++t) apply_asm(d, d.asm_recs + 4 * (int64_t)(fr.asm_off + t), F, ld, f);
+        __syncthreads();
+    }
+    for (int ci = 0; ci < fr.child_cnt; ++ci) {
+        const int c = d.children[fr.child_off + ci];
+        const DevFront ch = d.fronts[c];
+        const int nb = ch.nbnd, ldu = nb + 1;
+        const double *U = d.Ubuf + ch.U_off;
+        const int32_t *map = d.child_map + ch.map_off;
+        for (int idx = tid; idx < ldu * nb; idx += 256) {
+            int col = idx / ldu, row = idx - col * ldu;
+            if (row >= col) {
+                int pr = (row == nb) ? f : map[row], pc = map[col];
+                F[pc * ld + pr] += U[idx];
+            }
+        }
+        __syncthreads();
+    }
+    // right-looking partial Cholesky
+    const int tx = tid & 15, ty = tid >> 4;
+    for (int k = 0; k < npiv; ++k) {
+        double piv = F[k * ld + k];
+        if (!(piv > 0.0)) { if (tid == 0) atomicExch(d.fail, 1); piv = 1.0; }
+        const double dd = sqrt(piv), inv = 1.0 / dd;
+        __syncthreads();
+        for (int r = k + 1 + tid; r <= f; r += 256) F[k * ld + r] *= inv;
+        if (tid == 0) F[k * ld + k] = dd;
+        __syncthreads();
+        for (int c = k + 1 + ty; c < f; c += 16) {
+            const double lc = F[k * ld + c];
+            for (int r = c + tx; r <= f; r += 16) F[c * ld + r] -= F[k * ld + r] * lc;
+        }
+        __syncthreads();
+    }
+    // L panel: (f+1) x npiv, ld = f+1
+    double *L = d.Lbuf + fr.L_off;
+    const int ldl = f + 1;
+    for (int idx = tid; idx < ldl * npiv; idx += 256) { int c = idx / ldl, r = idx - c * ldl; L[idx] = F[c * ld + r]; }
+    double *U = d.Ubuf + fr.U_off;
+    const int ldu = nbnd + 1;
+    for (int idx = tid; idx < ldu * nbnd; idx += 256) { int c = idx / ldu, r = idx - c * ldu;
+        U[idx] = (r >= c) ? F[(npiv + c) * ld + npiv + r] : 0.0; }
+}
+
+static constexpr int LDS_LIMIT_BYTES = 160 * 1024;
+int factor_lds_limit_f() {
+    int f = 1;
+    while ((int64_t)(((f + 2) | 1)) * (f + 1) * 8 <= LDS_LIMIT_BYTES) ++f;
+    return f;
+}
+
+void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f, hipStream_t st) {
+    if (count <= 0) return;
+    int64_t bytes = (int64_t)((max_f + 1) | 1) * max_f * 8;
+    if (bytes <= LDS_LIMIT_BYTES) {
+        static bool attr_set = false;
+        if (!attr_set) { hipFuncSetAttribute((const void *)k_factor_level<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES); attr_set = true; }
+        hipLaunchKernelGGL(k_factor_level<true>, dim3(count), dim3(256), (size_t)bytes, st, d, level_off);
+    } else {
+        hipLaunchKernelGGL(k_factor_level<false>, dim3(count), dim3(256), 0, st, d, level_off);
+    }
+}
+
+// ------------------------------------------------------------------ A8 backward solve
+// x_piv = L11^-T (y1 - L21^T x_bnd), fronts of one level in parallel, root level first.
+__global__ void __launch_bounds__(256) k_backsolve_level(DevGraph d, int level_off) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int s = d.level_fronts[level_off + blockIdx.x];
+    const DevFront fr = d.fronts[s];
+    const int npiv = fr.npiv, nbnd = fr.nbnd, f = npiv + nbnd, ldl = f + 1;
+    double *xb = smem, *w = smem + nbnd;
+    const double *L = d.Lbuf + fr.L_off;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int r = tid; r < nbnd; r += 256) xb[r] = d.xe[d.bnd_rows[fr.bnd_off + r]];
+    __syncthreads();
+    for (int c = wave; c < npiv; c += 4) {
+        const double *col = L + (int64_t)c * ldl;
+        double acc = 0.0;
+        for (int r = lane; r < nbnd; r += 64) acc += col[npiv + r] * xb[r];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, WAVE);
+        if (lane == 0) w[c] = col[f] - acc;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int c = npiv - 1; c >= 0; --c) {
+            const double *col = L + (int64_t)c * ldl;
+            double acc = 0.0;
+            for (int r = c + 1 + lane; r < npiv; r += 64) acc += col[r] * w[r];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, WAVE);
+            if (lane == 0) w[c] = (w[c] - acc) / col[c];
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+        }
+        for (int c = lane; c < npiv; c += 64) d.xe[fr.piv0 + c] = w[c];
+    }
+}
+
+void launch_backsolve_level(const DevGraph &d, int level_off, int count, int max_npiv, int max_nbnd, hipStream_t st) {
+    if (count <= 0) return;
+    size_t bytes = (size_t)(max_npiv + max_nbnd + 2) * 8;
+    hipLaunchKernelGGL(k_backsolve_level, dim3(count), dim3(256), bytes, st, d, level_off);
+}
+
+// ------------------------------------------------------------------ A9
+__global__ void __launch_bounds__(256) k_update(DevGraph d) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < d.N) {
+        int g = d.pose_gidx[t];
+        double dx = 0, dy = 0, dt = 0;
+        if (g >= 0) { dx = d.xe[g]; dy = d.xe[g + 1]; dt = d.xe[g + 2];
+            d.pose_est[3 * t] += dx; d.pose_est[3 * t + 1] += dy;
+            d.pose_est[3 * t + 2] = normalize_theta(d.pose_est[3 * t + 2] + dt); }
+        d.dpose[3 * t] = dx; d.dpose[3 * t + 1] = dy; d.dpose[3 * t + 2] = dt;
+    } else if (t < d.N + d.M) {
+        int l = t - d.N, g = d.lm_gidx[l];
+        double dx = 0, dy = 0;
+        if (g >= 0) { dx = d.xe[g]; dy = d.xe[g + 1]; d.lm_est[2 * l] += dx; d.lm_est[2 * l + 1] += dy; }
+        d.dlm[2 * l] = dx; d.dlm[2 * l + 1] = dy;
+    }
+}
+void launch_update(const DevGraph &d, hipStream_t st) {
+    int n = d.N + d.M;
+    if (n > 0) hipLaunchKernelGGL(k_update, dim3((n + 255) / 256), dim3(256), 0, st, d);
+}
+
+void launch_polar_to_xy(int n, const double *az, const double *zen, const double *dist, double lidar, double *out, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_polar_to_xy, dim3((n + 255) / 256), dim3(256), 0, st, n, az, zen, dist, lidar, out);
+}
+void launch_cone_to_global(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar,
+                           double *out, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_cone_to_global, dim3((n + 255) / 256), dim3(256), 0, st, n, poses, pose_of_obs, obs, lidar, out);
+}
+void launch_associate(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar,
+                      int n_map, const double *map_xy, const int32_t *map_type, double thr, double type_tol,
+                      int32_t *out, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_associate, dim3((n + 255) / 256), dim3(256), 0, st, n, poses, pose_of_obs, obs, lidar,
+                                  n_map, map_xy, map_type, thr, type_tol, out);
+}
+
+}  // namespace gs

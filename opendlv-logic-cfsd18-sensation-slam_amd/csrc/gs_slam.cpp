@@ -1,0 +1,206 @@
+// gs_slam.cpp — host mirror of the graph side of class Slam (reference src/slam.hpp:43-137):
+// performSLAM (src/slam.cpp:298-338), addPoseToGraph / addOdometryMeasurement (:433-459),
+// addConesToMap (:552-635), addConeToGraph / addConeMeasurement (:525-550), loopClosing (:697-706),
+// optimizeGraph (:461-484), updateMap (:713-732), localizer (:340-414), updatePoseFromGraph (:416-422).
+//
+// The per-frame control flow stays on the host exactly as in the reference; the arithmetic it calls
+// (polar->XY, cone->global, the O(K*M) map scan, the optimiser) runs through the HIP kernels behind
+// the C-ABI.  Message decode/encode (nextCone, sendCones, ...) stays above this boundary.
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "gs_internal.hpp"
+
+struct MapCone { double x, y; int type, id; };              // reference src/cone.hpp:51-54
+
+struct gs_slam {
+    gs_config cfg{};
+    gs_graph *g = nullptr;
+    std::vector<MapCone> map;                                // m_map
+    std::vector<std::array<double, 3>> poses;                // m_poses (raw odometry, never overwritten)
+    int pose_id = 1000;                                      // m_poseId, reference src/slam.hpp:118
+    bool loop_closing = false, loop_closing_complete = false;
+    uint32_t current_cone_index = 0;                         // m_currentConeIndex
+    double send_pose[3] = {0, 0, 0};                         // m_sendPose
+    int optimise_calls = 0;
+};
+
+using gs::fail;
+
+extern "C" int gs_slam_create(const gs_config *cfg, gs_slam **out) {
+    if (!out) return fail(GS_ERR_INVALID, "null out");
+    *out = nullptr;
+    gs_graph *g = nullptr;
+    int rc = gs_create(cfg, &g);
+    if (rc != GS_OK) return rc;
+    gs_slam *s = new gs_slam();
+    s->g = g; s->cfg = g->cfg;
+    *out = s;
+    return GS_OK;
+}
+extern "C" int gs_slam_destroy(gs_slam *s) {
+    if (!s) return GS_OK;
+    gs_destroy(s->g);
+    delete s;
+    return GS_OK;
+}
+extern "C" gs_graph *gs_slam_graph(gs_slam *s) { return s ? s->g : nullptr; }
+extern "C" int gs_slam_map_size(gs_slam *s) { return s ? (int)s->map.size() : fail(GS_ERR_INVALID, "null slam"); }
+extern "C" int gs_slam_loop_closed(gs_slam *s) { return s ? (int)s->loop_closing_complete : fail(GS_ERR_INVALID, "null slam"); }
+extern "C" int gs_slam_current_cone_index(gs_slam *s) { return s ? (int)s->current_cone_index : fail(GS_ERR_INVALID, "null slam"); }
+extern "C" int gs_slam_get_send_pose(gs_slam *s, double out[3]) {
+    if (!s || !out) return fail(GS_ERR_INVALID, "null argument");
+    std::memcpy(out, s->send_pose, sizeof(s->send_pose));
+    return GS_OK;
+}
+extern "C" int gs_slam_get_map(gs_slam *s, int32_t cap, double *xy, int32_t *type) {
+    if (!s || !xy) return fail(GS_ERR_INVALID, "null argument");
+    if (cap < (int)s->map.size()) return fail(GS_ERR_CAPACITY, "buffer too small");
+    for (size_t j = 0; j < s->map.size(); ++j) { xy[2 * j] = s->map[j].x; xy[2 * j + 1] = s->map[j].y; if (type) type[j] = s->map[j].type; }
+    return (int)s->map.size();
+}
+
+static double normalize_theta(double th) {
+    if (th >= -M_PI && th < M_PI) return th;
+    double m = std::floor(th / (2 * M_PI)); th -= m * 2 * M_PI;
+    if (th >= M_PI) th -= 2 * M_PI;
+    if (th < -M_PI) th += 2 * M_PI;
+    return th;
+}
+
+// addConeMeasurement, reference src/slam.cpp:537-550 (z already converted by the A0 kernel)
+static int add_cone_measurement(gs_slam *s, int cone_id, const double z_xy[2]) {
+    const double w = s->cfg.cone_information;
+    const double info[4] = {w, 0, 0, w};
+    return gs_add_observation_edge(s->g, s->pose_id - 1, cone_id, z_xy, info);
+}
+// addConeToGraph, reference src/slam.cpp:525-535
+static int add_cone_to_graph(gs_slam *s, const MapCone &c, const double z_xy[2]) {
+    const double xy[2] = {c.x, c.y};
+    int rc = gs_add_landmark(s->g, c.id, xy);
+    if (rc != GS_OK) return rc;
+    return add_cone_measurement(s, c.id, z_xy);
+}
+// optimizeGraph + updateMap, reference src/slam.cpp:461-484, 713-732
+static int optimize_and_update_map(gs_slam *s) {
+    int rc;
+    if ((rc = gs_set_fixed_pose(s->g, 1000, 1)) != GS_OK) return rc;
+    if ((rc = gs_set_fixed_pose(s->g, 1001, 1)) != GS_OK) return rc;
+    if ((rc = gs_set_fixed_landmark(s->g, 0, 1)) != GS_OK) return rc;
+    if ((rc = gs_set_fixed_landmark(s->g, 1, 1)) != GS_OK) return rc;
+    rc = gs_optimize(s->g, s->cfg.optimize_iterations, nullptr);       // return value ignored by the reference (:481)
+    ++s->optimise_calls;
+    if (rc < 0) return rc;
+    for (auto &c : s->map) { double xy[2]; if ((rc = gs_get_landmark(s->g, c.id, xy)) != GS_OK) return rc; c.x = xy[0]; c.y = xy[1]; }
+    return GS_OK;
+}
+
+static double cone_distance(const MapCone &c, double x, double y) {     // distanceBetweenCones, :708-711
+    return std::sqrt((c.x - x) * (c.x - x) + (c.y - y) * (c.y - y));
+}
+
+extern "C" int gs_slam_perform(gs_slam *s, const double pose[3], const double *cones, int32_t k) {
+    if (!s || !pose || k < 0 || (k > 0 && !cones)) return fail(GS_ERR_INVALID, "bad argument");
+    if (std::fabs(pose[0]) > 200 || std::fabs(pose[1]) > 200) return GS_OK;      // :300-303
+    s->poses.push_back({pose[0], pose[1], pose[2]});
+    int rc;
+    // ---- addPoseToGraph + addOdometryMeasurement (:433-459)
+    if ((rc = gs_add_pose(s->g, s->pose_id, pose)) != GS_OK) return rc;
+    if (s->pose_id > 1000) {
+        double prev[3];
+        if ((rc = gs_get_pose(s->g, s->pose_id - 1, prev)) != GS_OK) return rc;
+        double th = normalize_theta(-prev[2]), c = std::cos(th), sn = std::sin(th);
+        double ix = c * (-prev[0]) - sn * (-prev[1]), iy = sn * (-prev[0]) + c * (-prev[1]);
+        double z[3] = {ix + (c * pose[0] - sn * pose[1]), iy + (sn * pose[0] + c * pose[1]), normalize_theta(th + pose[2])};
+        const double w = s->cfg.odometry_information;
+        const double info[9] = {w, 0, 0, 0, w, 0, 0, 0, w};
+        if ((rc = gs_add_odometry_edge(s->g, s->pose_id - 1, s->pose_id, z, info)) != GS_OK) return rc;
+    }
+    s->pose_id++;
+    if (k == 0) return GS_OK;
+
+    // ---- A0 for the whole frame on the device
+    std::vector<double> az(k), zen(k), dist(k), zxy(2 * (size_t)k), gxy(2 * (size_t)k);
+    std::vector<int32_t> pose_of(k, 0), idx(k, -1);
+    for (int i = 0; i < k; ++i) { az[i] = cones[4 * i]; zen[i] = cones[4 * i + 1]; dist[i] = cones[4 * i + 2]; }
+    if ((rc = gs_polar_to_xy_batch(s->g, k, az.data(), zen.data(), dist.data(), zxy.data())) != GS_OK) return rc;
+    if ((rc = gs_cone_to_global_batch(s->g, k, pose, 1, pose_of.data(), cones, gxy.data())) != GS_OK) return rc;
+
+    if (!s->loop_closing_complete) {
+        // ---- addConesToMap (:552-635)
+        const bool quirks = s->cfg.reference_quirks != 0;
+        int first = 0;
+        if (s->map.empty()) {
+            MapCone c{gxy[0], gxy[1], (int)cones[3], 0};
+            s->map.push_back(c);
+            if ((rc = add_cone_to_graph(s, c, &zxy[0])) != GS_OK) return rc;
+            if (!quirks) first = 1;                     // the reference re-matches i = 0 and adds the edge twice
+        }
+        // A1 against the map as it stands at the start of the frame, on the device
+        const int m0 = (int)s->map.size();
+        { std::vector<double> mxy(2 * (size_t)m0); std::vector<int32_t> mty(m0);
+          for (int j = 0; j < m0; ++j) { mxy[2 * j] = s->map[j].x; mxy[2 * j + 1] = s->map[j].y; mty[j] = s->map[j].type; }
+          if ((rc = gs_associate_batch(s->g, k, pose, 1, pose_of.data(), cones, m0, mxy.data(), mty.data(),
+                                       s->cfg.same_cone_threshold, 1e-4, idx.data())) != GS_OK) return rc; }
+        double min_distance = 100;
+        bool optimise_pending = false;
+        for (int i = first; i < k; ++i) {
+            const double d2car = cones[4 * i + 2], type_i = cones[4 * i + 3];
+            bool found = false; int j = -1;
+            if (!s->loop_closing) {
+                if (idx[i] >= 0) { found = true; j = idx[i]; }
+                else for (int t = m0; t < (int)s->map.size(); ++t)       // cones appended earlier in this frame
+                    if (std::fabs(s->map[t].type - type_i) < 1e-4 && cone_distance(s->map[t], gxy[2 * i], gxy[2 * i + 1]) < s->cfg.same_cone_threshold) { found = true; j = t; break; }
+            }
+            if (found) {
+                if ((rc = add_cone_measurement(s, s->map[j].id, &zxy[2 * i])) != GS_OK) return rc;
+                // loopClosing(), :697-706
+                if (cone_distance(s->map[0], s->map[j].x, s->map[j].y) < s->cfg.loop_closing_radius &&
+                    s->current_cone_index > (uint32_t)s->cfg.loop_closing_min_index && d2car < s->cfg.cone_mapping_threshold && !s->loop_closing)
+                    s->loop_closing = true;
+                if (d2car < min_distance) { s->current_cone_index = (uint32_t)j; min_distance = d2car; }
+            }
+            if (d2car < s->cfg.cone_mapping_threshold && !found && !s->loop_closing) {
+                MapCone c{gxy[2 * i], gxy[2 * i + 1], (int)type_i, (int)s->map.size()};
+                s->map.push_back(c);
+                if ((rc = add_cone_to_graph(s, c, &zxy[2 * i])) != GS_OK) return rc;
+            }
+            if (s->loop_closing) {
+                if (quirks) { if ((rc = optimize_and_update_map(s)) != GS_OK) return rc; s->loop_closing_complete = true; }   // §8-B.2: once per remaining observation
+                else optimise_pending = true;
+            }
+        }
+        if (optimise_pending) { if ((rc = optimize_and_update_map(s)) != GS_OK) return rc; s->loop_closing_complete = true; }
+        return GS_OK;
+    }
+
+    // ---- localizer (:340-414), only with at least two cones (:332)
+    if (k > 1) {
+        const bool quirks = s->cfg.reference_quirks != 0;
+        uint32_t current = s->current_cone_index; double min_distance = 100; int reobserved = 0;
+        for (int i = 0; i < k; ++i) {
+            const double d2car = cones[4 * i + 2]; const int type_i = (int)cones[4 * i + 3];
+            for (size_t j = 0; j < s->map.size(); ++j) {
+                // the reference omits fabs on the type difference (:360); kept only under reference_quirks
+                const double dt = (double)(s->map[j].type - type_i);
+                const bool type_ok = quirks ? (dt < 1e-4) : (std::fabs(dt) < 1e-4);
+                if (cone_distance(s->map[j], gxy[2 * i], gxy[2 * i + 1]) < s->cfg.same_cone_threshold && type_ok) {
+                    ++reobserved;
+                    double z[2] = {zxy[2 * i], zxy[2 * i + 1]};
+                    if (quirks) {   // §8-B.4: the reference passes the POSE where (az, zen, dist) is expected (:373)
+                        if ((rc = gs_polar_to_xy_batch(s->g, 1, &pose[0], &pose[1], &pose[2], z)) != GS_OK) return rc;
+                    }
+                    if ((rc = add_cone_measurement(s, s->map[j].id, z)) != GS_OK) return rc;
+                    if (d2car < min_distance) { current = (uint32_t)j; min_distance = d2car; }
+                    break;
+                }
+            }
+        }
+        if (reobserved > 0) s->current_cone_index = current;
+        // updatePoseFromGraph (:416-422): the raw estimate of the last pose vertex; no re-optimisation (:403)
+        if ((rc = gs_get_pose(s->g, s->pose_id - 1, s->send_pose)) != GS_OK) return rc;
+    }
+    return GS_OK;
+}

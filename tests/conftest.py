@@ -1,0 +1,95 @@
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+PKG_NAME = "opendlv-logic-cfsd18-sensation-slam_amd"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    """The product package; builds the native libraries if they are missing."""
+    m = importlib.import_module(PKG_NAME)
+    if not os.path.exists(m.binding.LIB_PATH) or not os.path.exists(m.track.LIB):
+        m.build()
+    return m
+
+
+@pytest.fixture(scope="session")
+def po():
+    """The CPU oracle binding (test infrastructure)."""
+    from oracle import pyoracle
+    pyoracle.build()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def frontend(po):
+    return po.OracleFrontend()
+
+
+def make_oracle_graph(po, g):
+    og = po.OracleGraph()
+    og.add_poses(g["pose_est"]); og.add_landmarks(g["lm_est"])
+    og.add_odometry_edges(g["pp_i"], g["pp_j"], g["pp_z"], g["pp_info"])
+    og.add_observation_edges(g["pl_p"], g["pl_l"], g["pl_z"], g["pl_info"])
+    for i in g["fixed_poses"]:
+        og.set_fixed_pose(int(i))
+    for l in g["fixed_landmarks"]:
+        og.set_fixed_landmark(int(l))
+    return og
+
+
+@pytest.fixture(scope="session")
+def bench_graphs(pkg, frontend):
+    """Lazily built bench graphs keyed by (N, M); arrays from the ORACLE front end."""
+    cache = {}
+
+    def get(N, M):
+        if (N, M) not in cache:
+            t = pkg.track.generate(N, M)
+            cache[(N, M)] = (t, pkg.track.bench_graph(t, frontend))
+        return cache[(N, M)]
+    return get
+
+
+def random_graph(seed, n_poses=40, n_lms=25, extra_pp=6, obs_per_pose=4, dup_edges=2):
+    """A small irregular graph (not a track): random observations, random extra pose-pose edges
+    (loop-closure style), anisotropic information matrices, parallel duplicate edges."""
+    rng = np.random.default_rng(seed)
+    poses = np.cumsum(rng.normal(0.5, 0.2, (n_poses, 3)) * [1, 0.3, 0.05], axis=0)
+    lms = rng.uniform(-5, 25, (n_lms, 2))
+
+    def spd(n):
+        A = rng.normal(size=(n, n)); S = A @ A.T + n * np.eye(n)
+        return (S + S.T) / 2
+
+    pp_i, pp_j = list(range(n_poses - 1)), list(range(1, n_poses))
+    for _ in range(extra_pp):
+        a, b = rng.choice(n_poses, 2, replace=False)
+        pp_i.append(int(a)); pp_j.append(int(b))
+    pp_z = rng.normal(0, 0.5, (len(pp_i), 3))
+    pp_info = np.stack([spd(3).reshape(9) for _ in pp_i])
+    pl_p, pl_l = [], []
+    for p in range(n_poses):
+        for l in rng.choice(n_lms, obs_per_pose, replace=False):
+            pl_p.append(p); pl_l.append(int(l))
+    for _ in range(dup_edges):                      # duplicated edge (SURVEY §8-B.1 style)
+        k = int(rng.integers(len(pl_p))); pl_p.append(pl_p[k]); pl_l.append(pl_l[k])
+    pl_z = rng.normal(0, 3, (len(pl_p), 2))
+    pl_info = np.stack([spd(2).reshape(4) for _ in pl_p])
+    return dict(pose_est=poses, lm_est=lms, pp_i=np.array(pp_i, dtype=np.int32), pp_j=np.array(pp_j, dtype=np.int32),
+                pp_z=pp_z, pp_info=pp_info, pl_p=np.array(pl_p, dtype=np.int32), pl_l=np.array(pl_l, dtype=np.int32),
+                pl_z=pl_z, pl_info=pl_info, fixed_poses=np.array([0], dtype=np.int32),
+                fixed_landmarks=np.array([3], dtype=np.int32))

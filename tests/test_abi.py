@@ -1,0 +1,115 @@
+"""C-ABI surface tests without a GPU: the library loads, exports every symbol include/graphslam.h
+declares, reports errors by code (never throws/aborts), and refuses to compute without a gfx950 device
+(there is no CPU fallback)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.binding.lib()
+    names = pkg.binding.declared_symbols()
+    assert len(names) >= 50
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.gs_version() == 1
+
+
+def test_default_config_carries_the_reference_constants(pkg):
+    cfg = pkg.default_config()
+    assert cfg.struct_size == C.sizeof(pkg.Config)
+    assert cfg.odometry_information == 5.0 and cfg.cone_information == 0.01      # reference src/slam.cpp:456,546
+    assert cfg.lidar_to_cog == 1.5 and cfg.optimize_iterations == 10            # src/slam.cpp:514,481
+    assert cfg.loop_closing_radius == 1.0 and cfg.loop_closing_min_index == 20   # src/slam.cpp:702
+
+
+def test_host_only_handle_refuses_every_compute_entry_point(pkg):
+    G = pkg.Graph(device=-2)
+    G.add_poses([0, 1], np.zeros((2, 3))); G.add_landmark(0, [1.0, 1.0])
+    G.add_odometry_edges([0], [1], np.zeros((1, 3)))                # default information = 5*I
+    G.add_observation_edges([1], [0], np.ones((1, 2)))              # default information = 0.01*I
+    for call in (G.initialize_optimization, lambda: G.optimize(1), G.chi2, G.linearize, lambda: G.time_linearize(1),
+                 lambda: G.polar_to_xy([1.0], [0.0], [2.0]),
+                 lambda: G.associate(np.zeros((1, 3)), [0], np.ones((1, 4)), np.zeros((1, 2)), [1], 1.0)):
+        with pytest.raises(pkg.GsError) as e:
+            call()
+        assert e.value.code == -4, call                              # GS_ERR_NO_DEVICE
+    with pytest.raises(pkg.GsError) as e:
+        G.iterate()
+    assert e.value.code in (-4, -6)
+    assert G.n_poses == 2 and G.n_landmarks == 1 and G.n_pp == 1 and G.n_pl == 1
+    assert np.array_equal(G.get_landmark(0), [1.0, 1.0])
+    G.close()
+
+
+def test_error_codes_follow_g2o_semantics(pkg):
+    G = pkg.Graph(device=-2)
+    G.add_pose(1000, [0, 0, 0])
+    with pytest.raises(pkg.GsError) as e:
+        G.add_pose(1000, [1, 1, 1])                                  # g2o addVertex returns false on a duplicate id
+    assert e.value.code == -2
+    with pytest.raises(pkg.GsError) as e:
+        G.add_odometry_edge(1000, 1001, [0, 0, 0], np.eye(3))        # vertex(id) == nullptr
+    assert e.value.code == -3
+    with pytest.raises(pkg.GsError) as e:
+        G.add_observation_edge(1000, 0, [0, 0], np.eye(2))
+    assert e.value.code == -3
+    G.add_pose(1001, [1, 0, 0])
+    with pytest.raises(pkg.GsError) as e:
+        G.add_odometry_edge(1000, 1001, [1, 0, 0], np.array([[1, 2, 0], [0, 1, 0], [0, 0, 1.0]]))   # not symmetric
+    assert e.value.code == -1
+    with pytest.raises(pkg.GsError) as e:
+        G.add_odometry_edge(1000, 1000, [0, 0, 0], np.eye(3))        # self edge
+    assert e.value.code == -1
+    with pytest.raises(pkg.GsError) as e:
+        G.set_fixed_landmark(5, True)
+    assert e.value.code == -3
+    # separate id spaces: landmark 1000 does not collide with pose 1000 (the reference collides beyond 1000 cones)
+    G.add_landmark(1000, [2.0, 3.0])
+    assert np.array_equal(G.get_landmark(1000), [2.0, 3.0]) and np.array_equal(G.get_pose(1000), [0, 0, 0])
+    G.set_pose_estimate(1001, [4, 5, 6]); assert np.array_equal(G.get_pose(1001), [4, 5, 6])
+    G.clear(); assert G.n_poses == 0 and G.n_landmarks == 0
+    G.close()
+
+
+def test_null_arguments_return_invalid(pkg):
+    L = pkg.binding.lib()
+    assert L.gs_create(None, None) == -1
+    assert L.gs_add_pose(None, 0, None) == -1
+    assert L.gs_optimize(None, 1, None) == -1
+    assert L.gs_destroy(None) == 0
+    assert L.gs_linearize_bytes(None) == 0
+
+
+def test_without_a_gpu_the_product_fails_loudly(pkg):
+    """No silent fallback: on a box without a gfx950 device gs_create must fail with GS_ERR_NO_DEVICE."""
+    if pkg.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(pkg.GsError) as e:
+        pkg.Graph()
+    assert e.value.code == -4
+    with pytest.raises(pkg.GsError) as e:
+        pkg.Slam()
+    assert e.value.code == -4
+
+
+def test_linearize_bytes_is_the_survey_formula(pkg):
+    G = pkg.Graph(device=-2)
+    G.add_poses([0, 1, 2], np.zeros((3, 3))); G.add_landmarks([0, 1], np.ones((2, 2)))
+    G.add_odometry_edges([0, 1], [1, 2], np.zeros((2, 3))); G.add_observation_edges([0, 1, 2], [0, 1, 1], np.ones((3, 2)))
+    assert G.linearize_bytes() == 2 * 152 + 3 * 96 + 3 * 120 + 2 * 64
+    G.close()
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: no file of the product package may import, load or link it."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkgdir = os.path.join(root, "opendlv-logic-cfsd18-sensation-slam_amd")
+    for dp, _, files in os.walk(pkgdir):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".c", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "pyoracle" not in txt and "liboracle" not in txt and "orc_" not in txt, os.path.join(dp, f)
+                assert "/root/reference" not in txt, os.path.join(dp, f)

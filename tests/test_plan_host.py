@@ -1,0 +1,104 @@
+"""CPU tests of the host-side structure phase (csrc/gs_plan.cpp) through the C-ABI's host-only handle.
+
+The plan (nested-dissection order, symbolic factorisation, assembly records, extend-add maps) is checked
+(a) for the invariants any valid multifrontal plan satisfies and (b) numerically: tests/plan_exec.py
+replays the plan in numpy on the oracle's H blocks and must reproduce the oracle's joint-system increment.
+No HIP code runs here."""
+import numpy as np
+import pytest
+
+from conftest import make_oracle_graph, random_graph
+from plan_exec import Plan
+
+
+def host_graph(pkg, g, **kw):
+    G = pkg.Graph(device=-2, **kw)
+    G.load_bench_graph(g)
+    return G
+
+
+def oracle_increment(po, g, ordering=1):
+    og = make_oracle_graph(po, g)
+    blocks = og.linearize_blocks()
+    og.build_system(); og.apply_update(og.solve_ldlt(ordering))
+    return blocks, og.delta()
+
+
+@pytest.mark.parametrize("N,M,leaf", [(50, 30, 0), (50, 30, 1), (1000, 200, 0), (1000, 200, 3), (1000, 200, 64)])
+def test_track_plan_invariants_and_numeric_replay(pkg, po, bench_graphs, N, M, leaf):
+    _, g = bench_graphs(N, M)
+    G = host_graph(pkg, g, leaf_poses=leaf)
+    info = G.plan_build_host()
+    assert info.n_scalar == 3 * (N - 2) + 2 * (len(g["lm_est"]) - 2)
+    P = Plan(G.plan_export()); P.check_invariants()
+    assert P.n_fronts == info.n_fronts and P.max_front == info.max_front
+    blocks, (dp_o, dl_o) = oracle_increment(po, g)
+    dp, dl, ok = P.solve(blocks)
+    scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
+    assert ok and np.abs(dp - dp_o).max() / scale < 1e-8 and np.abs(dl - dl_o).max() / scale < 1e-8
+    G.close()
+
+
+def test_track_plan_is_a_shallow_tree_of_small_fronts(pkg, bench_graphs):
+    """The design premise: separators of the joint pose+cone graph are tiny, so fronts stay
+    ~50 scalars wide and the tree has ~log2(N/leaf) levels."""
+    _, g = bench_graphs(10000, 2000)
+    G = host_graph(pkg, g)
+    info = G.plan_build_host()
+    assert info.max_front <= 96 and info.n_levels <= 16
+    P = Plan(G.plan_export()); P.check_invariants()
+    assert (P.npiv + P.nbnd).mean() < 64
+    G.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_irregular_graph_plan_numeric_replay(pkg, po, seed):
+    """Not a track: random observations, extra pose-pose edges spanning the split, duplicate parallel edges,
+    anisotropic information.  Ordering is a heuristic, the symbolic phase must still be exact."""
+    g = random_graph(seed)
+    for leaf in (0, 2):
+        G = host_graph(pkg, g, leaf_poses=leaf)
+        G.plan_build_host()
+        P = Plan(G.plan_export()); P.check_invariants()
+        assert P.asm_dup.sum() >= 1                      # the parallel duplicate edges were detected
+        blocks, (dp_o, dl_o) = oracle_increment(po, g, ordering=0)
+        dp, dl, ok = P.solve(blocks)
+        scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
+        assert ok and np.abs(dp - dp_o).max() / scale < 1e-9 and np.abs(dl - dl_o).max() / scale < 1e-9
+        G.close()
+
+
+def test_pose_only_chain_and_isolated_landmark(pkg, po):
+    rng = np.random.default_rng(0)
+    n = 30
+    g = dict(pose_est=np.cumsum(rng.normal(0.5, 0.1, (n, 3)), axis=0), lm_est=np.array([[1.0, 2.0], [4.0, 1.0]]),
+             pp_i=np.arange(n - 1, dtype=np.int32), pp_j=np.arange(1, n, dtype=np.int32), pp_z=rng.normal(0.5, 0.1, (n - 1, 3)),
+             pp_info=np.tile(np.eye(3).reshape(1, 9), (n - 1, 1)),
+             # landmark 0 is seen only from the FIXED pose: it couples to no free vertex; landmark 1 from pose 7
+             pl_p=np.array([0, 7], dtype=np.int32), pl_l=np.array([0, 1], dtype=np.int32), pl_z=np.array([[1.0, 2.1], [0.3, 0.2]]),
+             pl_info=np.tile(np.eye(2).reshape(1, 4), (2, 1)), fixed_poses=np.array([0], dtype=np.int32),
+             fixed_landmarks=np.array([], dtype=np.int32))
+    G = host_graph(pkg, g, leaf_poses=2); G.plan_build_host()
+    P = Plan(G.plan_export()); P.check_invariants()
+    blocks, (dp_o, dl_o) = oracle_increment(po, g, ordering=0)
+    dp, dl, ok = P.solve(blocks)
+    assert ok and np.abs(dp - dp_o).max() < 1e-10 and np.abs(dl - dl_o).max() < 1e-10
+    G.close()
+
+
+def test_no_free_vertex_is_an_error_not_a_crash(pkg):
+    G = pkg.Graph(device=-2)
+    G.add_pose(0, [0, 0, 0]); G.set_fixed_pose(0)
+    with pytest.raises(pkg.GsError) as e:
+        G.plan_build_host()
+    assert e.value.code == -7                           # GS_ERR_EMPTY
+    G.close()
+
+
+def test_plan_edge_orders_are_permutations(pkg, bench_graphs):
+    _, g = bench_graphs(1000, 200)
+    G = host_graph(pkg, g); G.plan_build_host(); P = Plan(G.plan_export())
+    assert sorted(P.pl_order.tolist()) == list(range(len(g["pl_p"])))
+    assert np.all(np.diff(g["pl_p"][P.pl_order]) >= 0)   # device order: grouped by pose
+    assert sorted(P.pp_order.tolist()) == list(range(len(g["pp_i"])))
+    G.close()
