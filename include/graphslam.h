@@ -60,7 +60,8 @@ typedef struct gs_config {
                                    (reference: setVerbose(true), src/slam.cpp:63)          */
     int32_t leaf_poses;         /* nested-dissection leaf size in poses; 0 = default        */
     int32_t use_hip_graph;      /* 1: replay one Gauss-Newton iteration as a hipGraph       */
-    int32_t reserved0;
+    int32_t linearize_gather;   /* 1: force the general gather kernels instead of the fused tiled
+                                   linearisation kernel (both are HIP; for tests and A/B timing)   */
     /* Slam-level constants, defaults are the reference's hard-coded values */
     double  odometry_information;   /* 5.0   (src/slam.cpp:456)                             */
     double  cone_information;       /* 0.01  (src/slam.cpp:546)                             */

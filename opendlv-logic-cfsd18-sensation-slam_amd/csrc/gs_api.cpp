@@ -67,7 +67,7 @@ extern "C" int gs_config_default(gs_config *c) {
     if (!c) return fail(GS_ERR_INVALID, "null config");
     std::memset(c, 0, sizeof(*c));
     c->struct_size = (int32_t)sizeof(gs_config);
-    c->device = -1; c->verbose = 0; c->leaf_poses = 0; c->use_hip_graph = 0;
+    c->device = -1; c->verbose = 0; c->leaf_poses = 0; c->use_hip_graph = 0; c->linearize_gather = 0;
     c->odometry_information = 5.0;       // reference src/slam.cpp:456
     c->cone_information = 0.01;          // reference src/slam.cpp:546
     c->same_cone_threshold = 1.0;        // m_newConeThreshold default, reference src/slam.hpp:114
@@ -98,7 +98,7 @@ extern "C" int gs_create(const gs_config *cfg, gs_graph **out) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(GS_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     gs_graph *g = new gs_graph();
-    g->cfg = c; g->device = dev;
+    g->cfg = c; g->device = dev; g->force_gather = c.linearize_gather != 0;
     HIP_TRY(hipSetDevice(dev));
     if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) { delete g; return fail(GS_ERR_HIP, "hipStreamCreate failed"); }
     g->own_stream = true;
@@ -322,21 +322,30 @@ static int upload_graph(gs_graph *g) {
 #define UP(dst, vec) if ((rc = dev_upload(g, &d.dst, vec)) != GS_OK) return rc
     UP(pose_est, h.pose_est); UP(lm_est, h.lm_est); UP(pose_fixed, h.pose_fixed); UP(lm_fixed, h.lm_fixed);
     UP(pose_gidx, P.pose_gidx); UP(lm_gidx, P.lm_gidx);
-    { std::vector<int32_t> p(Epl), l(Epl); std::vector<double> z((size_t)Epl * 2), w((size_t)Epl * 3);
+    { std::vector<int32_t> p(Epl), l(Epl); std::vector<double> z((size_t)Epl * 2), w((size_t)Epl * 3);      // SoA streams
+      const size_t E = (size_t)Epl;
       for (int pos = 0; pos < Epl; ++pos) { int k = P.pl_order[pos]; p[pos] = h.pl_p[k]; l[pos] = h.pl_l[k];
-          z[2 * (size_t)pos] = h.pl_z[2 * (size_t)k]; z[2 * (size_t)pos + 1] = h.pl_z[2 * (size_t)k + 1];
-          for (int t = 0; t < 3; ++t) w[3 * (size_t)pos + t] = h.pl_info[3 * (size_t)k + t]; }
+          z[pos] = h.pl_z[2 * (size_t)k]; z[E + pos] = h.pl_z[2 * (size_t)k + 1];
+          for (int t = 0; t < 3; ++t) w[t * E + pos] = h.pl_info[3 * (size_t)k + t]; }
       UP(pl_p, p); UP(pl_l, l); UP(pl_z, z); UP(pl_info, w); }
-    { std::vector<int32_t> a(Epp), b(Epp); std::vector<double> zi((size_t)Epp * 3), w((size_t)Epp * 6);
+    { std::vector<int32_t> a(Epp), b(Epp); std::vector<double> zi((size_t)Epp * 5), w((size_t)Epp * 6);
       for (int pos = 0; pos < Epp; ++pos) { int k = P.pp_order[pos]; a[pos] = h.pp_i[k]; b[pos] = h.pp_j[k];
-          se2_inverse_host(&h.pp_z[3 * (size_t)k], &zi[3 * (size_t)pos]);
+          double inv[3]; se2_inverse_host(&h.pp_z[3 * (size_t)k], inv);
+          double *o = &zi[5 * (size_t)pos]; o[0] = inv[0]; o[1] = inv[1]; o[2] = inv[2]; o[3] = std::cos(inv[2]); o[4] = std::sin(inv[2]);
           for (int t = 0; t < 6; ++t) w[6 * (size_t)pos + t] = h.pp_info[6 * (size_t)k + t]; }
       UP(pp_i, a); UP(pp_j, b); UP(pp_zinv, zi); UP(pp_info, w); }
     UP(pl_start, P.pl_start); UP(lm_start, P.lm_start); UP(lm_edges, P.lm_edges); UP(ppadj_start, P.ppadj_start); UP(ppadj, P.ppadj);
 #define AL(dst, cnt) if ((rc = dev_alloc(g, &d.dst, (size_t)(cnt))) != GS_OK) return rc
-    AL(Hpp_diag, (size_t)N * 9); AL(Hll_diag, (size_t)M * 4); AL(Hpp_off, (size_t)Epp * 9); AL(Hpl, (size_t)Epl * 6);
+    d.n_tiles = 0; d.n_groups = 0;
+    if (P.lin_tiles_ok && !g->force_gather) {
+        d.n_tiles = (int32_t)P.tile_pose_start.size() - 1; d.n_groups = (int32_t)P.grp_lm.size();
+        UP(tile_pose_start, P.tile_pose_start); UP(tile_grp_start, P.tile_grp_start); UP(grp_lm, P.grp_lm);
+        UP(grp_edge_start, P.grp_edge_start); UP(grp_edges, P.grp_edges); UP(lm_grp_start, P.lm_grp_start); UP(lm_grps, P.lm_grps);
+        AL(lm_part, (size_t)d.n_groups * 5);
+    }
+    AL(Hpp_diag, (size_t)N * 6); AL(Hll_diag, (size_t)M * 3); AL(Hpp_off, (size_t)Epp * 9); AL(Hpl, (size_t)Epl * 6);
     AL(b_pose, (size_t)N * 3); AL(b_lm, (size_t)M * 2);
-    d.n_chi2_partial = (N + 255) / 256;
+    d.n_chi2_partial = std::max((N + 255) / 256, d.n_tiles);
     AL(chi2_partial, d.n_chi2_partial); AL(chi2, 80);
     // plan
     { std::vector<DevFront> df(P.fronts.size());
@@ -558,12 +567,22 @@ extern "C" int gs_export_system(gs_graph *g, double *Hpp_diag, double *Hll_diag,
     if (!g->dev_valid) return fail(GS_ERR_NOT_INITIALIZED, "nothing linearised yet");
     int rc = ensure_device(g); if (rc != GS_OK) return rc;
     const DevGraph &d = g->d;
-    auto dl = [&](double *dst, const double *src, size_t n) -> hipError_t {
-        return (dst && n) ? hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, g->stream) : hipSuccess; };
-    HIP_TRY(dl(Hpp_diag, d.Hpp_diag, (size_t)d.N * 9)); HIP_TRY(dl(Hll_diag, d.Hll_diag, (size_t)d.M * 4));
-    HIP_TRY(dl(Hpp_off, d.Hpp_off, (size_t)d.Epp * 9)); HIP_TRY(dl(Hpl, d.Hpl, (size_t)d.Epl * 6));
-    HIP_TRY(dl(b_pose, d.b_pose, (size_t)d.N * 3)); HIP_TRY(dl(b_lm, d.b_lm, (size_t)d.M * 2));
+    // the device keeps these arrays structure-of-arrays (and the diagonal blocks packed symmetric); the
+    // export format is array-of-blocks, full and row-major
+    const size_t N = (size_t)d.N, M = (size_t)d.M, Epp = (size_t)d.Epp, Epl = (size_t)d.Epl;
+    std::vector<double> t0(N * 6), t1(M * 3), t2(Epp * 9), t3(Epl * 6), t4(N * 3), t5(M * 2);
+    auto dl = [&](std::vector<double> &dst, const double *src) -> hipError_t {
+        return dst.empty() ? hipSuccess : hipMemcpyAsync(dst.data(), src, dst.size() * sizeof(double), hipMemcpyDeviceToHost, g->stream); };
+    HIP_TRY(dl(t0, d.Hpp_diag)); HIP_TRY(dl(t1, d.Hll_diag)); HIP_TRY(dl(t2, d.Hpp_off)); HIP_TRY(dl(t3, d.Hpl));
+    HIP_TRY(dl(t4, d.b_pose)); HIP_TRY(dl(t5, d.b_lm));
     HIP_TRY(hipStreamSynchronize(g->stream));
+    static const int sym3[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}}, sym2[2][2] = {{0, 1}, {1, 2}};
+    if (Hpp_diag) for (size_t p = 0; p < N; ++p) for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Hpp_diag[9 * p + 3 * r + c] = t0[sym3[r][c] * N + p];
+    if (Hll_diag) for (size_t l = 0; l < M; ++l) for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) Hll_diag[4 * l + 2 * r + c] = t1[sym2[r][c] * M + l];
+    if (Hpp_off) for (size_t k = 0; k < Epp; ++k) for (int c = 0; c < 9; ++c) Hpp_off[9 * k + c] = t2[c * Epp + k];
+    if (Hpl) for (size_t k = 0; k < Epl; ++k) for (int c = 0; c < 6; ++c) Hpl[6 * k + c] = t3[c * Epl + k];
+    if (b_pose) for (size_t p = 0; p < N; ++p) for (int c = 0; c < 3; ++c) b_pose[3 * p + c] = t4[c * N + p];
+    if (b_lm) for (size_t l = 0; l < M; ++l) for (int c = 0; c < 2; ++c) b_lm[2 * l + c] = t5[c * M + l];
     if (pp_order) std::memcpy(pp_order, g->plan.pp_order.data(), g->plan.pp_order.size() * sizeof(int32_t));
     if (pl_order) std::memcpy(pl_order, g->plan.pl_order.data(), g->plan.pl_order.size() * sizeof(int32_t));
     return GS_OK;

@@ -69,6 +69,12 @@ struct Plan {
     std::vector<int32_t> lm_start, lm_edges;
     // CSR: pose -> incident pp edges (sorted position * 2 + role; role 0 = i endpoint)
     std::vector<int32_t> ppadj_start, ppadj;
+    // linearisation tiles of the fused A5-A7 kernel (valid when lin_tiles_ok)
+    bool lin_tiles_ok = false;
+    std::vector<int32_t> tile_pose_start;                 // [T+1] pose ranges
+    std::vector<int32_t> tile_grp_start;                  // [T+1] groups (= per-(tile, landmark) partial slots) of a tile
+    std::vector<int32_t> grp_lm, grp_edge_start, grp_edges;   // group -> landmark, tile-local edge list
+    std::vector<int32_t> lm_grp_start, lm_grps;           // landmark -> its groups in tile order
     // fronts in elimination (post)order
     std::vector<Front> fronts;
     std::vector<int32_t> bnd_rows, child_map, children;
@@ -85,6 +91,10 @@ struct Plan {
 };
 
 struct PlanOptions { int leaf_poses = 8; int world = 1; int rank = 0; };
+
+// tile shape of the fused linearisation kernel (one 256-thread workgroup per tile, one edge per thread)
+constexpr int LIN_TILE_EDGES = 256;
+constexpr int LIN_TILE_POSES = 256;
 
 // Builds the plan on the host (no device work).  Returns false (and sets err) on failure.
 bool build_plan(const HostGraph &g, const PlanOptions &opt, Plan &plan, std::string &err);

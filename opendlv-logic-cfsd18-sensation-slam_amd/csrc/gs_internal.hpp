@@ -27,6 +27,7 @@ struct gs_graph {
     std::vector<int> lvl_max_f, lvl_max_npiv, lvl_max_nbnd;
     double ms_structure = 0;
     int rank = 0, world = 1; double *exchange = nullptr;
+    bool force_gather = false;              // cfg.linearize_gather
 };
 
 namespace gs {

@@ -4,9 +4,10 @@
 //                                          (reference src/slam.cpp:513-523, 637-654, 499-510)
 //   A1  k_associate                        association loop of Slam::addConesToMap vs a fixed map
 //                                          (reference src/slam.cpp:570-607, 708-711)
-//   A5-A7 k_linearize_pose / k_linearize_lm   g2o computeError + linearizeOplus + constructQuadraticForm of
+//   A5-A7 k_linearize_tiles (+ _finalize)  g2o computeError + linearizeOplus + constructQuadraticForm of
 //                                          EdgeSE2 / EdgeSE2PointXY, summed per vertex (SURVEY.md §8-A.2-4;
-//                                          driven from reference src/slam.cpp:481)
+//                                          driven from reference src/slam.cpp:481); k_linearize_*_gather =
+//                                          general-graph fallback
 //   A8  k_factor_level / k_backsolve_level  multifrontal Cholesky of the joint system (replaces Eigen
 //                                          SimplicialLDLT, reference thirdparty/Eigen/src/SparseCholesky/
 //                                          SimplicialCholesky_impl.h:101-190), forward solve fused as an extra row
@@ -104,31 +105,26 @@ __global__ void __launch_bounds__(256) k_associate(int n, const double *__restri
 }
 
 // ------------------------------------------------------------------ A5-A7
-struct Sym3 { double xx, xy, xt, yy, yt, tt; };
-
-// EdgeSE2PointXY: error, Jacobian rows A0/A1 (2x3), B = R(theta)^T
-__device__ __forceinline__ void edge_pl(const double *__restrict__ xp, double lx, double ly, double zx, double zy,
-                                        double &ex, double &ey, double A0[3], double A1[3], double &c, double &s) {
-    sincos(xp[2], &s, &c);
-    double dx = lx - xp[0], dy = ly - xp[1];
+// EdgeSE2PointXY with the pose's cos/sin already known: error, Jacobian rows A0/A1 (2x3); B = R(theta)^T
+__device__ __forceinline__ void edge_pl(double px, double py, double c, double s, double lx, double ly, double zx, double zy,
+                                        double &ex, double &ey, double A0[3], double A1[3]) {
+    double dx = lx - px, dy = ly - py;
     ex = (c * dx + s * dy) - zx;
     ey = (-s * dx + c * dy) - zy;
     A0[0] = -c; A0[1] = -s; A0[2] = c * dy - s * dx;
     A1[0] = s;  A1[1] = -c; A1[2] = -s * dy - c * dx;
 }
 
-// EdgeSE2: e = vec(zinv * (xi^-1 * xj)), A = Z*Ji, B = Z*Jj (rows)
-__device__ __forceinline__ void edge_pp(const double *__restrict__ xi, const double *__restrict__ xj,
-                                        const double *__restrict__ zinv, double e[3], double A[3][3], double B[3][3]) {
-    double si, ci; sincos(xi[2], &si, &ci);
+// EdgeSE2: e = vec(zinv * (xi^-1 * xj)), A = Z*Ji, B = Z*Jj (rows); zinv5 = (x, y, theta, cos, sin) of z^-1
+__device__ __forceinline__ void edge_pp(const double *__restrict__ xi, const double *__restrict__ xj, double ci, double si,
+                                        const double *__restrict__ zinv5, double e[3], double A[3][3], double B[3][3]) {
     double dx = xj[0] - xi[0], dy = xj[1] - xi[1];
-    // rel = xi^-1 * xj
-    double rx = ci * dx + si * dy, ry = -si * dx + ci * dy;
+    double rx = ci * dx + si * dy, ry = -si * dx + ci * dy;           // rel = xi^-1 * xj
     double rth = normalize_theta(normalize_theta(-xi[2]) + xj[2]);
-    double sz, cz; sincos(zinv[2], &sz, &cz);
-    e[0] = zinv[0] + (cz * rx - sz * ry);
-    e[1] = zinv[1] + (sz * rx + cz * ry);
-    e[2] = normalize_theta(zinv[2] + rth);
+    double cz = zinv5[3], sz = zinv5[4];
+    e[0] = zinv5[0] + (cz * rx - sz * ry);
+    e[1] = zinv5[1] + (sz * rx + cz * ry);
+    e[2] = normalize_theta(zinv5[2] + rth);
     double Ji[3][3] = {{-ci, -si, -si * dx + ci * dy}, {si, -ci, -ci * dx - si * dy}, {0.0, 0.0, -1.0}};
     double Jj[3][3] = {{ci, si, 0.0}, {-si, ci, 0.0}, {0.0, 0.0, 1.0}};
 #pragma unroll
@@ -138,8 +134,89 @@ __device__ __forceinline__ void edge_pp(const double *__restrict__ xi, const dou
     }
 }
 
+// One observation edge: everything constructQuadraticForm produces, packed symmetric.
+//   Hp[6] = A^T W A (xx xy xt yy yt tt), bp[3] = -A^T W e, W6 = A^T W B (3x2 row-major),
+//   Hl[3] = B^T W B (00 01 11), bl[2] = -B^T W e, chi = e^T W e
+struct PlQuad { double Hp[6], bp[3], W6[6], Hl[3], bl[2], chi; };
+__device__ __forceinline__ void quad_pl(double px, double py, double c, double s, double lx, double ly, double zx, double zy,
+                                        double w00, double w01, double w11, PlQuad &q) {
+    double ex, ey, A0[3], A1[3];
+    edge_pl(px, py, c, s, lx, ly, zx, zy, ex, ey, A0, A1);
+    double We0 = w00 * ex + w01 * ey, We1 = w01 * ex + w11 * ey;
+    q.chi = ex * We0 + ey * We1;
+    double WA0[3], WA1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { WA0[k] = w00 * A0[k] + w01 * A1[k]; WA1[k] = w01 * A0[k] + w11 * A1[k]; }
+    q.Hp[0] = A0[0] * WA0[0] + A1[0] * WA1[0]; q.Hp[1] = A0[0] * WA0[1] + A1[0] * WA1[1]; q.Hp[2] = A0[0] * WA0[2] + A1[0] * WA1[2];
+    q.Hp[3] = A0[1] * WA0[1] + A1[1] * WA1[1]; q.Hp[4] = A0[1] * WA0[2] + A1[1] * WA1[2]; q.Hp[5] = A0[2] * WA0[2] + A1[2] * WA1[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) q.bp[r] = -(A0[r] * We0 + A1[r] * We1);
+    double WB0[2] = {w00 * c - w01 * s, w00 * s + w01 * c};            // W * B, B rows (c, s), (-s, c)
+    double WB1[2] = {w01 * c - w11 * s, w01 * s + w11 * c};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { q.W6[2 * r] = A0[r] * WB0[0] + A1[r] * WB1[0]; q.W6[2 * r + 1] = A0[r] * WB0[1] + A1[r] * WB1[1]; }
+    q.Hl[0] = c * WB0[0] - s * WB1[0]; q.Hl[1] = c * WB0[1] - s * WB1[1]; q.Hl[2] = s * WB0[1] + c * WB1[1];
+    q.bl[0] = -(c * We0 - s * We1); q.bl[1] = -(s * We0 + c * We1);
+}
+
+// The odometry edges incident to pose p: adds its share to H (6 packed) and b, writes the off-diagonal block of
+// the edges it owns (role 0 = i endpoint), returns the chi2 of the owned edges.
+template <bool WRITE_H>
+__device__ __forceinline__ double pose_pp_edges(const DevGraph &d, int p, double H[6], double b[3],
+                                                int tile_p0, int tile_np, const double *s_c, const double *s_s) {
+    double chi = 0.0;
+    for (int q = d.ppadj_start[p]; q < d.ppadj_start[p + 1]; ++q) {
+        const int code = d.ppadj[q], k = code >> 1, role = code & 1;
+        const int i = d.pp_i[k], j = d.pp_j[k];
+        double ci, si;
+        const int li = i - tile_p0;
+        if (li >= 0 && li < tile_np) { ci = s_c[li]; si = s_s[li]; } else sincos(d.pose_est[3 * i + 2], &si, &ci);
+        double e[3], A[3][3], B[3][3];
+        edge_pp(d.pose_est + 3 * i, d.pose_est + 3 * j, ci, si, d.pp_zinv + 5 * (int64_t)k, e, A, B);
+        const double *w = d.pp_info + 6 * (int64_t)k;
+        const double W[3][3] = {{w[0], w[1], w[2]}, {w[1], w[3], w[4]}, {w[2], w[4], w[5]}};
+        double We[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) We[r] = W[r][0] * e[0] + W[r][1] * e[1] + W[r][2] * e[2];
+        const bool fi = d.pose_fixed[i], fj = d.pose_fixed[j];
+        if (role == 0 && !(fi && fj)) chi += e[0] * We[0] + e[1] * We[1] + e[2] * We[2];
+        if (WRITE_H) {
+            double WA[3][3], WB[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    WA[r][c] = W[r][0] * A[0][c] + W[r][1] * A[1][c] + W[r][2] * A[2][c];
+                    WB[r][c] = W[r][0] * B[0][c] + W[r][1] * B[1][c] + W[r][2] * B[2][c];
+                }
+            if (role == 0) {
+                int t = 0;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        if (c >= r) H[t++] += A[0][r] * WA[0][c] + A[1][r] * WA[1][c] + A[2][r] * WA[2][c];
+                        double off = A[0][r] * WB[0][c] + A[1][r] * WB[1][c] + A[2][r] * WB[2][c];
+                        d.Hpp_off[(int64_t)(3 * r + c) * d.Epp + k] = (!fi && !fj) ? off : 0.0;
+                    }
+                    b[r] -= A[0][r] * We[0] + A[1][r] * We[1] + A[2][r] * We[2];
+                }
+            } else {
+                int t = 0;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int c = r; c < 3; ++c) H[t++] += B[0][r] * WB[0][c] + B[1][r] * WB[1][c] + B[2][r] * WB[2][c];
+                    b[r] -= B[0][r] * We[0] + B[1][r] * We[1] + B[2][r] * We[2];
+                }
+            }
+        }
+    }
+    return chi;
+}
+
 __device__ __forceinline__ double block_sum_256(double v, double *red) {
-    // fixed-order tree: wave shuffle then 4 partials
+    // fixed-order tree: wave shuffle then the wave partials in order
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
     int w = threadIdx.x >> 6;
@@ -150,145 +227,192 @@ __device__ __forceinline__ double block_sum_256(double v, double *red) {
     return r;
 }
 
-// thread per pose: diagonal block + b of the pose, off-diagonal blocks of the edges it owns, chi2
+// ---- general fallback: gather kernels (any graph; used when a pose has more edges than a tile holds,
+//      and for the chi2-only pass).  thread per pose / thread per landmark, every sum in fixed order.
 template <bool WRITE_H>
-__global__ void __launch_bounds__(256) k_linearize_pose(DevGraph d) {
+__global__ void __launch_bounds__(256) k_linearize_pose_gather(DevGraph d) {
     __shared__ double red[4];
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
     double chi = 0.0;
     if (p < d.N) {
-        const double xp[3] = {d.pose_est[3 * p], d.pose_est[3 * p + 1], d.pose_est[3 * p + 2]};
+        const double px = d.pose_est[3 * p], py = d.pose_est[3 * p + 1];
+        double s, c; sincos(d.pose_est[3 * p + 2], &s, &c);
         const bool fp = d.pose_fixed[p];
-        double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, b[3] = {0, 0, 0};
+        double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+        const int64_t E = d.Epl;
         for (int e = d.pl_start[p]; e < d.pl_start[p + 1]; ++e) {
-            int l = d.pl_l[e];
-            double ex, ey, A0[3], A1[3], c, s;
-            edge_pl(xp, d.lm_est[2 * l], d.lm_est[2 * l + 1], d.pl_z[2 * e], d.pl_z[2 * e + 1], ex, ey, A0, A1, c, s);
-            double w00 = d.pl_info[3 * e], w01 = d.pl_info[3 * e + 1], w11 = d.pl_info[3 * e + 2];
-            double We0 = w00 * ex + w01 * ey, We1 = w01 * ex + w11 * ey;
+            const int l = d.pl_l[e];
+            PlQuad q;
+            quad_pl(px, py, c, s, d.lm_est[2 * l], d.lm_est[2 * l + 1], d.pl_z[e], d.pl_z[E + e],
+                    d.pl_info[e], d.pl_info[E + e], d.pl_info[2 * E + e], q);
             const bool fl = d.lm_fixed[l];
-            if (!(fp && fl)) chi += ex * We0 + ey * We1;
+            if (!(fp && fl)) chi += q.chi;
             if (WRITE_H) {
-                double WA0[3], WA1[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { WA0[k] = w00 * A0[k] + w01 * A1[k]; WA1[k] = w01 * A0[k] + w11 * A1[k]; }
+                for (int k = 0; k < 6; ++k) H[k] += q.Hp[k];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) H[r][k] += A0[r] * WA0[k] + A1[r] * WA1[k];
-                    b[r] -= A0[r] * We0 + A1[r] * We1;
-                }
-                // Hpl = A^T W B, B rows (c, s), (-s, c)
-                double WB0[2] = {w00 * c - w01 * s, w00 * s + w01 * c};
-                double WB1[2] = {w01 * c - w11 * s, w01 * s + w11 * c};
+                for (int k = 0; k < 3; ++k) b[k] += q.bp[k];
                 const bool both = !fp && !fl;
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    d.Hpl[6 * e + 2 * r]     = both ? A0[r] * WB0[0] + A1[r] * WB1[0] : 0.0;
-                    d.Hpl[6 * e + 2 * r + 1] = both ? A0[r] * WB0[1] + A1[r] * WB1[1] : 0.0;
-                }
+                for (int k = 0; k < 6; ++k) d.Hpl[k * E + e] = both ? q.W6[k] : 0.0;
             }
         }
-        for (int q = d.ppadj_start[p]; q < d.ppadj_start[p + 1]; ++q) {
-            int code = d.ppadj[q], k = code >> 1, role = code & 1;
-            int i = d.pp_i[k], j = d.pp_j[k];
-            double e[3], A[3][3], B[3][3];
-            edge_pp(d.pose_est + 3 * i, d.pose_est + 3 * j, d.pp_zinv + 3 * k, e, A, B);
-            const double *w = d.pp_info + 6 * k;
-            double W[3][3] = {{w[0], w[1], w[2]}, {w[1], w[3], w[4]}, {w[2], w[4], w[5]}};
-            double We[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) We[r] = W[r][0] * e[0] + W[r][1] * e[1] + W[r][2] * e[2];
-            const bool fi = d.pose_fixed[i], fj = d.pose_fixed[j];
-            if (role == 0 && !(fi && fj)) chi += e[0] * We[0] + e[1] * We[1] + e[2] * We[2];
-            if (WRITE_H) {
-                double WA[3][3], WB[3][3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        WA[r][c] = W[r][0] * A[0][c] + W[r][1] * A[1][c] + W[r][2] * A[2][c];
-                        WB[r][c] = W[r][0] * B[0][c] + W[r][1] * B[1][c] + W[r][2] * B[2][c];
-                    }
-                if (role == 0) {
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            H[r][c] += A[0][r] * WA[0][c] + A[1][r] * WA[1][c] + A[2][r] * WA[2][c];
-                            double off = A[0][r] * WB[0][c] + A[1][r] * WB[1][c] + A[2][r] * WB[2][c];
-                            d.Hpp_off[9 * k + 3 * r + c] = (!fi && !fj) ? off : 0.0;
-                        }
-                        b[r] -= A[0][r] * We[0] + A[1][r] * We[1] + A[2][r] * We[2];
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) H[r][c] += B[0][r] * WB[0][c] + B[1][r] * WB[1][c] + B[2][r] * WB[2][c];
-                        b[r] -= B[0][r] * We[0] + B[1][r] * We[1] + B[2][r] * We[2];
-                    }
-                }
-            }
-        }
+        chi += pose_pp_edges<WRITE_H>(d, p, H, b, 0, 0, nullptr, nullptr);
         if (WRITE_H) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
+            for (int k = 0; k < 6; ++k) d.Hpp_diag[(int64_t)k * d.N + p] = fp ? 0.0 : H[k];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) d.Hpp_diag[9 * p + 3 * r + c] = fp ? 0.0 : H[r][c];
-                d.b_pose[3 * p + r] = fp ? 0.0 : b[r];
-            }
+            for (int k = 0; k < 3; ++k) d.b_pose[(int64_t)k * d.N + p] = fp ? 0.0 : b[k];
         }
     }
     double tot = block_sum_256(chi, red);
     if (threadIdx.x == 0) d.chi2_partial[blockIdx.x] = tot;
 }
 
-// thread per landmark: diagonal block + b of the landmark (recomputes B and e of its edges)
-__global__ void __launch_bounds__(256) k_linearize_lm(DevGraph d) {
-    int l = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_linearize_lm_gather(DevGraph d) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= d.M) return;
     double h00 = 0, h01 = 0, h11 = 0, b0 = 0, b1 = 0;
     if (!d.lm_fixed[l]) {
-        double lx = d.lm_est[2 * l], ly = d.lm_est[2 * l + 1];
+        const double lx = d.lm_est[2 * l], ly = d.lm_est[2 * l + 1];
+        const int64_t E = d.Epl;
         for (int q = d.lm_start[l]; q < d.lm_start[l + 1]; ++q) {
-            int e = d.lm_edges[q], p = d.pl_p[e];
+            const int e = d.lm_edges[q], p = d.pl_p[e];
             double s, c; sincos(d.pose_est[3 * p + 2], &s, &c);
-            double dx = lx - d.pose_est[3 * p], dy = ly - d.pose_est[3 * p + 1];
-            double ex = (c * dx + s * dy) - d.pl_z[2 * e], ey = (-s * dx + c * dy) - d.pl_z[2 * e + 1];
-            double w00 = d.pl_info[3 * e], w01 = d.pl_info[3 * e + 1], w11 = d.pl_info[3 * e + 2];
-            double We0 = w00 * ex + w01 * ey, We1 = w01 * ex + w11 * ey;
-            double WB0[2] = {w00 * c - w01 * s, w00 * s + w01 * c};
-            double WB1[2] = {w01 * c - w11 * s, w01 * s + w11 * c};
-            // B rows: B0 = (c, s), B1 = (-s, c);  Hll[r][k] = B0[r]*WB0[k] + B1[r]*WB1[k]
-            h00 += c * WB0[0] - s * WB1[0];
-            h01 += c * WB0[1] - s * WB1[1];
-            h11 += s * WB0[1] + c * WB1[1];
-            b0 -= c * We0 - s * We1;
-            b1 -= s * We0 + c * We1;
+            PlQuad r;
+            quad_pl(d.pose_est[3 * p], d.pose_est[3 * p + 1], c, s, lx, ly, d.pl_z[e], d.pl_z[E + e],
+                    d.pl_info[e], d.pl_info[E + e], d.pl_info[2 * E + e], r);
+            h00 += r.Hl[0]; h01 += r.Hl[1]; h11 += r.Hl[2]; b0 += r.bl[0]; b1 += r.bl[1];
         }
     }
-    d.Hll_diag[4 * l] = h00; d.Hll_diag[4 * l + 1] = h01; d.Hll_diag[4 * l + 2] = h01; d.Hll_diag[4 * l + 3] = h11;
-    d.b_lm[2 * l] = b0; d.b_lm[2 * l + 1] = b1;
+    d.Hll_diag[l] = h00; d.Hll_diag[(int64_t)d.M + l] = h01; d.Hll_diag[2 * (int64_t)d.M + l] = h11;
+    d.b_lm[l] = b0; d.b_lm[(int64_t)d.M + l] = b1;
 }
 
-__global__ void k_reduce_chi2(DevGraph d) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0; for (int k = 0; k < d.n_chi2_partial; ++k) s += d.chi2_partial[k];
-        d.chi2[0] = s;
+// ---- fused tiled kernel: one 256-thread workgroup per tile of <= 256 consecutive observation edges.
+//   phase 0  thread per tile pose : state + sincos once per pose into LDS
+//   phase A  thread per edge      : coalesced SoA loads, quadratic form in registers, H_pl block streamed out
+//                                   (coalesced, 8 B per lane per component), per-edge diagonal shares into LDS
+//   phase B1 thread per tile pose : sums its edge run from LDS (+ its odometry edges) -> H_pp, b_p, H_pp_off
+//   phase B2 thread per (landmark group, component): sums the tile's shares of one landmark -> partial slot
+// LDS columns are skewed by e + (e >> 3) so that the stride-8 runs of phase B1 are bank-conflict free.
+static constexpr int LIN_E = 256;                 // == gs::LIN_TILE_EDGES
+static constexpr int LIN_W = LIN_E + LIN_E / 8;   // skewed row width
+__global__ void __launch_bounds__(256) k_linearize_tiles(DevGraph d) {
+    __shared__ double s_px[LIN_E], s_py[LIN_E], s_c[LIN_E], s_s[LIN_E];
+    __shared__ double s_pc[9][LIN_W];
+    __shared__ double s_lc[5][LIN_W];
+    __shared__ double red[4];
+    __shared__ uint8_t s_fix[LIN_E];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int p0 = d.tile_pose_start[t], np = d.tile_pose_start[t + 1] - p0;
+    const int e0 = d.pl_start[p0], ne = d.pl_start[p0 + np] - e0;
+    const int64_t E = d.Epl;
+    if (tid < np) {
+        const int p = p0 + tid;
+        double s, c; sincos(d.pose_est[3 * p + 2], &s, &c);
+        s_px[tid] = d.pose_est[3 * p]; s_py[tid] = d.pose_est[3 * p + 1]; s_c[tid] = c; s_s[tid] = s;
+        s_fix[tid] = d.pose_fixed[p];
+    }
+    __syncthreads();
+    double chi = 0.0;
+    if (tid < ne) {
+        const int e = e0 + tid;
+        const int lp = d.pl_p[e] - p0, l = d.pl_l[e];
+        PlQuad q;
+        quad_pl(s_px[lp], s_py[lp], s_c[lp], s_s[lp], d.lm_est[2 * l], d.lm_est[2 * l + 1], d.pl_z[e], d.pl_z[E + e],
+                d.pl_info[e], d.pl_info[E + e], d.pl_info[2 * E + e], q);
+        const bool fp = s_fix[lp], fl = d.lm_fixed[l];
+        if (!(fp && fl)) chi = q.chi;
+        const bool both = !fp && !fl;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d.Hpl[k * E + e] = both ? q.W6[k] : 0.0;
+        const int col = tid + (tid >> 3);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_pc[k][col] = q.Hp[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s_pc[6 + k][col] = q.bp[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s_lc[k][col] = q.Hl[k];
+        s_lc[3][col] = q.bl[0]; s_lc[4][col] = q.bl[1];
+    }
+    __syncthreads();
+    if (tid < np) {
+        const int p = p0 + tid;
+        double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+        const int r0 = d.pl_start[p] - e0, r1 = d.pl_start[p + 1] - e0;
+        for (int r = r0; r < r1; ++r) {
+            const int col = r + (r >> 3);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) H[k] += s_pc[k][col];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) b[k] += s_pc[6 + k][col];
+        }
+        chi += pose_pp_edges<true>(d, p, H, b, p0, np, s_c, s_s);
+        const bool fp = s_fix[tid];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d.Hpp_diag[(int64_t)k * d.N + p] = fp ? 0.0 : H[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d.b_pose[(int64_t)k * d.N + p] = fp ? 0.0 : b[k];
+    }
+    {
+        const int g0 = d.tile_grp_start[t], ng = d.tile_grp_start[t + 1] - g0;
+        for (int idx = tid; idx < ng * 5; idx += 256) {
+            const int comp = idx / ng, g = g0 + (idx - comp * ng);
+            double sum = 0.0;
+            for (int q = d.grp_edge_start[g]; q < d.grp_edge_start[g + 1]; ++q) { const int le = d.grp_edges[q]; sum += s_lc[comp][le + (le >> 3)]; }
+            d.lm_part[(int64_t)comp * d.n_groups + g] = sum;
+        }
+    }
+    const double tot = block_sum_256(chi, red);
+    if (tid == 0) d.chi2_partial[t] = tot;
+}
+
+// landmark diagonal blocks from the per-(tile, landmark) partials (tile order) + the chi2 total (fixed order)
+__global__ void __launch_bounds__(256) k_linearize_finalize(DevGraph d, int n_partial) {
+    __shared__ double red[4];
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l < d.M) {
+        double a[5] = {0, 0, 0, 0, 0};
+        if (!d.lm_fixed[l]) {
+            for (int q = d.lm_grp_start[l]; q < d.lm_grp_start[l + 1]; ++q) { const int g = d.lm_grps[q];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) a[k] += d.lm_part[(int64_t)k * d.n_groups + g]; }
+        }
+        d.Hll_diag[l] = a[0]; d.Hll_diag[(int64_t)d.M + l] = a[1]; d.Hll_diag[2 * (int64_t)d.M + l] = a[2];
+        d.b_lm[l] = a[3]; d.b_lm[(int64_t)d.M + l] = a[4];
+    }
+    if (blockIdx.x == 0) {
+        double s = 0.0;
+        for (int k = threadIdx.x; k < n_partial; k += 256) s += d.chi2_partial[k];
+        const double tot = block_sum_256(s, red);
+        if (threadIdx.x == 0) d.chi2[0] = tot;
     }
 }
 
+__global__ void __launch_bounds__(256) k_reduce_chi2(DevGraph d, int n_partial) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int k = threadIdx.x; k < n_partial; k += 256) s += d.chi2_partial[k];
+    const double tot = block_sum_256(s, red);
+    if (threadIdx.x == 0) d.chi2[0] = tot;
+}
+
+void launch_linearize_gather(const DevGraph &d, hipStream_t st) {
+    const int gp = (d.N + 255) / 256, gl = (d.M + 255) / 256;
+    if (gp > 0) hipLaunchKernelGGL(k_linearize_pose_gather<true>, dim3(gp), dim3(256), 0, st, d);
+    if (gl > 0) hipLaunchKernelGGL(k_linearize_lm_gather, dim3(gl), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_reduce_chi2, dim3(1), dim3(256), 0, st, d, gp);
+}
 void launch_linearize(const DevGraph &d, hipStream_t st) {
-    int gp = (d.N + 255) / 256, gl = (d.M + 255) / 256;
-    if (gp > 0) hipLaunchKernelGGL(k_linearize_pose<true>, dim3(gp), dim3(256), 0, st, d);
-    if (gl > 0) hipLaunchKernelGGL(k_linearize_lm, dim3(gl), dim3(256), 0, st, d);
-    hipLaunchKernelGGL(k_reduce_chi2, dim3(1), dim3(64), 0, st, d);
+    if (d.n_tiles <= 0) { launch_linearize_gather(d, st); return; }
+    hipLaunchKernelGGL(k_linearize_tiles, dim3(d.n_tiles), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_linearize_finalize, dim3(max(1, (d.M + 255) / 256)), dim3(256), 0, st, d, d.n_tiles);
 }
 void launch_chi2_only(const DevGraph &d, hipStream_t st) {
-    int gp = (d.N + 255) / 256;
-    if (gp > 0) hipLaunchKernelGGL(k_linearize_pose<false>, dim3(gp), dim3(256), 0, st, d);
-    hipLaunchKernelGGL(k_reduce_chi2, dim3(1), dim3(64), 0, st, d);
+    const int gp = (d.N + 255) / 256;
+    if (gp > 0) hipLaunchKernelGGL(k_linearize_pose_gather<false>, dim3(gp), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_reduce_chi2, dim3(1), dim3(256), 0, st, d, gp);
 }
 
 // ------------------------------------------------------------------ A8 factorisation
@@ -296,46 +420,40 @@ void launch_chi2_only(const DevGraph &d, hipStream_t st) {
 // an odd leading dimension; lower triangle only.  assemble originals -> extend-add children -> partial
 // Cholesky of the npiv pivot columns -> L panel and update matrix to HBM.
 __device__ __forceinline__ void apply_asm(const DevGraph &d, const int32_t *rec, double *F, int ld, int f) {
-    int kind = rec[0], src = rec[1], r0 = rec[2], c0 = rec[3];
+    const int kind = rec[0], src = rec[1], r0 = rec[2], c0 = rec[3];
     switch (kind) {
-        case 0: {   // pose diagonal + rhs
-            const double *H = d.Hpp_diag + 9 * (int64_t)src;
+        case 0: {   // pose diagonal (packed xx xy xt yy yt tt) + rhs
+            const double *H = d.Hpp_diag + src; const int64_t S = d.N;
+            F[(c0 + 0) * ld + r0 + 0] += H[0];     F[(c0 + 0) * ld + r0 + 1] += H[S];     F[(c0 + 0) * ld + r0 + 2] += H[2 * S];
+            F[(c0 + 1) * ld + r0 + 1] += H[3 * S]; F[(c0 + 1) * ld + r0 + 2] += H[4 * S]; F[(c0 + 2) * ld + r0 + 2] += H[5 * S];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-#pragma unroll
-                for (int r = c; r < 3; ++r) F[(c0 + c) * ld + r0 + r] += H[3 * r + c];
-                F[(c0 + c) * ld + f] += d.b_pose[3 * (int64_t)src + c];
-            }
+            for (int c = 0; c < 3; ++c) F[(c0 + c) * ld + f] += d.b_pose[c * S + src];
         } break;
-        case 1: {
-            const double *H = d.Hll_diag + 4 * (int64_t)src;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-#pragma unroll
-                for (int r = c; r < 2; ++r) F[(c0 + c) * ld + r0 + r] += H[2 * r + c];
-                F[(c0 + c) * ld + f] += d.b_lm[2 * (int64_t)src + c];
-            }
+        case 1: {   // landmark diagonal (packed 00 01 11) + rhs
+            const double *H = d.Hll_diag + src; const int64_t S = d.M;
+            F[(c0 + 0) * ld + r0 + 0] += H[0]; F[(c0 + 0) * ld + r0 + 1] += H[S]; F[(c0 + 1) * ld + r0 + 1] += H[2 * S];
+            F[(c0 + 0) * ld + f] += d.b_lm[src]; F[(c0 + 1) * ld + f] += d.b_lm[S + src];
         } break;
         case 2: case 3: {
-            const double *H = d.Hpp_off + 9 * (int64_t)src;
+            const double *H = d.Hpp_off + src; const int64_t S = d.Epp;
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
-                for (int b = 0; b < 3; ++b) F[(c0 + b) * ld + r0 + a] += (kind == 2) ? H[3 * a + b] : H[3 * b + a];
+                for (int b = 0; b < 3; ++b) F[(c0 + b) * ld + r0 + a] += (kind == 2) ? H[(3 * a + b) * S] : H[(3 * b + a) * S];
         } break;
         case 4: {   // 3x2 as is
-            const double *H = d.Hpl + 6 * (int64_t)src;
+            const double *H = d.Hpl + src; const int64_t S = d.Epl;
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) F[(c0 + b) * ld + r0 + a] += H[2 * a + b];
+                for (int b = 0; b < 2; ++b) F[(c0 + b) * ld + r0 + a] += H[(2 * a + b) * S];
         } break;
         default: {  // 2x3 transposed
-            const double *H = d.Hpl + 6 * (int64_t)src;
+            const double *H = d.Hpl + src; const int64_t S = d.Epl;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 3; ++b) F[(c0 + b) * ld + r0 + a] += H[2 * b + a];
+                for (int b = 0; b < 3; ++b) F[(c0 + b) * ld + r0 + a] += H[(2 * b + a) * S];
         } break;
     }
 }

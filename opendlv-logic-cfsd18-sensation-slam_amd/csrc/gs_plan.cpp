@@ -163,6 +163,47 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     { std::vector<int32_t> fill(plan.ppadj_start.begin(), plan.ppadj_start.end() - 1);
       for (int k = 0; k < Epp; ++k) { plan.ppadj[fill[g.pp_i[k]]++] = 2 * k; plan.ppadj[fill[g.pp_j[k]]++] = 2 * k + 1; } }
 
+    // ---- linearisation tiles (fused A5-A7 kernel): contiguous pose ranges with <= LIN_TILE_EDGES observation
+    // edges and <= LIN_TILE_POSES poses; per tile the distinct landmarks it touches ("groups") with the
+    // tile-local edge lists.  Group index == slot of the per-(tile, landmark) partial sum, and the groups of one
+    // landmark are summed in tile order by the finalize kernel => fixed summation order, no atomics.
+    {
+        plan.lin_tiles_ok = true;
+        for (int p = 0; p < N; ++p) if (plan.pl_start[p + 1] - plan.pl_start[p] > LIN_TILE_EDGES) { plan.lin_tiles_ok = false; break; }
+        if (plan.lin_tiles_ok) {
+            plan.tile_pose_start.push_back(0);
+            int p = 0;
+            while (p < N) {
+                int q = p, e0 = plan.pl_start[p];
+                while (q < N && q - p < LIN_TILE_POSES && plan.pl_start[q + 1] - e0 <= LIN_TILE_EDGES) ++q;
+                plan.tile_pose_start.push_back(q); p = q;
+            }
+            const int T = (int)plan.tile_pose_start.size() - 1;
+            plan.tile_grp_start.assign(T + 1, 0);
+            std::vector<std::pair<int32_t, int32_t>> tmp;              // (landmark, local edge)
+            for (int t = 0; t < T; ++t) {
+                int e0 = plan.pl_start[plan.tile_pose_start[t]], e1 = plan.pl_start[plan.tile_pose_start[t + 1]];
+                tmp.clear();
+                for (int e = e0; e < e1; ++e) tmp.emplace_back(g.pl_l[plan.pl_order[e]], e - e0);
+                std::sort(tmp.begin(), tmp.end());
+                for (size_t i = 0; i < tmp.size(); ++i) {
+                    if (i == 0 || tmp[i].first != tmp[i - 1].first) { plan.grp_lm.push_back(tmp[i].first); plan.grp_edge_start.push_back((int32_t)plan.grp_edges.size()); }
+                    plan.grp_edges.push_back(tmp[i].second);
+                }
+                plan.tile_grp_start[t + 1] = (int32_t)plan.grp_lm.size();
+            }
+            plan.grp_edge_start.push_back((int32_t)plan.grp_edges.size());
+            // landmark -> its groups, ascending (= tile order)
+            const int G = (int)plan.grp_lm.size();
+            plan.lm_grp_start.assign(M + 1, 0);
+            for (int q = 0; q < G; ++q) plan.lm_grp_start[plan.grp_lm[q] + 1]++;
+            for (int l = 0; l < M; ++l) plan.lm_grp_start[l + 1] += plan.lm_grp_start[l];
+            plan.lm_grps.resize(G);
+            std::vector<int32_t> fill(plan.lm_grp_start.begin(), plan.lm_grp_start.end() - 1);
+            for (int q = 0; q < G; ++q) plan.lm_grps[fill[plan.grp_lm[q]]++] = q;
+        }
+    }
+
     // ---- elimination order by nested dissection ----
     B.build_adjacency(pl_pos_of_ins);
     B.assigned.assign(B.nfp, 0);

@@ -103,6 +103,40 @@ def test_linearize_blocks_match_oracle(pkg, po, bench_graphs, N, M):
     G.close()
 
 
+@pytest.mark.parametrize("gather", [0, 1])
+def test_both_linearisation_kernels_match_oracle(pkg, po, bench_graphs, gather):
+    """The fused tiled kernel (default) and the general gather kernels (fallback for poses with more
+    observations than a tile holds) are two HIP implementations of A5-A7; both must match the oracle."""
+    _, g = bench_graphs(10000, 2000)
+    og = make_oracle_graph(po, g); ref = og.linearize_blocks()
+    G = fresh(pkg, g, linearize_gather=gather)
+    G.initialize_optimization(); G.linearize(); got = G.export_system()
+    for k in ("Hpp_diag", "Hll_diag", "Hpp_off", "Hpl", "b_pose", "b_lm"):
+        assert rel(got[k], ref[k]) < 1e-11, k
+    assert abs(G.chi2() - og.chi2()) <= 1e-10 * og.chi2()
+    done, st = G.optimize(3); assert done == 3
+    og.optimize(3, ordering=1)
+    assert rel(G.poses(), og.poses()) < 1e-9
+    G.close()
+
+
+def test_pose_with_more_observations_than_a_tile_falls_back_to_gather(pkg, po):
+    rng = np.random.default_rng(5)
+    n_l = 300                                              # one pose sees 300 landmarks (> 256 edges per tile)
+    g = dict(pose_est=np.array([[0, 0, 0], [1.0, 0.1, 0.05], [2.0, 0.3, 0.1]]), lm_est=rng.uniform(-20, 20, (n_l, 2)),
+             pp_i=np.array([0, 1], np.int32), pp_j=np.array([1, 2], np.int32), pp_z=np.array([[1, 0.1, 0.05], [1, 0.2, 0.05]]),
+             pp_info=np.tile((5 * np.eye(3)).reshape(1, 9), (2, 1)),
+             pl_p=np.concatenate([np.full(n_l, 1), np.arange(3).repeat(4)]).astype(np.int32),
+             pl_l=np.concatenate([np.arange(n_l), rng.integers(0, n_l, 12)]).astype(np.int32),
+             pl_z=rng.normal(0, 5, (n_l + 12, 2)), pl_info=np.tile((0.5 * np.eye(2)).reshape(1, 4), (n_l + 12, 1)),
+             fixed_poses=np.array([0], np.int32), fixed_landmarks=np.array([], np.int32))
+    og = make_oracle_graph(po, g); ref = og.linearize_blocks()
+    G = fresh(pkg, g); G.initialize_optimization(); G.linearize(); got = G.export_system()
+    for k in ("Hpp_diag", "Hll_diag", "Hpp_off", "Hpl", "b_pose", "b_lm"):
+        assert rel(got[k], ref[k]) < 1e-11, k
+    G.close()
+
+
 def test_linearize_random_graph_with_anisotropic_information(pkg, po):
     g = random_graph(7)
     og = make_oracle_graph(po, g); ref = og.linearize_blocks()
