@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -322,30 +323,32 @@ static int upload_graph(gs_graph *g) {
 #define UP(dst, vec) if ((rc = dev_upload(g, &d.dst, vec)) != GS_OK) return rc
     UP(pose_est, h.pose_est); UP(lm_est, h.lm_est); UP(pose_fixed, h.pose_fixed); UP(lm_fixed, h.lm_fixed);
     UP(pose_gidx, P.pose_gidx); UP(lm_gidx, P.lm_gidx);
-    { std::vector<int32_t> p(Epl), l(Epl); std::vector<double> z((size_t)Epl * 2), w((size_t)Epl * 3);      // SoA streams
-      const size_t E = (size_t)Epl;
-      for (int pos = 0; pos < Epl; ++pos) { int k = P.pl_order[pos]; p[pos] = h.pl_p[k]; l[pos] = h.pl_l[k];
-          z[pos] = h.pl_z[2 * (size_t)k]; z[E + pos] = h.pl_z[2 * (size_t)k + 1];
-          for (int t = 0; t < 3; ++t) w[t * E + pos] = h.pl_info[3 * (size_t)k + t]; }
-      UP(pl_p, p); UP(pl_l, l); UP(pl_z, z); UP(pl_info, w); }
-    { std::vector<int32_t> a(Epp), b(Epp); std::vector<double> zi((size_t)Epp * 5), w((size_t)Epp * 6);
-      for (int pos = 0; pos < Epp; ++pos) { int k = P.pp_order[pos]; a[pos] = h.pp_i[k]; b[pos] = h.pp_j[k];
+    d.ell_T = P.ell_T; d.ell_R = P.ell_R; d.ell_len = P.ell_len;
+    { const size_t L = (size_t)P.ell_len;                                                                    // ELL streams
+      std::vector<int32_t> l(L, -1); std::vector<double> z(L * 2, 0.0), w(L * 3, 0.0);
+      for (size_t e = 0; e < L; ++e) { const int k = P.ell_ins[e]; if (k < 0) continue;
+          l[e] = h.pl_l[k]; z[e] = h.pl_z[2 * (size_t)k]; z[L + e] = h.pl_z[2 * (size_t)k + 1];
+          for (int t = 0; t < 3; ++t) w[t * L + e] = h.pl_info[3 * (size_t)k + t]; }
+      UP(ell_l, l); UP(ell_z, z); UP(ell_w, w); }
+    { std::vector<double> zi((size_t)Epp * 5), w((size_t)Epp * 6);
+      for (int pos = 0; pos < Epp; ++pos) { int k = P.pp_order[pos];
           double inv[3]; se2_inverse_host(&h.pp_z[3 * (size_t)k], inv);
           double *o = &zi[5 * (size_t)pos]; o[0] = inv[0]; o[1] = inv[1]; o[2] = inv[2]; o[3] = std::cos(inv[2]); o[4] = std::sin(inv[2]);
           for (int t = 0; t < 6; ++t) w[6 * (size_t)pos + t] = h.pp_info[6 * (size_t)k + t]; }
-      UP(pp_i, a); UP(pp_j, b); UP(pp_zinv, zi); UP(pp_info, w); }
-    UP(pl_start, P.pl_start); UP(lm_start, P.lm_start); UP(lm_edges, P.lm_edges); UP(ppadj_start, P.ppadj_start); UP(ppadj, P.ppadj);
+      UP(pp_zinv, zi); UP(pp_info, w); }
+    UP(lm_start, P.lm_start); UP(lm_edges, P.lm_edges); UP(ppadj_start, P.ppadj_start); UP(ppinc, P.ppinc);
 #define AL(dst, cnt) if ((rc = dev_alloc(g, &d.dst, (size_t)(cnt))) != GS_OK) return rc
-    d.n_tiles = 0; d.n_groups = 0;
-    if (P.lin_tiles_ok && !g->force_gather) {
-        d.n_tiles = (int32_t)P.tile_pose_start.size() - 1; d.n_groups = (int32_t)P.grp_lm.size();
-        UP(tile_pose_start, P.tile_pose_start); UP(tile_grp_start, P.tile_grp_start); UP(grp_lm, P.grp_lm);
-        UP(grp_edge_start, P.grp_edge_start); UP(grp_edges, P.grp_edges); UP(lm_grp_start, P.lm_grp_start); UP(lm_grps, P.lm_grps);
+    d.n_wtiles = 0; d.n_groups = 0;
+    if (P.lin_ell_ok && !g->force_gather) {
+        d.n_wtiles = P.n_wtiles; d.n_groups = (int32_t)P.grp_lm.size();
+        UP(wt_desc, P.wt_desc); UP(grp_pos_start, P.grp_pos_start); UP(grp_slot, P.grp_slot); UP(lm_grp_start, P.lm_grp_start);
+        std::vector<uint16_t> pos16(P.grp_pos.begin(), P.grp_pos.end());
+        UP(grp_pos, pos16);
         AL(lm_part, (size_t)d.n_groups * 5);
     }
-    AL(Hpp_diag, (size_t)N * 6); AL(Hll_diag, (size_t)M * 3); AL(Hpp_off, (size_t)Epp * 9); AL(Hpl, (size_t)Epl * 6);
+    AL(Hpp_diag, (size_t)N * 6); AL(Hll_diag, (size_t)M * 3); AL(Hpp_off, (size_t)Epp * 9); AL(Hpl, (size_t)P.ell_len * 6);
     AL(b_pose, (size_t)N * 3); AL(b_lm, (size_t)M * 2);
-    d.n_chi2_partial = std::max((N + 255) / 256, d.n_tiles);
+    d.n_chi2_partial = std::max((N + 255) / 256, d.n_wtiles);
     AL(chi2_partial, d.n_chi2_partial); AL(chi2, 80);
     // plan
     { std::vector<DevFront> df(P.fronts.size());
@@ -390,6 +393,7 @@ static int upload_graph(gs_graph *g) {
 
 static int build_plan_host(gs_graph *g) {
     PlanOptions o; o.leaf_poses = g->cfg.leaf_poses; o.world = g->world; o.rank = g->rank;
+    if (const char *e = std::getenv("GS_ELL_LANES")) o.ell_lanes = std::atoi(e);       // tuning knob: lanes per pose of the ELL layout
     std::string err;
     if (!build_plan(g->h, o, g->plan, err)) { g->plan_version = ~0ull; return fail(GS_ERR_EMPTY, "plan: " + err); }
     g->plan_version = g->h.structure_version;
@@ -541,6 +545,7 @@ extern "C" int gs_linearize(gs_graph *g) {
     if (!g) return fail(GS_ERR_INVALID, "null graph");
     int rc = ensure_ready(g); if (rc != GS_OK) return rc;
     launch_linearize(g->d, g->stream);
+    launch_linearize_finalize(g->d, g->stream);              // stand-alone pass: materialise H_ll, b_l, chi2 for export
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("linearize: ") + hipGetErrorString(e));
     return GS_OK;
@@ -570,7 +575,8 @@ extern "C" int gs_export_system(gs_graph *g, double *Hpp_diag, double *Hll_diag,
     // the device keeps these arrays structure-of-arrays (and the diagonal blocks packed symmetric); the
     // export format is array-of-blocks, full and row-major
     const size_t N = (size_t)d.N, M = (size_t)d.M, Epp = (size_t)d.Epp, Epl = (size_t)d.Epl;
-    std::vector<double> t0(N * 6), t1(M * 3), t2(Epp * 9), t3(Epl * 6), t4(N * 3), t5(M * 2);
+    const size_t L = (size_t)d.ell_len;
+    std::vector<double> t0(N * 6), t1(M * 3), t2(Epp * 9), t3(L * 6), t4(N * 3), t5(M * 2);
     auto dl = [&](std::vector<double> &dst, const double *src) -> hipError_t {
         return dst.empty() ? hipSuccess : hipMemcpyAsync(dst.data(), src, dst.size() * sizeof(double), hipMemcpyDeviceToHost, g->stream); };
     HIP_TRY(dl(t0, d.Hpp_diag)); HIP_TRY(dl(t1, d.Hll_diag)); HIP_TRY(dl(t2, d.Hpp_off)); HIP_TRY(dl(t3, d.Hpl));
@@ -580,11 +586,11 @@ extern "C" int gs_export_system(gs_graph *g, double *Hpp_diag, double *Hll_diag,
     if (Hpp_diag) for (size_t p = 0; p < N; ++p) for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Hpp_diag[9 * p + 3 * r + c] = t0[sym3[r][c] * N + p];
     if (Hll_diag) for (size_t l = 0; l < M; ++l) for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) Hll_diag[4 * l + 2 * r + c] = t1[sym2[r][c] * M + l];
     if (Hpp_off) for (size_t k = 0; k < Epp; ++k) for (int c = 0; c < 9; ++c) Hpp_off[9 * k + c] = t2[c * Epp + k];
-    if (Hpl) for (size_t k = 0; k < Epl; ++k) for (int c = 0; c < 6; ++c) Hpl[6 * k + c] = t3[c * Epl + k];
+    if (Hpl) for (size_t k = 0; k < Epl; ++k) for (int c = 0; c < 6; ++c) Hpl[6 * k + c] = t3[c * L + (size_t)g->plan.ell_of_ins[k]];   // insertion order
     if (b_pose) for (size_t p = 0; p < N; ++p) for (int c = 0; c < 3; ++c) b_pose[3 * p + c] = t4[c * N + p];
     if (b_lm) for (size_t l = 0; l < M; ++l) for (int c = 0; c < 2; ++c) b_lm[2 * l + c] = t5[c * M + l];
     if (pp_order) std::memcpy(pp_order, g->plan.pp_order.data(), g->plan.pp_order.size() * sizeof(int32_t));
-    if (pl_order) std::memcpy(pl_order, g->plan.pl_order.data(), g->plan.pl_order.size() * sizeof(int32_t));
+    if (pl_order) for (size_t k = 0; k < Epl; ++k) pl_order[k] = (int32_t)k;                 // exported in insertion order
     return GS_OK;
 }
 extern "C" int gs_export_delta(gs_graph *g, double *dpose, double *dlm) {

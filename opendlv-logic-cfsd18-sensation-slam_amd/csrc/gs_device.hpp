@@ -2,10 +2,13 @@
 //
 // HBM layout (fp64 values, int32 indices).  Streams that the edge kernels sweep are structure-of-arrays so
 // that consecutive lanes touch consecutive addresses:
-//   observation edges, sorted by pose:  pl_p[E] pl_l[E] | pl_z [2][E] | pl_info [3][E] (xx xy yy)
-//   odometry edges, insertion order  :  pp_i[E] pp_j[E] | pp_zinv [E][5] (x y theta cos sin of z^-1) | pp_info [E][6]
+//   observation edges, ELL with T lanes per pose and R slots per lane, L = R*T*N entries, the s-th edge of
+//   pose p at idx = (s / T)*(T*N) + T*p + (s % T):
+//                                       ell_l[L] (landmark, -1 = empty) | ell_z [2][L] | ell_w [3][L] (xx xy yy)
+//   odometry edges, insertion order  :  pp_zinv [E][5] (x y theta cos sin of z^-1) | pp_info [E][6]
+//                                       ppinc [Q][4] {edge, role, i, j} per (pose, edge) incidence, grouped by pose
 //   estimates                        :  pose_est [N][3], lm_est [M][2]           (AoS, gathered)
-//   block-sparse H and b (A6/A7 out) :  Hpl [6][Epl] | Hpp_off [9][Epp] | Hpp_diag [6][N] (xx xy xt yy yt tt)
+//   block-sparse H and b (A6/A7 out) :  Hpl [6][L] | Hpp_off [9][Epp] | Hpp_diag [6][N] (xx xy xt yy yt tt)
 //                                       b_pose [3][N] | Hll_diag [3][M] (00 01 11) | b_lm [2][M]
 #pragma once
 #include <hip/hip_runtime.h>
@@ -27,17 +30,20 @@ struct DevGraph {
     double *pose_est = nullptr, *lm_est = nullptr;             // [N*3], [M*2]
     uint8_t *pose_fixed = nullptr, *lm_fixed = nullptr;
     int32_t *pose_gidx = nullptr, *lm_gidx = nullptr;          // first scalar in elimination order, -1 fixed
-    // observation edges sorted by pose (SoA)
-    int32_t *pl_p = nullptr, *pl_l = nullptr; double *pl_z = nullptr, *pl_info = nullptr;   // z [2][E], info [3][E]
+    // observation edges, ELL
+    int32_t ell_T = 1, ell_R = 1; int64_t ell_len = 0;
+    int32_t *ell_l = nullptr; double *ell_z = nullptr, *ell_w = nullptr;
     // odometry edges; the measurement is stored inverted (g2o keeps _inverseMeasurement) with its cos/sin
-    int32_t *pp_i = nullptr, *pp_j = nullptr; double *pp_zinv = nullptr, *pp_info = nullptr; // zinv [E][5], info [E][6]
-    // adjacency
-    int32_t *pl_start = nullptr, *lm_start = nullptr, *lm_edges = nullptr, *ppadj_start = nullptr, *ppadj = nullptr;
-    // fused-kernel tiles
-    int32_t n_tiles = 0, n_groups = 0;
-    int32_t *tile_pose_start = nullptr, *tile_grp_start = nullptr, *grp_lm = nullptr, *grp_edge_start = nullptr, *grp_edges = nullptr;
-    int32_t *lm_grp_start = nullptr, *lm_grps = nullptr;
-    double *lm_part = nullptr;                                  // [5][n_groups] per-(tile, landmark) partial sums
+    double *pp_zinv = nullptr, *pp_info = nullptr;              // zinv [E][5], info [E][6]
+    int32_t *ppinc = nullptr, *ppadj_start = nullptr;           // incidence records, pose -> incidence range
+    // landmark -> ELL indices of its edges (gather kernels)
+    int32_t *lm_start = nullptr, *lm_edges = nullptr;
+    // fused-kernel wave tiles
+    int32_t n_wtiles = 0, n_groups = 0;
+    int32_t *wt_desc = nullptr;                                 // [WT][4] first group, #groups, first position, #positions
+    int32_t *grp_pos_start = nullptr, *grp_slot = nullptr, *lm_grp_start = nullptr;
+    uint16_t *grp_pos = nullptr;
+    double *lm_part = nullptr;                                  // [5][n_groups] per-(wave tile, landmark) partial sums
     // block-sparse H and b (A6/A7 output), SoA
     double *Hpp_diag = nullptr, *Hll_diag = nullptr, *Hpp_off = nullptr, *Hpl = nullptr, *b_pose = nullptr, *b_lm = nullptr;
     double *chi2_partial = nullptr; int32_t n_chi2_partial = 0; double *chi2 = nullptr;     // chi2[0] = last value
@@ -53,8 +59,9 @@ struct DevGraph {
 };
 
 // launchers (gs_kernels.hip); all asynchronous on `st`
-void launch_linearize(const DevGraph &d, hipStream_t st);       // fused tiled kernel when tiles exist, else gather kernels
+void launch_linearize(const DevGraph &d, hipStream_t st);       // fused ELL kernel when wave tiles exist, else gather kernels
 void launch_linearize_gather(const DevGraph &d, hipStream_t st);
+void launch_linearize_finalize(const DevGraph &d, hipStream_t st);   // H_ll, b_l, chi2 total from the fused kernel's partials
 void launch_chi2_only(const DevGraph &d, hipStream_t st);
 void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f, hipStream_t st);
 void launch_backsolve_level(const DevGraph &d, int level_off, int count, int max_npiv, int max_nbnd, hipStream_t st);

@@ -65,16 +65,22 @@ struct Plan {
     std::vector<int32_t> pl_order, pp_order;
     // CSR: pose -> its pl edges are [pl_start[p], pl_start[p+1]) in sorted order
     std::vector<int32_t> pl_start;
-    // CSR: landmark -> sorted pl edge positions
+    // CSR: landmark -> ELL indices of its edges
     std::vector<int32_t> lm_start, lm_edges;
     // CSR: pose -> incident pp edges (sorted position * 2 + role; role 0 = i endpoint)
     std::vector<int32_t> ppadj_start, ppadj;
-    // linearisation tiles of the fused A5-A7 kernel (valid when lin_tiles_ok)
-    bool lin_tiles_ok = false;
-    std::vector<int32_t> tile_pose_start;                 // [T+1] pose ranges
-    std::vector<int32_t> tile_grp_start;                  // [T+1] groups (= per-(tile, landmark) partial slots) of a tile
-    std::vector<int32_t> grp_lm, grp_edge_start, grp_edges;   // group -> landmark, tile-local edge list
-    std::vector<int32_t> lm_grp_start, lm_grps;           // landmark -> its groups in tile order
+    // ELL layout of the observation edges on the device: T lanes per pose, R slots per lane
+    int32_t ell_T = 1, ell_R = 1; int64_t ell_len = 0;
+    std::vector<int32_t> ell_ins;                         // [ell_len] ELL index -> insertion index (-1 = empty slot)
+    std::vector<int32_t> ell_of_ins;                      // insertion index -> ELL index
+    std::vector<int32_t> ppinc;                           // [Q][4] edge, role, i, j per (pose, odometry edge) incidence
+    // wave tiles of the fused A5-A7 kernel (valid when lin_ell_ok): one wave = 64/T consecutive poses
+    bool lin_ell_ok = false; int32_t n_wtiles = 0;
+    std::vector<int32_t> wt_grp_start;                    // [WT+1] landmark groups of a wave tile
+    std::vector<int32_t> wt_desc;                         // [WT][4] first group, #groups, first position, #positions
+    std::vector<int32_t> grp_lm, grp_pos_start, grp_pos;  // group -> landmark, wave-local positions (slot*64 + lane)
+    std::vector<int32_t> lm_grp_start;                    // landmark -> its run of partial-sum slots
+    std::vector<int32_t> grp_slot;                        // group -> partial-sum slot, slots ordered by (landmark, wave tile)
     // fronts in elimination (post)order
     std::vector<Front> fronts;
     std::vector<int32_t> bnd_rows, child_map, children;
@@ -90,11 +96,9 @@ struct Plan {
     double ms_build = 0;
 };
 
-struct PlanOptions { int leaf_poses = 8; int world = 1; int rank = 0; };
+struct PlanOptions { int leaf_poses = 8; int world = 1; int rank = 0; int ell_lanes = 0; };
 
-// tile shape of the fused linearisation kernel (one 256-thread workgroup per tile, one edge per thread)
-constexpr int LIN_TILE_EDGES = 256;
-constexpr int LIN_TILE_POSES = 256;
+constexpr int LIN_R = 4;               // observation slots per lane handled by the fused linearisation kernel
 
 // Builds the plan on the host (no device work).  Returns false (and sets err) on failure.
 bool build_plan(const HostGraph &g, const PlanOptions &opt, Plan &plan, std::string &err);

@@ -4,7 +4,7 @@
 //                                          (reference src/slam.cpp:513-523, 637-654, 499-510)
 //   A1  k_associate                        association loop of Slam::addConesToMap vs a fixed map
 //                                          (reference src/slam.cpp:570-607, 708-711)
-//   A5-A7 k_linearize_tiles (+ _finalize)  g2o computeError + linearizeOplus + constructQuadraticForm of
+//   A5-A7 k_linearize_ell (+ _finalize)    g2o computeError + linearizeOplus + constructQuadraticForm of
 //                                          EdgeSE2 / EdgeSE2PointXY, summed per vertex (SURVEY.md §8-A.2-4;
 //                                          driven from reference src/slam.cpp:481); k_linearize_*_gather =
 //                                          general-graph fallback
@@ -116,8 +116,8 @@ __device__ __forceinline__ void edge_pl(double px, double py, double c, double s
 }
 
 // EdgeSE2: e = vec(zinv * (xi^-1 * xj)), A = Z*Ji, B = Z*Jj (rows); zinv5 = (x, y, theta, cos, sin) of z^-1
-__device__ __forceinline__ void edge_pp(const double *__restrict__ xi, const double *__restrict__ xj, double ci, double si,
-                                        const double *__restrict__ zinv5, double e[3], double A[3][3], double B[3][3]) {
+__device__ __forceinline__ void edge_pp(const double xi[3], const double xj[3], double ci, double si,
+                                        const double zinv5[5], double e[3], double A[3][3], double B[3][3]) {
     double dx = xj[0] - xi[0], dy = xj[1] - xi[1];
     double rx = ci * dx + si * dy, ry = -si * dx + ci * dy;           // rel = xi^-1 * xj
     double rth = normalize_theta(normalize_theta(-xi[2]) + xj[2]);
@@ -159,28 +159,23 @@ __device__ __forceinline__ void quad_pl(double px, double py, double c, double s
     q.bl[0] = -(c * We0 - s * We1); q.bl[1] = -(s * We0 + c * We1);
 }
 
-// The odometry edges incident to pose p: adds its share to H (6 packed) and b, writes the off-diagonal block of
-// the edges it owns (role 0 = i endpoint), returns the chi2 of the owned edges.
+// One (pose, odometry edge) incidence with its operands already in registers: adds the edge's share for that
+// endpoint to H (6 packed) and b, writes the off-diagonal block if this endpoint owns the edge (role 0 = i
+// endpoint); returns the chi2 of an owned edge.
 template <bool WRITE_H>
-__device__ __forceinline__ double pose_pp_edges(const DevGraph &d, int p, double H[6], double b[3],
-                                                int tile_p0, int tile_np, const double *s_c, const double *s_s) {
+__device__ __forceinline__ double pp_incidence(const DevGraph &d, int k, int role, const double xi[3], const double xj[3],
+                                               double ci, double si, const double zinv5[5], const double w[6],
+                                               bool fi, bool fj, double H[6], double b[3]) {
     double chi = 0.0;
-    for (int q = d.ppadj_start[p]; q < d.ppadj_start[p + 1]; ++q) {
-        const int code = d.ppadj[q], k = code >> 1, role = code & 1;
-        const int i = d.pp_i[k], j = d.pp_j[k];
-        double ci, si;
-        const int li = i - tile_p0;
-        if (li >= 0 && li < tile_np) { ci = s_c[li]; si = s_s[li]; } else sincos(d.pose_est[3 * i + 2], &si, &ci);
-        double e[3], A[3][3], B[3][3];
-        edge_pp(d.pose_est + 3 * i, d.pose_est + 3 * j, ci, si, d.pp_zinv + 5 * (int64_t)k, e, A, B);
-        const double *w = d.pp_info + 6 * (int64_t)k;
-        const double W[3][3] = {{w[0], w[1], w[2]}, {w[1], w[3], w[4]}, {w[2], w[4], w[5]}};
-        double We[3];
+    double e[3], A[3][3], B[3][3];
+    edge_pp(xi, xj, ci, si, zinv5, e, A, B);
+    const double W[3][3] = {{w[0], w[1], w[2]}, {w[1], w[3], w[4]}, {w[2], w[4], w[5]}};
+    double We[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) We[r] = W[r][0] * e[0] + W[r][1] * e[1] + W[r][2] * e[2];
-        const bool fi = d.pose_fixed[i], fj = d.pose_fixed[j];
-        if (role == 0 && !(fi && fj)) chi += e[0] * We[0] + e[1] * We[1] + e[2] * We[2];
-        if (WRITE_H) {
+    for (int r = 0; r < 3; ++r) We[r] = W[r][0] * e[0] + W[r][1] * e[1] + W[r][2] * e[2];
+    if (role == 0 && !(fi && fj)) chi = e[0] * We[0] + e[1] * We[1] + e[2] * We[2];
+    if (WRITE_H) {
+        if (role == 0) {
             double WA[3][3], WB[3][3];
 #pragma unroll
             for (int r = 0; r < 3; ++r)
@@ -189,49 +184,71 @@ __device__ __forceinline__ double pose_pp_edges(const DevGraph &d, int p, double
                     WA[r][c] = W[r][0] * A[0][c] + W[r][1] * A[1][c] + W[r][2] * A[2][c];
                     WB[r][c] = W[r][0] * B[0][c] + W[r][1] * B[1][c] + W[r][2] * B[2][c];
                 }
-            if (role == 0) {
-                int t = 0;
+            int t = 0;
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
+            for (int r = 0; r < 3; ++r) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        if (c >= r) H[t++] += A[0][r] * WA[0][c] + A[1][r] * WA[1][c] + A[2][r] * WA[2][c];
-                        double off = A[0][r] * WB[0][c] + A[1][r] * WB[1][c] + A[2][r] * WB[2][c];
-                        d.Hpp_off[(int64_t)(3 * r + c) * d.Epp + k] = (!fi && !fj) ? off : 0.0;
-                    }
-                    b[r] -= A[0][r] * We[0] + A[1][r] * We[1] + A[2][r] * We[2];
+                for (int c = 0; c < 3; ++c) {
+                    if (c >= r) H[t++] += A[0][r] * WA[0][c] + A[1][r] * WA[1][c] + A[2][r] * WA[2][c];
+                    double off = A[0][r] * WB[0][c] + A[1][r] * WB[1][c] + A[2][r] * WB[2][c];
+                    d.Hpp_off[(int64_t)(3 * r + c) * d.Epp + k] = (!fi && !fj) ? off : 0.0;
                 }
-            } else {
-                int t = 0;
+                b[r] -= A[0][r] * We[0] + A[1][r] * We[1] + A[2][r] * We[2];
+            }
+        } else {
+            double WB[3][3];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int c = r; c < 3; ++c) H[t++] += B[0][r] * WB[0][c] + B[1][r] * WB[1][c] + B[2][r] * WB[2][c];
-                    b[r] -= B[0][r] * We[0] + B[1][r] * We[1] + B[2][r] * We[2];
-                }
+                for (int c = 0; c < 3; ++c) WB[r][c] = W[r][0] * B[0][c] + W[r][1] * B[1][c] + W[r][2] * B[2][c];
+            int t = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = r; c < 3; ++c) H[t++] += B[0][r] * WB[0][c] + B[1][r] * WB[1][c] + B[2][r] * WB[2][c];
+                b[r] -= B[0][r] * We[0] + B[1][r] * We[1] + B[2][r] * We[2];
             }
         }
     }
     return chi;
 }
+// the same with the operands fetched here (q = index of the incidence record)
+template <bool WRITE_H>
+__device__ __forceinline__ double pp_incidence_q(const DevGraph &d, int q, double H[6], double b[3]) {
+    const int4 inc = reinterpret_cast<const int4 *>(d.ppinc)[q];                 // {edge, role, i, j}
+    const int k = inc.x, i = inc.z, j = inc.w;
+    double xi[3], xj[3], z5[5], w[6];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { xi[t] = d.pose_est[3 * i + t]; xj[t] = d.pose_est[3 * j + t]; }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) z5[t] = d.pp_zinv[5 * (int64_t)k + t];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) w[t] = d.pp_info[6 * (int64_t)k + t];
+    double si, ci; sincos(xi[2], &si, &ci);
+    return pp_incidence<WRITE_H>(d, k, inc.y, xi, xj, ci, si, z5, w, d.pose_fixed[i], d.pose_fixed[j], H, b);
+}
 
-__device__ __forceinline__ double block_sum_256(double v, double *red) {
-    // fixed-order tree: wave shuffle then the wave partials in order
+__device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
-    int w = threadIdx.x >> 6;
+    return v;                                                      // valid in lane 0
+}
+__device__ __forceinline__ double block_sum(double v, double *red) {
+    // fixed-order tree: wave shuffle, then the wave partials in wave order (red has >= blockDim/64 slots)
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) red[w] = v;
     __syncthreads();
     double r = 0;
-    if (threadIdx.x == 0) { for (int k = 0; k < (int)(blockDim.x >> 6); ++k) r += red[k]; }
+    if (threadIdx.x == 0) { for (int k = 0; k < (int)((blockDim.x + 63) >> 6); ++k) r += red[k]; }
     return r;
 }
 
-// ---- general fallback: gather kernels (any graph; used when a pose has more edges than a tile holds,
-//      and for the chi2-only pass).  thread per pose / thread per landmark, every sum in fixed order.
+// ---- general fallback: gather kernels on the same ELL arrays (any slot count R; also the chi2-only pass).
+//      thread per pose / thread per landmark, every sum in fixed order.
 template <bool WRITE_H>
 __global__ void __launch_bounds__(256) k_linearize_pose_gather(DevGraph d) {
-    __shared__ double red[4];
+    __shared__ double red[8];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     double chi = 0.0;
     if (p < d.N) {
@@ -239,12 +256,14 @@ __global__ void __launch_bounds__(256) k_linearize_pose_gather(DevGraph d) {
         double s, c; sincos(d.pose_est[3 * p + 2], &s, &c);
         const bool fp = d.pose_fixed[p];
         double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-        const int64_t E = d.Epl;
-        for (int e = d.pl_start[p]; e < d.pl_start[p + 1]; ++e) {
-            const int l = d.pl_l[e];
+        const int64_t L = d.ell_len, S = (int64_t)d.ell_T * d.N;
+        for (int sl = 0; sl < d.ell_R * d.ell_T; ++sl) {
+            const int64_t e = (int64_t)(sl / d.ell_T) * S + (int64_t)d.ell_T * p + (sl % d.ell_T);
+            const int l = d.ell_l[e];
+            if (l < 0) continue;
             PlQuad q;
-            quad_pl(px, py, c, s, d.lm_est[2 * l], d.lm_est[2 * l + 1], d.pl_z[e], d.pl_z[E + e],
-                    d.pl_info[e], d.pl_info[E + e], d.pl_info[2 * E + e], q);
+            quad_pl(px, py, c, s, d.lm_est[2 * l], d.lm_est[2 * l + 1], d.ell_z[e], d.ell_z[L + e],
+                    d.ell_w[e], d.ell_w[L + e], d.ell_w[2 * L + e], q);
             const bool fl = d.lm_fixed[l];
             if (!(fp && fl)) chi += q.chi;
             if (WRITE_H) {
@@ -254,10 +273,10 @@ __global__ void __launch_bounds__(256) k_linearize_pose_gather(DevGraph d) {
                 for (int k = 0; k < 3; ++k) b[k] += q.bp[k];
                 const bool both = !fp && !fl;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) d.Hpl[k * E + e] = both ? q.W6[k] : 0.0;
+                for (int k = 0; k < 6; ++k) d.Hpl[k * L + e] = both ? q.W6[k] : 0.0;
             }
         }
-        chi += pose_pp_edges<WRITE_H>(d, p, H, b, 0, 0, nullptr, nullptr);
+        for (int q = d.ppadj_start[p]; q < d.ppadj_start[p + 1]; ++q) chi += pp_incidence_q<WRITE_H>(d, q, H, b);
         if (WRITE_H) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) d.Hpp_diag[(int64_t)k * d.N + p] = fp ? 0.0 : H[k];
@@ -265,7 +284,7 @@ __global__ void __launch_bounds__(256) k_linearize_pose_gather(DevGraph d) {
             for (int k = 0; k < 3; ++k) d.b_pose[(int64_t)k * d.N + p] = fp ? 0.0 : b[k];
         }
     }
-    double tot = block_sum_256(chi, red);
+    double tot = block_sum(chi, red);
     if (threadIdx.x == 0) d.chi2_partial[blockIdx.x] = tot;
 }
 
@@ -275,13 +294,14 @@ __global__ void __launch_bounds__(256) k_linearize_lm_gather(DevGraph d) {
     double h00 = 0, h01 = 0, h11 = 0, b0 = 0, b1 = 0;
     if (!d.lm_fixed[l]) {
         const double lx = d.lm_est[2 * l], ly = d.lm_est[2 * l + 1];
-        const int64_t E = d.Epl;
+        const int64_t L = d.ell_len, S = (int64_t)d.ell_T * d.N;
         for (int q = d.lm_start[l]; q < d.lm_start[l + 1]; ++q) {
-            const int e = d.lm_edges[q], p = d.pl_p[e];
+            const int64_t e = d.lm_edges[q];
+            const int p = (int)((e % S) / d.ell_T);
             double s, c; sincos(d.pose_est[3 * p + 2], &s, &c);
             PlQuad r;
-            quad_pl(d.pose_est[3 * p], d.pose_est[3 * p + 1], c, s, lx, ly, d.pl_z[e], d.pl_z[E + e],
-                    d.pl_info[e], d.pl_info[E + e], d.pl_info[2 * E + e], r);
+            quad_pl(d.pose_est[3 * p], d.pose_est[3 * p + 1], c, s, lx, ly, d.ell_z[e], d.ell_z[L + e],
+                    d.ell_w[e], d.ell_w[L + e], d.ell_w[2 * L + e], r);
             h00 += r.Hl[0]; h01 += r.Hl[1]; h11 += r.Hl[2]; b0 += r.bl[0]; b1 += r.bl[1];
         }
     }
@@ -289,112 +309,167 @@ __global__ void __launch_bounds__(256) k_linearize_lm_gather(DevGraph d) {
     d.b_lm[l] = b0; d.b_lm[(int64_t)d.M + l] = b1;
 }
 
-// ---- fused tiled kernel: one 256-thread workgroup per tile of <= 256 consecutive observation edges.
-//   phase 0  thread per tile pose : state + sincos once per pose into LDS
-//   phase A  thread per edge      : coalesced SoA loads, quadratic form in registers, H_pl block streamed out
-//                                   (coalesced, 8 B per lane per component), per-edge diagonal shares into LDS
-//   phase B1 thread per tile pose : sums its edge run from LDS (+ its odometry edges) -> H_pp, b_p, H_pp_off
-//   phase B2 thread per (landmark group, component): sums the tile's shares of one landmark -> partial slot
-// LDS columns are skewed by e + (e >> 3) so that the stride-8 runs of phase B1 are bank-conflict free.
-static constexpr int LIN_E = 256;                 // == gs::LIN_TILE_EDGES
-static constexpr int LIN_W = LIN_E + LIN_E / 8;   // skewed row width
-__global__ void __launch_bounds__(256) k_linearize_tiles(DevGraph d) {
-    __shared__ double s_px[LIN_E], s_py[LIN_E], s_c[LIN_E], s_s[LIN_E];
-    __shared__ double s_pc[9][LIN_W];
-    __shared__ double s_lc[5][LIN_W];
-    __shared__ double red[4];
-    __shared__ uint8_t s_fix[LIN_E];
-    const int t = blockIdx.x, tid = threadIdx.x;
-    const int p0 = d.tile_pose_start[t], np = d.tile_pose_start[t + 1] - p0;
-    const int e0 = d.pl_start[p0], ne = d.pl_start[p0 + np] - e0;
-    const int64_t E = d.Epl;
-    if (tid < np) {
-        const int p = p0 + tid;
-        double s, c; sincos(d.pose_est[3 * p + 2], &s, &c);
-        s_px[tid] = d.pose_est[3 * p]; s_py[tid] = d.pose_est[3 * p + 1]; s_c[tid] = c; s_s[tid] = s;
-        s_fix[tid] = d.pose_fixed[p];
-    }
-    __syncthreads();
-    double chi = 0.0;
-    if (tid < ne) {
-        const int e = e0 + tid;
-        const int lp = d.pl_p[e] - p0, l = d.pl_l[e];
-        PlQuad q;
-        quad_pl(s_px[lp], s_py[lp], s_c[lp], s_s[lp], d.lm_est[2 * l], d.lm_est[2 * l + 1], d.pl_z[e], d.pl_z[E + e],
-                d.pl_info[e], d.pl_info[E + e], d.pl_info[2 * E + e], q);
-        const bool fp = s_fix[lp], fl = d.lm_fixed[l];
-        if (!(fp && fl)) chi = q.chi;
-        const bool both = !fp && !fl;
+// ---- fused kernel: T lanes per pose, every wave independent (no block barrier).
+// The pass is bound by load latency, not arithmetic, so it is shaped for memory-level parallelism:
+//   1. each thread issues, back to back, the loads of ALL its observation edges (<= LIN_R slots of the ELL
+//      streams, coalesced: consecutive lanes read consecutive addresses in every slot), its pose state, its
+//      odometry incidence record and the descriptors of its landmark-sum items;
+//   2. second level, again all at once: landmark gathers and the incidence's endpoint states / z^-1 / information;
+//   3. quadratic forms in registers; H_pl blocks are streamed out coalesced (8 B per lane per component); the
+//      pose-side sums never leave registers (xor-shuffle over the T lanes of a pose);
+//   4. landmark-side shares go through a wave-private LDS region; each lane sums (landmark group, component)
+//      items in a fixed order into the per-(wave tile, landmark) partial slot.
+static constexpr int LIN_R = 4;                   // == gs::LIN_R: observation slots per lane
+#ifndef LIN_WAVES_PER_SIMD
+#define LIN_WAVES_PER_SIMD 3
+#endif
+template <int T>
+__global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGraph d) {
+    constexpr int PW = 64 / T;
+    __shared__ double s_lc[4][5][LIN_R * 64];
+    __shared__ uint16_t s_gp[4][LIN_R * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wt = blockIdx.x * 4 + wave;
+    if (wt >= d.n_wtiles) return;                                  // whole wave leaves; no block-level barrier below
+    const int p = wt * PW + lane / T, h = lane % T;
+    const bool live = p < d.N;
+    const int64_t L = d.ell_len, S = (int64_t)T * d.N;
+    const int R = d.ell_R;
+    // ---- level 1
+    int l[LIN_R]; double zx[LIN_R], zy[LIN_R], w00[LIN_R], w01[LIN_R], w11[LIN_R];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) d.Hpl[k * E + e] = both ? q.W6[k] : 0.0;
-        const int col = tid + (tid >> 3);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) s_pc[k][col] = q.Hp[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) s_pc[6 + k][col] = q.bp[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) s_lc[k][col] = q.Hl[k];
-        s_lc[3][col] = q.bl[0]; s_lc[4][col] = q.bl[1];
-    }
-    __syncthreads();
-    if (tid < np) {
-        const int p = p0 + tid;
-        double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-        const int r0 = d.pl_start[p] - e0, r1 = d.pl_start[p + 1] - e0;
-        for (int r = r0; r < r1; ++r) {
-            const int col = r + (r >> 3);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) H[k] += s_pc[k][col];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) b[k] += s_pc[6 + k][col];
+    for (int i = 0; i < LIN_R; ++i) {
+        l[i] = -1; zx[i] = zy[i] = w00[i] = w01[i] = w11[i] = 0.0;
+        if (live && i < R) {
+            const int64_t e = (int64_t)i * S + (int64_t)T * p + h;
+            l[i] = d.ell_l[e]; zx[i] = d.ell_z[e]; zy[i] = d.ell_z[L + e];
+            w00[i] = d.ell_w[e]; w01[i] = d.ell_w[L + e]; w11[i] = d.ell_w[2 * L + e];
         }
-        chi += pose_pp_edges<true>(d, p, H, b, p0, np, s_c, s_s);
-        const bool fp = s_fix[tid];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) d.Hpp_diag[(int64_t)k * d.N + p] = fp ? 0.0 : H[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) d.b_pose[(int64_t)k * d.N + p] = fp ? 0.0 : b[k];
     }
-    {
-        const int g0 = d.tile_grp_start[t], ng = d.tile_grp_start[t + 1] - g0;
-        for (int idx = tid; idx < ng * 5; idx += 256) {
-            const int comp = idx / ng, g = g0 + (idx - comp * ng);
+    double px = 0, py = 0, th = 0; bool fp = true; int q0 = 0, q1 = 0;
+    if (live) { px = d.pose_est[3 * p]; py = d.pose_est[3 * p + 1]; th = d.pose_est[3 * p + 2]; fp = d.pose_fixed[p];
+                q0 = d.ppadj_start[p]; q1 = d.ppadj_start[p + 1]; }
+    const int4 wd = reinterpret_cast<const int4 *>(d.wt_desc)[wt];        // {first group, #groups, first position, #positions}
+    const int g0 = wd.x, ng = wd.y, pos_off = wd.z, npos = wd.w, nitems = ng * 5;
+    int it_s[2] = {0, 0}, it_e[2] = {0, 0}, it_slot[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int item = lane + 64 * u;
+        if (item < nitems) { const int gl = item % ng; it_s[u] = d.grp_pos_start[g0 + gl] - pos_off; it_e[u] = d.grp_pos_start[g0 + gl + 1] - pos_off; it_slot[u] = d.grp_slot[g0 + gl]; } }
+    uint16_t gp[LIN_R];                                                    // the tile's position list, coalesced
+#pragma unroll
+    for (int i = 0; i < LIN_R; ++i) { const int k = i * 64 + lane; gp[i] = (k < npos) ? d.grp_pos[pos_off + k] : (uint16_t)0; }
+    // ---- level 2
+    double lx[LIN_R], ly[LIN_R]; bool fl[LIN_R];
+#pragma unroll
+    for (int i = 0; i < LIN_R; ++i) { lx[i] = ly[i] = 0.0; fl[i] = true;
+        if (l[i] >= 0) { lx[i] = d.lm_est[2 * l[i]]; ly[i] = d.lm_est[2 * l[i] + 1]; fl[i] = d.lm_fixed[l[i]]; } }
+    // first odometry incidence of this lane (lane h takes incidences q0+h, q0+h+T, ...)
+    const bool has_inc = live && (q0 + h < q1);
+    int4 inc = make_int4(0, 0, 0, 0);
+    double xi[3] = {0, 0, 0}, xj[3] = {0, 0, 0}, z5[5] = {0, 0, 0, 1, 0}, wpp[6] = {0, 0, 0, 0, 0, 0}; bool fi = true, fj = true;
+    if (has_inc) {
+        inc = reinterpret_cast<const int4 *>(d.ppinc)[q0 + h];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { xi[t] = d.pose_est[3 * inc.z + t]; xj[t] = d.pose_est[3 * inc.w + t]; }
+#pragma unroll
+        for (int t = 0; t < 5; ++t) z5[t] = d.pp_zinv[5 * (int64_t)inc.x + t];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) wpp[t] = d.pp_info[6 * (int64_t)inc.x + t];
+        fi = d.pose_fixed[inc.z]; fj = d.pose_fixed[inc.w];
+    }
+    double sn, cs; sincos(th, &sn, &cs);
+    // ---- observation edges
+    double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, chi = 0.0;
+#pragma unroll
+    for (int i = 0; i < LIN_R; ++i) {
+        double hl0 = 0, hl1 = 0, hl2 = 0, bl0 = 0, bl1 = 0;
+        if (l[i] >= 0) {
+            const int64_t e = (int64_t)i * S + (int64_t)T * p + h;
+            PlQuad q;
+            quad_pl(px, py, cs, sn, lx[i], ly[i], zx[i], zy[i], w00[i], w01[i], w11[i], q);
+            if (!(fp && fl[i])) chi += q.chi;
+            const bool both = !fp && !fl[i];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d.Hpl[k * L + e] = both ? q.W6[k] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) H[k] += q.Hp[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) b[k] += q.bp[k];
+            hl0 = q.Hl[0]; hl1 = q.Hl[1]; hl2 = q.Hl[2]; bl0 = q.bl[0]; bl1 = q.bl[1];
+        }
+        if (i < R) { const int pos = i * 64 + lane;
+            s_lc[wave][0][pos] = hl0; s_lc[wave][1][pos] = hl1; s_lc[wave][2][pos] = hl2; s_lc[wave][3][pos] = bl0; s_lc[wave][4][pos] = bl1; }
+    }
+    // ---- odometry incidences
+    if (has_inc) {
+        double si, ci;
+        if (inc.z == p) { si = sn; ci = cs; } else sincos(xi[2], &si, &ci);
+        chi += pp_incidence<true>(d, inc.x, inc.y, xi, xj, ci, si, z5, wpp, fi, fj, H, b);
+        for (int q = q0 + h + T; q < q1; q += T) chi += pp_incidence_q<true>(d, q, H, b);
+    }
+    // ---- pose sums: xor-shuffle over the T lanes of the pose, then each lane stores its share of the 9 components
+#pragma unroll
+    for (int off = 1; off < T; off <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) H[k] += __shfl_xor(H[k], off, WAVE);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) b[k] += __shfl_xor(b[k], off, WAVE);
+    }
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (k % T == h) { const double v = fp ? 0.0 : (k < 6 ? H[k] : b[k - 6]);
+                if (k < 6) d.Hpp_diag[(int64_t)k * d.N + p] = v; else d.b_pose[(int64_t)(k - 6) * d.N + p] = v; }
+        }
+    }
+    // ---- landmark groups of this wave tile (wave-private LDS region; same-wave LDS accesses are ordered)
+#pragma unroll
+    for (int i = 0; i < LIN_R; ++i) s_gp[wave][i * 64 + lane] = gp[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int item = lane + 64 * u;
+        if (item < nitems) { const int comp = item / ng;
             double sum = 0.0;
-            for (int q = d.grp_edge_start[g]; q < d.grp_edge_start[g + 1]; ++q) { const int le = d.grp_edges[q]; sum += s_lc[comp][le + (le >> 3)]; }
-            d.lm_part[(int64_t)comp * d.n_groups + g] = sum;
-        }
-    }
-    const double tot = block_sum_256(chi, red);
-    if (tid == 0) d.chi2_partial[t] = tot;
+            for (int q = it_s[u]; q < it_e[u]; ++q) sum += s_lc[wave][comp][s_gp[wave][q]];
+            d.lm_part[(int64_t)comp * d.n_groups + it_slot[u]] = sum; } }
+    for (int item = lane + 128; item < nitems; item += 64) { const int comp = item / ng, gl = item % ng;
+        double sum = 0.0;
+        for (int q = d.grp_pos_start[g0 + gl] - pos_off; q < d.grp_pos_start[g0 + gl + 1] - pos_off; ++q) sum += s_lc[wave][comp][s_gp[wave][q]];
+        d.lm_part[(int64_t)comp * d.n_groups + d.grp_slot[g0 + gl]] = sum; }
+    chi = wave_sum(chi);
+    if (lane == 0) d.chi2_partial[wt] = chi;
 }
 
-// landmark diagonal blocks from the per-(tile, landmark) partials (tile order) + the chi2 total (fixed order)
+// landmark diagonal blocks from the per-(wave tile, landmark) partials (slots ordered by landmark, then tile)
+// + the chi2 total (fixed order)
 __global__ void __launch_bounds__(256) k_linearize_finalize(DevGraph d, int n_partial) {
-    __shared__ double red[4];
+    __shared__ double red[8];
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l < d.M) {
         double a[5] = {0, 0, 0, 0, 0};
         if (!d.lm_fixed[l]) {
-            for (int q = d.lm_grp_start[l]; q < d.lm_grp_start[l + 1]; ++q) { const int g = d.lm_grps[q];
+            for (int q = d.lm_grp_start[l]; q < d.lm_grp_start[l + 1]; ++q) {
 #pragma unroll
-                for (int k = 0; k < 5; ++k) a[k] += d.lm_part[(int64_t)k * d.n_groups + g]; }
+                for (int k = 0; k < 5; ++k) a[k] += d.lm_part[(int64_t)k * d.n_groups + q]; }
         }
         d.Hll_diag[l] = a[0]; d.Hll_diag[(int64_t)d.M + l] = a[1]; d.Hll_diag[2 * (int64_t)d.M + l] = a[2];
         d.b_lm[l] = a[3]; d.b_lm[(int64_t)d.M + l] = a[4];
     }
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == gridDim.x - 1) {
         double s = 0.0;
         for (int k = threadIdx.x; k < n_partial; k += 256) s += d.chi2_partial[k];
-        const double tot = block_sum_256(s, red);
+        const double tot = block_sum(s, red);
         if (threadIdx.x == 0) d.chi2[0] = tot;
     }
 }
 
 __global__ void __launch_bounds__(256) k_reduce_chi2(DevGraph d, int n_partial) {
-    __shared__ double red[4];
+    __shared__ double red[8];
     double s = 0.0;
     for (int k = threadIdx.x; k < n_partial; k += 256) s += d.chi2_partial[k];
-    const double tot = block_sum_256(s, red);
+    const double tot = block_sum(s, red);
     if (threadIdx.x == 0) d.chi2[0] = tot;
 }
 
@@ -404,10 +479,21 @@ void launch_linearize_gather(const DevGraph &d, hipStream_t st) {
     if (gl > 0) hipLaunchKernelGGL(k_linearize_lm_gather, dim3(gl), dim3(256), 0, st, d);
     hipLaunchKernelGGL(k_reduce_chi2, dim3(1), dim3(256), 0, st, d, gp);
 }
+// materialise H_ll, b_l and the chi2 total from the fused kernel's partials (export / chi2 queries only: inside an
+// iteration the front assembly sums the landmark slots itself and k_update totals chi2)
+void launch_linearize_finalize(const DevGraph &d, hipStream_t st) {
+    if (d.n_wtiles > 0)
+        hipLaunchKernelGGL(k_linearize_finalize, dim3(max(1, (d.M + 255) / 256)), dim3(256), 0, st, d, d.n_wtiles);
+}
 void launch_linearize(const DevGraph &d, hipStream_t st) {
-    if (d.n_tiles <= 0) { launch_linearize_gather(d, st); return; }
-    hipLaunchKernelGGL(k_linearize_tiles, dim3(d.n_tiles), dim3(256), 0, st, d);
-    hipLaunchKernelGGL(k_linearize_finalize, dim3(max(1, (d.M + 255) / 256)), dim3(256), 0, st, d, d.n_tiles);
+    if (d.n_wtiles <= 0) { launch_linearize_gather(d, st); return; }
+    const dim3 grid((d.n_wtiles + 3) / 4), block(256);
+    switch (d.ell_T) {
+        case 1: hipLaunchKernelGGL(k_linearize_ell<1>, grid, block, 0, st, d); break;
+        case 2: hipLaunchKernelGGL(k_linearize_ell<2>, grid, block, 0, st, d); break;
+        case 4: hipLaunchKernelGGL(k_linearize_ell<4>, grid, block, 0, st, d); break;
+        default: hipLaunchKernelGGL(k_linearize_ell<8>, grid, block, 0, st, d); break;
+    }
 }
 void launch_chi2_only(const DevGraph &d, hipStream_t st) {
     const int gp = (d.N + 255) / 256;
@@ -430,9 +516,19 @@ __device__ __forceinline__ void apply_asm(const DevGraph &d, const int32_t *rec,
             for (int c = 0; c < 3; ++c) F[(c0 + c) * ld + f] += d.b_pose[c * S + src];
         } break;
         case 1: {   // landmark diagonal (packed 00 01 11) + rhs
-            const double *H = d.Hll_diag + src; const int64_t S = d.M;
-            F[(c0 + 0) * ld + r0 + 0] += H[0]; F[(c0 + 0) * ld + r0 + 1] += H[S]; F[(c0 + 1) * ld + r0 + 1] += H[2 * S];
-            F[(c0 + 0) * ld + f] += d.b_lm[src]; F[(c0 + 1) * ld + f] += d.b_lm[S + src];
+            if (d.n_wtiles > 0) {
+                // fused linearisation: sum the landmark's per-(wave tile) partial slots here, in slot order
+                double a[5] = {0, 0, 0, 0, 0};
+                for (int q = d.lm_grp_start[src]; q < d.lm_grp_start[src + 1]; ++q) {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) a[k] += d.lm_part[(int64_t)k * d.n_groups + q]; }
+                F[(c0 + 0) * ld + r0 + 0] += a[0]; F[(c0 + 0) * ld + r0 + 1] += a[1]; F[(c0 + 1) * ld + r0 + 1] += a[2];
+                F[(c0 + 0) * ld + f] += a[3]; F[(c0 + 1) * ld + f] += a[4];
+            } else {
+                const double *H = d.Hll_diag + src; const int64_t S = d.M;
+                F[(c0 + 0) * ld + r0 + 0] += H[0]; F[(c0 + 0) * ld + r0 + 1] += H[S]; F[(c0 + 1) * ld + r0 + 1] += H[2 * S];
+                F[(c0 + 0) * ld + f] += d.b_lm[src]; F[(c0 + 1) * ld + f] += d.b_lm[S + src];
+            }
         } break;
         case 2: case 3: {
             const double *H = d.Hpp_off + src; const int64_t S = d.Epp;
@@ -442,14 +538,14 @@ __device__ __forceinline__ void apply_asm(const DevGraph &d, const int32_t *rec,
                 for (int b = 0; b < 3; ++b) F[(c0 + b) * ld + r0 + a] += (kind == 2) ? H[(3 * a + b) * S] : H[(3 * b + a) * S];
         } break;
         case 4: {   // 3x2 as is
-            const double *H = d.Hpl + src; const int64_t S = d.Epl;
+            const double *H = d.Hpl + src; const int64_t S = d.ell_len;
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) F[(c0 + b) * ld + r0 + a] += H[(2 * a + b) * S];
         } break;
         default: {  // 2x3 transposed
-            const double *H = d.Hpl + src; const int64_t S = d.Epl;
+            const double *H = d.Hpl + src; const int64_t S = d.ell_len;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -592,6 +688,14 @@ __global__ void __launch_bounds__(256) k_update(DevGraph d) {
         double dx = 0, dy = 0;
         if (g >= 0) { dx = d.xe[g]; dy = d.xe[g + 1]; d.lm_est[2 * l] += dx; d.lm_est[2 * l + 1] += dy; }
         d.dlm[2 * l] = dx; d.dlm[2 * l + 1] = dy;
+    }
+    // fused linearisation leaves one chi2 partial per wave tile: total them here (fixed order), no extra launch
+    if (blockIdx.x == gridDim.x - 1 && d.n_wtiles > 0) {
+        __shared__ double red[8];
+        double s = 0.0;
+        for (int k = threadIdx.x; k < d.n_wtiles; k += 256) s += d.chi2_partial[k];
+        const double tot = block_sum(s, red);
+        if (threadIdx.x == 0) d.chi2[0] = tot;
     }
 }
 void launch_update(const DevGraph &d, hipStream_t st) {

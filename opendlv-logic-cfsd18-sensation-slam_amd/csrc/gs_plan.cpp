@@ -138,7 +138,13 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     if (B.nv == 0) { err = "no free vertex"; return false; }
     const int N = g.n_poses(), M = g.n_lms(), Epl = g.n_pl(), Epp = g.n_pp();
 
-    // ---- device edge order: pl edges sorted by pose (stable), pp edges in insertion order ----
+    // ---- device layout of the observation edges: ELL, T lanes per pose -------------------------------
+    // pl_start/pl_order: edges grouped by pose (stable) on the host.  On the device the s-th edge of pose p
+    // sits at  idx = (s / T) * (T*N) + T*p + (s % T):  the T lanes of a pose each own up to R = ceil(Kmax/T)
+    // edges (slots i = 0..R-1), consecutive lanes read consecutive addresses in every slot, and the loads of
+    // all R slots of a thread are independent (memory-level parallelism instead of occupancy).  T is the
+    // smallest power of two with R <= 4; graphs with a pose of more than 32 observations use T = 8 and a
+    // larger R, which only the gather kernels handle.
     plan.pl_start.assign(N + 1, 0);
     for (int k = 0; k < Epl; ++k) plan.pl_start[g.pl_p[k] + 1]++;
     for (int p = 0; p < N; ++p) plan.pl_start[p + 1] += plan.pl_start[p];
@@ -148,64 +154,82 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
       for (int k = 0; k < Epl; ++k) { int pos = fill[g.pl_p[k]]++; plan.pl_order[pos] = k; pl_pos_of_ins[k] = pos; } }
     plan.pp_order.resize(Epp);
     for (int k = 0; k < Epp; ++k) plan.pp_order[k] = k;
-    // landmark -> sorted pl positions
+    int kmax = 0;
+    for (int p = 0; p < N; ++p) kmax = std::max(kmax, plan.pl_start[p + 1] - plan.pl_start[p]);
+    int T = 1;
+    while (T < 8 && (kmax + T - 1) / T > LIN_R) T *= 2;
+    // fewer, fatter lanes give more loads in flight per wave, but the chip wants >= ~3 waves per SIMD
+    // (1024 SIMDs): small graphs take more lanes per pose (measured on MI355X: 100k poses T=2 30 us vs T=4 40 us;
+    // 10k poses T=2 13.6 us vs T=4 8.5 us)
+    while (T < 8 && (int64_t)N * T / 64 < 3072) T *= 2;
+    if (opt.ell_lanes == 1 || opt.ell_lanes == 2 || opt.ell_lanes == 4 || opt.ell_lanes == 8) T = opt.ell_lanes;   // tuning override (too few lanes => gather kernels)
+    const int R = std::max(1, (kmax + T - 1) / T);
+    plan.ell_T = T; plan.ell_R = R; plan.ell_len = (int64_t)R * T * N;
+    plan.lin_ell_ok = R <= LIN_R;
+    plan.ell_ins.assign((size_t)plan.ell_len, -1);
+    plan.ell_of_ins.resize(Epl);
+    for (int p = 0; p < N; ++p)
+        for (int s = 0; s < plan.pl_start[p + 1] - plan.pl_start[p]; ++s) {
+            const int64_t idx = (int64_t)(s / T) * ((int64_t)T * N) + (int64_t)T * p + (s % T);
+            const int k = plan.pl_order[plan.pl_start[p] + s];
+            plan.ell_ins[(size_t)idx] = k; plan.ell_of_ins[k] = (int32_t)idx;
+        }
+    // landmark -> ELL indices of its edges (pose order)
     plan.lm_start.assign(M + 1, 0);
     for (int k = 0; k < Epl; ++k) plan.lm_start[g.pl_l[k] + 1]++;
     for (int l = 0; l < M; ++l) plan.lm_start[l + 1] += plan.lm_start[l];
     plan.lm_edges.resize(Epl);
     { std::vector<int32_t> fill(plan.lm_start.begin(), plan.lm_start.end() - 1);
-      for (int pos = 0; pos < Epl; ++pos) { int k = plan.pl_order[pos]; plan.lm_edges[fill[g.pl_l[k]]++] = pos; } }
-    // pose -> incident pp edges
+      for (int pos = 0; pos < Epl; ++pos) { int k = plan.pl_order[pos]; plan.lm_edges[fill[g.pl_l[k]]++] = plan.ell_of_ins[k]; } }
+    // pose -> incident pp edges, and the flattened incidence records {edge, role, i, j}
     plan.ppadj_start.assign(N + 1, 0);
     for (int k = 0; k < Epp; ++k) { plan.ppadj_start[g.pp_i[k] + 1]++; plan.ppadj_start[g.pp_j[k] + 1]++; }
     for (int p = 0; p < N; ++p) plan.ppadj_start[p + 1] += plan.ppadj_start[p];
     plan.ppadj.resize(2 * (size_t)Epp);
     { std::vector<int32_t> fill(plan.ppadj_start.begin(), plan.ppadj_start.end() - 1);
       for (int k = 0; k < Epp; ++k) { plan.ppadj[fill[g.pp_i[k]]++] = 2 * k; plan.ppadj[fill[g.pp_j[k]]++] = 2 * k + 1; } }
+    plan.ppinc.resize(plan.ppadj.size() * 4);
+    for (size_t q = 0; q < plan.ppadj.size(); ++q) { const int code = plan.ppadj[q], k = code >> 1;
+        plan.ppinc[4 * q] = k; plan.ppinc[4 * q + 1] = code & 1; plan.ppinc[4 * q + 2] = g.pp_i[k]; plan.ppinc[4 * q + 3] = g.pp_j[k]; }
 
-    // ---- linearisation tiles (fused A5-A7 kernel): contiguous pose ranges with <= LIN_TILE_EDGES observation
-    // edges and <= LIN_TILE_POSES poses; per tile the distinct landmarks it touches ("groups") with the
-    // tile-local edge lists.  Group index == slot of the per-(tile, landmark) partial sum, and the groups of one
-    // landmark are summed in tile order by the finalize kernel => fixed summation order, no atomics.
-    {
-        plan.lin_tiles_ok = true;
-        for (int p = 0; p < N; ++p) if (plan.pl_start[p + 1] - plan.pl_start[p] > LIN_TILE_EDGES) { plan.lin_tiles_ok = false; break; }
-        if (plan.lin_tiles_ok) {
-            plan.tile_pose_start.push_back(0);
-            int p = 0;
-            while (p < N) {
-                int q = p, e0 = plan.pl_start[p];
-                while (q < N && q - p < LIN_TILE_POSES && plan.pl_start[q + 1] - e0 <= LIN_TILE_EDGES) ++q;
-                plan.tile_pose_start.push_back(q); p = q;
+    // ---- wave tiles of the fused A5-A7 kernel: one wave = 64/T consecutive poses.  Per wave tile the distinct
+    // landmarks it touches ("groups") with the wave-local positions (slot*64 + lane) of their edges.  Partial-sum
+    // slots are ordered by (landmark, wave tile): the finalize pass reads one contiguous run per landmark and the
+    // summation order is fixed => bitwise reproducible without atomics.
+    if (plan.lin_ell_ok) {
+        const int PW = 64 / T, WT = (N + PW - 1) / PW;
+        plan.n_wtiles = WT;
+        plan.wt_grp_start.assign(WT + 1, 0);
+        std::vector<std::pair<int32_t, int32_t>> tmp;              // (landmark, local position)
+        for (int w = 0; w < WT; ++w) {
+            tmp.clear();
+            for (int lane = 0; lane < 64; ++lane) { const int p = w * PW + lane / T, h = lane % T;
+                if (p >= N) break;
+                for (int i = 0; i < R; ++i) { const int s = i * T + h;
+                    if (s < plan.pl_start[p + 1] - plan.pl_start[p]) tmp.emplace_back(g.pl_l[plan.pl_order[plan.pl_start[p] + s]], i * 64 + lane); } }
+            std::sort(tmp.begin(), tmp.end());
+            for (size_t i = 0; i < tmp.size(); ++i) {
+                if (i == 0 || tmp[i].first != tmp[i - 1].first) { plan.grp_lm.push_back(tmp[i].first); plan.grp_pos_start.push_back((int32_t)plan.grp_pos.size()); }
+                plan.grp_pos.push_back(tmp[i].second);
             }
-            const int T = (int)plan.tile_pose_start.size() - 1;
-            plan.tile_grp_start.assign(T + 1, 0);
-            std::vector<std::pair<int32_t, int32_t>> tmp;              // (landmark, local edge)
-            for (int t = 0; t < T; ++t) {
-                int e0 = plan.pl_start[plan.tile_pose_start[t]], e1 = plan.pl_start[plan.tile_pose_start[t + 1]];
-                tmp.clear();
-                for (int e = e0; e < e1; ++e) tmp.emplace_back(g.pl_l[plan.pl_order[e]], e - e0);
-                std::sort(tmp.begin(), tmp.end());
-                for (size_t i = 0; i < tmp.size(); ++i) {
-                    if (i == 0 || tmp[i].first != tmp[i - 1].first) { plan.grp_lm.push_back(tmp[i].first); plan.grp_edge_start.push_back((int32_t)plan.grp_edges.size()); }
-                    plan.grp_edges.push_back(tmp[i].second);
-                }
-                plan.tile_grp_start[t + 1] = (int32_t)plan.grp_lm.size();
-            }
-            plan.grp_edge_start.push_back((int32_t)plan.grp_edges.size());
-            // landmark -> its groups, ascending (= tile order)
-            const int G = (int)plan.grp_lm.size();
-            plan.lm_grp_start.assign(M + 1, 0);
-            for (int q = 0; q < G; ++q) plan.lm_grp_start[plan.grp_lm[q] + 1]++;
-            for (int l = 0; l < M; ++l) plan.lm_grp_start[l + 1] += plan.lm_grp_start[l];
-            plan.lm_grps.resize(G);
-            std::vector<int32_t> fill(plan.lm_grp_start.begin(), plan.lm_grp_start.end() - 1);
-            for (int q = 0; q < G; ++q) plan.lm_grps[fill[plan.grp_lm[q]]++] = q;
+            plan.wt_grp_start[w + 1] = (int32_t)plan.grp_lm.size();
         }
+        plan.grp_pos_start.push_back((int32_t)plan.grp_pos.size());
+        plan.wt_desc.resize((size_t)WT * 4);
+        for (int w = 0; w < WT; ++w) { const int a = plan.wt_grp_start[w], b = plan.wt_grp_start[w + 1];
+            plan.wt_desc[4 * (size_t)w] = a; plan.wt_desc[4 * (size_t)w + 1] = b - a;
+            plan.wt_desc[4 * (size_t)w + 2] = plan.grp_pos_start[a]; plan.wt_desc[4 * (size_t)w + 3] = plan.grp_pos_start[b] - plan.grp_pos_start[a]; }
+        const int G = (int)plan.grp_lm.size();
+        plan.lm_grp_start.assign(M + 1, 0);
+        for (int q = 0; q < G; ++q) plan.lm_grp_start[plan.grp_lm[q] + 1]++;
+        for (int l = 0; l < M; ++l) plan.lm_grp_start[l + 1] += plan.lm_grp_start[l];
+        plan.grp_slot.resize(G);
+        std::vector<int32_t> fill(plan.lm_grp_start.begin(), plan.lm_grp_start.end() - 1);
+        for (int q = 0; q < G; ++q) plan.grp_slot[q] = fill[plan.grp_lm[q]]++;
     }
 
     // ---- elimination order by nested dissection ----
-    B.build_adjacency(pl_pos_of_ins);
+    B.build_adjacency(plan.ell_of_ins);
     B.assigned.assign(B.nfp, 0);
     { std::vector<int32_t> all(B.nfl); for (int l = 0; l < B.nfl; ++l) all[l] = l; B.nd(0, B.nfp, all); }
     const int S = (int)B.sn.size();
@@ -303,8 +327,8 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
 
 // Flat dump: header[16] then arrays, all int32:
 //   header: magic, n_scalar, n_fronts, n_levels, max_front, n_poses, n_lms, n_pl, n_pp, n_asm,
-//           len(bnd_rows), len(child_map), len(children), 0, 0, 0
-//   pose_gidx[n_poses] lm_gidx[n_lms] pl_order[n_pl] pp_order[n_pp]
+//           len(bnd_rows), len(child_map), len(children), ell_len, ell_T, ell_R
+//   pose_gidx[n_poses] lm_gidx[n_lms] pl_order[n_pl] pp_order[n_pp] ell_ins[ell_len]
 //   fronts[n_fronts][13]: npiv nbnd piv0 parent level owner bnd_off map_off asm_off asm_cnt asm_dup child_off child_cnt
 //   bnd_rows child_map children asm_recs[n_asm][4] level_start[n_levels+1] level_fronts[n_fronts]
 void export_plan(const Plan &p, std::vector<int32_t> &out) {
@@ -313,10 +337,10 @@ void export_plan(const Plan &p, std::vector<int32_t> &out) {
     int32_t hdr[16] = {0x47535031, p.n_scalar, (int32_t)p.fronts.size(), nlev, p.max_front,
                        (int32_t)p.pose_gidx.size(), (int32_t)p.lm_gidx.size(), (int32_t)p.pl_order.size(),
                        (int32_t)p.pp_order.size(), (int32_t)p.asm_recs.size(), (int32_t)p.bnd_rows.size(),
-                       (int32_t)p.child_map.size(), (int32_t)p.children.size(), 0, 0, 0};
+                       (int32_t)p.child_map.size(), (int32_t)p.children.size(), (int32_t)p.ell_len, p.ell_T, p.ell_R};
     out.insert(out.end(), hdr, hdr + 16);
     auto app = [&](const std::vector<int32_t> &v) { out.insert(out.end(), v.begin(), v.end()); };
-    app(p.pose_gidx); app(p.lm_gidx); app(p.pl_order); app(p.pp_order);
+    app(p.pose_gidx); app(p.lm_gidx); app(p.pl_order); app(p.pp_order); app(p.ell_ins);
     for (const auto &F : p.fronts) {
         int32_t r[13] = {F.npiv, F.nbnd, F.piv0, F.parent, F.level, F.owner, (int32_t)F.bnd_off, (int32_t)F.map_off,
                          F.asm_off, F.asm_cnt, F.asm_dup, F.child_off, F.child_cnt};

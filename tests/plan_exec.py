@@ -15,7 +15,7 @@ class Plan:
         f = np.asarray(flat, dtype=np.int64)
         assert f[0] == 0x47535031, "bad magic"
         (self.n_scalar, self.n_fronts, self.n_levels, self.max_front, self.n_poses, self.n_lms, self.n_pl,
-         self.n_pp, n_asm, n_bnd, n_map, n_child) = [int(v) for v in f[1:13]]
+         self.n_pp, n_asm, n_bnd, n_map, n_child, self.ell_len, self.ell_T, self.ell_R) = [int(v) for v in f[1:16]]
         o = 16
 
         def take(n, width=1):
@@ -28,6 +28,7 @@ class Plan:
         self.lm_gidx = take(self.n_lms)
         self.pl_order = take(self.n_pl)
         self.pp_order = take(self.n_pp)
+        self.ell_ins = take(self.ell_len)       # device (ELL) index of an observation edge -> insertion index, -1 empty
         fr = take(self.n_fronts, 13)
         (self.npiv, self.nbnd, self.piv0, self.parent, self.level, self.owner, self.bnd_off, self.map_off,
          self.asm_off, self.asm_cnt, self.asm_dup, self.child_off, self.child_cnt) = [fr[:, k] for k in range(13)]
@@ -75,7 +76,10 @@ class Plan:
     def solve(self, blocks):
         """blocks: dict with Hpp_diag [N,9], Hll_diag [M,4], Hpp_off [Epp,9], Hpl [Epl,6], b_pose [N,3], b_lm [M,2]
         in INSERTION order (as the oracle's linearize_blocks returns them).  Returns (dpose [N,3], dlm [M,2], ok)."""
-        Hpl = blocks["Hpl"][self.pl_order] if self.n_pl else blocks["Hpl"]
+        Hpl = np.zeros((self.ell_len, 6))       # assembly records address observation edges by their ELL index
+        if self.n_pl:
+            live = self.ell_ins >= 0
+            Hpl[live] = blocks["Hpl"][self.ell_ins[live]]
         Hpp_off = blocks["Hpp_off"][self.pp_order] if self.n_pp else blocks["Hpp_off"]
         S = self.n_fronts
         Ls, Us = [None] * S, [None] * S
