@@ -232,11 +232,17 @@ int  gs_associate_batch(gs_graph *g, int32_t n, const double *poses_xytheta, int
  * factorises only its own subtrees, exports the update contributions to the shared top of the
  * assembly tree into a dense exchange buffer (device memory), the caller all-reduces that
  * buffer (RCCL sum, fp64), and every rank finishes the top of the tree redundantly. */
-int  gs_dist_configure(gs_graph *g, int32_t rank, int32_t world_size);
-int64_t gs_dist_exchange_doubles(gs_graph *g);         /* length of the exchange buffer   */
-int  gs_dist_set_exchange_buffer(gs_graph *g, void *device_ptr);
-int  gs_dist_iterate_local(gs_graph *g);               /* linearise + local subtrees      */
-int  gs_dist_iterate_finish(gs_graph *g);              /* top of tree + solve + update    */
+int  gs_dist_configure(gs_graph *g, int32_t rank, int32_t world_size);   /* before gs_initialize_optimization */
+int64_t gs_dist_exchange_doubles(gs_graph *g);         /* length of the exchange buffer (after initialize)   */
+int  gs_dist_set_exchange_buffer(gs_graph *g, void *device_ptr);   /* NULL: the library allocates its own   */
+int  gs_dist_iterate_local(gs_graph *g);               /* linearise own edges + own subtrees + contribution  */
+int  gs_dist_iterate_finish(gs_graph *g);              /* after the all-reduce: shared top, solve, update    */
+/* host copies of the exchange buffer (tests; all-reduce over a CPU backend when ranks share one GPU) */
+int  gs_dist_read_exchange(gs_graph *g, double *host_out);
+int  gs_dist_write_exchange(gs_graph *g, const double *host_in);
+/* per vertex (insertion order): known = this rank tracks its estimate; primary = exactly one rank per vertex
+ * (shared and fixed vertices: rank 0), so summing primary-masked estimates over the ranks merges them */
+int  gs_dist_known(gs_graph *g, uint8_t *pose_known, uint8_t *lm_known, uint8_t *pose_primary, uint8_t *lm_primary);
 
 /* ---- Slam-level host mirror (rows f-1/f-2 of SURVEY §8f) ----------------------
  * gs_slam_perform <- Slam::performSLAM graph part (src/slam.cpp:298-338): addPoseToGraph,

@@ -136,6 +136,10 @@ def lib():
     L.gs_cone_to_global_batch.argtypes = [vp, C.c_int32, _dp, C.c_int32, _ip, _dp, _dp]
     L.gs_associate_batch.argtypes = [vp, C.c_int32, _dp, C.c_int32, _ip, _dp, C.c_int32, _dp, _ip,
                                      C.c_double, C.c_double, _ip]
+    L.gs_dist_read_exchange.argtypes = [vp, _dp]
+    L.gs_dist_write_exchange.argtypes = [vp, _dp]
+    u8 = C.POINTER(C.c_uint8)
+    L.gs_dist_known.argtypes = [vp, u8, u8, u8, u8]
     L.gs_slam_perform.argtypes = [vp, _dp, _dp, C.c_int32]
     L.gs_slam_get_map.argtypes = [vp, C.c_int32, _dp, _ip]
     L.gs_slam_get_send_pose.argtypes = [vp, _dp]
@@ -355,6 +359,42 @@ class Graph:
         self._check(self.L.gs_associate_batch(self.h, len(obs), _d(poses), len(poses), _i(po), _d(obs), len(map_xy),
                                               _d(map_xy), _i(map_type), float(thr), float(type_tol), _i(out)))
         return out
+
+    # ---- pose-window shards (one handle per rank / GPU)
+    def dist_configure(self, rank, world):
+        self._check(self.L.gs_dist_configure(self.h, int(rank), int(world)))
+
+    def dist_exchange_doubles(self):
+        return int(self.L.gs_dist_exchange_doubles(self.h))
+
+    def dist_set_exchange_buffer(self, device_ptr):
+        self._check(self.L.gs_dist_set_exchange_buffer(self.h, C.c_void_p(device_ptr)))
+
+    def dist_iterate_local(self):
+        self._check(self.L.gs_dist_iterate_local(self.h))
+
+    def dist_iterate_finish(self):
+        self._check(self.L.gs_dist_iterate_finish(self.h))
+
+    def dist_read_exchange(self):
+        out = np.zeros(max(self.dist_exchange_doubles(), 1))
+        self._check(self.L.gs_dist_read_exchange(self.h, _d(out)))
+        return out[:self.dist_exchange_doubles()]
+
+    def dist_write_exchange(self, buf):
+        buf = _f64(buf)
+        if len(buf) == 0:
+            buf = np.zeros(1)
+        self._check(self.L.gs_dist_write_exchange(self.h, _d(buf)))
+
+    def dist_known(self):
+        """(pose_known, lm_known, pose_primary, lm_primary) boolean arrays, insertion order."""
+        N, M = self.n_poses, self.n_landmarks
+        a = [np.zeros(max(N, 1), dtype=np.uint8), np.zeros(max(M, 1), dtype=np.uint8),
+             np.zeros(max(N, 1), dtype=np.uint8), np.zeros(max(M, 1), dtype=np.uint8)]
+        u8 = C.POINTER(C.c_uint8)
+        self._check(self.L.gs_dist_known(self.h, *[x.ctypes.data_as(u8) for x in a]))
+        return a[0][:N].astype(bool), a[1][:M].astype(bool), a[2][:N].astype(bool), a[3][:M].astype(bool)
 
     # ---- convenience: load the arrays of track.bench_graph (ids = indices)
     def load_bench_graph(self, g):

@@ -327,6 +327,7 @@ static int upload_graph(gs_graph *g) {
     { const size_t L = (size_t)P.ell_len;                                                                    // ELL streams
       std::vector<int32_t> l(L, -1); std::vector<double> z(L * 2, 0.0), w(L * 3, 0.0);
       for (size_t e = 0; e < L; ++e) { const int k = P.ell_ins[e]; if (k < 0) continue;
+          if (P.world > 1 && P.pl_rank[k] != P.rank) continue;          // pose-window shards: evaluated by another rank
           l[e] = h.pl_l[k]; z[e] = h.pl_z[2 * (size_t)k]; z[L + e] = h.pl_z[2 * (size_t)k + 1];
           for (int t = 0; t < 3; ++t) w[t * L + e] = h.pl_info[3 * (size_t)k + t]; }
       UP(ell_l, l); UP(ell_z, z); UP(ell_w, w); }
@@ -336,20 +337,37 @@ static int upload_graph(gs_graph *g) {
           double *o = &zi[5 * (size_t)pos]; o[0] = inv[0]; o[1] = inv[1]; o[2] = inv[2]; o[3] = std::cos(inv[2]); o[4] = std::sin(inv[2]);
           for (int t = 0; t < 6; ++t) w[6 * (size_t)pos + t] = h.pp_info[6 * (size_t)k + t]; }
       UP(pp_zinv, zi); UP(pp_info, w); }
-    UP(lm_start, P.lm_start); UP(lm_edges, P.lm_edges); UP(ppadj_start, P.ppadj_start); UP(ppinc, P.ppinc);
+    UP(lm_start, P.lm_start); UP(lm_edges, P.lm_edges); UP(ppadj_start, P.ppadj_start);
+    { std::vector<int32_t> inc = P.ppinc;                                 // incidences of edges another rank evaluates: edge = -1
+      if (P.world > 1) for (size_t q = 0; q * 4 < inc.size(); ++q) if (P.pp_rank[inc[4 * q]] != P.rank) inc[4 * q] = -1;
+      UP(ppinc, inc); }
 #define AL(dst, cnt) if ((rc = dev_alloc(g, &d.dst, (size_t)(cnt))) != GS_OK) return rc
-    d.n_wtiles = 0; d.n_groups = 0;
+#define ZERO(dst, cnt) HIP_TRY(hipMemsetAsync(d.dst, 0, std::max<size_t>((size_t)(cnt), 1) * sizeof(*d.dst), g->stream))
+    d.n_wtiles = 0; d.n_groups = 0; d.wt_lo = 0; d.wt_hi = 0; d.rank = P.rank;
     if (P.lin_ell_ok && !g->force_gather) {
         d.n_wtiles = P.n_wtiles; d.n_groups = (int32_t)P.grp_lm.size();
         UP(wt_desc, P.wt_desc); UP(grp_pos_start, P.grp_pos_start); UP(grp_slot, P.grp_slot); UP(lm_grp_start, P.lm_grp_start);
         std::vector<uint16_t> pos16(P.grp_pos.begin(), P.grp_pos.end());
         UP(grp_pos, pos16);
-        AL(lm_part, (size_t)d.n_groups * 5);
-    }
+        AL(lm_part, (size_t)d.n_groups * 5); ZERO(lm_part, (size_t)d.n_groups * 5);
+        d.wt_lo = 0; d.wt_hi = P.n_wtiles;
+        if (P.world > 1) {                                                // the wave tiles this shard has any edge in
+            const int PW = 64 / P.ell_T; int lo = P.n_wtiles, hi = 0;
+            for (int p = 0; p < N; ++p) { bool any = false;
+                for (int s = P.pl_start[p]; s < P.pl_start[p + 1] && !any; ++s) any = P.pl_rank[P.pl_order[s]] == P.rank;
+                for (int q = P.ppadj_start[p]; q < P.ppadj_start[p + 1] && !any; ++q) any = P.pp_rank[P.ppadj[q] >> 1] == P.rank;
+                if (any) { lo = std::min(lo, p / PW); hi = std::max(hi, p / PW + 1); } }
+            d.wt_lo = std::min(lo, hi); d.wt_hi = hi;
+        }
+    } else if (P.world > 1) return fail(GS_ERR_INVALID, "pose-window shards need the fused linearisation layout (<= 32 observations per pose)");
     AL(Hpp_diag, (size_t)N * 6); AL(Hll_diag, (size_t)M * 3); AL(Hpp_off, (size_t)Epp * 9); AL(Hpl, (size_t)P.ell_len * 6);
     AL(b_pose, (size_t)N * 3); AL(b_lm, (size_t)M * 2);
+    // blocks of edges / tiles this rank never evaluates must read as zero
+    ZERO(Hpp_diag, (size_t)N * 6); ZERO(Hll_diag, (size_t)M * 3); ZERO(Hpp_off, (size_t)Epp * 9); ZERO(Hpl, (size_t)P.ell_len * 6);
+    ZERO(b_pose, (size_t)N * 3); ZERO(b_lm, (size_t)M * 2);
     d.n_chi2_partial = std::max((N + 255) / 256, d.n_wtiles);
-    AL(chi2_partial, d.n_chi2_partial); AL(chi2, 80);
+    AL(chi2_partial, d.n_chi2_partial); AL(chi2, 80); ZERO(chi2_partial, d.n_chi2_partial);
+    UP(pose_known, P.pose_known); UP(lm_known, P.lm_known);
     // plan
     { std::vector<DevFront> df(P.fronts.size());
       for (size_t s = 0; s < P.fronts.size(); ++s) { const Front &F = P.fronts[s]; DevFront &o = df[s];
@@ -357,7 +375,14 @@ static int upload_graph(gs_graph *g) {
           o.asm_dup = F.asm_dup; o.child_off = F.child_off; o.child_cnt = F.child_cnt; o.owner = F.owner; o.level = F.level; o.pad0 = 0;
           o.bnd_off = F.bnd_off; o.map_off = F.map_off; o.L_off = F.L_off; o.U_off = F.U_off; }
       UP(fronts, df); d.n_fronts = (int32_t)df.size(); }
-    UP(bnd_rows, P.bnd_rows); UP(child_map, P.child_map); UP(children, P.children); UP(level_fronts, P.level_fronts);
+    UP(bnd_rows, P.bnd_rows); UP(child_map, P.child_map); UP(children, P.children);
+    // level lists on the device: this rank's own fronts, then the shared top (empty when world == 1)
+    { std::vector<int32_t> lf = P.level_fronts_owned; g->shared_base = (int)lf.size();
+      lf.insert(lf.end(), P.level_fronts_shared.begin(), P.level_fronts_shared.end());
+      UP(level_fronts, lf); }
+    if (P.world > 1) { UP(x_off, P.x_off);
+        if (!g->exchange_external) { AL(exchange, P.exchange_doubles); ZERO(exchange, P.exchange_doubles); }
+        else d.exchange = g->exchange; }
     { std::vector<int32_t> recs(P.asm_recs.size() * 4);
       for (size_t t = 0; t < P.asm_recs.size(); ++t) { recs[4 * t] = P.asm_recs[t].kind; recs[4 * t + 1] = P.asm_recs[t].src;
           recs[4 * t + 2] = P.asm_recs[t].r0; recs[4 * t + 3] = P.asm_recs[t].c0; }
@@ -369,22 +394,28 @@ static int upload_graph(gs_graph *g) {
     HIP_TRY(hipMemsetAsync(d.dlm, 0, std::max<size_t>((size_t)M * 2, 1) * sizeof(double), g->stream));
     // per-level launch parameters and the global workspace for fronts beyond the LDS limit
     const int nlev = (int)P.level_start.size() - 1;
-    g->lvl_max_f.assign(nlev, 0); g->lvl_max_npiv.assign(nlev, 0); g->lvl_max_nbnd.assign(nlev, 0);
-    int64_t ws = 0; const int lim = factor_lds_limit_f();
-    for (int l = 0; l < nlev; ++l) {
-        for (int q = P.level_start[l]; q < P.level_start[l + 1]; ++q) { const Front &F = P.fronts[P.level_fronts[q]];
-            g->lvl_max_f[l] = std::max(g->lvl_max_f[l], F.npiv + F.nbnd);
-            g->lvl_max_npiv[l] = std::max(g->lvl_max_npiv[l], F.npiv); g->lvl_max_nbnd[l] = std::max(g->lvl_max_nbnd[l], F.nbnd); }
-        if (g->lvl_max_f[l] > lim) { int64_t f = g->lvl_max_f[l]; int64_t stride = ((f + 1) | 1) * f;
-            d.front_ws_stride = std::max(d.front_ws_stride, stride); ws = std::max(ws, stride * (int64_t)(P.level_start[l + 1] - P.level_start[l])); }
-    }
-    if (ws > 0) { // every oversize level uses the same stride
-        int64_t need = 0;
-        for (int l = 0; l < nlev; ++l) if (g->lvl_max_f[l] > lim) need = std::max(need, d.front_ws_stride * (int64_t)(P.level_start[l + 1] - P.level_start[l]));
-        AL(front_ws, need);
+    const int lim = factor_lds_limit_f();
+    int64_t max_blocks_oversize = 0;
+    auto level_params = [&](const std::vector<int32_t> &start, const std::vector<int32_t> &list, gs_graph::LevelSet &ls) {
+        ls.start = start; ls.max_f.assign(nlev, 0); ls.max_npiv.assign(nlev, 0); ls.max_nbnd.assign(nlev, 0);
+        for (int l = 0; l < nlev; ++l) {
+            for (int q = start[l]; q < start[l + 1]; ++q) { const Front &F = P.fronts[list[q]];
+                ls.max_f[l] = std::max(ls.max_f[l], F.npiv + F.nbnd);
+                ls.max_npiv[l] = std::max(ls.max_npiv[l], F.npiv); ls.max_nbnd[l] = std::max(ls.max_nbnd[l], F.nbnd); }
+            if (ls.max_f[l] > lim) { const int64_t f = ls.max_f[l];
+                d.front_ws_stride = std::max(d.front_ws_stride, ((f + 1) | 1) * f);
+                max_blocks_oversize = std::max<int64_t>(max_blocks_oversize, start[l + 1] - start[l]); }
+        }
+    };
+    level_params(P.level_start_owned, P.level_fronts_owned, g->own);
+    level_params(P.level_start_shared, P.level_fronts_shared, g->shared);
+    if (max_blocks_oversize > 0) {      // fronts beyond the LDS limit use a global workspace, one slice per block
+        max_blocks_oversize = std::max<int64_t>(max_blocks_oversize, (int64_t)P.level_fronts_shared.size());
+        AL(front_ws, d.front_ws_stride * max_blocks_oversize);
     }
 #undef UP
 #undef AL
+#undef ZERO
     HIP_TRY(hipStreamSynchronize(g->stream));
     g->dev_valid = true; g->dev_estimates_newer = false;
     g->dev_estimate_version = h.estimate_version;
@@ -447,32 +478,45 @@ static int ensure_ready(gs_graph *g) {
 }
 
 // ------------------------------------------------------------------ one Gauss-Newton iteration (A5-A9)
-static void enqueue_factor(gs_graph *g) {
-    const Plan &P = g->plan; const int nlev = (int)P.level_start.size() - 1;
+// own fronts bottom-up (mode 0), shared top bottom-up from the all-reduced exchange buffer (mode 2)
+static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int base, int mode) {
+    const int nlev = (int)ls.start.size() - 1;
     for (int l = 0; l < nlev; ++l)
-        launch_factor_level(g->d, P.level_start[l], P.level_start[l + 1] - P.level_start[l], g->lvl_max_f[l], g->stream);
+        launch_factor_level(g->d, base + ls.start[l], ls.start[l + 1] - ls.start[l], ls.max_f[l], mode, g->stream);
 }
-static void enqueue_backsolve(gs_graph *g) {
-    const Plan &P = g->plan; const int nlev = (int)P.level_start.size() - 1;
+static void enqueue_backsolve_levels(gs_graph *g, const gs_graph::LevelSet &ls, int base) {
+    const int nlev = (int)ls.start.size() - 1;
     for (int l = nlev - 1; l >= 0; --l)
-        launch_backsolve_level(g->d, P.level_start[l], P.level_start[l + 1] - P.level_start[l], g->lvl_max_npiv[l], g->lvl_max_nbnd[l], g->stream);
+        launch_backsolve_level(g->d, base + ls.start[l], ls.start[l + 1] - ls.start[l], ls.max_npiv[l], ls.max_nbnd[l], g->stream);
 }
-static void enqueue_iteration(gs_graph *g, bool timed) {
+// pose-window shards, first half: linearise this shard's edges, factorise its own subtrees, write its contribution
+// to every shared front into the exchange buffer (the caller all-reduces that buffer: RCCL sum, fp64)
+static void enqueue_local(gs_graph *g, bool timed) {
     if (timed) hipEventRecord(g->ev[0], g->stream);
     launch_linearize(g->d, g->stream);
     if (timed) hipEventRecord(g->ev[1], g->stream);
-    enqueue_factor(g);
+    enqueue_factor_levels(g, g->own, 0, 0);
+    const int nshared = (int)g->plan.level_fronts_shared.size();
+    if (nshared > 0) { int mf = 0; for (int v : g->shared.max_f) mf = std::max(mf, v);
+        launch_factor_level(g->d, g->shared_base, nshared, mf, 1, g->stream); }
+}
+// second half: the shared top (redundantly on every rank), backward solve top-down, update
+static void enqueue_finish(gs_graph *g, bool timed) {
+    enqueue_factor_levels(g, g->shared, g->shared_base, 2);
     if (timed) hipEventRecord(g->ev[2], g->stream);
-    enqueue_backsolve(g);
+    enqueue_backsolve_levels(g, g->shared, g->shared_base);
+    enqueue_backsolve_levels(g, g->own, 0);
     if (timed) hipEventRecord(g->ev[3], g->stream);
     launch_update(g->d, g->stream);
     if (timed) hipEventRecord(g->ev[4], g->stream);
     g->dev_estimates_newer = true;
 }
+static void enqueue_iteration(gs_graph *g, bool timed) { enqueue_local(g, timed); enqueue_finish(g, timed); }
 
 extern "C" int gs_iterate(gs_graph *g) {
     if (!g) return fail(GS_ERR_INVALID, "null graph");
     if (!g->dev_valid || g->plan_version != g->h.structure_version) return fail(GS_ERR_NOT_INITIALIZED, "call gs_initialize_optimization first");
+    if (g->plan.world > 1) return fail(GS_ERR_INVALID, "sharded graph: use gs_dist_iterate_local / all-reduce / gs_dist_iterate_finish");
     int rc = ensure_device(g); if (rc != GS_OK) return rc;
     enqueue_iteration(g, false);
     hipError_t e = hipGetLastError();
@@ -501,6 +545,7 @@ extern "C" int gs_get_stats(gs_graph *g, gs_stats *s) {
 extern "C" int gs_optimize(gs_graph *g, int32_t iterations, gs_stats *stats) {
     if (!g) return fail(GS_ERR_INVALID, "null graph");
     if (iterations < 0) return fail(GS_ERR_INVALID, "negative iteration count");
+    if (g->world > 1) return fail(GS_ERR_INVALID, "sharded graph: drive gs_dist_iterate_local / all-reduce / gs_dist_iterate_finish");
     // g2o: optimize() is always preceded by initializeOptimization() (reference src/slam.cpp:480-481);
     // the plan is rebuilt only when the structure changed since the last call.
     int rc = ensure_ready(g); if (rc != GS_OK) return rc;
@@ -604,6 +649,7 @@ extern "C" int gs_export_delta(gs_graph *g, double *dpose, double *dlm) {
 }
 extern "C" int gs_time_iterations(gs_graph *g, int32_t reps, gs_stats *s) {
     if (!g || !s || reps <= 0) return fail(GS_ERR_INVALID, "bad argument");
+    if (g->world > 1) return fail(GS_ERR_INVALID, "sharded graph: time the two halves from the caller");
     int rc = ensure_ready(g); if (rc != GS_OK) return rc;
     const int N = g->d.N, M = g->d.M;
     double *sp = nullptr, *sl = nullptr;                        // save estimates
@@ -693,6 +739,67 @@ extern "C" int gs_dist_configure(gs_graph *g, int32_t rank, int32_t world) {
     return GS_OK;
 }
 extern "C" int64_t gs_dist_exchange_doubles(gs_graph *g) { return (g && g->plan.valid) ? g->plan.exchange_doubles : 0; }
-extern "C" int gs_dist_set_exchange_buffer(gs_graph *g, void *p) { if (!g) return fail(GS_ERR_INVALID, "null graph"); g->exchange = (double *)p; return GS_OK; }
-extern "C" int gs_dist_iterate_local(gs_graph *g) { (void)g; return fail(GS_ERR_NOT_INITIALIZED, "pose-window sharding not configured"); }
-extern "C" int gs_dist_iterate_finish(gs_graph *g) { (void)g; return fail(GS_ERR_NOT_INITIALIZED, "pose-window sharding not configured"); }
+extern "C" int gs_dist_set_exchange_buffer(gs_graph *g, void *p) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    g->exchange = (double *)p; g->exchange_external = p != nullptr;
+    if (g->dev_valid && p) g->d.exchange = (double *)p;        // the previous (own) buffer stays allocated until the next upload
+    return GS_OK;
+}
+static int dist_ready(gs_graph *g) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    if (!g->dev_valid || g->plan_version != g->h.structure_version) return fail(GS_ERR_NOT_INITIALIZED, "call gs_initialize_optimization first");
+    if (g->plan.world > 1 && !g->d.exchange) return fail(GS_ERR_NOT_INITIALIZED, "no exchange buffer");
+    return ensure_device(g);
+}
+extern "C" int gs_dist_iterate_local(gs_graph *g) {
+    int rc = dist_ready(g); if (rc != GS_OK) return rc;
+    enqueue_local(g, false);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return GS_OK;
+}
+extern "C" int gs_dist_iterate_finish(gs_graph *g) {
+    int rc = dist_ready(g); if (rc != GS_OK) return rc;
+    enqueue_finish(g, false);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return 1;
+}
+// host copies of the exchange buffer (tests; all-reduce over a CPU backend when ranks share one GPU)
+extern "C" int gs_dist_read_exchange(gs_graph *g, double *host) {
+    int rc = dist_ready(g); if (rc != GS_OK) return rc;
+    if (!host) return fail(GS_ERR_INVALID, "null buffer");
+    if (g->plan.exchange_doubles > 0) HIP_TRY(hipMemcpyAsync(host, g->d.exchange, (size_t)g->plan.exchange_doubles * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return GS_OK;
+}
+extern "C" int gs_dist_write_exchange(gs_graph *g, const double *host) {
+    int rc = dist_ready(g); if (rc != GS_OK) return rc;
+    if (!host) return fail(GS_ERR_INVALID, "null buffer");
+    if (g->plan.exchange_doubles > 0) HIP_TRY(hipMemcpyAsync(g->d.exchange, host, (size_t)g->plan.exchange_doubles * sizeof(double), hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return GS_OK;
+}
+// which vertex estimates this rank tracks (its own subtrees + the shared top), insertion order; a vertex is
+// `primary` on exactly one rank (shared vertices: rank 0), so summing primary-masked estimates over ranks merges them
+extern "C" int gs_dist_known(gs_graph *g, uint8_t *pose_known, uint8_t *lm_known, uint8_t *pose_primary, uint8_t *lm_primary) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    if (!g->plan.valid) return fail(GS_ERR_NOT_INITIALIZED, "no plan built");
+    const Plan &P = g->plan;
+    auto primary = [&](int gidx, uint8_t known, uint8_t fixed) -> uint8_t {
+        if (fixed || gidx < 0) return P.rank == 0;                      // fixed vertices never move: take them from rank 0
+        if (!known) return 0;
+        // shared <=> known on every rank
+        return 1; };
+    // a shared vertex is known everywhere; make rank 0 its primary holder
+    std::vector<int32_t> front_of_scalar;                              // scalar -> front owner lookup via pivots
+    front_of_scalar.assign(P.n_scalar, 0);
+    for (size_t s = 0; s < P.fronts.size(); ++s) for (int k = 0; k < P.fronts[s].npiv; ++k) front_of_scalar[P.fronts[s].piv0 + k] = P.fronts[s].owner;
+    for (int p = 0; p < g->h.n_poses(); ++p) { const int gi = P.pose_gidx[p]; uint8_t kn = P.pose_known[p], pr = primary(gi, kn, g->h.pose_fixed[p]);
+        if (gi >= 0 && kn && front_of_scalar[gi] < 0) pr = P.rank == 0;
+        if (pose_known) pose_known[p] = kn; if (pose_primary) pose_primary[p] = pr; }
+    for (int l = 0; l < g->h.n_lms(); ++l) { const int gi = P.lm_gidx[l]; uint8_t kn = P.lm_known[l], pr = primary(gi, kn, g->h.lm_fixed[l]);
+        if (gi >= 0 && kn && front_of_scalar[gi] < 0) pr = P.rank == 0;
+        if (lm_known) lm_known[l] = kn; if (lm_primary) lm_primary[l] = pr; }
+    return GS_OK;
+}

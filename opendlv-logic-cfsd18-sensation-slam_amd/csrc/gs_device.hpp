@@ -56,6 +56,11 @@ struct DevGraph {
     double *dpose = nullptr, *dlm = nullptr;                    // last increment per vertex
     int32_t *fail = nullptr;                                    // [0] != 0 : non-positive pivot met
     double *front_ws = nullptr; int64_t front_ws_stride = 0;    // global workspace for fronts too big for LDS
+    // pose-window shards (world == 1: everything is "own", no exchange)
+    int32_t rank = 0, wt_lo = 0, wt_hi = 0;                     // this shard sweeps wave tiles [wt_lo, wt_hi)
+    uint8_t *pose_known = nullptr, *lm_known = nullptr;         // vertex estimates tracked by this rank
+    int64_t *x_off = nullptr;                                   // front -> slot offset in the exchange buffer
+    double *exchange = nullptr;                                 // dense slots of the shared fronts (all-reduced)
 };
 
 // launchers (gs_kernels.hip); all asynchronous on `st`
@@ -63,7 +68,8 @@ void launch_linearize(const DevGraph &d, hipStream_t st);       // fused ELL ker
 void launch_linearize_gather(const DevGraph &d, hipStream_t st);
 void launch_linearize_finalize(const DevGraph &d, hipStream_t st);   // H_ll, b_l, chi2 total from the fused kernel's partials
 void launch_chi2_only(const DevGraph &d, hipStream_t st);
-void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f, hipStream_t st);
+// mode: 0 own front, 1 contribution of this rank to a shared front (-> exchange), 2 shared front from the exchange
+void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f, int mode, hipStream_t st);
 void launch_backsolve_level(const DevGraph &d, int level_off, int count, int max_npiv, int max_nbnd, hipStream_t st);
 void launch_update(const DevGraph &d, hipStream_t st);
 void launch_polar_to_xy(int n, const double *az, const double *zen, const double *dist, double lidar, double *out, hipStream_t st);

@@ -92,7 +92,12 @@ struct Plan {
     // multi-GPU
     int32_t world = 1, rank = 0;
     int32_t n_shared_fronts = 0;            // fronts with owner == -1
-    int64_t exchange_doubles = 0;           // total size of the update matrices feeding shared fronts
+    int64_t exchange_doubles = 0;           // dense (f+1) x f slots of all shared fronts: the all-reduced buffer
+    std::vector<int32_t> pl_rank, pp_rank;  // insertion order: the rank that evaluates the edge
+    std::vector<uint8_t> pose_known, lm_known;   // this rank tracks the vertex's estimate (own subtree or shared top)
+    std::vector<int32_t> level_start_owned, level_fronts_owned;    // this rank's fronts by level
+    std::vector<int32_t> level_start_shared, level_fronts_shared;  // shared top by level
+    std::vector<int64_t> x_off;             // front -> offset of its slot in the exchange buffer (-1 not shared)
     double ms_build = 0;
 };
 

@@ -11,6 +11,9 @@
 #include "gs_host.hpp"
 
 struct gs_graph {
+    // launch parameters of one list of fronts grouped by level
+    struct LevelSet { std::vector<int32_t> start; std::vector<int> max_f, max_npiv, max_nbnd; };
+
     gs_config cfg{};
     int device = 0;
     bool host_only = false;                 // cfg.device == -2: no HIP calls, no arithmetic
@@ -24,9 +27,11 @@ struct gs_graph {
     uint64_t dev_estimate_version = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
     hipEvent_t ev[8]{};
-    std::vector<int> lvl_max_f, lvl_max_npiv, lvl_max_nbnd;
+    LevelSet own, shared;                   // this rank's fronts / the shared top (pose-window shards)
+    int shared_base = 0;                    // offset of the shared list inside d.level_fronts
     double ms_structure = 0;
-    int rank = 0, world = 1; double *exchange = nullptr;
+    int rank = 0, world = 1;
+    double *exchange = nullptr; bool exchange_external = false;   // caller-provided exchange buffer (e.g. a torch tensor)
     bool force_gather = false;              // cfg.linearize_gather
 };
 

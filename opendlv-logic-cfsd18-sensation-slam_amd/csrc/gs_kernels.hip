@@ -217,6 +217,7 @@ template <bool WRITE_H>
 __device__ __forceinline__ double pp_incidence_q(const DevGraph &d, int q, double H[6], double b[3]) {
     const int4 inc = reinterpret_cast<const int4 *>(d.ppinc)[q];                 // {edge, role, i, j}
     const int k = inc.x, i = inc.z, j = inc.w;
+    if (k < 0) return 0.0;                                                       // evaluated by another shard
     double xi[3], xj[3], z5[5], w[6];
 #pragma unroll
     for (int t = 0; t < 3; ++t) { xi[t] = d.pose_est[3 * i + t]; xj[t] = d.pose_est[3 * j + t]; }
@@ -329,8 +330,8 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
     __shared__ double s_lc[4][5][LIN_R * 64];
     __shared__ uint16_t s_gp[4][LIN_R * 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int wt = blockIdx.x * 4 + wave;
-    if (wt >= d.n_wtiles) return;                                  // whole wave leaves; no block-level barrier below
+    const int wt = d.wt_lo + blockIdx.x * 4 + wave;                // a shard only sweeps the wave tiles it has edges in
+    if (wt >= d.wt_hi) return;                                     // whole wave leaves; no block-level barrier below
     const int p = wt * PW + lane / T, h = lane % T;
     const bool live = p < d.N;
     const int64_t L = d.ell_len, S = (int64_t)T * d.N;
@@ -367,8 +368,9 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
     const bool has_inc = live && (q0 + h < q1);
     int4 inc = make_int4(0, 0, 0, 0);
     double xi[3] = {0, 0, 0}, xj[3] = {0, 0, 0}, z5[5] = {0, 0, 0, 1, 0}, wpp[6] = {0, 0, 0, 0, 0, 0}; bool fi = true, fj = true;
-    if (has_inc) {
-        inc = reinterpret_cast<const int4 *>(d.ppinc)[q0 + h];
+    if (has_inc) inc = reinterpret_cast<const int4 *>(d.ppinc)[q0 + h];
+    const bool inc_mine = has_inc && inc.x >= 0;                   // edge -1: evaluated by another shard
+    if (inc_mine) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) { xi[t] = d.pose_est[3 * inc.z + t]; xj[t] = d.pose_est[3 * inc.w + t]; }
 #pragma unroll
@@ -401,12 +403,12 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
             s_lc[wave][0][pos] = hl0; s_lc[wave][1][pos] = hl1; s_lc[wave][2][pos] = hl2; s_lc[wave][3][pos] = bl0; s_lc[wave][4][pos] = bl1; }
     }
     // ---- odometry incidences
-    if (has_inc) {
+    if (inc_mine) {
         double si, ci;
         if (inc.z == p) { si = sn; ci = cs; } else sincos(xi[2], &si, &ci);
         chi += pp_incidence<true>(d, inc.x, inc.y, xi, xj, ci, si, z5, wpp, fi, fj, H, b);
-        for (int q = q0 + h + T; q < q1; q += T) chi += pp_incidence_q<true>(d, q, H, b);
     }
+    if (has_inc) for (int q = q0 + h + T; q < q1; q += T) chi += pp_incidence_q<true>(d, q, H, b);
     // ---- pose sums: xor-shuffle over the T lanes of the pose, then each lane stores its share of the 9 components
 #pragma unroll
     for (int off = 1; off < T; off <<= 1) {
@@ -487,7 +489,8 @@ void launch_linearize_finalize(const DevGraph &d, hipStream_t st) {
 }
 void launch_linearize(const DevGraph &d, hipStream_t st) {
     if (d.n_wtiles <= 0) { launch_linearize_gather(d, st); return; }
-    const dim3 grid((d.n_wtiles + 3) / 4), block(256);
+    if (d.wt_hi <= d.wt_lo) return;
+    const dim3 grid((d.wt_hi - d.wt_lo + 3) / 4), block(256);
     switch (d.ell_T) {
         case 1: hipLaunchKernelGGL(k_linearize_ell<1>, grid, block, 0, st, d); break;
         case 2: hipLaunchKernelGGL(k_linearize_ell<2>, grid, block, 0, st, d); break;
@@ -554,26 +557,39 @@ __device__ __forceinline__ void apply_asm(const DevGraph &d, const int32_t *rec,
     }
 }
 
+// mode 0: a front of this rank's own subtree (or the single-GPU case): originals + all children, factorise.
+// mode 1: this rank's CONTRIBUTION to a shared front (pose-window shards): originals it evaluated + the update
+//         matrices of the children it owns, written to the front's slot of the exchange buffer; no factorisation.
+// mode 2: a shared front after the all-reduce: start from the summed slot, add the shared children, factorise.
+enum { FRONT_OWN = 0, FRONT_CONTRIB = 1, FRONT_TOP = 2 };
 template <bool USE_LDS>
-__global__ void __launch_bounds__(256) k_factor_level(DevGraph d, int level_off) {
+__global__ void __launch_bounds__(256) k_factor_level(DevGraph d, int level_off, int mode) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int s = d.level_fronts[level_off + blockIdx.x];
     const DevFront fr = d.fronts[s];
     const int npiv = fr.npiv, nbnd = fr.nbnd, f = npiv + nbnd, ld = (f + 1) | 1;
     double *F = USE_LDS ? smem : d.front_ws + (int64_t)blockIdx.x * d.front_ws_stride;
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < ld * f; idx += 256) F[idx] = 0.0;
-    __syncthreads();
-    const int nuniq = fr.asm_cnt - fr.asm_dup;
-    for (int t = tid; t < nuniq; t += 256) apply_asm(d, d.asm_recs + 4 * (int64_t)(fr.asm_off + t), F, ld, f);
-    __syncthreads();
-    if (fr.asm_dup > 0) {
-        if (tid == 0) for (int t = nuniq; t < fr.asm_cnt; ++t) apply_asm(d, d.asm_recs + 4 * (int64_t)(fr.asm_off + t), F, ld, f);
+    if (mode == FRONT_TOP) {
+        const double *X = d.exchange + d.x_off[s];
+        for (int idx = tid; idx < (f + 1) * f; idx += 256) { int c = idx / (f + 1), r = idx - c * (f + 1); F[c * ld + r] = X[idx]; }
         __syncthreads();
+    } else {
+        for (int idx = tid; idx < ld * f; idx += 256) F[idx] = 0.0;
+        __syncthreads();
+        const int nuniq = fr.asm_cnt - fr.asm_dup;
+        for (int t = tid; t < nuniq; t += 256) apply_asm(d, d.asm_recs + 4 * (int64_t)(fr.asm_off + t), F, ld, f);
+        __syncthreads();
+        if (fr.asm_dup > 0) {
+            if (tid == 0) for (int t = nuniq; t < fr.asm_cnt; ++t) apply_asm(d, d.asm_recs + 4 * (int64_t)(fr.asm_off + t), F, ld, f);
+            __syncthreads();
+        }
     }
     for (int ci = 0; ci < fr.child_cnt; ++ci) {
         const int c = d.children[fr.child_off + ci];
         const DevFront ch = d.fronts[c];
+        if (mode == FRONT_CONTRIB && ch.owner != d.rank) continue;      // block-uniform
+        if (mode == FRONT_TOP && ch.owner >= 0) continue;               // owned children came in through the all-reduce
         const int nb = ch.nbnd, ldu = nb + 1;
         const double *U = d.Ubuf + ch.U_off;
         const int32_t *map = d.child_map + ch.map_off;
@@ -585,6 +601,11 @@ __global__ void __launch_bounds__(256) k_factor_level(DevGraph d, int level_off)
             }
         }
         __syncthreads();
+    }
+    if (mode == FRONT_CONTRIB) {
+        double *X = d.exchange + d.x_off[s];
+        for (int idx = tid; idx < (f + 1) * f; idx += 256) { int c = idx / (f + 1), r = idx - c * (f + 1); X[idx] = (r >= c) ? F[c * ld + r] : 0.0; }
+        return;
     }
     // right-looking partial Cholesky
     const int tx = tid & 15, ty = tid >> 4;
@@ -619,15 +640,15 @@ int factor_lds_limit_f() {
     return f;
 }
 
-void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f, hipStream_t st) {
+void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f, int mode, hipStream_t st) {
     if (count <= 0) return;
     int64_t bytes = (int64_t)((max_f + 1) | 1) * max_f * 8;
     if (bytes <= LDS_LIMIT_BYTES) {
         static bool attr_set = false;
         if (!attr_set) { hipFuncSetAttribute((const void *)k_factor_level<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES); attr_set = true; }
-        hipLaunchKernelGGL(k_factor_level<true>, dim3(count), dim3(256), (size_t)bytes, st, d, level_off);
+        hipLaunchKernelGGL(k_factor_level<true>, dim3(count), dim3(256), (size_t)bytes, st, d, level_off, mode);
     } else {
-        hipLaunchKernelGGL(k_factor_level<false>, dim3(count), dim3(256), 0, st, d, level_off);
+        hipLaunchKernelGGL(k_factor_level<false>, dim3(count), dim3(256), 0, st, d, level_off, mode);
     }
 }
 
@@ -676,15 +697,16 @@ void launch_backsolve_level(const DevGraph &d, int level_off, int count, int max
 // ------------------------------------------------------------------ A9
 __global__ void __launch_bounds__(256) k_update(DevGraph d) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
+    // pose-window shards: a rank only tracks the vertices of its own subtrees and of the shared top
     if (t < d.N) {
-        int g = d.pose_gidx[t];
+        int g = d.pose_known[t] ? d.pose_gidx[t] : -1;
         double dx = 0, dy = 0, dt = 0;
         if (g >= 0) { dx = d.xe[g]; dy = d.xe[g + 1]; dt = d.xe[g + 2];
             d.pose_est[3 * t] += dx; d.pose_est[3 * t + 1] += dy;
             d.pose_est[3 * t + 2] = normalize_theta(d.pose_est[3 * t + 2] + dt); }
         d.dpose[3 * t] = dx; d.dpose[3 * t + 1] = dy; d.dpose[3 * t + 2] = dt;
     } else if (t < d.N + d.M) {
-        int l = t - d.N, g = d.lm_gidx[l];
+        int l = t - d.N, g = d.lm_known[l] ? d.lm_gidx[l] : -1;
         double dx = 0, dy = 0;
         if (g >= 0) { dx = d.xe[g]; dy = d.xe[g + 1]; d.lm_est[2 * l] += dx; d.lm_est[2 * l + 1] += dy; }
         d.dlm[2 * l] = dx; d.dlm[2 * l + 1] = dy;

@@ -319,7 +319,62 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     plan.level_fronts.resize(S);
     { std::vector<int32_t> fill(plan.level_start.begin(), plan.level_start.end() - 1);
       for (int s = 0; s < S; ++s) plan.level_fronts[fill[plan.fronts[s].level]++] = s; }
-    plan.world = opt.world; plan.rank = opt.rank;
+    // ---- pose-window shards: rank r owns the subtrees whose poses all lie in the r-th contiguous
+    // window of the free-pose sequence; every front above them is "shared" (owner -1): the window-boundary
+    // separator poses and the landmarks seen from more than one window.  An edge is evaluated by exactly one rank,
+    // one that knows both endpoint estimates (owner of an interior endpoint, else the window of the pose).
+    plan.world = std::max(1, opt.world); plan.rank = opt.rank;
+    plan.pl_rank.assign(Epl, 0); plan.pp_rank.assign(Epp, 0);
+    plan.pose_known.assign(N, 1); plan.lm_known.assign(M, 1);
+    plan.level_start_owned = plan.level_start; plan.level_fronts_owned = plan.level_fronts;
+    plan.level_start_shared.assign(nlev + 1, 0);
+    if (plan.world > 1) {
+        const int W = plan.world;
+        auto window = [&](int fpos) { return (int)((int64_t)fpos * W / std::max(1, B.nfp)); };
+        std::vector<int32_t> wmin(S, INT32_MAX), wmax(S, -1);
+        for (int s = 0; s < S; ++s) {
+            for (int v : B.sn[s]) if (v < B.nfp) { const int w = window(v); wmin[s] = std::min(wmin[s], w); wmax[s] = std::max(wmax[s], w); }
+            for (int c : kids[s]) { wmin[s] = std::min(wmin[s], wmin[c]); wmax[s] = std::max(wmax[s], wmax[c]); }
+        }
+        for (int s = S - 1; s >= 0; --s) {
+            Front &F = plan.fronts[s];
+            if (wmax[s] < 0) F.owner = parent[s] >= 0 ? plan.fronts[parent[s]].owner : -1;      // no pose below: follow the parent
+            else F.owner = (wmin[s] == wmax[s]) ? wmin[s] : -1;
+        }
+        auto vowner = [&](int v) { return plan.fronts[sn_of[v]].owner; };
+        for (int k = 0; k < Epl; ++k) {
+            const int fp = B.fp_of_pose[g.pl_p[k]], fl = B.fl_of_lm[g.pl_l[k]];
+            int r = 0;
+            if (fp >= 0 && vowner(fp) >= 0) r = vowner(fp);
+            else if (fl >= 0 && vowner(B.nfp + fl) >= 0) r = vowner(B.nfp + fl);
+            else if (fp >= 0) r = window(fp);
+            plan.pl_rank[k] = r;
+        }
+        for (int k = 0; k < Epp; ++k) {
+            const int fi = B.fp_of_pose[g.pp_i[k]], fj = B.fp_of_pose[g.pp_j[k]];
+            int r = 0;
+            if (fi >= 0 && vowner(fi) >= 0) r = vowner(fi);
+            else if (fj >= 0 && vowner(fj) >= 0) r = vowner(fj);
+            else if (fi >= 0) r = window(fi);
+            else if (fj >= 0) r = window(fj);
+            plan.pp_rank[k] = r;
+        }
+        for (int i = 0; i < B.nfp; ++i) { const int o = vowner(i); plan.pose_known[B.pose_of_fp[i]] = (o < 0 || o == plan.rank); }
+        for (int l = 0; l < B.nfl; ++l) { const int o = vowner(B.nfp + l); plan.lm_known[B.lm_of_fl[l]] = (o < 0 || o == plan.rank); }
+        // per-rank level lists: owned fronts, then the shared top; exchange slots of the shared fronts
+        plan.level_start_owned.assign(nlev + 1, 0); plan.level_fronts_owned.clear(); plan.level_fronts_shared.clear();
+        for (int l = 0; l < nlev; ++l) {
+            for (int q = plan.level_start[l]; q < plan.level_start[l + 1]; ++q) { const int s = plan.level_fronts[q];
+                if (plan.fronts[s].owner == plan.rank) plan.level_fronts_owned.push_back(s);
+                else if (plan.fronts[s].owner < 0) plan.level_fronts_shared.push_back(s); }
+            plan.level_start_owned[l + 1] = (int32_t)plan.level_fronts_owned.size();
+            plan.level_start_shared[l + 1] = (int32_t)plan.level_fronts_shared.size();
+        }
+        plan.n_shared_fronts = (int32_t)plan.level_fronts_shared.size();
+        plan.x_off.assign(S, -1);
+        for (int s : plan.level_fronts_shared) { const Front &F = plan.fronts[s]; const int64_t f = F.npiv + F.nbnd;
+            plan.x_off[s] = plan.exchange_doubles; plan.exchange_doubles += (f + 1) * f; }
+    }
     plan.valid = true;
     plan.ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return true;
@@ -349,6 +404,15 @@ void export_plan(const Plan &p, std::vector<int32_t> &out) {
     app(p.bnd_rows); app(p.child_map); app(p.children);
     for (const auto &a : p.asm_recs) { out.push_back(a.kind); out.push_back(a.src); out.push_back(a.r0); out.push_back(a.c0); }
     app(p.level_start); app(p.level_fronts);
+    // pose-window shards: world, rank, #shared fronts, exchange doubles, then pl_rank[n_pl] pp_rank[n_pp] (insertion
+    // order), pose_known[n_poses], lm_known[n_lms], x_off[n_fronts] (only when world > 1)
+    out.push_back(p.world); out.push_back(p.rank); out.push_back(p.n_shared_fronts); out.push_back((int32_t)p.exchange_doubles);
+    if (p.world > 1) {
+        app(p.pl_rank); app(p.pp_rank);
+        for (auto v : p.pose_known) out.push_back(v);
+        for (auto v : p.lm_known) out.push_back(v);
+        for (auto v : p.x_off) out.push_back((int32_t)v);
+    }
 }
 
 }  // namespace gs

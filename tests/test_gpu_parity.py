@@ -248,6 +248,49 @@ def test_leaf_size_does_not_change_the_answer(pkg, bench_graphs):
         assert rel(P, outs[0][0]) < 1e-8 and rel(L, outs[0][1]) < 1e-8
 
 
+# ---------------------------------------------------------------- pose-window shards through the HIP kernels
+@pytest.mark.parametrize("world,N,M", [(2, 1000, 200), (4, 10000, 2000)])
+def test_sharded_iterations_match_oracle(pkg, po, bench_graphs, world, N, M):
+    """`world` rank handles share this one GPU; the exchange buffers are summed in-process exactly where the
+    multi-GPU run all-reduces them over RCCL.  After 5 Gauss-Newton iterations the merged estimates must match
+    the oracle's (and the single-GPU path's)."""
+    _, g = bench_graphs(N, M)
+    ranks = []
+    for r in range(world):
+        G = fresh(pkg, g); G.dist_configure(r, world); G.initialize_optimization(); ranks.append(G)
+    assert ranks[0].dist_exchange_doubles() > 0
+    for _ in range(5):
+        for G in ranks:
+            G.dist_iterate_local()
+        total = sum(G.dist_read_exchange() for G in ranks)
+        for G in ranks:
+            G.dist_write_exchange(total); G.dist_iterate_finish()
+    P = np.zeros((N, 3)); L = np.zeros((len(g["lm_est"]), 2)); cp = np.zeros(N); cl = np.zeros(len(g["lm_est"]))
+    for G in ranks:
+        G.sync_estimates()
+        pk, lk, pprim, lprim = G.dist_known()
+        P += G.poses() * pprim[:, None]; L += G.landmarks() * lprim[:, None]; cp += pprim; cl += lprim
+    assert np.all(cp == 1) and np.all(cl == 1)
+    og = make_oracle_graph(po, g); og.optimize(5, ordering=1)
+    rms = np.sqrt((og.poses()[:, :2] ** 2).sum(1).mean())
+    assert np.sqrt(((P[:, :2] - og.poses()[:, :2]) ** 2).sum(1).mean()) / rms < 1e-6
+    assert np.sqrt(((L - og.landmarks()) ** 2).sum(1).mean()) / rms < 1e-6
+    assert np.abs(P[:, 2] - og.poses()[:, 2]).max() < 1e-6
+    # every rank evaluated only its own share of the edges
+    for G in ranks:
+        G.close()
+
+
+def test_sharded_handle_refuses_the_single_gpu_entry_points(pkg, bench_graphs):
+    _, g = bench_graphs(50, 30)
+    G = fresh(pkg, g); G.dist_configure(0, 2); G.initialize_optimization()
+    with pytest.raises(pkg.GsError):
+        G.iterate()
+    with pytest.raises(pkg.GsError):
+        G.optimize(1)
+    G.close()
+
+
 # ---------------------------------------------------------------- full-size properties (config 4)
 def test_cfg4_properties(pkg, frontend):
     """100k poses / 10k cones: too slow for the oracle in a test; size-independent properties instead:

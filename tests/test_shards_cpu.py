@@ -1,0 +1,90 @@
+"""Pose-window shards on the CPU: the host-side partition of the plan (front ownership, which rank
+evaluates which edge, exchange-buffer layout) is exercised by real multi-process runs, torch.distributed with
+the gloo backend and world_size 2 / 4: every rank replays ITS part of the plan in numpy (tests/plan_exec.py)
+on the oracle's H blocks of ITS edges, the exchange buffer is all-reduced (sum) over gloo exactly where the HIP
+path all-reduces it over RCCL, each rank finishes the shared top redundantly, and the merged increment must
+equal the oracle's joint-system increment."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, N, M, out_dir):
+    import importlib
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from conftest import make_oracle_graph
+    from oracle import pyoracle as po
+    from plan_exec import Plan
+    pkg = importlib.import_module("opendlv-logic-cfsd18-sensation-slam_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = pkg.track.generate(N, M)
+    g = pkg.track.bench_graph(t, po.OracleFrontend())
+    G = pkg.Graph(device=-2)                          # host-only handle: plan logic, no arithmetic
+    G.load_bench_graph(g)
+    G.dist_configure(rank, world)
+    G.plan_build_host()
+    P = Plan(G.plan_export()); P.check_invariants()
+    assert P.world == world and P.rank == rank and P.n_shared >= 1
+    # H blocks of the edges THIS rank evaluates: an oracle graph holding only those edges
+    sub = dict(g)
+    kp = P.pp_rank == rank; kl = P.pl_rank == rank
+    for k in ("pp_i", "pp_j", "pp_z", "pp_info"):
+        sub[k] = g[k][kp]
+    for k in ("pl_p", "pl_l", "pl_z", "pl_info"):
+        sub[k] = g[k][kl]
+    blk_sub = make_oracle_graph(po, sub).linearize_blocks()
+    blocks = dict(blk_sub)                           # scatter the per-edge blocks back to global edge numbering
+    blocks["Hpp_off"] = np.zeros((len(g["pp_i"]), 9)); blocks["Hpp_off"][kp] = blk_sub["Hpp_off"]
+    blocks["Hpl"] = np.zeros((len(g["pl_p"]), 6)); blocks["Hpl"][kl] = blk_sub["Hpl"]
+    X, ok1 = P.shard_local(blocks)
+    xt = torch.from_numpy(X)
+    dist.all_reduce(xt, op=dist.ReduceOp.SUM)        # <- the one exchange step of an iteration
+    dp, dl, ok2 = P.shard_finish(xt.numpy())
+    # merge: every vertex is "primary" on exactly one rank
+    pk, lk, pprim, lprim = G.dist_known()
+    assert np.array_equal(pk, P.pose_known) and np.array_equal(lk, P.lm_known)
+    mp = torch.from_numpy(dp * pprim[:, None]); ml = torch.from_numpy(dl * lprim[:, None])
+    cnt = torch.from_numpy(np.concatenate([pprim, lprim]).astype(np.float64))
+    dist.all_reduce(mp); dist.all_reduce(ml); dist.all_reduce(cnt)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), dp=mp.numpy(), dl=ml.numpy(), cnt=cnt.numpy(), ok=ok1 and ok2,
+             n_shared=P.n_shared, exchange=P.exchange_doubles, owned=int((P.owner == rank).sum()),
+             my_pl=int(kl.sum()), my_pp=int(kp.sum()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,N,M", [(2, 50, 30), (2, 1000, 200), (4, 1000, 200)])
+def test_sharded_increment_over_gloo_equals_joint_solve(po, bench_graphs, tmp_path, world, N, M):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, M, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    from conftest import make_oracle_graph
+    _, g = bench_graphs(N, M)
+    og = make_oracle_graph(po, g); og.build_system(); og.apply_update(og.solve_ldlt(1)); dp_o, dl_o = og.delta()
+    scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
+    outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for o in outs:
+        assert bool(o["ok"])
+        assert np.array_equal(o["cnt"], np.ones_like(o["cnt"]))            # every vertex primary exactly once
+        assert np.abs(o["dp"] - dp_o).max() / scale < 1e-8 and np.abs(o["dl"] - dl_o).max() / scale < 1e-8
+    # the edges are partitioned, the work is spread, the exchange is small
+    assert sum(int(o["my_pl"]) for o in outs) == len(g["pl_p"]) and sum(int(o["my_pp"]) for o in outs) == len(g["pp_i"])
+    assert all(int(o["owned"]) > 0 for o in outs)
+    assert int(outs[0]["exchange"]) * 8 < 2_000_000
