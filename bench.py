@@ -3,14 +3,20 @@
 
   python bench.py --gpus N --steps K --warmup W [--workload cfg4]
 
-A "step" is ONE full Gauss-Newton iteration (linearise A5-A7, factorise + solve A8, update A9) of the
-hot path over the resident graph.  At N=1 the workload is the configuration the north_star target is
-quoted on, 100k poses / 10k cones (BASELINE.json configs[3], "cfg4"); inputs are in HBM before the timed
-region.  For N>1 (launched by torch.distributed.run, one rank per GPU over RCCL) every rank owns a pose
-window of the same size: weak scaling, value = iterations/s of the whole job x windows.
+A "step" is ONE full Gauss-Newton iteration (linearise A5-A7, factorise + solve A8, update A9) of the hot path
+over the resident graph; inputs are in HBM before the timed region.
 
-One JSON line on stdout from rank 0, with `roofline` (edge-linearisation kernel, HIP events in this
-process) and `cpu_baseline` (the CPU oracle + the reference's vendored Eigen solver on this host).
+N = 1: the workload is the configuration the north_star target is quoted on, 100k poses / 10k cones
+(BASELINE.json configs[3], "cfg4").
+N > 1 (launched by torch.distributed.run, one rank per GPU): ONE graph of N x 100k poses / N x 10k cones is
+sharded by contiguous pose window: every rank linearises and factorises its own window, the
+contributions to the shared top of the assembly tree (window-boundary poses and the landmarks seen from two
+windows — the shared rows of Omega / xi) are summed by one RCCL all-reduce (fp64) per iteration, and every rank
+finishes the top redundantly.  Weak scaling: value = N x (iterations/s of the whole graph), i.e. 100k-pose-window
+iterations per second, the same unit as the N = 1 line.
+
+One JSON line on stdout from rank 0, with `roofline` (edge-linearisation kernel, HIP events in this process)
+and, at N = 1, `cpu_baseline` (the CPU oracle + the reference's vendored Eigen solver on this host).
 """
 import argparse
 import importlib
@@ -72,21 +78,55 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a gfx950 GPU: the GraphSLAM back-end has no CPU fallback")
+    # GS_BENCH_BACKEND=gloo: rehearsal of the multi-rank launch on a ONE-GPU box (all ranks share device 0 and the
+    # exchange buffer is all-reduced through host copies); the driver's 8-GPU run uses nccl (= RCCL over xGMI)
+    backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local = 0
     torch.cuda.set_device(local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     pkg = importlib.import_module("opendlv-logic-cfsd18-sensation-slam_amd")
 
-    N, M = pkg.track.CONFIGS[args.workload]
+    Nw, Mw = pkg.track.CONFIGS[args.workload]     # one pose window = the single-GPU workload
+    N, M = Nw * world, Mw * world
     track = pkg.track.generate(N, M)
     fe = pkg.Graph(device=local)
     g = pkg.track.bench_graph(track, fe)           # A0 on the device
     fe.close()
     G = pkg.Graph(device=local)
     G.load_bench_graph(g)
+    stream = None
+    if world > 1:
+        G.dist_configure(rank, world)
+        stream = torch.cuda.Stream()               # kernels and the RCCL all-reduce are ordered on ONE stream
+        G.set_stream(stream.cuda_stream)
     G.initialize_optimization()                    # structure phase (iteration-0 work): plan + upload to HBM
     plan = G.stats()
+    xbuf = None
+    if world > 1:
+        if backend != "gloo":
+            xbuf = torch.zeros(max(G.dist_exchange_doubles(), 1), dtype=torch.float64, device="cuda")
+            G.dist_set_exchange_buffer(xbuf.data_ptr())
+
+    def step():
+        if world == 1:
+            G.iterate()
+        elif backend == "gloo":
+            G.dist_iterate_local()
+            xh = torch.from_numpy(G.dist_read_exchange())
+            dist.all_reduce(xh, op=dist.ReduceOp.SUM)
+            G.dist_write_exchange(xh.numpy()); G.dist_iterate_finish()
+        else:
+            with torch.cuda.stream(stream):
+                G.dist_iterate_local()
+                dist.all_reduce(xbuf, op=dist.ReduceOp.SUM)     # shared rows of Omega / xi, fp64, over xGMI
+                G.dist_iterate_finish()
 
     def barrier():
         if world > 1:
@@ -94,48 +134,49 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        G.iterate()
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        G.iterate()
+        step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt * 1e3 / args.steps
-    value = world * args.steps / dt                # every rank iterates its own window of N poses (weak scaling)
+    value = world * args.steps / dt                # 100k-pose-window iterations per second over the whole job
 
     # ---- roofline of the edge-linearisation kernel (HIP events on the library's stream, this process)
-    phases = G.time_iterations(20)
-    lin_ms = G.time_linearize(50)
-    alg_bytes = G.linearize_bytes()                # E_pp*152 + E_pl*96 + N*120 + M*64  
+    lin_ms = G.time_linearize(50)                  # this rank's window when sharded
+    alg_bytes = G.linearize_bytes() // world       # E_pp*152 + E_pl*96 + N*120 + M*64  (SURVEY §8d), per window
     achieved = alg_bytes / (lin_ms * 1e-3) / 1e9
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                    traffic=None, kernel="edge linearisation + assembly (A5-A7)", ms_per_launch=lin_ms,
-                    algorithmic_bytes=alg_bytes)
-
-    # ---- parity of what was timed: the reference's optimize(10) from the initial estimates vs the oracle
+                    traffic=None, kernel="k_linearize_ell: edge linearisation + assembly (A5-A7)", ms_per_launch=lin_ms,
+                    algorithmic_bytes=alg_bytes, note="back-to-back launches; inside an iteration see phases_ms.linearize")
     out = dict(metric="GraphSLAM Gauss-Newton iters/sec at N poses x M cones; pose RMSE vs ref",
-               value=value, unit="GN iterations/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+               value=value, unit="GN iterations/s (100k-pose windows)", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64",
                data="synthetic",
-               config=dict(workload="%s: %d poses / %d cones closed synthetic cone track, K=8 observations per pose, "
-                                    "gauge = first 2 poses + first 2 cones" % (args.workload, N, M),
+               config=dict(workload="%s x %d: %d poses / %d cones closed synthetic cone track, K=8 observations per pose, "
+                                    "gauge = first 2 poses + first 2 cones" % (args.workload, world, N, M),
                            n_poses=N, n_cones=M, n_odometry_edges=G.n_pp, n_observation_edges=G.n_pl,
                            unknowns=3 * plan.n_free_poses + 2 * plan.n_free_landmarks,
-                           parallelism="1 pose window per GPU" if world > 1 else "single GPU",
+                           parallelism=("%d pose windows, one per GPU; RCCL all-reduce of %d doubles per iteration"
+                                        % (world, G.dist_exchange_doubles())) if world > 1 else "single GPU",
                            fronts=plan.n_fronts, levels=plan.n_levels, max_front=plan.max_front),
-               roofline=roofline,
-               phases_ms=dict(linearize=phases.ms_linearize, factor=phases.ms_factor, backsolve=phases.ms_backsolve,
-                              update=phases.ms_update, structure_once=plan.ms_structure))
-    if rank == 0 and not args.no_cpu:
+               roofline=roofline)
+    if world == 1:
+        phases = G.time_iterations(20)
+        out["phases_ms"] = dict(linearize=phases.ms_linearize, factor=phases.ms_factor, backsolve=phases.ms_backsolve,
+                                update=phases.ms_update, structure_once=plan.ms_structure)
+        out["roofline"]["achieved_inside_iteration"] = alg_bytes / (phases.ms_linearize * 1e-3) / 1e9
+    if rank == 0 and world == 1 and not args.no_cpu:
         og, cb = cpu_baseline(pkg, g, args.cpu_iters)
         out["cpu_baseline"] = cb
-        out["speedup_vs_cpu_baseline"] = value / world / cb["value"]
-        # same number of iterations from the same initial estimates on the GPU
+        out["speedup_vs_cpu_baseline"] = value / cb["value"]
+        # parity of what was timed: the same number of iterations from the same initial estimates
         G2 = pkg.Graph(device=local); G2.load_bench_graph(g)
         done, st = G2.optimize(args.cpu_iters)
         P, Lm = G2.poses(), G2.landmarks()
@@ -145,7 +186,7 @@ def main():
         out["heading_max_abs_diff_vs_oracle"] = float(np.abs(P[:, 2] - og.poses()[:, 2]).max())
         out["parity_iterations"] = int(done)
         G2.close()
-    elif rank == 0:
+    else:
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
