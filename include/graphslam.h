@@ -59,7 +59,10 @@ typedef struct gs_config {
     int32_t verbose;            /* 1: print g2o-style "iteration= i chi2= ..." to stderr
                                    (reference: setVerbose(true), src/slam.cpp:63)          */
     int32_t leaf_poses;         /* nested-dissection leaf size in poses; 0 = default        */
-    int32_t use_hip_graph;      /* 1: replay one Gauss-Newton iteration as a hipGraph       */
+    int32_t factor_variant;     /* front factorisation kernel: 0 = default (block-per-front VALU),
+                                   1 = wave-per-front VALU, 2 = wave-per-front on the fp64 matrix
+                                   cores (v_mfma_f64_16x16x4_f64); 1 and 2 need every front <= 63
+                                   scalars and silently fall back to 0 otherwise                 */
     int32_t linearize_gather;   /* 1: force the general gather kernels instead of the fused tiled
                                    linearisation kernel (both are HIP; for tests and A/B timing)   */
     /* Slam-level constants, defaults are the reference's hard-coded values */

@@ -32,7 +32,7 @@ class GsError(RuntimeError):
 
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("verbose", C.c_int32),
-                ("leaf_poses", C.c_int32), ("use_hip_graph", C.c_int32), ("linearize_gather", C.c_int32),
+                ("leaf_poses", C.c_int32), ("factor_variant", C.c_int32), ("linearize_gather", C.c_int32),
                 ("odometry_information", C.c_double), ("cone_information", C.c_double),
                 ("same_cone_threshold", C.c_double), ("cone_mapping_threshold", C.c_double),
                 ("lidar_to_cog", C.c_double), ("loop_closing_radius", C.c_double),

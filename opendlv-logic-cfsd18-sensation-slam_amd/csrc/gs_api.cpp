@@ -68,7 +68,7 @@ extern "C" int gs_config_default(gs_config *c) {
     if (!c) return fail(GS_ERR_INVALID, "null config");
     std::memset(c, 0, sizeof(*c));
     c->struct_size = (int32_t)sizeof(gs_config);
-    c->device = -1; c->verbose = 0; c->leaf_poses = 0; c->use_hip_graph = 0; c->linearize_gather = 0;
+    c->device = -1; c->verbose = 0; c->leaf_poses = 0; c->factor_variant = 0; c->linearize_gather = 0;
     c->odometry_information = 5.0;       // reference src/slam.cpp:456
     c->cone_information = 0.01;          // reference src/slam.cpp:546
     c->same_cone_threshold = 1.0;        // m_newConeThreshold default, reference src/slam.hpp:114
@@ -99,7 +99,7 @@ extern "C" int gs_create(const gs_config *cfg, gs_graph **out) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(GS_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     gs_graph *g = new gs_graph();
-    g->cfg = c; g->device = dev; g->force_gather = c.linearize_gather != 0;
+    g->cfg = c; g->device = dev; g->force_gather = c.linearize_gather != 0; g->default_factor_variant = c.factor_variant;
     HIP_TRY(hipSetDevice(dev));
     if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) { delete g; return fail(GS_ERR_HIP, "hipStreamCreate failed"); }
     g->own_stream = true;
@@ -376,6 +376,10 @@ static int upload_graph(gs_graph *g) {
           o.bnd_off = F.bnd_off; o.map_off = F.map_off; o.L_off = F.L_off; o.U_off = F.U_off; }
       UP(fronts, df); d.n_fronts = (int32_t)df.size(); }
     UP(bnd_rows, P.bnd_rows); UP(child_map, P.child_map); UP(children, P.children);
+    { std::vector<int32_t> cd(P.children.size() * 4);
+      for (size_t q = 0; q < P.children.size(); ++q) { const Front &C = P.fronts[P.children[q]];
+          cd[4 * q] = P.children[q]; cd[4 * q + 1] = C.npiv | (C.nbnd << 16); cd[4 * q + 2] = C.owner; cd[4 * q + 3] = (int32_t)C.map_off; }
+      UP(child_desc, cd); }
     // level lists on the device: this rank's own fronts, then the shared top (empty when world == 1)
     { std::vector<int32_t> lf = P.level_fronts_owned; g->shared_base = (int)lf.size();
       lf.insert(lf.end(), P.level_fronts_shared.begin(), P.level_fronts_shared.end());
@@ -387,6 +391,14 @@ static int upload_graph(gs_graph *g) {
       for (size_t t = 0; t < P.asm_recs.size(); ++t) { recs[4 * t] = P.asm_recs[t].kind; recs[4 * t + 1] = P.asm_recs[t].src;
           recs[4 * t + 2] = P.asm_recs[t].r0; recs[4 * t + 3] = P.asm_recs[t].c0; }
       UP(asm_recs, recs); }
+    // factor kernel variant: 2 = wave-per-front on the fp64 matrix cores (every front <= 63 scalars), 0 = block-per-
+    // front VALU (any size), 1 = wave-per-front VALU (A/B only).  GS_FACTOR_VARIANT overrides.
+    { int v = P.max_front <= 63 ? g->default_factor_variant : 0;
+      if (const char *e = std::getenv("GS_FACTOR_VARIANT")) v = std::atoi(e);
+      if (v == 2 && P.max_front > 63) v = 0;
+      d.factor_variant = v;
+      if (const char *e = std::getenv("GS_DBG")) d.dbg = std::atoi(e);
+      if (v == 2) { AL(Uimg, (size_t)P.fronts.size() * 2560); } }
     AL(Lbuf, P.l_doubles); AL(Ubuf, P.u_doubles); AL(xe, P.n_scalar); AL(dpose, (size_t)N * 3); AL(dlm, (size_t)M * 2); AL(fail, 4);
     HIP_TRY(hipMemsetAsync(d.fail, 0, 4 * sizeof(int32_t), g->stream));
     HIP_TRY(hipMemsetAsync(d.chi2, 0, 80 * sizeof(double), g->stream));

@@ -51,11 +51,15 @@ struct DevGraph {
     DevFront *fronts = nullptr; int32_t n_fronts = 0;
     int32_t *bnd_rows = nullptr, *child_map = nullptr, *children = nullptr, *asm_recs = nullptr /* [n*4] */;
     int32_t *level_fronts = nullptr;
+    int32_t *child_desc = nullptr;                              // [children][4] child front, npiv | nbnd << 16, owner, map offset
     double *Lbuf = nullptr, *Ubuf = nullptr;                   // factor and update-matrix arenas
     double *xe = nullptr;                                       // solution in elimination order [n_scalar]
     double *dpose = nullptr, *dlm = nullptr;                    // last increment per vertex
     int32_t *fail = nullptr;                                    // [0] != 0 : non-positive pivot met
     double *front_ws = nullptr; int64_t front_ws_stride = 0;    // global workspace for fronts too big for LDS
+    int32_t dbg = 0;                                            // GS_DBG ablation bits (timing experiments only)
+    int32_t factor_variant = 0;                                 // 0 block-per-front VALU, 1 wave-per-front VALU, 2 wave-per-front MFMA
+    double *Uimg = nullptr;                                     // MFMA variant: update matrices as 16x16 tile images
     // pose-window shards (world == 1: everything is "own", no exchange)
     int32_t rank = 0, wt_lo = 0, wt_hi = 0;                     // this shard sweeps wave tiles [wt_lo, wt_hi)
     uint8_t *pose_known = nullptr, *lm_known = nullptr;         // vertex estimates tracked by this rank

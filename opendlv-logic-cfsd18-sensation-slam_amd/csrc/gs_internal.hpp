@@ -33,6 +33,7 @@ struct gs_graph {
     int rank = 0, world = 1;
     double *exchange = nullptr; bool exchange_external = false;   // caller-provided exchange buffer (e.g. a torch tensor)
     bool force_gather = false;              // cfg.linearize_gather
+    int default_factor_variant = 0;         // see upload_graph
 };
 
 namespace gs {

@@ -1,0 +1,111 @@
+"""Test-only restatement, in Python over the CPU oracle, of the graph side of the reference's class Slam:
+performSLAM (reference src/slam.cpp:298-338), addPoseToGraph/addOdometryMeasurement (:433-459), addConesToMap
+(:552-635), addConeToGraph/addConeMeasurement (:525-550), loopClosing (:697-706), optimizeGraph (:461-484),
+updateMap (:713-732), localizer (:340-414), updatePoseFromGraph (:416-422).
+
+It is the checker for the product's host mirror csrc/gs_slam.cpp (C++ over the HIP C-ABI): two independent
+implementations of the same control flow, one on the oracle, one on the GPU path.  `quirks=False` is the
+documented clean mode (SURVEY §8-B items 1, 2, 4 off); `quirks=True` keeps them."""
+import numpy as np
+
+from oracle import pyoracle as po
+
+
+class RefSlam:
+    def __init__(self, same_cone_threshold=1.2, cone_mapping_threshold=67.0, quirks=False, iterations=10):
+        self.g = po.OracleGraph(); self.fe = po.OracleFrontend()
+        self.thr = same_cone_threshold; self.map_thr = cone_mapping_threshold
+        self.quirks = quirks; self.iterations = iterations
+        self.map = []                      # [x, y, type, id]
+        self.n_poses = 0
+        self.loop_closing = False; self.loop_closing_complete = False
+        self.current_cone_index = 0
+        self.send_pose = np.zeros(3)
+        self.optimise_calls = 0
+
+    # --- helpers on the oracle graph (indices: pose k = id 1000 + k)
+    def _add_measurement(self, cone_id, z):
+        self.g.add_observation_edges([self.n_poses - 1], [cone_id], [z], (0.01 * np.eye(2)).reshape(1, 4))
+
+    def _add_cone(self, xy, ctype, z):
+        cid = len(self.map)
+        self.map.append([xy[0], xy[1], int(ctype), cid])
+        self.g.add_landmarks([xy])
+        self._add_measurement(cid, z)
+
+    def _optimise(self):
+        self.g.set_fixed_pose(0); self.g.set_fixed_pose(1); self.g.set_fixed_landmark(0); self.g.set_fixed_landmark(1)
+        self.g.optimize(self.iterations, ordering=1)
+        self.optimise_calls += 1
+        L = self.g.landmarks()
+        for c in self.map:
+            c[0], c[1] = L[c[3]]
+
+    def perform(self, pose, cones):
+        pose = np.asarray(pose, dtype=np.float64); cones = np.asarray(cones, dtype=np.float64).reshape(-1, 4)
+        if abs(pose[0]) > 200 or abs(pose[1]) > 200:
+            return
+        self.g.add_poses([pose])
+        if self.n_poses > 0:
+            prev = self.g.poses()[self.n_poses - 1]
+            L = po.lib()
+            inv = np.zeros(3); z = np.zeros(3)
+            L.orc_se2_inverse(po._d(np.ascontiguousarray(prev)), po._d(inv)); L.orc_se2_compose(po._d(inv), po._d(pose.copy()), po._d(z))
+            self.g.add_odometry_edges([self.n_poses - 1], [self.n_poses], [z], (5 * np.eye(3)).reshape(1, 9))
+        self.n_poses += 1
+        K = len(cones)
+        if K == 0:
+            return
+        zxy = self.fe.polar_to_xy(cones[:, 0], cones[:, 1], cones[:, 2])
+        gxy = self.fe.cone_to_global(pose[None], np.zeros(K, dtype=np.int32), cones)
+        if not self.loop_closing_complete:
+            first = 0
+            if not self.map:
+                self._add_cone(gxy[0], cones[0, 3], zxy[0])
+                if not self.quirks:
+                    first = 1
+            min_distance = 100.0; pending = False
+            for i in range(first, K):
+                d2car, ty = cones[i, 2], cones[i, 3]
+                found, j = False, -1
+                if not self.loop_closing:
+                    for t, c in enumerate(self.map):
+                        if abs(c[2] - ty) < 1e-4 and np.hypot(c[0] - gxy[i, 0], c[1] - gxy[i, 1]) < self.thr:
+                            found, j = True, t
+                            break
+                if found:
+                    self._add_measurement(self.map[j][3], zxy[i])
+                    if (np.hypot(self.map[0][0] - self.map[j][0], self.map[0][1] - self.map[j][1]) < 1.0 and
+                            self.current_cone_index > 20 and d2car < self.map_thr and not self.loop_closing):
+                        self.loop_closing = True
+                    if d2car < min_distance:
+                        self.current_cone_index = j; min_distance = d2car
+                if d2car < self.map_thr and not found and not self.loop_closing:
+                    self._add_cone(gxy[i], ty, zxy[i])
+                if self.loop_closing:
+                    if self.quirks:
+                        self._optimise(); self.loop_closing_complete = True
+                    else:
+                        pending = True
+            if pending:
+                self._optimise(); self.loop_closing_complete = True
+            return
+        if K > 1:
+            current, min_distance, reobserved = self.current_cone_index, 100.0, 0
+            for i in range(K):
+                d2car, ty = cones[i, 2], int(cones[i, 3])
+                for j, c in enumerate(self.map):
+                    dt = c[2] - ty
+                    type_ok = (dt < 1e-4) if self.quirks else (abs(dt) < 1e-4)
+                    if np.hypot(c[0] - gxy[i, 0], c[1] - gxy[i, 1]) < self.thr and type_ok:
+                        reobserved += 1
+                        z = zxy[i]
+                        if self.quirks:
+                            z = self.fe.polar_to_xy([pose[0]], [pose[1]], [pose[2]])[0]
+                        self._add_measurement(c[3], z)
+                        if d2car < min_distance:
+                            current, min_distance = j, d2car
+                        break
+            if reobserved > 0:
+                self.current_cone_index = current
+            self.send_pose = self.g.poses()[self.n_poses - 1].copy()

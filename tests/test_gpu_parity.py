@@ -248,6 +248,57 @@ def test_leaf_size_does_not_change_the_answer(pkg, bench_graphs):
         assert rel(P, outs[0][0]) < 1e-8 and rel(L, outs[0][1]) < 1e-8
 
 
+# ---------------------------------------------------------------- A8: every front-factorisation kernel variant
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_factor_kernel_variants_match_oracle(pkg, po, bench_graphs, variant):
+    """0 = block-per-front VALU (default), 1 = wave-per-front VALU, 2 = wave-per-front on the fp64 matrix cores
+    (v_mfma_f64_16x16x4_f64, update matrices as 16x16 tile images).  Same plan, same answer."""
+    for N, M in ((1000, 200), (10000, 2000)):
+        _, g = bench_graphs(N, M)
+        og = make_oracle_graph(po, g); og.optimize(4, ordering=1)
+        G = fresh(pkg, g, factor_variant=variant); done, st = G.optimize(4)
+        assert done == 4 and st.numeric_failure == 0
+        assert rel(G.poses(), og.poses()) < 1e-9 and rel(G.landmarks(), og.landmarks()) < 1e-9
+        G.close()
+    g = random_graph(21)                                   # irregular graph, anisotropic information, duplicate edges
+    og = make_oracle_graph(po, g); og.build_system(); og.apply_update(og.solve_ldlt(0)); dp_o, dl_o = og.delta()
+    G = fresh(pkg, g, factor_variant=variant); G.optimize(1); dp, dl = G.export_delta()
+    scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
+    assert np.abs(dp - dp_o).max() / scale < 1e-9 and np.abs(dl - dl_o).max() / scale < 1e-9
+    G.close()
+
+
+# ---------------------------------------------------------------- f-1: the Slam host mirror (performSLAM graph side)
+@pytest.mark.parametrize("quirks", [0, 1])
+def test_slam_mirror_frame_by_frame_matches_reference_logic(pkg, quirks):
+    """csrc/gs_slam.cpp (C++ over the HIP C-ABI) against tests/ref_slam.py (Python over the CPU oracle), fed the same
+    keyframes: odometry pose + 4 x K cone collector matrix per frame, through loop closure (optimizeGraph + updateMap,
+    reference src/slam.cpp:625-633) and a few localizer frames after it (reference src/slam.cpp:340-414)."""
+    from ref_slam import RefSlam
+    N, M = 120, 60
+    t = pkg.track.generate(N, M)
+    S = pkg.Slam(same_cone_threshold=1.2, cone_mapping_threshold=67.0, reference_quirks=quirks)
+    R = RefSlam(same_cone_threshold=1.2, cone_mapping_threshold=67.0, quirks=bool(quirks))
+    frames = list(range(N)) + list(range(6))               # one lap, then re-drive the first frames (localizer mode)
+    closed_at = None
+    for n, k in enumerate(frames):
+        S.perform_slam(t["odom_poses"][k], t["obs"][k]); R.perform(t["odom_poses"][k], t["obs"][k])
+        assert S.map_size == len(R.map), (n, S.map_size, len(R.map))
+        assert S.loop_closed == R.loop_closing_complete, n
+        assert S.current_cone_index == R.current_cone_index, n
+        if closed_at is None and S.loop_closed:
+            closed_at = n
+    assert closed_at is not None and closed_at < N          # the lap closes on re-observing the first cone
+    xy, ty = S.map()
+    Rm = np.array([[c[0], c[1]] for c in R.map]); Rt = np.array([c[2] for c in R.map])
+    assert np.array_equal(ty, Rt)
+    assert np.abs(xy - Rm).max() < 1e-7                     # optimised map, GPU vs oracle
+    assert np.abs(S.send_pose() - R.send_pose).max() < 1e-7
+    assert S.graph.n_poses == R.n_poses and S.graph.n_pl == R.g.n_pl and S.graph.n_pp == R.g.n_pp
+    assert np.abs(S.graph.poses() - R.g.poses()).max() < 1e-7
+    S.close()
+
+
 # ---------------------------------------------------------------- pose-window shards through the HIP kernels
 @pytest.mark.parametrize("world,N,M", [(2, 1000, 200), (4, 10000, 2000)])
 def test_sharded_iterations_match_oracle(pkg, po, bench_graphs, world, N, M):
