@@ -344,11 +344,11 @@ static int upload_graph(gs_graph *g) {
 #define AL(dst, cnt) if ((rc = dev_alloc(g, &d.dst, (size_t)(cnt))) != GS_OK) return rc
 #define ZERO(dst, cnt) HIP_TRY(hipMemsetAsync(d.dst, 0, std::max<size_t>((size_t)(cnt), 1) * sizeof(*d.dst), g->stream))
     d.n_wtiles = 0; d.n_groups = 0; d.wt_lo = 0; d.wt_hi = 0; d.rank = P.rank;
-    if (P.lin_ell_ok && !g->force_gather) {
+    // the fused kernel addresses the ELL planes with 32-bit byte offsets: 8 B * ell_len must stay below 4 GiB
+    if (P.lin_ell_ok && !g->force_gather && P.ell_len < ((int64_t)1 << 29)) {
         d.n_wtiles = P.n_wtiles; d.n_groups = (int32_t)P.grp_lm.size();
         UP(wt_desc, P.wt_desc); UP(grp_pos_start, P.grp_pos_start); UP(grp_slot, P.grp_slot); UP(lm_grp_start, P.lm_grp_start);
-        std::vector<uint16_t> pos16(P.grp_pos.begin(), P.grp_pos.end());
-        UP(grp_pos, pos16);
+        UP(ell_dst, P.ell_dst);
         AL(lm_part, (size_t)d.n_groups * 5); ZERO(lm_part, (size_t)d.n_groups * 5);
         d.wt_lo = 0; d.wt_hi = P.n_wtiles;
         if (P.world > 1) {                                                // the wave tiles this shard has any edge in

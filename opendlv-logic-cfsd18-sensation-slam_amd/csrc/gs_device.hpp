@@ -42,7 +42,7 @@ struct DevGraph {
     int32_t n_wtiles = 0, n_groups = 0;
     int32_t *wt_desc = nullptr;                                 // [WT][4] first group, #groups, first position, #positions
     int32_t *grp_pos_start = nullptr, *grp_slot = nullptr, *lm_grp_start = nullptr;
-    uint16_t *grp_pos = nullptr;
+    uint16_t *ell_dst = nullptr;        // per ELL entry: LDS position (group-sorted order inside its wave tile), 0xFFFF = padding
     double *lm_part = nullptr;                                  // [5][n_groups] per-(wave tile, landmark) partial sums
     // block-sparse H and b (A6/A7 output), SoA
     double *Hpp_diag = nullptr, *Hll_diag = nullptr, *Hpp_off = nullptr, *Hpl = nullptr, *b_pose = nullptr, *b_lm = nullptr;

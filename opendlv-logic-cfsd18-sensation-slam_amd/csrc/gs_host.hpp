@@ -79,6 +79,7 @@ struct Plan {
     std::vector<int32_t> wt_grp_start;                    // [WT+1] landmark groups of a wave tile
     std::vector<int32_t> wt_desc;                         // [WT][4] first group, #groups, first position, #positions
     std::vector<int32_t> grp_lm, grp_pos_start, grp_pos;  // group -> landmark, wave-local positions (slot*64 + lane)
+    std::vector<uint16_t> ell_dst;                        // per ELL entry: its index in its wave tile's group-sorted position list (0xFFFF = padding)
     std::vector<int32_t> lm_grp_start;                    // landmark -> its run of partial-sum slots
     std::vector<int32_t> grp_slot;                        // group -> partial-sum slot, slots ordered by (landmark, wave tile)
     // fronts in elimination (post)order

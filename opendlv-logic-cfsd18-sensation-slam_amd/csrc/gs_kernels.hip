@@ -166,55 +166,50 @@ template <bool WRITE_H>
 __device__ __forceinline__ double pp_incidence(const DevGraph &d, int k, int role, const double xi[3], const double xj[3],
                                                double ci, double si, const double zinv5[5], const double w[6],
                                                bool fi, bool fj, double H[6], double b[3]) {
+    // Structure of the EdgeSE2 Jacobians (edge_pp above): with M = rot(z^-1) * R_i^T = [[m0, m1], [-m1, m0]],
+    //   B = [[m0, m1, 0], [-m1, m0, 0], [0, 0, 1]],   A = [-B(:,0), -B(:,1), a2],  a2 = (a02, a12, -1),
+    // so with G = B^T W B and wa2 = W a2 everything needed is G (6), wa2 (3) and three dot products:
+    //   A^T W A = [[g00, g01, -t0], [., g11, -t1], [., ., t2]],  A^T W B = [[-g00, -g01, -g02], [-g01, -g11, -g12], [t0, t1, wa2_2]],
+    //   t0 = b0.wa2, t1 = b1.wa2, t2 = a2.wa2.   (Same quantities as the dense products, ~1/3 of the live values.)
     double chi = 0.0;
-    double e[3], A[3][3], B[3][3];
-    edge_pp(xi, xj, ci, si, zinv5, e, A, B);
-    const double W[3][3] = {{w[0], w[1], w[2]}, {w[1], w[3], w[4]}, {w[2], w[4], w[5]}};
-    double We[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) We[r] = W[r][0] * e[0] + W[r][1] * e[1] + W[r][2] * e[2];
-    if (role == 0 && !(fi && fj)) chi = e[0] * We[0] + e[1] * We[1] + e[2] * We[2];
+    const double dx = xj[0] - xi[0], dy = xj[1] - xi[1];
+    const double rx = ci * dx + si * dy, ry = -si * dx + ci * dy;     // rel = xi^-1 * xj
+    const double rth = normalize_theta(normalize_theta(-xi[2]) + xj[2]);
+    const double cz = zinv5[3], sz = zinv5[4];
+    const double e0 = zinv5[0] + (cz * rx - sz * ry), e1 = zinv5[1] + (sz * rx + cz * ry), e2 = normalize_theta(zinv5[2] + rth);
+    const double w00 = w[0], w01 = w[1], w02 = w[2], w11 = w[3], w12 = w[4], w22 = w[5];
+    const double We0 = w00 * e0 + w01 * e1 + w02 * e2, We1 = w01 * e0 + w11 * e1 + w12 * e2, We2 = w02 * e0 + w12 * e1 + w22 * e2;
+    if (role == 0 && !(fi && fj)) chi = e0 * We0 + e1 * We1 + e2 * We2;
     if (WRITE_H) {
+        const double m0 = cz * ci + sz * si, m1 = cz * si - sz * ci;
+        const double bw0 = m0 * We0 - m1 * We1, bw1 = m1 * We0 + m0 * We1;      // b0.We, b1.We
+        // G = B^T W B
+        const double wb00 = w00 * m0 - w01 * m1, wb01 = w00 * m1 + w01 * m0;      // (W B)[0][0..1]
+        const double wb10 = w01 * m0 - w11 * m1, wb11 = w01 * m1 + w11 * m0;      // (W B)[1][0..1]
+        const double g00 = m0 * wb00 - m1 * wb10, g01 = m0 * wb01 - m1 * wb11, g11 = m1 * wb01 + m0 * wb11;
+        const double g02 = m0 * w02 - m1 * w12, g12 = m1 * w02 + m0 * w12;
         if (role == 0) {
-            double WA[3][3], WB[3][3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    WA[r][c] = W[r][0] * A[0][c] + W[r][1] * A[1][c] + W[r][2] * A[2][c];
-                    WB[r][c] = W[r][0] * B[0][c] + W[r][1] * B[1][c] + W[r][2] * B[2][c];
-                }
-            int t = 0;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if (c >= r) H[t++] += A[0][r] * WA[0][c] + A[1][r] * WA[1][c] + A[2][r] * WA[2][c];
-                    double off = A[0][r] * WB[0][c] + A[1][r] * WB[1][c] + A[2][r] * WB[2][c];
-                    d.Hpp_off[(int64_t)(3 * r + c) * d.Epp + k] = (!fi && !fj) ? off : 0.0;
-                }
-                b[r] -= A[0][r] * We[0] + A[1][r] * We[1] + A[2][r] * We[2];
-            }
+            const double a02 = cz * ry + sz * rx, a12 = sz * ry - cz * rx;
+            const double wa0 = w00 * a02 + w01 * a12 - w02, wa1 = w01 * a02 + w11 * a12 - w12, wa2 = w02 * a02 + w12 * a12 - w22;
+            const double t0 = m0 * wa0 - m1 * wa1, t1 = m1 * wa0 + m0 * wa1, t2 = a02 * wa0 + a12 * wa1 - wa2;
+            H[0] += g00; H[1] += g01; H[2] -= t0; H[3] += g11; H[4] -= t1; H[5] += t2;
+            b[0] += bw0; b[1] += bw1; b[2] -= a02 * We0 + a12 * We1 - We2;
+            const bool both = !fi && !fj;
+            const int64_t E = d.Epp;
+            double *o = d.Hpp_off + k;
+            o[0] = both ? -g00 : 0.0;     o[E] = both ? -g01 : 0.0;     o[2 * E] = both ? -g02 : 0.0;
+            o[3 * E] = both ? -g01 : 0.0; o[4 * E] = both ? -g11 : 0.0; o[5 * E] = both ? -g12 : 0.0;
+            o[6 * E] = both ? t0 : 0.0;   o[7 * E] = both ? t1 : 0.0;   o[8 * E] = both ? wa2 : 0.0;
         } else {
-            double WB[3][3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) WB[r][c] = W[r][0] * B[0][c] + W[r][1] * B[1][c] + W[r][2] * B[2][c];
-            int t = 0;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                for (int c = r; c < 3; ++c) H[t++] += B[0][r] * WB[0][c] + B[1][r] * WB[1][c] + B[2][r] * WB[2][c];
-                b[r] -= B[0][r] * We[0] + B[1][r] * We[1] + B[2][r] * We[2];
-            }
+            H[0] += g00; H[1] += g01; H[2] += g02; H[3] += g11; H[4] += g12; H[5] += w22;
+            b[0] -= bw0; b[1] -= bw1; b[2] -= We2;
         }
     }
     return chi;
 }
 // the same with the operands fetched here (q = index of the incidence record)
 template <bool WRITE_H>
-__device__ __forceinline__ double pp_incidence_q(const DevGraph &d, int q, double H[6], double b[3]) {
+__device__ __forceinline__ double pp_incidence_q(const DevGraph &d, int q, double H[6], double b[3], int own_pose = -1, double own_c = 1.0, double own_s = 0.0) {
     const int4 inc = reinterpret_cast<const int4 *>(d.ppinc)[q];                 // {edge, role, i, j}
     const int k = inc.x, i = inc.z, j = inc.w;
     if (k < 0) return 0.0;                                                       // evaluated by another shard
@@ -225,10 +220,16 @@ __device__ __forceinline__ double pp_incidence_q(const DevGraph &d, int q, doubl
     for (int t = 0; t < 5; ++t) z5[t] = d.pp_zinv[5 * (int64_t)k + t];
 #pragma unroll
     for (int t = 0; t < 6; ++t) w[t] = d.pp_info[6 * (int64_t)k + t];
-    double si, ci; sincos(xi[2], &si, &ci);
+    double si, ci;
+    if (i == own_pose) { si = own_s; ci = own_c; } else sincos(xi[2], &si, &ci);
     return pp_incidence<WRITE_H>(d, k, inc.y, xi, xj, ci, si, z5, w, d.pose_fixed[i], d.pose_fixed[j], H, b);
 }
 
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
@@ -322,15 +323,21 @@ __global__ void __launch_bounds__(256) k_linearize_lm_gather(DevGraph d) {
 //      items in a fixed order into the per-(wave tile, landmark) partial slot.
 static constexpr int LIN_R = 4;                   // == gs::LIN_R: observation slots per lane
 #ifndef LIN_WAVES_PER_SIMD
-#define LIN_WAVES_PER_SIMD 3
+// base[byte_off / sizeof(T)] with a wave-uniform base and a 32-bit per-lane byte offset: compiles to the
+// "SGPR base + VGPR offset" global addressing form, so no 64-bit per-lane address has to live in VGPRs.
+template <class Tp> __device__ __forceinline__ Tp ld_off(const Tp *base, uint32_t byte_off) {
+    return *reinterpret_cast<const Tp *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <class Tp> __device__ __forceinline__ void st_off(Tp *base, uint32_t byte_off, Tp v) {
+    *reinterpret_cast<Tp *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
+#define LIN_WAVES_PER_SIMD 4
 #endif
 template <int T>
 __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGraph d) {
     constexpr int PW = 64 / T;
-    __shared__ double s_lc[4][5][LIN_R * 64];
-    __shared__ uint16_t s_gp[4][LIN_R * 64];
-    // the wave id is wave-uniform: say so (readfirstlane), otherwise everything derived from it (front id, f, loop
-    // bounds, readlane sources) is treated as divergent and every readlane becomes a waterfall loop
+    __shared__ double s_lc[4][5][LIN_R * 64];       // 40 KB per block = 4 blocks per CU in the 160 KB LDS: 4 waves per SIMD
+    // the wave id is wave-uniform: say so (readfirstlane), otherwise everything derived from it is treated as divergent
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wt = d.wt_lo + blockIdx.x * 4 + wave;                // a shard only sweeps the wave tiles it has edges in
     if (wt >= d.wt_hi) return;                                     // whole wave leaves; no block-level barrier below
@@ -338,79 +345,60 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
     const bool live = p < d.N;
     const int64_t L = d.ell_len, S = (int64_t)T * d.N;
     const int R = d.ell_R;
-    // ---- level 1
-    int l[LIN_R]; double zx[LIN_R], zy[LIN_R], w00[LIN_R], w01[LIN_R], w11[LIN_R];
-#pragma unroll
-    for (int i = 0; i < LIN_R; ++i) {
-        l[i] = -1; zx[i] = zy[i] = w00[i] = w01[i] = w11[i] = 0.0;
-        if (live && i < R) {
-            const int64_t e = (int64_t)i * S + (int64_t)T * p + h;
-            l[i] = d.ell_l[e]; zx[i] = d.ell_z[e]; zy[i] = d.ell_z[L + e];
-            w00[i] = d.ell_w[e]; w01[i] = d.ell_w[L + e]; w11[i] = d.ell_w[2 * L + e];
-        }
-    }
+    // ---- pose state, incidence range, landmark-sum item descriptors, the tile's position list
     double px = 0, py = 0, th = 0; bool fp = true; int q0 = 0, q1 = 0;
     if (live) { px = d.pose_est[3 * p]; py = d.pose_est[3 * p + 1]; th = d.pose_est[3 * p + 2]; fp = d.pose_fixed[p];
                 q0 = d.ppadj_start[p]; q1 = d.ppadj_start[p + 1]; }
     const int4 wd = reinterpret_cast<const int4 *>(d.wt_desc)[wt];        // {first group, #groups, first position, #positions}
-    const int g0 = wd.x, ng = wd.y, pos_off = wd.z, npos = wd.w, nitems = ng * 5;
+    const int g0 = wd.x, ng = wd.y, pos_off = wd.z, nitems = ng * 5;
     int it_s[2] = {0, 0}, it_e[2] = {0, 0}, it_slot[2] = {0, 0};
 #pragma unroll
     for (int u = 0; u < 2; ++u) { const int item = lane + 64 * u;
         if (item < nitems) { const int gl = item % ng; it_s[u] = d.grp_pos_start[g0 + gl] - pos_off; it_e[u] = d.grp_pos_start[g0 + gl + 1] - pos_off; it_slot[u] = d.grp_slot[g0 + gl]; } }
-    uint16_t gp[LIN_R];                                                    // the tile's position list, coalesced
-#pragma unroll
-    for (int i = 0; i < LIN_R; ++i) { const int k = i * 64 + lane; gp[i] = (k < npos) ? d.grp_pos[pos_off + k] : (uint16_t)0; }
-    // ---- level 2
-    double lx[LIN_R], ly[LIN_R]; bool fl[LIN_R];
-#pragma unroll
-    for (int i = 0; i < LIN_R; ++i) { lx[i] = ly[i] = 0.0; fl[i] = true;
-        if (l[i] >= 0) { lx[i] = d.lm_est[2 * l[i]]; ly[i] = d.lm_est[2 * l[i] + 1]; fl[i] = d.lm_fixed[l[i]]; } }
-    // first odometry incidence of this lane (lane h takes incidences q0+h, q0+h+T, ...)
-    const bool has_inc = live && (q0 + h < q1);
-    int4 inc = make_int4(0, 0, 0, 0);
-    double xi[3] = {0, 0, 0}, xj[3] = {0, 0, 0}, z5[5] = {0, 0, 0, 1, 0}, wpp[6] = {0, 0, 0, 0, 0, 0}; bool fi = true, fj = true;
-    if (has_inc) inc = reinterpret_cast<const int4 *>(d.ppinc)[q0 + h];
-    const bool inc_mine = has_inc && inc.x >= 0;                   // edge -1: evaluated by another shard
-    if (inc_mine) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t) { xi[t] = d.pose_est[3 * inc.z + t]; xj[t] = d.pose_est[3 * inc.w + t]; }
-#pragma unroll
-        for (int t = 0; t < 5; ++t) z5[t] = d.pp_zinv[5 * (int64_t)inc.x + t];
-#pragma unroll
-        for (int t = 0; t < 6; ++t) wpp[t] = d.pp_info[6 * (int64_t)inc.x + t];
-        fi = d.pose_fixed[inc.z]; fj = d.pose_fixed[inc.w];
-    }
     double sn, cs; sincos(th, &sn, &cs);
-    // ---- observation edges
+    // ---- observation edges, two slots at a time: loads of both slots, both landmark gathers, then the arithmetic.
+    // (All four slots at once need ~170 VGPRs = 3 waves per SIMD, and 100k poses are 3125 waves for 3072 slots: a
+    // second round for 53 waves.  Two at a time fit 128 VGPRs = 4 waves per SIMD: one round, and the other three
+    // waves of the SIMD cover the shorter per-thread load queue.)
     double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, chi = 0.0;
+    const uint32_t off8 = (uint32_t)(T * p + h) * 8u;             // byte offset of this lane's edge inside one ELL slot plane (< 4 GiB: host-checked)
+    const uint32_t plane8 = (uint32_t)S * 8u;
+#pragma unroll 1
+    for (int c = 0; c < LIN_R; c += 2) {
+        if (c >= R) break;                                          // uniform
+        int l[2]; uint32_t dst[2]; double zx[2], zy[2], w00[2], w01[2], w11[2], lx[2], ly[2]; bool fl[2];
 #pragma unroll
-    for (int i = 0; i < LIN_R; ++i) {
-        double hl0 = 0, hl1 = 0, hl2 = 0, bl0 = 0, bl1 = 0;
-        if (l[i] >= 0) {
-            const int64_t e = (int64_t)i * S + (int64_t)T * p + h;
-            PlQuad q;
-            quad_pl(px, py, cs, sn, lx[i], ly[i], zx[i], zy[i], w00[i], w01[i], w11[i], q);
-            if (!(fp && fl[i])) chi += q.chi;
-            const bool both = !fp && !fl[i];
+        for (int j = 0; j < 2; ++j) { const int i = c + j;
+            l[j] = -1; dst[j] = 0xFFFFu; zx[j] = zy[j] = w00[j] = w01[j] = w11[j] = 0.0;
+            if (live && i < R) { const uint32_t o = off8 + (uint32_t)i * plane8;      // SGPR base + 32-bit lane offset addressing
+                l[j] = ld_off(d.ell_l, o >> 1); dst[j] = ld_off(d.ell_dst, o >> 2); zx[j] = ld_off(d.ell_z, o); zy[j] = ld_off(d.ell_z + L, o);
+                w00[j] = ld_off(d.ell_w, o); w01[j] = ld_off(d.ell_w + L, o); w11[j] = ld_off(d.ell_w + 2 * L, o); } }
 #pragma unroll
-            for (int k = 0; k < 6; ++k) d.Hpl[k * L + e] = both ? q.W6[k] : 0.0;
+        for (int j = 0; j < 2; ++j) { lx[j] = ly[j] = 0.0; fl[j] = true;
+            if (l[j] >= 0) { lx[j] = d.lm_est[2 * l[j]]; ly[j] = d.lm_est[2 * l[j] + 1]; fl[j] = d.lm_fixed[l[j]]; } }
 #pragma unroll
-            for (int k = 0; k < 6; ++k) H[k] += q.Hp[k];
+        for (int j = 0; j < 2; ++j) { const int i = c + j;
+            double hl0 = 0, hl1 = 0, hl2 = 0, bl0 = 0, bl1 = 0;
+            if (l[j] >= 0) {
+                const uint32_t o = off8 + (uint32_t)i * plane8;
+                PlQuad q;
+                quad_pl(px, py, cs, sn, lx[j], ly[j], zx[j], zy[j], w00[j], w01[j], w11[j], q);
+                if (!(fp && fl[j])) chi += q.chi;
+                const bool both = !fp && !fl[j];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) b[k] += q.bp[k];
-            hl0 = q.Hl[0]; hl1 = q.Hl[1]; hl2 = q.Hl[2]; bl0 = q.bl[0]; bl1 = q.bl[1];
+                for (int k = 0; k < 6; ++k) st_off(d.Hpl + k * L, o, both ? q.W6[k] : 0.0);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) H[k] += q.Hp[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) b[k] += q.bp[k];
+                hl0 = q.Hl[0]; hl1 = q.Hl[1]; hl2 = q.Hl[2]; bl0 = q.bl[0]; bl1 = q.bl[1];
+            }
+            if (dst[j] != 0xFFFFu) { const int pos = dst[j];          // an edge another shard evaluates (l < 0) still owns its position: zeros
+                s_lc[wave][0][pos] = hl0; s_lc[wave][1][pos] = hl1; s_lc[wave][2][pos] = hl2; s_lc[wave][3][pos] = bl0; s_lc[wave][4][pos] = bl1; }
         }
-        if (i < R) { const int pos = i * 64 + lane;
-            s_lc[wave][0][pos] = hl0; s_lc[wave][1][pos] = hl1; s_lc[wave][2][pos] = hl2; s_lc[wave][3][pos] = bl0; s_lc[wave][4][pos] = bl1; }
     }
-    // ---- odometry incidences
-    if (inc_mine) {
-        double si, ci;
-        if (inc.z == p) { si = sn; ci = cs; } else sincos(xi[2], &si, &ci);
-        chi += pp_incidence<true>(d, inc.x, inc.y, xi, xj, ci, si, z5, wpp, fi, fj, H, b);
-    }
-    if (has_inc) for (int q = q0 + h + T; q < q1; q += T) chi += pp_incidence_q<true>(d, q, H, b);
+    // ---- odometry incidences: lane h takes incidences q0+h, q0+h+T, ... of its pose
+    if (live) for (int q = q0 + h; q < q1; q += T) chi += pp_incidence_q<true>(d, q, H, b, p, cs, sn);
     // ---- pose sums: xor-shuffle over the T lanes of the pose, then each lane stores its share of the 9 components
 #pragma unroll
     for (int off = 1; off < T; off <<= 1) {
@@ -427,20 +415,16 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
         }
     }
     // ---- landmark groups of this wave tile (wave-private LDS region; same-wave LDS accesses are ordered)
-#pragma unroll
-    for (int i = 0; i < LIN_R; ++i) s_gp[wave][i * 64 + lane] = gp[i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_lds_sync();
 #pragma unroll
     for (int u = 0; u < 2; ++u) { const int item = lane + 64 * u;
         if (item < nitems) { const int comp = item / ng;
             double sum = 0.0;
-            for (int q = it_s[u]; q < it_e[u]; ++q) sum += s_lc[wave][comp][s_gp[wave][q]];
+            for (int q = it_s[u]; q < it_e[u]; ++q) sum += s_lc[wave][comp][q];
             d.lm_part[(int64_t)comp * d.n_groups + it_slot[u]] = sum; } }
     for (int item = lane + 128; item < nitems; item += 64) { const int comp = item / ng, gl = item % ng;
         double sum = 0.0;
-        for (int q = d.grp_pos_start[g0 + gl] - pos_off; q < d.grp_pos_start[g0 + gl + 1] - pos_off; ++q) sum += s_lc[wave][comp][s_gp[wave][q]];
+        for (int q = d.grp_pos_start[g0 + gl] - pos_off; q < d.grp_pos_start[g0 + gl + 1] - pos_off; ++q) sum += s_lc[wave][comp][q];
         d.lm_part[(int64_t)comp * d.n_groups + d.grp_slot[g0 + gl]] = sum; }
     chi = wave_sum(chi);
     if (lane == 0) d.chi2_partial[wt] = chi;
@@ -728,11 +712,6 @@ __device__ __forceinline__ void apply_asm_packed(const DevGraph &d, const int32_
     }
 }
 
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 __device__ __forceinline__ double lane_bcast(double v, int src_lane) {      // src_lane is wave-uniform
     int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
     return __hiloint2double(hi, lo);

@@ -201,6 +201,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         plan.n_wtiles = WT;
         plan.wt_grp_start.assign(WT + 1, 0);
         std::vector<std::pair<int32_t, int32_t>> tmp;              // (landmark, local position)
+        plan.ell_dst.assign((size_t)plan.ell_len, (uint16_t)0xFFFF);
         for (int w = 0; w < WT; ++w) {
             tmp.clear();
             for (int lane = 0; lane < 64; ++lane) { const int p = w * PW + lane / T, h = lane % T;
@@ -211,6 +212,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
             for (size_t i = 0; i < tmp.size(); ++i) {
                 if (i == 0 || tmp[i].first != tmp[i - 1].first) { plan.grp_lm.push_back(tmp[i].first); plan.grp_pos_start.push_back((int32_t)plan.grp_pos.size()); }
                 plan.grp_pos.push_back(tmp[i].second);
+                plan.ell_dst[(size_t)((int64_t)(tmp[i].second >> 6) * ((int64_t)T * N) + (int64_t)w * 64 + (tmp[i].second & 63))] = (uint16_t)i;
             }
             plan.wt_grp_start[w + 1] = (int32_t)plan.grp_lm.size();
         }
