@@ -59,10 +59,12 @@ typedef struct gs_config {
     int32_t verbose;            /* 1: print g2o-style "iteration= i chi2= ..." to stderr
                                    (reference: setVerbose(true), src/slam.cpp:63)          */
     int32_t leaf_poses;         /* nested-dissection leaf size in poses; 0 = default        */
-    int32_t factor_variant;     /* front factorisation kernel: 0 = default (block-per-front VALU),
-                                   1 = wave-per-front VALU, 2 = wave-per-front on the fp64 matrix
-                                   cores (v_mfma_f64_16x16x4_f64); 1 and 2 need every front <= 63
-                                   scalars and silently fall back to 0 otherwise                 */
+    int32_t factor_variant;     /* front factorisation kernel: 0 = default (3 when every front has <= 63
+                                   scalars, else 4); 3 = wave-per-front LDL^T on the fp64 matrix cores
+                                   (v_mfma_f64_16x16x4_f64), children gathered by destination;
+                                   2 = wave-per-front Cholesky on the matrix cores; 1 = wave-per-front
+                                   VALU; 4 = block-per-front VALU, any front size.  1-3 need every front
+                                   <= 63 scalars and fall back to 4 otherwise                      */
     int32_t linearize_gather;   /* 1: force the general gather kernels instead of the fused tiled
                                    linearisation kernel (both are HIP; for tests and A/B timing)   */
     /* Slam-level constants, defaults are the reference's hard-coded values */
@@ -185,6 +187,12 @@ int  gs_get_stats(gs_graph *g, gs_stats *stats);      /* plan statistics after i
  *      (zeros for fixed vertices): dpose [N*3], dlm [M*2]. */
 int  gs_linearize(gs_graph *g);
 int  gs_time_linearize(gs_graph *g, int32_t reps, double *out_ms_per_pass);
+
+/* Tuning aid: with GS_DBG = 8 | (count << 8) in the environment, the factor / backsolve kernels of the level that
+ * holds `count` fronts record 100 MHz timestamps at their phase boundaries for that level's first front
+ * (factor: slots 0.., backsolve: slots 32..).  Copies the 64 slots out.  No reference counterpart. */
+int gs_debug_timestamps(gs_graph *g, int64_t *out64);
+
 int64_t gs_linearize_bytes(gs_graph *g);
 int  gs_export_system(gs_graph *g, double *Hpp_diag, double *Hll_diag, double *Hpp_off,
                       double *Hpl, double *b_pose, double *b_lm,

@@ -102,6 +102,7 @@ def lib():
                  "gs_slam_current_cone_index"):
         getattr(L, name).argtypes = [vp]
     L.gs_linearize_bytes.argtypes = [vp]
+    L.gs_debug_timestamps.argtypes = [vp, C.POINTER(C.c_int64)]
     L.gs_dist_exchange_doubles.argtypes = [vp]
     L.gs_slam_graph.argtypes = [vp]
     L.gs_set_stream.argtypes = [vp, vp]
@@ -312,6 +313,10 @@ class Graph:
 
     def linearize_bytes(self):
         return int(self.L.gs_linearize_bytes(self.h))
+
+    def debug_timestamps(self):
+        """100 MHz phase timestamps of one front (tuning aid, see include/graphslam.h gs_debug_timestamps)."""
+        buf = (C.c_int64 * 64)(); self._check(self.L.gs_debug_timestamps(self.h, buf)); return np.array(buf[:], dtype=np.int64)
 
     def time_iterations(self, reps):
         st = Stats(); self._check(self.L.gs_time_iterations(self.h, int(reps), C.byref(st))); return st

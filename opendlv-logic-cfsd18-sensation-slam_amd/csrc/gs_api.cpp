@@ -349,7 +349,6 @@ static int upload_graph(gs_graph *g) {
         d.n_wtiles = P.n_wtiles; d.n_groups = (int32_t)P.grp_lm.size();
         UP(wt_desc, P.wt_desc); UP(grp_pos_start, P.grp_pos_start); UP(grp_slot, P.grp_slot); UP(lm_grp_start, P.lm_grp_start);
         UP(ell_dst, P.ell_dst);
-        AL(lm_part, (size_t)d.n_groups * 5); ZERO(lm_part, (size_t)d.n_groups * 5);
         d.wt_lo = 0; d.wt_hi = P.n_wtiles;
         if (P.world > 1) {                                                // the wave tiles this shard has any edge in
             const int PW = 64 / P.ell_T; int lo = P.n_wtiles, hi = 0;
@@ -360,11 +359,17 @@ static int upload_graph(gs_graph *g) {
             d.wt_lo = std::min(lo, hi); d.wt_hi = hi;
         }
     } else if (P.world > 1) return fail(GS_ERR_INVALID, "pose-window shards need the fused linearisation layout (<= 32 observations per pose)");
-    AL(Hpp_diag, (size_t)N * 6); AL(Hll_diag, (size_t)M * 3); AL(Hpp_off, (size_t)Epp * 9); AL(Hpl, (size_t)P.ell_len * 6);
-    AL(b_pose, (size_t)N * 3); AL(b_lm, (size_t)M * 2);
-    // blocks of edges / tiles this rank never evaluates must read as zero
-    ZERO(Hpp_diag, (size_t)N * 6); ZERO(Hll_diag, (size_t)M * 3); ZERO(Hpp_off, (size_t)Epp * 9); ZERO(Hpl, (size_t)P.ell_len * 6);
-    ZERO(b_pose, (size_t)N * 3); ZERO(b_lm, (size_t)M * 2);
+    // block-sparse H and b live in ONE arena (the variant-3 front assembly addresses every scalar by its offset in it)
+    int64_t arena_off[8];
+    { const int64_t sizes[7] = {(int64_t)N * 6, (int64_t)N * 3, (int64_t)Epp * 9, (int64_t)P.ell_len * 6, (int64_t)d.n_groups * 5, (int64_t)M * 3, (int64_t)M * 2};
+      arena_off[0] = 0;
+      for (int k = 0; k < 7; ++k) arena_off[k + 1] = arena_off[k] + ((sizes[k] + 1) & ~(int64_t)1);       // 16-byte aligned parts
+      if (arena_off[7] >= ((int64_t)1 << 31)) return fail(GS_ERR_INVALID, "graph too large for 32-bit arena offsets");
+      AL(H_arena, (size_t)arena_off[7] + 2);
+      // blocks of edges / tiles this rank never evaluates must read as zero
+      ZERO(H_arena, (size_t)arena_off[7] + 2);
+      d.Hpp_diag = d.H_arena + arena_off[0]; d.b_pose = d.H_arena + arena_off[1]; d.Hpp_off = d.H_arena + arena_off[2];
+      d.Hpl = d.H_arena + arena_off[3]; d.lm_part = d.H_arena + arena_off[4]; d.Hll_diag = d.H_arena + arena_off[5]; d.b_lm = d.H_arena + arena_off[6]; }
     d.n_chi2_partial = std::max((N + 255) / 256, d.n_wtiles);
     AL(chi2_partial, d.n_chi2_partial); AL(chi2, 80); ZERO(chi2_partial, d.n_chi2_partial);
     UP(pose_known, P.pose_known); UP(lm_known, P.lm_known);
@@ -391,14 +396,90 @@ static int upload_graph(gs_graph *g) {
       for (size_t t = 0; t < P.asm_recs.size(); ++t) { recs[4 * t] = P.asm_recs[t].kind; recs[4 * t + 1] = P.asm_recs[t].src;
           recs[4 * t + 2] = P.asm_recs[t].r0; recs[4 * t + 3] = P.asm_recs[t].c0; }
       UP(asm_recs, recs); }
-    // factor kernel variant: 2 = wave-per-front on the fp64 matrix cores (every front <= 63 scalars), 0 = block-per-
-    // front VALU (any size), 1 = wave-per-front VALU (A/B only).  GS_FACTOR_VARIANT overrides.
-    { int v = P.max_front <= 63 ? g->default_factor_variant : 0;
+    // factor kernel variant (gs_config.factor_variant, GS_FACTOR_VARIANT overrides): 0 = default = 3 when every front
+    // fits 63 scalars, else 4.  3 = wave-per-front LDL^T on the fp64 matrix cores, latency-shaped; 2 = wave-per-front
+    // Cholesky on the matrix cores (first version); 1 = wave-per-front VALU; 4 = block-per-front VALU (any front size).
+    { int v = g->default_factor_variant;
       if (const char *e = std::getenv("GS_FACTOR_VARIANT")) v = std::atoi(e);
-      if (v == 2 && P.max_front > 63) v = 0;
+      if (v <= 0 || v > 4) v = 3;                                     // 0 = default
+      if (v != 4 && P.max_front > 63) v = 4;                          // the wave-per-front kernels hold a front in 64 lanes
+      if (v == 4) v = 0;                                              // device-side code for the block-per-front kernel
       d.factor_variant = v;
       if (const char *e = std::getenv("GS_DBG")) d.dbg = std::atoi(e);
-      if (v == 2) { AL(Uimg, (size_t)P.fronts.size() * 2560); } }
+      if (v == 2 || v == 3) { AL(Uimg, (size_t)P.fronts.size() * 2568); ZERO(Uimg, (size_t)P.fronts.size() * 2568); }   // 2560-double tile image + 8 zero doubles
+      if (v == 3) {
+          std::vector<int32_t> lf = P.level_fronts_owned;
+          lf.insert(lf.end(), P.level_fronts_shared.begin(), P.level_fronts_shared.end());
+          constexpr int F3W = 160;                           // 32 descriptor ints + the row tables of the first two children
+          std::vector<int32_t> fd(lf.size() * F3W, 0);
+          for (size_t q = 0; q < lf.size(); ++q) { const int sidx = lf[q]; const Front &F = P.fronts[sidx]; int32_t *r = &fd[F3W * q];
+              r[0] = sidx; r[1] = F.npiv; r[2] = F.nbnd; r[3] = F.asm_off; r[4] = F.asm_cnt - F.asm_dup; r[5] = F.asm_dup;
+              r[6] = F.child_cnt; r[7] = F.child_off; r[8] = (int32_t)(F.L_off & 0xffffffffLL); r[9] = (int32_t)(F.L_off >> 32);
+              r[10] = F.piv0; r[11] = (int32_t)F.bnd_off;
+              for (int k = 0; k < 2; ++k) { r[12 + k] = -1; r[14 + k] = 0; r[16 + k] = 0;
+                  if (k < F.child_cnt) { const int c = P.children[F.child_off + k]; const Front &C = P.fronts[c];
+                      r[12 + k] = c; r[14 + k] = C.npiv | (C.nbnd << 16); r[16 + k] = C.owner; } }
+              const int64_t xo = (P.world > 1 && (size_t)sidx < P.x_off.size()) ? P.x_off[sidx] : 0;
+              r[18] = (int32_t)(xo & 0xffffffffLL); r[19] = (int32_t)(xo >> 32); }
+          std::vector<int32_t> recs(P.asm_recs.size() * 4);
+          const bool fused = P.lin_ell_ok && d.n_wtiles > 0;
+          for (size_t t = 0; t < P.asm_recs.size(); ++t) { int kind = P.asm_recs[t].kind, src = P.asm_recs[t].src;
+              if (kind == 1 && fused) { const int q0 = P.lm_grp_start[src], q1 = P.lm_grp_start[src + 1];
+                  if (q1 - q0 >= (1 << 22)) return fail(GS_ERR_INVALID, "landmark seen from too many wave tiles");
+                  kind = 1 | ((q1 - q0) << 8); src = q0; }
+              recs[4 * t] = kind; recs[4 * t + 1] = src; recs[4 * t + 2] = P.asm_recs[t].r0; recs[4 * t + 3] = P.asm_recs[t].c0; }
+          UP(asm3, recs);
+          // per front: where each row R of its PARENT finds this front's row in its tile image, as byte offsets split
+          // into a row part (low 16 bits) and a column part (high 16 bits); -30000 = no such row (sum goes negative)
+          std::vector<int32_t> pinv(P.fronts.size() * 64);
+          const int32_t pinv_none = (int32_t)((uint32_t)((-30000) & 0xffff) | ((uint32_t)(-30000) << 16));
+          { auto pack = [](int cr) -> int32_t { const int Ic = cr >> 4;
+                const int ro8 = (((Ic * (Ic + 1)) >> 1) * 256 + (cr & 15) * 16) * 8, co8 = ((cr >> 4) * 256 + (cr & 15)) * 8;
+                return (int32_t)((uint32_t)(ro8 & 0xffff) | ((uint32_t)co8 << 16)); };
+            std::fill(pinv.begin(), pinv.end(), pinv_none);
+            for (size_t c = 0; c < P.fronts.size(); ++c) { const Front &C = P.fronts[c]; if (C.parent < 0) continue;
+                const Front &Pa = P.fronts[C.parent]; int32_t *row = &pinv[64 * c];
+                for (int i = 0; i < C.nbnd; ++i) row[P.child_map[C.map_off + i]] = pack(C.npiv + i);
+                row[Pa.npiv + Pa.nbnd] = pack(C.npiv + C.nbnd); } }
+          UP(pinv, pinv);
+          // scalar assembly records {offset in H_arena, offset in the staging image}, padded per front to a multiple of
+          // 64 with (0 -> image offset 1, a don't-care upper-triangle slot); fused landmark diagonals go to lm3
+          { std::vector<int32_t> sc, lm; std::vector<int32_t> sc_off(P.fronts.size()), sc_cnt(P.fronts.size()), lm_off(P.fronts.size()), lm_cnt(P.fronts.size());
+            auto img = [](int r, int c) { const int I = r >> 4, J = c >> 4; return (((I * (I + 1)) >> 1) + J) * 256 + (r & 15) * 16 + (c & 15); };
+            const int64_t L = P.ell_len;
+            for (size_t sidx = 0; sidx < P.fronts.size(); ++sidx) { const Front &F = P.fronts[sidx]; const int f = F.npiv + F.nbnd;
+                sc_off[sidx] = (int32_t)(sc.size() / 2); lm_off[sidx] = (int32_t)(lm.size() / 4);
+                auto add = [&](int64_t src, int r, int c) { sc.push_back((int32_t)src); sc.push_back(img(r, c)); };
+                for (int t = F.asm_off; t < F.asm_off + F.asm_cnt - F.asm_dup; ++t) { const AsmRec &R = P.asm_recs[t]; const int r0 = R.r0, c0 = R.c0; const int64_t src = R.src;
+                    switch (R.kind) {
+                        case 0: { const int64_t H = arena_off[0], B = arena_off[1];
+                            add(H + src, r0, c0); add(H + N + src, r0 + 1, c0); add(H + 2 * (int64_t)N + src, r0 + 2, c0);
+                            add(H + 3 * (int64_t)N + src, r0 + 1, c0 + 1); add(H + 4 * (int64_t)N + src, r0 + 2, c0 + 1); add(H + 5 * (int64_t)N + src, r0 + 2, c0 + 2);
+                            for (int k = 0; k < 3; ++k) add(B + k * (int64_t)N + src, f, c0 + k); } break;
+                        case 1:
+                            if (fused) { const int q0 = P.lm_grp_start[src], q1 = P.lm_grp_start[src + 1];
+                                lm.push_back(q1 - q0); lm.push_back(q0); lm.push_back(r0); lm.push_back(c0); }
+                            else { const int64_t H = arena_off[5], B = arena_off[6];
+                                add(H + src, r0, c0); add(H + M + src, r0 + 1, c0); add(H + 2 * (int64_t)M + src, r0 + 1, c0 + 1);
+                                add(B + src, f, c0); add(B + M + src, f, c0 + 1); }
+                            break;
+                        case 2: for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) add(arena_off[2] + (3 * a + b) * (int64_t)Epp + src, r0 + a, c0 + b); break;
+                        case 3: for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) add(arena_off[2] + (3 * b + a) * (int64_t)Epp + src, r0 + a, c0 + b); break;
+                        case 4: for (int a = 0; a < 3; ++a) for (int b = 0; b < 2; ++b) add(arena_off[3] + (2 * a + b) * L + src, r0 + a, c0 + b); break;
+                        default: for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b) add(arena_off[3] + (2 * b + a) * L + src, r0 + a, c0 + b); break;
+                    } }
+                while ((sc.size() / 2 - (size_t)sc_off[sidx]) % 64) { sc.push_back(0); sc.push_back(1); }
+                sc_cnt[sidx] = (int32_t)(sc.size() / 2) - sc_off[sidx]; lm_cnt[sidx] = (int32_t)(lm.size() / 4) - lm_off[sidx]; }
+            if (sc.size() / 2 >= ((size_t)1 << 31)) return fail(GS_ERR_INVALID, "too many assembly scalars");
+            for (size_t q = 0; q < lf.size(); ++q) { int32_t *r = &fd[F3W * q]; const int sidx = lf[q];
+                r[20] = sc_off[sidx]; r[21] = sc_cnt[sidx]; r[22] = lm_off[sidx]; r[23] = lm_cnt[sidx]; }
+            UP(sc3, sc); UP(lm3, lm); }
+          for (size_t q = 0; q < lf.size(); ++q) { int32_t *r = &fd[F3W * q];
+              for (int k = 0; k < 2; ++k) { const int c = r[12 + k];
+                  for (int R = 0; R < 64; ++R) r[32 + 64 * k + R] = c >= 0 ? pinv[64 * (size_t)c + R] : pinv_none; } }
+          UP(f3_desc, fd);
+      } }
+    AL(dbg_ts, 64); ZERO(dbg_ts, 64);
     AL(Lbuf, P.l_doubles); AL(Ubuf, P.u_doubles); AL(xe, P.n_scalar); AL(dpose, (size_t)N * 3); AL(dlm, (size_t)M * 2); AL(fail, 4);
     HIP_TRY(hipMemsetAsync(d.fail, 0, 4 * sizeof(int32_t), g->stream));
     HIP_TRY(hipMemsetAsync(d.chi2, 0, 80 * sizeof(double), g->stream));
@@ -617,6 +698,13 @@ extern "C" int gs_time_linearize(gs_graph *g, int32_t reps, double *out_ms) {
     HIP_TRY(hipEventSynchronize(g->ev[1]));
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, g->ev[0], g->ev[1]));
     *out_ms = (double)ms / reps;
+    return GS_OK;
+}
+extern "C" int gs_debug_timestamps(gs_graph *g, int64_t *out64) {
+    if (!g || !out64) return fail(GS_ERR_INVALID, "null argument");
+    if (!g->dev_valid) return fail(GS_ERR_NOT_INITIALIZED, "nothing on the device yet");
+    HIP_TRY(hipMemcpyAsync(out64, g->d.dbg_ts, 64 * sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
     return GS_OK;
 }
 extern "C" int64_t gs_linearize_bytes(gs_graph *g) {

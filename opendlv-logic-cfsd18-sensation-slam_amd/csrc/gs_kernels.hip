@@ -969,8 +969,411 @@ __global__ void __launch_bounds__(256, 2) k_factor_mfma(DevGraph d, int level_of
         }
 }
 
+// ---- variant 3: latency-shaped wave-per-front kernels (f <= 63).  The time of a level is the latency of ONE front
+// (the top of the tree has fewer fronts than the chip has wave slots, and the leaf level is a few rounds of that
+// latency), so these kernels are built around the number of dependent memory round trips per front:
+//   1. one 96-byte descriptor per level position (front, its first two children, arena offsets): one coalesced load;
+//   2. assembly records + the children's inverse row maps;                     (one round trip)
+//   3. the original H values AND both children's update matrices, all in flight together: children are GATHERED by
+//      destination — accumulator element (R, C) of the parent reads element (pinv[R], pinv[C]) of the child's tile
+//      image — so there is no scatter through LDS, no read-modify-write chain, and the sum order is fixed
+//      (originals + child 0 + child 1 + ...).  (Measured alternatives: coalesced tile loads + ds_add_f64 scatter is
+//      3x slower — LDS f64 atomics retire ~270 cycles per wave instruction; register read-modify-write through LDS
+//      costs two more LDS round trips per child.)
+//   4. LDL^T panels of 4 pivots on the fp64 matrix cores: T(I,J) -= (c/d) c^T, one reciprocal per pivot instead of a
+//      square root and a division; the rhs is row f of the front, so row f of the L panel is D^-1 L^-1 b and the
+//      backward solve has a unit diagonal (no division there either).
+// Record formats (built in gs_api.cpp upload_graph):
+//   f3_desc [level position][24] int32: 0 front, 1 npiv, 2 nbnd, 3 asm_off, 4 #unique records, 5 #duplicate records,
+//      6 #children, 7 child_off, 8-9 L_off, 10 piv0, 11 bnd_off, 12-13 child front (-1 none), 14-15 child npiv | nbnd << 16,
+//      16-17 child owner, 18-19 exchange slot offset, 20 sc_off, 21 #scalar records (multiple of 64), 22 lm_off, 23 #landmark records
+//   sc3 [scalar][2]: {offset of the value in H_arena, offset in the staging image}: the original blocks flattened to
+//      scalars, so the assembly is branch-free (load record, load value, one LDS store)
+//   lm3 [record][4]: {#slots, first slot, r0, c0}: landmark diagonal blocks of the fused linearisation (sum of the
+//      per-wave-tile partial slots, in slot order)
+//   asm3 [record][4]: kind | count << 8, src, r0, c0 — as asm_recs, except that a landmark diagonal record carries its
+//      partial-sum slot range (src = first slot, count = #slots) so that no index load precedes the value loads
+//   pinv [front][64] int32: for row R of the PARENT, where THIS front's matching row sits in its tile image: byte offset
+//      split into a row part (low 16 bits, signed) and a column part (high 16 bits); -30000 in both = no such row.
+//      The tables of a front's first two children sit right behind its descriptor (f3_desc stride 160 ints), so the
+//      gathers can be issued after the FIRST round trip.
+struct F3 {
+    int s, npiv, nbnd, asm_off, asm_uniq, asm_dup, nchild, child_off, piv0, bnd_off, c_id[2], c_info[2], c_owner[2];
+    int sc_off, sc_cnt, lm_off, lm_cnt;
+    int64_t L_off, x_off;
+};
+static constexpr int F3_INTS = 32, F3_STRIDE = 160;   // 32 descriptor ints, then pinv of child 0 and of child 1 (64 ints each)
+static constexpr int MF_SLOT = MF_IMG + 8;         // HBM stride of a tile image: 8 always-zero doubles behind it (target of clamped gathers)
+__device__ __forceinline__ F3 f3_load(const int32_t *desc, int idx, int lane) {
+    const int v = (lane < F3_INTS) ? desc[(int64_t)idx * F3_STRIDE + lane] : 0;
+    auto g = [&](int i) { return __builtin_amdgcn_readlane(v, i); };
+    F3 r;
+    r.s = g(0); r.npiv = g(1); r.nbnd = g(2); r.asm_off = g(3); r.asm_uniq = g(4); r.asm_dup = g(5); r.nchild = g(6); r.child_off = g(7);
+    r.L_off = (int64_t)(uint32_t)g(8) | ((int64_t)g(9) << 32); r.piv0 = g(10); r.bnd_off = g(11);
+    r.c_id[0] = g(12); r.c_id[1] = g(13); r.c_info[0] = g(14); r.c_info[1] = g(15); r.c_owner[0] = g(16); r.c_owner[1] = g(17);
+    r.x_off = (int64_t)(uint32_t)g(18) | ((int64_t)g(19) << 32);
+    r.sc_off = g(20); r.sc_cnt = g(21); r.lm_off = g(22); r.lm_cnt = g(23);
+    return r;
+}
+
+// values of one assembly record (phase A: loads only)
+__device__ __forceinline__ void asm3_load(const DevGraph &d, int kind_cnt, int src, double (&v)[9]) {
+    const int kind = kind_cnt & 0xff;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v[k] = 0.0;
+    switch (kind) {
+        case 0: { const int64_t S = d.N;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v[k] = d.Hpp_diag[k * S + src];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[6 + k] = d.b_pose[k * S + src]; } break;
+        case 1: {
+            if (d.n_wtiles > 0) { const int cnt = kind_cnt >> 8; const int64_t G = d.n_groups;
+                for (int q0 = 0; q0 < cnt; q0 += 4) {                // four slots' loads in flight, added in slot order
+                    double t[4][5];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int q = min(q0 + j, cnt - 1);
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) t[j][k] = d.lm_part[k * G + src + q]; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) v[k] += (q0 + j < cnt) ? t[j][k] : 0.0; }
+            } else { const int64_t S = d.M;
+                v[0] = d.Hll_diag[src]; v[1] = d.Hll_diag[S + src]; v[2] = d.Hll_diag[2 * S + src]; v[3] = d.b_lm[src]; v[4] = d.b_lm[S + src]; }
+        } break;
+        case 2: case 3: { const int64_t S = d.Epp;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) v[k] = d.Hpp_off[k * S + src]; } break;
+        default: { const int64_t S = d.ell_len;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v[k] = d.Hpl[k * S + src]; } break;
+    }
+}
+// phase B: the values into the staging image
+template <bool ADD>
+__device__ __forceinline__ void asm3_put(const StageFront &P, int kind_cnt, int r0, int c0, const double (&v)[9]) {
+    const int kind = kind_cnt & 0xff, f = P.f;
+    auto put = [&](int r, int c, double x) { if (ADD) P.at(r, c) += x; else P.at(r, c) = x; };
+    switch (kind) {
+        case 0:
+            put(r0, c0, v[0]); put(r0 + 1, c0, v[1]); put(r0 + 2, c0, v[2]);
+            put(r0 + 1, c0 + 1, v[3]); put(r0 + 2, c0 + 1, v[4]); put(r0 + 2, c0 + 2, v[5]);
+            put(f, c0, v[6]); put(f, c0 + 1, v[7]); put(f, c0 + 2, v[8]);
+            break;
+        case 1:
+            put(r0, c0, v[0]); put(r0 + 1, c0, v[1]); put(r0 + 1, c0 + 1, v[2]); put(f, c0, v[3]); put(f, c0 + 1, v[4]);
+            break;
+        case 2: case 3:
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) put(r0 + a, c0 + b, (kind == 2) ? v[3 * a + b] : v[3 * b + a]);
+            break;
+        case 4:
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) put(r0 + a, c0 + b, v[2 * a + b]);
+            break;
+        default:
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) put(r0 + a, c0 + b, v[2 * b + a]);
+            break;
+    }
+}
+
+// gather one child's update matrix by destination: pv = pinv[child][lane]; accumulator element (R, C) of the parent
+// reads byte offset rowpart(R) + colpart(C) of the child's tile image.  A missing row makes the sum negative, which
+// the unsigned min clamps to the zero padding behind the image: three instructions per element, no branches.
+// (Upper-triangle elements of the diagonal tiles read some other, finite, element: they are don't-care everywhere.)
+__device__ __forceinline__ void f3_gather_child(const double *Uc, int pv, int lane, double (&u)[10][4]) {
+    const int lc = lane & 15, lr = lane >> 4;
+    int co[4];
+#pragma unroll
+    for (int J = 0; J < 4; ++J) co[J] = __shfl(pv, 16 * J + lc, WAVE) >> 16;
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ro = (int)(short)(__shfl(pv, 16 * I + lr + 4 * q, WAVE) & 0xffff);
+#pragma unroll
+            for (int J = 0; J <= I; ++J)
+                u[mf_tile(I, J)][q] = ld_off(Uc, min((uint32_t)(ro + co[J]), (uint32_t)(MF_IMG * 8)));
+        }
+}
+
+__device__ __forceinline__ double rcp_f64(double x) {             // reciprocal to ~1 ulp: hardware seed + two Newton steps
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0); r = fma(r, e, r);
+    e = fma(-x, r, 1.0); r = fma(r, e, r);
+    return r;
+}
+
+template <int B>      // panel B: pivots 4B .. 4B+3 (tile column J0 = B / 4), LDL^T
+__device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[10], double *Pn, double *L, int npiv, int f, int lane) {
+    constexpr int k0 = 4 * B, J0 = B / 4, jc = (B % 4) * 4;
+    if (k0 >= npiv) return false;                                   // uniform
+    const int lc = lane & 15, lr = lane >> 4;
+    // 1. the panel's four columns (rows of tiles J0..3) to LDS, row-major 64 x 4
+    if (lc >= jc && lc < jc + 4) {
+#pragma unroll
+        for (int I = J0; I < 4; ++I) if (16 * I <= f) {              // uniform: tile rows beyond the rhs row hold nothing
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Pn[(16 * I + lr + 4 * q) * 4 + (lc - jc)] = acc[mf_tile(I, J0)][q]; }
+    }
+    wave_lds_sync();
+    // 2. factorise the panel, lane r = row r:  l = c / d below the diagonal, d on it, 0 above
+    double p[4], dd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = Pn[lane * 4 + j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = k0 + j;
+        dd[j] = 0.0;
+        if (col < npiv) {                                           // uniform
+            double piv = lane_bcast(p[j], col);
+            const bool ok = piv > 0.0;                              // a non-positive pivot is reported once, at the end of the front
+            bad = bad || !ok; piv = ok ? piv : 1.0;
+            const double inv = rcp_f64(piv);
+            const double lj = (lane > col) ? p[j] * inv : 0.0;
+#pragma unroll
+            for (int j2 = j + 1; j2 < 4; ++j2) { const double c2 = lane_bcast(p[j], k0 + j2); p[j2] -= lj * c2; }
+            p[j] = (lane == col) ? piv : lj;
+            dd[j] = piv;
+            if (lane <= f) L[(int64_t)col * (f + 1) + lane] = p[j];   // column `col` of the L panel (rows < col are 0, row col = d)
+        } else p[j] = 0.0;                                          // not a pivot: contributes nothing to the update
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Pn[lane * 4 + j] = p[j];
+    wave_lds_sync();
+    // 3. trailing update on the matrix cores: T(I,J) -= A_I B_J^T, A = l (scaled), B = l * d (the unscaled column)
+    const double dk = lr == 0 ? dd[0] : (lr == 1 ? dd[1] : (lr == 2 ? dd[2] : dd[3]));      // k = lane >> 4
+    double a[4];
+#pragma unroll
+    for (int I = J0; I < 4; ++I) a[I] = Pn[(16 * I + lc) * 4 + lr];  // A[i = lane & 15][k = lane >> 4] = l[16 I + i][k]
+#pragma unroll
+    for (int I = J0; I < 4; ++I) if (16 * I <= f) {
+#pragma unroll
+        for (int J = J0; J <= I; ++J)
+            acc[mf_tile(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[I], a[J] * dk, acc[mf_tile(I, J)], 0, 0, 0); }
+    wave_lds_sync();
+    return true;
+}
+
+__global__ void __launch_bounds__(256, 2) k_factor3(DevGraph d, int level_off, int count, int mode) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int fi = blockIdx.x * 4 + wave;
+    if (fi >= count) return;                                        // whole wave leaves; no block barrier below
+    const bool ts_on = (d.dbg & 8) && count == (d.dbg >> 8) && fi == 0;
+#define F3_TS(i) do { if (ts_on) { __builtin_amdgcn_s_waitcnt(0); if (lane == 0) d.dbg_ts[i] = wall_clock64(); } } while (0)
+    F3_TS(0);
+    int pv[2];                                                       // the children's row tables ride behind the descriptor
+    pv[0] = d.f3_desc[(int64_t)(level_off + fi) * F3_STRIDE + F3_INTS + lane];
+    pv[1] = d.f3_desc[(int64_t)(level_off + fi) * F3_STRIDE + F3_INTS + 64 + lane];
+    const F3 fr = f3_load(d.f3_desc, level_off + fi, lane);
+    const int npiv = fr.npiv, f = npiv + fr.nbnd;
+    StageFront P{smem + (int64_t)wave * MF_IMG, f};
+    const int lc = lane & 15, lr = lane >> 4;
+    F3_TS(1);
+    const bool top = mode == FRONT_TOP;
+    // ---- round trip 2a: the children's update matrices, gathered by destination (in flight until the accumulators are built)
+    bool use[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        use[k] = fr.c_id[k] >= 0 && !(mode == FRONT_CONTRIB && fr.c_owner[k] != d.rank) && !(top && fr.c_owner[k] >= 0);   // uniform
+    double u0[10][4], u1[10][4];
+    if (use[0]) f3_gather_child(d.Uimg + (int64_t)fr.c_id[0] * MF_SLOT, pv[0], lane, u0);
+    if (use[1]) f3_gather_child(d.Uimg + (int64_t)fr.c_id[1] * MF_SLOT, pv[1], lane, u1);
+    // ---- round trip 2b: scalar assembly records (eight per lane up front), landmark records
+    const int nsc = top ? 0 : fr.sc_cnt, nlm = top ? 0 : fr.lm_cnt;
+    const int2 *sc3 = reinterpret_cast<const int2 *>(d.sc3) + fr.sc_off;
+    int2 sc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sc[u] = (64 * u < nsc) ? sc3[64 * u + lane] : make_int2(0, 1);        // uniform predicate
+    int4 lmr = make_int4(0, 0, 0, 0);
+    if (lane < nlm) lmr = reinterpret_cast<const int4 *>(d.lm3)[fr.lm_off + lane];
+    F3_TS(2);
+    // the staging image: originals only touch pivot columns, i.e. tile columns 0 .. (npiv - 1) / 16
+    const int Jmax = top ? 3 : ((npiv - 1) >> 4);
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J) if (J <= Jmax) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) P.F[mf_tile(I, J) * 256 + q * 64 + lane] = 0.0; }
+    wave_lds_sync();
+    F3_TS(3);
+    // ---- round trip 3: the original values
+    F3_TS(4);
+    if (top) {
+        const double *X = d.exchange + fr.x_off;                     // slot layout: (f+1) x f column-major, ld = f+1
+        for (int c = 0; c < f; ++c) if (lane >= c && lane <= f) P.at(lane, c) = X[c * (f + 1) + lane];
+    } else {
+        double val[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (64 * u < nsc) val[u] = ld_off(d.H_arena, (uint32_t)sc[u].x * 8u);
+        double lv[5] = {0, 0, 0, 0, 0};
+        if (lane < nlm) { const int64_t G = d.n_groups;
+            for (int q0 = 0; q0 < lmr.x; q0 += 4) {                  // four slots' loads in flight, added in slot order
+                double t[4][5];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int q = min(q0 + j, lmr.x - 1);
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) t[j][k] = d.lm_part[k * G + lmr.y + q]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) lv[k] += (q0 + j < lmr.x) ? t[j][k] : 0.0; } }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (64 * u < nsc) P.F[sc[u].y] = val[u];
+        for (int base = 512; base < nsc; base += 64) { const int2 r = sc3[base + lane]; P.F[r.y] = ld_off(d.H_arena, (uint32_t)r.x * 8u); }   // fronts with > 512 scalars
+        if (lane < nlm) { const int r0 = lmr.z, c0 = lmr.w;
+            P.at(r0, c0) = lv[0]; P.at(r0 + 1, c0) = lv[1]; P.at(r0 + 1, c0 + 1) = lv[2]; P.at(f, c0) = lv[3]; P.at(f, c0 + 1) = lv[4]; }
+        for (int t = 64 + lane; t < nlm; t += 64) {                  // fronts with > 64 landmark pivots (not on f <= 63 fronts; kept for safety)
+            const int4 r = reinterpret_cast<const int4 *>(d.lm3)[fr.lm_off + t]; const int64_t G = d.n_groups; double a[5] = {0, 0, 0, 0, 0};
+            for (int q = 0; q < r.x; ++q)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) a[k] += d.lm_part[k * G + r.y + q];
+            P.at(r.z, r.w) = a[0]; P.at(r.z + 1, r.w) = a[1]; P.at(r.z + 1, r.w + 1) = a[2]; P.at(f, r.w) = a[3]; P.at(f, r.w + 1) = a[4]; }
+        wave_lds_sync();
+        if (fr.asm_dup > 0) {                                        // parallel edges: added one by one, in record order
+            if (lane == 0) for (int t = fr.asm_uniq; t < fr.asm_uniq + fr.asm_dup; ++t) {
+                const int4 r = reinterpret_cast<const int4 *>(d.asm3)[fr.asm_off + t];
+                double w[9]; asm3_load(d, r.x, r.y, w); asm3_put<true>(P, r.x, r.z, r.w, w); }
+        }
+    }
+    wave_lds_sync();
+    F3_TS(5);
+    // ---- accumulators = originals + child 0 + child 1 (+ further children, rare)
+    v4d acc[10];
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J) { const int t = mf_tile(I, J);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[t][q] = (J <= Jmax) ? P.F[t * 256 + q * 64 + lane] : 0.0; }
+    if (use[0]) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[t][q] += u0[t][q]; }
+    if (use[1]) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[t][q] += u1[t][q]; }
+    for (int ci = 2; ci < fr.nchild; ++ci) {
+        const int4 dc = reinterpret_cast<const int4 *>(d.child_desc)[fr.child_off + ci];    // {front, npiv | nbnd << 16, owner, map offset}
+        if (mode == FRONT_CONTRIB && dc.z != d.rank) continue;
+        if (top && dc.z >= 0) continue;
+        const int pvx = d.pinv[(int64_t)dc.x * 64 + lane];
+        f3_gather_child(d.Uimg + (int64_t)dc.x * MF_SLOT, pvx, lane, u0);
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[t][q] += u0[t][q];
+    }
+    wave_lds_sync();
+    if (mode == FRONT_CONTRIB) {                                     // this rank's share of a shared front -> exchange slot
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) P.F[t * 256 + q * 64 + lane] = acc[t][q];
+        wave_lds_sync();
+        double *X = d.exchange + fr.x_off;
+        for (int c = 0; c < f; ++c) if (lane <= f) X[c * (f + 1) + lane] = (lane >= c) ? P.at(lane, c) : 0.0;
+        return;
+    }
+    F3_TS(6);
+    // ---- panels of 4 pivots; the LDS image is free now, its first 256 doubles serve as the panel buffer
+    double *Pn = P.F;
+    double *L = d.Lbuf + fr.L_off;
+    bool go = true, bad = false;
+    go = go && f3_panel_step<0>(bad, acc, Pn, L, npiv, f, lane);   go = go && f3_panel_step<1>(bad, acc, Pn, L, npiv, f, lane);
+    go = go && f3_panel_step<2>(bad, acc, Pn, L, npiv, f, lane);   go = go && f3_panel_step<3>(bad, acc, Pn, L, npiv, f, lane);
+    go = go && f3_panel_step<4>(bad, acc, Pn, L, npiv, f, lane);   go = go && f3_panel_step<5>(bad, acc, Pn, L, npiv, f, lane);
+    go = go && f3_panel_step<6>(bad, acc, Pn, L, npiv, f, lane);   go = go && f3_panel_step<7>(bad, acc, Pn, L, npiv, f, lane);
+    go = go && f3_panel_step<8>(bad, acc, Pn, L, npiv, f, lane);   go = go && f3_panel_step<9>(bad, acc, Pn, L, npiv, f, lane);
+    go = go && f3_panel_step<10>(bad, acc, Pn, L, npiv, f, lane);  go = go && f3_panel_step<11>(bad, acc, Pn, L, npiv, f, lane);
+    go = go && f3_panel_step<12>(bad, acc, Pn, L, npiv, f, lane);  go = go && f3_panel_step<13>(bad, acc, Pn, L, npiv, f, lane);
+    go = go && f3_panel_step<14>(bad, acc, Pn, L, npiv, f, lane);  go = go && f3_panel_step<15>(bad, acc, Pn, L, npiv, f, lane);
+    if (bad && lane == 0) atomicExch(d.fail, 1);
+    F3_TS(7);
+    // ---- Schur complement out as a tile image (only tiles that hold entries with row, col >= npiv)
+    double *U = d.Uimg + (int64_t)fr.s * MF_SLOT;
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J) {
+            if (16 * I + 15 < npiv || 16 * J + 15 < npiv) continue;   // uniform
+#pragma unroll
+            for (int q = 0; q < 4; ++q) U[(mf_tile(I, J) * 4 + q) * 64 + lane] = acc[mf_tile(I, J)][q];
+        }
+    F3_TS(8);
+}
+
+// backward solve of variant 3's LDL^T panels (unit diagonal): x_piv = L11^-T (y - L21^T x_bnd), one wave per front
+__global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, int count, int slot_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int fi = blockIdx.x * 4 + wave;
+    if (fi >= count) return;
+    const bool ts_on = (d.dbg & 8) && count == (d.dbg >> 8) && fi == 0;
+    F3_TS(32);
+    const F3 fr = f3_load(d.f3_desc, level_off + fi, lane);
+    const int npiv = fr.npiv, nbnd = fr.nbnd, f = npiv + nbnd, ldl = f + 1, lds = (f + 1) | 1;
+    F3_TS(33);
+    double *S = smem + (int64_t)wave * slot_doubles;
+    const double *L = d.Lbuf + fr.L_off;
+    const int row = (lane < nbnd) ? d.bnd_rows[fr.bnd_off + lane] : -1;
+    // the L panel, column by column (coalesced), four loads in flight per lane
+    const int lrow = min(lane, f);                                   // lanes beyond the panel re-read row f and drop it
+    for (int c0 = 0; c0 < npiv; c0 += 32) {                          // 32 column loads in flight per lane: one round trip for npiv <= 32
+        double t[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) t[j] = L[(int64_t)min(c0 + j, npiv - 1) * ldl + lrow];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) if (c0 + j < npiv && lane <= f) S[(c0 + j) * lds + lane] = t[j];
+    }
+    F3_TS(34);
+    const double xb = (row >= 0) ? d.xe[row] : 0.0;
+    wave_lds_sync();
+    F3_TS(35);
+    const int me = min(lane, npiv - 1);                              // lanes >= npiv compute on a valid column and drop the result
+    double w = S[me * lds + f];
+    for (int r0 = 0; r0 < nbnd; r0 += 16) {                          // 16 LDS reads in flight, then the FMAs in row order
+        double l16[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) l16[j] = S[me * lds + npiv + min(r0 + j, nbnd - 1)];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w -= ((r0 + j < nbnd) ? l16[j] : 0.0) * lane_bcast(xb, min(r0 + j, 63));
+    }
+    F3_TS(36);
+    for (int c1 = npiv - 1; c1 > 0; c1 -= 4) {                       // the L11 entries of four steps are read ahead of the chain
+        double l4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int cc = max(c1 - j, 1); l4[j] = S[min(lane, cc - 1) * lds + cc]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int cc = c1 - j;
+            if (cc > 0) { const double xcc = lane_bcast(w, cc); if (lane < cc) w -= l4[j] * xcc; } }
+    }
+    F3_TS(37);
+    if (lane < npiv) d.xe[fr.piv0 + lane] = w;
+    F3_TS(38);
+}
+
 void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f, int mode, hipStream_t st) {
     if (count <= 0) return;
+    if (max_f <= 63 && d.factor_variant == 3) {
+        static bool attr_set_3 = false;
+        if (!attr_set_3) { hipFuncSetAttribute((const void *)k_factor3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_3 = true; }
+        hipLaunchKernelGGL(k_factor3, dim3((count + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, level_off, count, mode);
+        return;
+    }
     if (max_f <= 63 && d.factor_variant == 2) {
         static bool attr_set_m = false;
         if (!attr_set_m) { hipFuncSetAttribute((const void *)k_factor_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_m = true; }
@@ -1064,6 +1467,13 @@ __global__ void __launch_bounds__(256) k_backsolve_wave(DevGraph d, int level_of
 
 void launch_backsolve_level(const DevGraph &d, int level_off, int count, int max_npiv, int max_nbnd, hipStream_t st) {
     if (count <= 0) return;
+    if (d.factor_variant == 3) {                                     // LDL^T panels: unit-diagonal backward solve
+        const int f = max_npiv + max_nbnd, slot = ((((f + 1) | 1) * max_npiv) + 1) & ~1;
+        static bool attr_set_b3 = false;
+        if (!attr_set_b3) { hipFuncSetAttribute((const void *)k_backsolve3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_b3 = true; }
+        hipLaunchKernelGGL(k_backsolve3, dim3((count + 3) / 4), dim3(256), (size_t)slot * 4 * sizeof(double), st, d, level_off, count, slot);
+        return;
+    }
     if (max_npiv + max_nbnd <= 63) {
         const int f = max_npiv + max_nbnd, slot = ((((f + 1) | 1) * max_npiv) + 1) & ~1;
         static bool attr_set_b = false;

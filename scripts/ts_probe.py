@@ -1,0 +1,18 @@
+"""Phase timestamps of one front inside the variant-3 factor / backsolve kernels.
+usage: GS_FACTOR_VARIANT=3 GS_DBG=$((8 | (COUNT << 8))) python scripts/ts_probe.py [cfg]   (COUNT = fronts in the probed level)"""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("opendlv-logic-cfsd18-sensation-slam_amd")
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
+N, M = pkg.track.CONFIGS[name]
+t = pkg.track.generate(N, M); fe = pkg.Graph(); g = pkg.track.bench_graph(t, fe)
+G = pkg.Graph(); G.load_bench_graph(g); G.initialize_optimization()
+for _ in range(4):
+    G.iterate()
+G.synchronize()
+ts = G.debug_timestamps()
+f = ts[0:9]; b = ts[32:39]
+print("factor  phases (us):", [round((int(f[i + 1]) - int(f[i])) / 100.0, 2) for i in range(8)], "total", (int(f[8]) - int(f[0])) / 100.0)
+print("   0 desc | 1 issue rec+pinv | 2 wait | 3 zero LDS | 4 gather issue+wait | 5 originals | 6 acc sum | 7 panels | 8 U out")
+print("backsolve phases (us):", [round((int(b[i + 1]) - int(b[i])) / 100.0, 2) for i in range(6)], "total", (int(b[6]) - int(b[0])) / 100.0)
+print("   32 desc | 33 L->LDS | 34 xe gather | 35 boundary mat-vec | 36 substitution | 37 store")
