@@ -164,7 +164,7 @@ def main():
         traffic = None
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                     traffic=traffic, kernel="k_linearize_ell: edge linearisation + assembly (A5-A7)", ms_per_launch=lin_ms,
-                    algorithmic_bytes=alg_bytes, note="back-to-back launches; inside an iteration see phases_ms.linearize")
+                    algorithmic_bytes=alg_bytes, note="back-to-back launches of this rank's window (N > 1: no per-phase events inside the sharded step)")
     out = dict(metric="GraphSLAM Gauss-Newton iters/sec at N poses x M cones; pose RMSE vs ref",
                value=value, unit="GN iterations/s (100k-pose windows)", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64",
@@ -181,7 +181,14 @@ def main():
         phases = G.time_iterations(20)
         out["phases_ms"] = dict(linearize=phases.ms_linearize, factor=phases.ms_factor, backsolve=phases.ms_backsolve,
                                 update=phases.ms_update, structure_once=plan.ms_structure)
-        out["roofline"]["achieved_inside_iteration"] = alg_bytes / (phases.ms_linearize * 1e-3) / 1e9
+        # the roofline entry is the kernel AS IT RUNS INSIDE the Gauss-Newton iteration (HIP events around the phase, same
+        # launch sequence as the timed region): its inputs are cold there.  Back-to-back launches of the same kernel find
+        # cfg4's 105 MB still in the 256 MB Infinity Cache and are reported beside it, not as `achieved`.
+        inside = alg_bytes / (phases.ms_linearize * 1e-3) / 1e9
+        out["roofline"].update(achieved=inside, frac=inside / HBM_PEAK_GBS, ms_per_launch=phases.ms_linearize,
+                               achieved_back_to_back=achieved, ms_per_launch_back_to_back=lin_ms,
+                               note="HIP events around the linearisation phase inside full iterations (cold inputs); "
+                                    "achieved_back_to_back = the same kernel launched 50x in a row (inputs cached)")
     if rank == 0 and world == 1 and not args.no_cpu:
         og, cb = cpu_baseline(pkg, g, args.cpu_iters)
         out["cpu_baseline"] = cb

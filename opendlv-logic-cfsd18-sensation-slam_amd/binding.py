@@ -12,7 +12,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libgraphslam_hip.so")
+LIB_PATH = os.environ.get("GS_LIB", os.path.join(CSRC, "libgraphslam_hip.so"))    # GS_LIB: A/B builds of the same library (tuning)
 HEADER = os.path.join(os.path.dirname(HERE), "include", "graphslam.h")
 
 _dp = C.POINTER(C.c_double)

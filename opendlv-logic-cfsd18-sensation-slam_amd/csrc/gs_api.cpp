@@ -322,6 +322,8 @@ static int upload_graph(gs_graph *g) {
     int rc;
 #define UP(dst, vec) if ((rc = dev_upload(g, &d.dst, vec)) != GS_OK) return rc
     UP(pose_est, h.pose_est); UP(lm_est, h.lm_est); UP(pose_fixed, h.pose_fixed); UP(lm_fixed, h.lm_fixed);
+    if ((rc = dev_alloc(g, &d.pose_cs, (size_t)h.n_poses() * 2)) != GS_OK) return rc;
+    launch_pose_trig(d, g->stream);
     UP(pose_gidx, P.pose_gidx); UP(lm_gidx, P.lm_gidx);
     d.ell_T = P.ell_T; d.ell_R = P.ell_R; d.ell_len = P.ell_len;
     { const size_t L = (size_t)P.ell_len;                                                                    // ELL streams
@@ -368,6 +370,7 @@ static int upload_graph(gs_graph *g) {
       AL(H_arena, (size_t)arena_off[7] + 2);
       // blocks of edges / tiles this rank never evaluates must read as zero
       ZERO(H_arena, (size_t)arena_off[7] + 2);
+      // (the fused linearisation kernel stores Hpp_diag's 6 planes and b_pose's 3 as 9 contiguous planes: 6N is even, no padding between)
       d.Hpp_diag = d.H_arena + arena_off[0]; d.b_pose = d.H_arena + arena_off[1]; d.Hpp_off = d.H_arena + arena_off[2];
       d.Hpl = d.H_arena + arena_off[3]; d.lm_part = d.H_arena + arena_off[4]; d.Hll_diag = d.H_arena + arena_off[5]; d.b_lm = d.H_arena + arena_off[6]; }
     d.n_chi2_partial = std::max((N + 255) / 256, d.n_wtiles);
@@ -564,6 +567,7 @@ static int ensure_ready(gs_graph *g) {
         const int N = g->d.N, M = g->d.M;
         if (N > 0) HIP_TRY(hipMemcpyAsync(g->d.pose_est, g->h.pose_est.data(), (size_t)N * 3 * sizeof(double), hipMemcpyHostToDevice, g->stream));
         if (M > 0) HIP_TRY(hipMemcpyAsync(g->d.lm_est, g->h.lm_est.data(), (size_t)M * 2 * sizeof(double), hipMemcpyHostToDevice, g->stream));
+        launch_pose_trig(g->d, g->stream);
         HIP_TRY(hipStreamSynchronize(g->stream));
         g->dev_estimate_version = g->h.estimate_version; g->dev_estimates_newer = false;
     }
@@ -771,6 +775,7 @@ extern "C" int gs_time_iterations(gs_graph *g, int32_t reps, gs_stats *s) {
     s->ms_linearize /= reps; s->ms_factor /= reps; s->ms_backsolve /= reps; s->ms_update /= reps;
     s->ms_total = s->ms_linearize + s->ms_factor + s->ms_backsolve + s->ms_update; s->iterations = reps;
     hipMemcpyAsync(g->d.pose_est, sp, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToDevice, g->stream);
+    launch_pose_trig(g->d, g->stream);
     hipMemcpyAsync(g->d.lm_est, sl, (size_t)M * 2 * sizeof(double), hipMemcpyDeviceToDevice, g->stream);
     int32_t failflag = 0;
     hipMemcpyAsync(&failflag, g->d.fail, sizeof(int32_t), hipMemcpyDeviceToHost, g->stream);

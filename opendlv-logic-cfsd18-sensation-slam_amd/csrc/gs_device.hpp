@@ -28,6 +28,7 @@ struct DevGraph {
     int32_t N = 0, M = 0, Epp = 0, Epl = 0, n_scalar = 0;
     // state
     double *pose_est = nullptr, *lm_est = nullptr;             // [N*3], [M*2]
+    double *pose_cs = nullptr;                                  // [N*2] cos, sin of every pose's theta (kept by k_pose_trig / k_update)
     uint8_t *pose_fixed = nullptr, *lm_fixed = nullptr;
     int32_t *pose_gidx = nullptr, *lm_gidx = nullptr;          // first scalar in elimination order, -1 fixed
     // observation edges, ELL
@@ -81,6 +82,7 @@ void launch_chi2_only(const DevGraph &d, hipStream_t st);
 void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f, int mode, hipStream_t st);
 void launch_backsolve_level(const DevGraph &d, int level_off, int count, int max_npiv, int max_nbnd, hipStream_t st);
 void launch_update(const DevGraph &d, hipStream_t st);
+void launch_pose_trig(const DevGraph &d, hipStream_t st);       // pose_cs from pose_est (after every host -> device estimate copy)
 void launch_polar_to_xy(int n, const double *az, const double *zen, const double *dist, double lidar, double *out, hipStream_t st);
 void launch_cone_to_global(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar,
                            double *out, hipStream_t st);

@@ -162,6 +162,16 @@ __device__ __forceinline__ void quad_pl(double px, double py, double c, double s
 // One (pose, odometry edge) incidence with its operands already in registers: adds the edge's share for that
 // endpoint to H (6 packed) and b, writes the off-diagonal block if this endpoint owns the edge (role 0 = i
 // endpoint); returns the chi2 of an owned edge.
+// device-scope store (sc1): see st_off_wt below
+template <class Tp> __device__ __forceinline__ void st_wt(Tp *ptr, Tp v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#ifndef LIN_NT
+#define LIN_NT 1
+#endif
+#if LIN_NT & 4
+#define ST_O(ptr, v) st_wt(ptr, v)
+#else
+#define ST_O(ptr, v) (*(ptr) = (v))
+#endif
 template <bool WRITE_H>
 __device__ __forceinline__ double pp_incidence(const DevGraph &d, int k, int role, const double xi[3], const double xj[3],
                                                double ci, double si, const double zinv5[5], const double w[6],
@@ -197,9 +207,9 @@ __device__ __forceinline__ double pp_incidence(const DevGraph &d, int k, int rol
             const bool both = !fi && !fj;
             const int64_t E = d.Epp;
             double *o = d.Hpp_off + k;
-            o[0] = both ? -g00 : 0.0;     o[E] = both ? -g01 : 0.0;     o[2 * E] = both ? -g02 : 0.0;
-            o[3 * E] = both ? -g01 : 0.0; o[4 * E] = both ? -g11 : 0.0; o[5 * E] = both ? -g12 : 0.0;
-            o[6 * E] = both ? t0 : 0.0;   o[7 * E] = both ? t1 : 0.0;   o[8 * E] = both ? wa2 : 0.0;
+            ST_O(o, both ? -g00 : 0.0);         ST_O(o + E, both ? -g01 : 0.0);     ST_O(o + 2 * E, both ? -g02 : 0.0);
+            ST_O(o + 3 * E, both ? -g01 : 0.0); ST_O(o + 4 * E, both ? -g11 : 0.0); ST_O(o + 5 * E, both ? -g12 : 0.0);
+            ST_O(o + 6 * E, both ? t0 : 0.0);   ST_O(o + 7 * E, both ? t1 : 0.0);   ST_O(o + 8 * E, both ? wa2 : 0.0);
         } else {
             H[0] += g00; H[1] += g01; H[2] += g02; H[3] += g11; H[4] += g12; H[5] += w22;
             b[0] -= bw0; b[1] -= bw1; b[2] -= We2;
@@ -209,9 +219,8 @@ __device__ __forceinline__ double pp_incidence(const DevGraph &d, int k, int rol
 }
 // the same with the operands fetched here (q = index of the incidence record)
 template <bool WRITE_H>
-__device__ __forceinline__ double pp_incidence_q(const DevGraph &d, int q, double H[6], double b[3], int own_pose = -1, double own_c = 1.0, double own_s = 0.0) {
-    const int4 inc = reinterpret_cast<const int4 *>(d.ppinc)[q];                 // {edge, role, i, j}
-    const int k = inc.x, i = inc.z, j = inc.w;
+__device__ __forceinline__ double pp_incidence_rec(const DevGraph &d, const int4 inc, double H[6], double b[3], int own_pose = -1, double own_c = 1.0, double own_s = 0.0) {
+    const int k = inc.x, i = inc.z, j = inc.w;                                   // {edge, role, i, j}
     if (k < 0) return 0.0;                                                       // evaluated by another shard
     double xi[3], xj[3], z5[5], w[6];
 #pragma unroll
@@ -221,8 +230,14 @@ __device__ __forceinline__ double pp_incidence_q(const DevGraph &d, int q, doubl
 #pragma unroll
     for (int t = 0; t < 6; ++t) w[t] = d.pp_info[6 * (int64_t)k + t];
     double si, ci;
-    if (i == own_pose) { si = own_s; ci = own_c; } else sincos(xi[2], &si, &ci);
+    if (i == own_pose) { si = own_s; ci = own_c; }
+    else if (own_pose >= 0) { const double2 t2 = reinterpret_cast<const double2 *>(d.pose_cs)[i]; ci = t2.x; si = t2.y; }   // fused kernel: cached
+    else sincos(xi[2], &si, &ci);
     return pp_incidence<WRITE_H>(d, k, inc.y, xi, xj, ci, si, z5, w, d.pose_fixed[i], d.pose_fixed[j], H, b);
+}
+template <bool WRITE_H>
+__device__ __forceinline__ double pp_incidence_q(const DevGraph &d, int q, double H[6], double b[3], int own_pose = -1, double own_c = 1.0, double own_s = 0.0) {
+    return pp_incidence_rec<WRITE_H>(d, reinterpret_cast<const int4 *>(d.ppinc)[q], H, b, own_pose, own_c, own_s);
 }
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -331,7 +346,49 @@ template <class Tp> __device__ __forceinline__ Tp ld_off(const Tp *base, uint32_
 template <class Tp> __device__ __forceinline__ void st_off(Tp *base, uint32_t byte_off, Tp v) {
     *reinterpret_cast<Tp *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
+// streaming variants (read-once / written-once planes of the linearisation pass): non-temporal hint
+template <class Tp> __device__ __forceinline__ Tp ld_off_nt(const Tp *base, uint32_t byte_off) {
+    return __builtin_nontemporal_load(reinterpret_cast<const Tp *>(reinterpret_cast<const char *>(base) + byte_off));
+}
+template <class Tp> __device__ __forceinline__ void st_off_nt(Tp *base, uint32_t byte_off, Tp v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<Tp *>(reinterpret_cast<char *>(base) + byte_off));
+}
+// device-scope store (sc1): written through the XCD's L2 instead of staying dirty in it until the end-of-kernel
+// write-back that makes a kernel's output visible to the other XCDs
+template <class Tp> __device__ __forceinline__ void st_off_wt(Tp *base, uint32_t byte_off, Tp v) {
+    __hip_atomic_store(reinterpret_cast<Tp *>(reinterpret_cast<char *>(base) + byte_off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 #define LIN_WAVES_PER_SIMD 4
+#endif
+// LIN_NT bit 0: non-temporal loads of the read-once ELL streams, bit 1: non-temporal stores of the Hpl planes.
+// Measured on MI355X, cfg4 (105 MB per pass, fits the 256 MB Infinity Cache), microseconds per launch:
+//   back-to-back launches  nt=0 26.1  nt=1 30.4  nt=2 26.8  nt=3 29.8   (streams still cached from the last launch)
+//   inside a GN iteration  nt=0 37.5  nt=1 33.0  nt=2 38.7  nt=3 33.8   (streams cold: the solver moved ~1 GB since)
+// and cfg5 (1 GB per pass) back to back: nt=0 230, nt=3 210.  The iteration is what ships: loads non-temporal.
+#ifndef LIN_NT
+#define LIN_NT 1
+#endif
+#if LIN_NT & 1
+#define LD_S ld_off_nt
+#else
+#define LD_S ld_off
+#endif
+#if LIN_NT & 4
+#define ST_S st_off_wt
+#elif LIN_NT & 2
+#define ST_S st_off_nt
+#else
+#define ST_S st_off
+#endif
+// LIN_TS (tuning builds only): 100 MHz timestamps of three wave tiles (first, middle, last) at the phase boundaries,
+// without extra waits — they show where a wave stalls.  Slots 40 + 8 * {0, 1, 2} + phase of dbg_ts.
+#ifndef LIN_TS
+#define LIN_TS 0
+#endif
+#if LIN_TS
+#define LTS(i) do { if (ts_k >= 0 && lane == 0) d.dbg_ts[40 + 8 * ts_k + (i)] = wall_clock64(); } while (0)
+#else
+#define LTS(i) do { } while (0)
 #endif
 template <int T>
 __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGraph d) {
@@ -341,6 +398,10 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wt = d.wt_lo + blockIdx.x * 4 + wave;                // a shard only sweeps the wave tiles it has edges in
     if (wt >= d.wt_hi) return;                                     // whole wave leaves; no block-level barrier below
+#if LIN_TS
+    const int ts_k = wt == 0 ? 0 : (wt == d.n_wtiles / 2 ? 1 : (wt == d.n_wtiles - 1 ? 2 : -1));
+#endif
+    LTS(0);
     const int p = wt * PW + lane / T, h = lane % T;
     const bool live = p < d.N;
     const int64_t L = d.ell_len, S = (int64_t)T * d.N;
@@ -350,12 +411,15 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
     if (live) { px = d.pose_est[3 * p]; py = d.pose_est[3 * p + 1]; th = d.pose_est[3 * p + 2]; fp = d.pose_fixed[p];
                 q0 = d.ppadj_start[p]; q1 = d.ppadj_start[p + 1]; }
     const int4 wd = reinterpret_cast<const int4 *>(d.wt_desc)[wt];        // {first group, #groups, first position, #positions}
+    int4 inc0 = make_int4(-1, 0, 0, 0);                           // this lane's first odometry incidence, fetched now, used after the edges
+    if (q0 + h < q1) inc0 = reinterpret_cast<const int4 *>(d.ppinc)[q0 + h];
     const int g0 = wd.x, ng = wd.y, pos_off = wd.z, nitems = ng * 5;
     int it_s[2] = {0, 0}, it_e[2] = {0, 0}, it_slot[2] = {0, 0};
 #pragma unroll
     for (int u = 0; u < 2; ++u) { const int item = lane + 64 * u;
         if (item < nitems) { const int gl = item % ng; it_s[u] = d.grp_pos_start[g0 + gl] - pos_off; it_e[u] = d.grp_pos_start[g0 + gl + 1] - pos_off; it_slot[u] = d.grp_slot[g0 + gl]; } }
-    double sn, cs; sincos(th, &sn, &cs);
+    double sn = 0.0, cs = 1.0;                                     // cos/sin of theta are kept per pose (k_update): no sincos here
+    if (live) { const double2 t2 = reinterpret_cast<const double2 *>(d.pose_cs)[p]; cs = t2.x; sn = t2.y; }
     // ---- observation edges, two slots at a time: loads of both slots, both landmark gathers, then the arithmetic.
     // (All four slots at once need ~170 VGPRs = 3 waves per SIMD, and 100k poses are 3125 waves for 3072 slots: a
     // second round for 53 waves.  Two at a time fit 128 VGPRs = 4 waves per SIMD: one round, and the other three
@@ -366,13 +430,14 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
 #pragma unroll 1
     for (int c = 0; c < LIN_R; c += 2) {
         if (c >= R) break;                                          // uniform
+        LTS(1 + c / 2);
         int l[2]; uint32_t dst[2]; double zx[2], zy[2], w00[2], w01[2], w11[2], lx[2], ly[2]; bool fl[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) { const int i = c + j;
             l[j] = -1; dst[j] = 0xFFFFu; zx[j] = zy[j] = w00[j] = w01[j] = w11[j] = 0.0;
             if (live && i < R) { const uint32_t o = off8 + (uint32_t)i * plane8;      // SGPR base + 32-bit lane offset addressing
-                l[j] = ld_off(d.ell_l, o >> 1); dst[j] = ld_off(d.ell_dst, o >> 2); zx[j] = ld_off(d.ell_z, o); zy[j] = ld_off(d.ell_z + L, o);
-                w00[j] = ld_off(d.ell_w, o); w01[j] = ld_off(d.ell_w + L, o); w11[j] = ld_off(d.ell_w + 2 * L, o); } }
+                l[j] = LD_S(d.ell_l, o >> 1); dst[j] = LD_S(d.ell_dst, o >> 2); zx[j] = LD_S(d.ell_z, o); zy[j] = LD_S(d.ell_z + L, o);
+                w00[j] = LD_S(d.ell_w, o); w01[j] = LD_S(d.ell_w + L, o); w11[j] = LD_S(d.ell_w + 2 * L, o); } }
 #pragma unroll
         for (int j = 0; j < 2; ++j) { lx[j] = ly[j] = 0.0; fl[j] = true;
             if (l[j] >= 0) { lx[j] = d.lm_est[2 * l[j]]; ly[j] = d.lm_est[2 * l[j] + 1]; fl[j] = d.lm_fixed[l[j]]; } }
@@ -386,7 +451,7 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
                 if (!(fp && fl[j])) chi += q.chi;
                 const bool both = !fp && !fl[j];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) st_off(d.Hpl + k * L, o, both ? q.W6[k] : 0.0);
+                for (int k = 0; k < 6; ++k) ST_S(d.Hpl + k * L, o, both ? q.W6[k] : 0.0);
 #pragma unroll
                 for (int k = 0; k < 6; ++k) H[k] += q.Hp[k];
 #pragma unroll
@@ -397,8 +462,11 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
                 s_lc[wave][0][pos] = hl0; s_lc[wave][1][pos] = hl1; s_lc[wave][2][pos] = hl2; s_lc[wave][3][pos] = bl0; s_lc[wave][4][pos] = bl1; }
         }
     }
+    LTS(3);
     // ---- odometry incidences: lane h takes incidences q0+h, q0+h+T, ... of its pose
-    if (live) for (int q = q0 + h; q < q1; q += T) chi += pp_incidence_q<true>(d, q, H, b, p, cs, sn);
+    if (q0 + h < q1) chi += pp_incidence_rec<true>(d, inc0, H, b, p, cs, sn);
+    for (int q = q0 + h + T; q < q1; q += T) chi += pp_incidence_q<true>(d, q, H, b, p, cs, sn);
+    LTS(4);
     // ---- pose sums: xor-shuffle over the T lanes of the pose, then each lane stores its share of the 9 components
 #pragma unroll
     for (int off = 1; off < T; off <<= 1) {
@@ -407,27 +475,36 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
 #pragma unroll
         for (int k = 0; k < 3; ++k) b[k] += __shfl_xor(b[k], off, WAVE);
     }
-    if (live) {
+    if (live) {                                                    // lane h stores planes h, h + T, ...: the 9 planes (Hpp_diag, then
+        double *plane0 = d.Hpp_diag + p;                           // b_pose) are contiguous in the arena, stride N
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            if (k % T == h) { const double v = fp ? 0.0 : (k < 6 ? H[k] : b[k - 6]);
-                if (k < 6) d.Hpp_diag[(int64_t)k * d.N + p] = v; else d.b_pose[(int64_t)(k - 6) * d.N + p] = v; }
+        for (int j = 0; j * T < 9; ++j) {
+            double v = (j * T < 6) ? H[(j * T) % 6] : b[(j * T - 6 + 3) % 3];
+#pragma unroll
+            for (int t = 1; t < T; ++t) if (j * T + t < 9) { const int k = j * T + t; v = (h == t) ? (k < 6 ? H[k % 6] : b[(k + 3 - 6) % 3]) : v; }
+            const int k = j * T + h;
+            if (j * T + T - 1 < 9 || k < 9) ST_O(plane0 + (int64_t)k * d.N, fp ? 0.0 : v);
         }
     }
+    LTS(5);
     // ---- landmark groups of this wave tile (wave-private LDS region; same-wave LDS accesses are ordered)
     wave_lds_sync();
 #pragma unroll
     for (int u = 0; u < 2; ++u) { const int item = lane + 64 * u;
         if (item < nitems) { const int comp = item / ng;
             double sum = 0.0;
-            for (int q = it_s[u]; q < it_e[u]; ++q) sum += s_lc[wave][comp][q];
-            d.lm_part[(int64_t)comp * d.n_groups + it_slot[u]] = sum; } }
+            const double *col = s_lc[wave][comp]; const int e = it_e[u];
+            for (int q = it_s[u]; q < e; q += 4) {                 // four LDS reads in flight, added in position order
+                const double a0 = col[q], a1 = col[min(q + 1, e - 1)], a2 = col[min(q + 2, e - 1)], a3 = col[min(q + 3, e - 1)];
+                sum += a0; sum += (q + 1 < e) ? a1 : 0.0; sum += (q + 2 < e) ? a2 : 0.0; sum += (q + 3 < e) ? a3 : 0.0; }
+            ST_O(d.lm_part + (int64_t)comp * d.n_groups + it_slot[u], sum); } }
     for (int item = lane + 128; item < nitems; item += 64) { const int comp = item / ng, gl = item % ng;
         double sum = 0.0;
         for (int q = d.grp_pos_start[g0 + gl] - pos_off; q < d.grp_pos_start[g0 + gl + 1] - pos_off; ++q) sum += s_lc[wave][comp][q];
         d.lm_part[(int64_t)comp * d.n_groups + d.grp_slot[g0 + gl]] = sum; }
     chi = wave_sum(chi);
     if (lane == 0) d.chi2_partial[wt] = chi;
+    LTS(6);
 }
 
 // landmark diagonal blocks from the per-(wave tile, landmark) partials (slots ordered by landmark, then tile)
@@ -1485,6 +1562,18 @@ void launch_backsolve_level(const DevGraph &d, int level_off, int count, int max
     hipLaunchKernelGGL(k_backsolve_level, dim3(count), dim3(256), bytes, st, d, level_off);
 }
 
+// cos/sin of every pose angle, refreshed whenever the host hands over new estimates; inside the iteration k_update
+// keeps it current, so the linearisation pass reads 16 bytes per pose instead of evaluating sincos per lane
+__global__ void __launch_bounds__(256) k_pose_trig(int n, const double *__restrict__ pose_est, double *__restrict__ pose_cs) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double sn, cs; sincos(pose_est[3 * t + 2], &sn, &cs);
+    pose_cs[2 * t] = cs; pose_cs[2 * t + 1] = sn;
+}
+void launch_pose_trig(const DevGraph &d, hipStream_t st) {
+    if (d.N > 0) hipLaunchKernelGGL(k_pose_trig, dim3((d.N + 255) / 256), dim3(256), 0, st, d.N, d.pose_est, d.pose_cs);
+}
+
 // ------------------------------------------------------------------ A9
 __global__ void __launch_bounds__(256) k_update(DevGraph d) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1494,7 +1583,9 @@ __global__ void __launch_bounds__(256) k_update(DevGraph d) {
         double dx = 0, dy = 0, dt = 0;
         if (g >= 0) { dx = d.xe[g]; dy = d.xe[g + 1]; dt = d.xe[g + 2];
             d.pose_est[3 * t] += dx; d.pose_est[3 * t + 1] += dy;
-            d.pose_est[3 * t + 2] = normalize_theta(d.pose_est[3 * t + 2] + dt); }
+            const double th = normalize_theta(d.pose_est[3 * t + 2] + dt);
+            d.pose_est[3 * t + 2] = th;
+            double sn, cs; sincos(th, &sn, &cs); d.pose_cs[2 * t] = cs; d.pose_cs[2 * t + 1] = sn; }
         d.dpose[3 * t] = dx; d.dpose[3 * t + 1] = dy; d.dpose[3 * t + 2] = dt;
     } else if (t < d.N + d.M) {
         int l = t - d.N, g = d.lm_known[l] ? d.lm_gidx[l] : -1;

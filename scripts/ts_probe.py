@@ -16,3 +16,12 @@ print("factor  phases (us):", [round((int(f[i + 1]) - int(f[i])) / 100.0, 2) for
 print("   0 desc | 1 issue rec+pinv | 2 wait | 3 zero LDS | 4 gather issue+wait | 5 originals | 6 acc sum | 7 panels | 8 U out")
 print("backsolve phases (us):", [round((int(b[i + 1]) - int(b[i])) / 100.0, 2) for i in range(6)], "total", (int(b[6]) - int(b[0])) / 100.0)
 print("   32 desc | 33 L->LDS | 34 xe gather | 35 boundary mat-vec | 36 substitution | 37 store")
+for k, name in enumerate(("first", "middle", "last")):
+    l = ts[40 + 8 * k: 40 + 8 * k + 7]
+    if l[0]:
+        print("linearise wave tile %-6s (us, LIN_TS build):" % name, [round((int(l[i + 1]) - int(l[i])) / 100.0, 2) for i in range(6)], "total", (int(l[6]) - int(l[0])) / 100.0)
+print("   0 prologue | 1 edge slots 0-1 | 2 edge slots 2-3 | 3 odometry incidences | 4 pose sums | 5 landmark groups")
+t0 = min(int(ts[40 + 8 * k]) for k in range(3) if ts[40 + 8 * k])  if any(ts[40 + 8 * k] for k in range(3)) else 0
+for k, name in enumerate(("first", "middle", "last")):
+    if ts[40 + 8 * k]:
+        print("   wave tile %-6s starts at %+.2f us, ends at %+.2f us (relative to the earliest start of the three)" % (name, (int(ts[40 + 8 * k]) - t0) / 100.0, (int(ts[46 + 8 * k]) - t0) / 100.0))
