@@ -831,6 +831,38 @@ extern "C" int gs_associate_batch(gs_graph *g, int32_t n, const double *poses, i
     double *ob = s.up(obs, 4 * (size_t)n, g->stream); double *mx = s.up(map_xy, 2 * (size_t)n_map, g->stream);
     int32_t *mt = s.up(map_type, n_map, g->stream), *o = s.up<int32_t>(nullptr, n, g->stream);
     if (!p || !po || !ob || !mx || !mt || !o) return fail(GS_ERR_HIP, "hipMalloc failed");
+    // maps beyond a few LDS tiles go through a uniform grid (cell edge a hair above the threshold, so that every cone
+    // within the threshold sits in the 3 x 3 cells around the query); the brute-force kernel stays for small maps,
+    // non-positive thresholds and degenerate extents.  GS_ASSOC_GRID=0/1 forces either (A/B, tests).
+    bool grid = n_map >= 2048 && thr > 0.0;
+    if (const char *e = std::getenv("GS_ASSOC_GRID")) grid = std::atoi(e) != 0 && n_map > 0 && thr > 0.0;
+    double minx = 0, miny = 0, maxx = 0, maxy = 0;
+    if (grid) { minx = maxx = map_xy[0]; miny = maxy = map_xy[1];
+        for (int j = 0; j < n_map; ++j) { const double x = map_xy[2 * (size_t)j], y = map_xy[2 * (size_t)j + 1];
+            if (!(std::isfinite(x) && std::isfinite(y))) { grid = false; break; }
+            minx = std::min(minx, x); maxx = std::max(maxx, x); miny = std::min(miny, y); maxy = std::max(maxy, y); } }
+    if (grid) {
+        double cell = thr * (1.0 + 1e-9);
+        int64_t nx, ny;
+        for (;;) { nx = (int64_t)std::floor((maxx - minx) / cell) + 1; ny = (int64_t)std::floor((maxy - miny) / cell) + 1;
+            if (nx * ny <= std::max<int64_t>(4096, 8 * (int64_t)n_map)) break;      // a sparse map (cones along a 25 km line) gets coarser cells, not millions of empty ones
+            cell *= 1.5; }
+        const double inv_cell = 1.0 / cell;
+        std::vector<int32_t> cell_of(n_map), start((size_t)(nx * ny) + 1, 0), items(n_map);
+        for (int j = 0; j < n_map; ++j) {
+            int64_t cx = (int64_t)std::floor((map_xy[2 * (size_t)j] - minx) * inv_cell), cy = (int64_t)std::floor((map_xy[2 * (size_t)j + 1] - miny) * inv_cell);
+            cx = std::min(std::max<int64_t>(cx, 0), nx - 1); cy = std::min(std::max<int64_t>(cy, 0), ny - 1);
+            cell_of[j] = (int32_t)(cy * nx + cx); start[(size_t)cell_of[j] + 1]++; }
+        for (size_t c = 0; c + 1 < start.size(); ++c) start[c + 1] += start[c];
+        { std::vector<int32_t> fill(start.begin(), start.end() - 1);
+          for (int j = 0; j < n_map; ++j) items[(size_t)fill[cell_of[j]]++] = j; }          // ascending map index inside a cell
+        int32_t *cs = s.up(start.data(), start.size(), g->stream), *ci = s.up(items.data(), items.size(), g->stream);
+        if (!cs || !ci) return fail(GS_ERR_HIP, "hipMalloc failed");
+        launch_associate_grid(n, p, po, ob, g->cfg.lidar_to_cog, mx, mt, thr, type_tol, minx, miny, inv_cell, (int)nx, (int)ny, cs, ci, o, g->stream);
+        HIP_TRY(hipMemcpyAsync(out, o, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));        // the host vectors above must outlive the uploads
+        return GS_OK;
+    }
     launch_associate(n, p, po, ob, g->cfg.lidar_to_cog, n_map, mx, mt, thr, type_tol, o, g->stream);
     HIP_TRY(hipMemcpyAsync(out, o, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));

@@ -89,6 +89,9 @@ void launch_cone_to_global(int n, const double *poses, const int32_t *pose_of_ob
 void launch_associate(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar,
                       int n_map, const double *map_xy, const int32_t *map_type, double thr, double type_tol,
                       int32_t *out, hipStream_t st);
+void launch_associate_grid(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar,
+                           const double *map_xy, const int32_t *map_type, double thr, double type_tol, double minx, double miny,
+                           double inv_cell, int nx, int ny, const int32_t *cell_start, const int32_t *cell_items, int32_t *out, hipStream_t st);
 int  factor_lds_limit_f();      // largest front dimension that fits the LDS variant
 
 }  // namespace gs

@@ -104,6 +104,35 @@ __global__ void __launch_bounds__(256) k_associate(int n, const double *__restri
     if (live) out[i] = found;
 }
 
+// The same association against a uniform grid over the map (cell edge >= threshold, built by the caller: cones of a
+// cell listed in ascending map index): only the 3 x 3 cells around the query can hold a cone within the threshold,
+// and the LOWEST matching index over them is the reference's first match in insertion order.  Same pair test, same
+// arithmetic as k_associate => identical indices; O(n) instead of O(n * n_map).
+__global__ void __launch_bounds__(256) k_associate_grid(int n, const double *__restrict__ poses,
+        const int32_t *__restrict__ pose_of_obs, const double *__restrict__ obs, double lidar,
+        const double *__restrict__ map_xy, const int32_t *__restrict__ map_type, double thr, double type_tol,
+        double minx, double miny, double inv_cell, int nx, int ny, const int32_t *__restrict__ cell_start,
+        const int32_t *__restrict__ cell_items, int32_t *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double gx, gy; cone_to_global(poses + 3 * pose_of_obs[i], obs + 4 * i, lidar, gx, gy);
+    const double ty = obs[4 * i + 3];
+    int found = 0x7fffffff;
+    const double fx = (gx - minx) * inv_cell, fy = (gy - miny) * inv_cell;
+    if (fx >= -1.0 && fx < (double)nx + 1.0 && fy >= -1.0 && fy < (double)ny + 1.0) {       // false for NaN (azimuth 0)
+        const int cx = (int)floor(fx), cy = (int)floor(fy);
+        for (int dy = -1; dy <= 1; ++dy) { const int y = cy + dy; if (y < 0 || y >= ny) continue;
+            for (int dx = -1; dx <= 1; ++dx) { const int x = cx + dx; if (x < 0 || x >= nx) continue;
+                const int c = y * nx + x;
+                for (int q = cell_start[c]; q < cell_start[c + 1]; ++q) { const int j = cell_items[q];
+                    if (j >= found) break;                          // ascending inside a cell
+                    if (fabs((double)map_type[j] - ty) < type_tol) {
+                        const double ddx = map_xy[2 * j] - gx, ddy = map_xy[2 * j + 1] - gy;
+                        if (sqrt(ddx * ddx + ddy * ddy) < thr) { found = j; break; } } } } }
+    }
+    out[i] = found == 0x7fffffff ? -1 : found;
+}
+
 // ------------------------------------------------------------------ A5-A7
 // EdgeSE2PointXY with the pose's cos/sin already known: error, Jacobian rows A0/A1 (2x3); B = R(theta)^T
 __device__ __forceinline__ void edge_pl(double px, double py, double c, double s, double lx, double ly, double zx, double zy,
@@ -1619,6 +1648,13 @@ void launch_associate(int n, const double *poses, const int32_t *pose_of_obs, co
                       int32_t *out, hipStream_t st) {
     if (n > 0) hipLaunchKernelGGL(k_associate, dim3((n + 255) / 256), dim3(256), 0, st, n, poses, pose_of_obs, obs, lidar,
                                   n_map, map_xy, map_type, thr, type_tol, out);
+}
+
+void launch_associate_grid(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar,
+                           const double *map_xy, const int32_t *map_type, double thr, double type_tol, double minx, double miny,
+                           double inv_cell, int nx, int ny, const int32_t *cell_start, const int32_t *cell_items, int32_t *out, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_associate_grid, dim3((n + 255) / 256), dim3(256), 0, st, n, poses, pose_of_obs, obs, lidar,
+                                  map_xy, map_type, thr, type_tol, minx, miny, inv_cell, nx, ny, cell_start, cell_items, out);
 }
 
 }  // namespace gs

@@ -90,6 +90,32 @@ def test_association_first_match_wins_over_nearest(G, frontend):
     assert got[0] == 0 and np.array_equal(got, frontend.associate(poses, [0], obs, map_xy, ty, 1.2))
 
 
+@pytest.mark.parametrize("N,M", [(1000, 200), (10000, 2000)])
+def test_association_grid_equals_brute_force_equals_oracle(G, frontend, bench_graphs, monkeypatch, N, M):
+    """A1 at scale goes through a uniform grid over the map (k_associate_grid, O(n)); small maps through the LDS-tiled
+    brute-force scan (k_associate, O(n * n_map)).  Same pair test => the same indices, bit for bit, and both equal the
+    oracle's insertion-order scan (reference src/slam.cpp:570-607).  Decoys: wrong-colour cones on top of real ones,
+    same-colour duplicates later in the map (first match must win), queries far outside the map, an azimuth-0 (NaN)
+    query."""
+    t, g = bench_graphs(N, M)
+    Np, K = len(t["odom_poses"]), t["K"]
+    obs = t["obs"].reshape(-1, 4).copy(); po_ = np.repeat(np.arange(Np, dtype=np.int32), K)
+    base = t["cone_xy"][g["map_true_id"]]
+    map_xy = np.concatenate([base, base[:50] + 0.05, base[100:150] + [0.3, -0.2], [[1e4, 1e4], [-1e4, 3.0]]])
+    map_type = np.concatenate([g["lm_type"], (g["lm_type"][:50] % 4) + 1, g["lm_type"][100:150], [1, 2]]).astype(np.int32)
+    obs[7, 0] = 0.0                                        # azimuth exactly 0 -> NaN coordinates -> no match
+    obs[11, 2] = 5e3                                       # a cone "seen" 5 km away: outside the grid
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GS_ASSOC_GRID", mode)
+        outs[mode] = G.associate(t["truth_poses"], po_, obs, map_xy, map_type, 1.2)
+    monkeypatch.delenv("GS_ASSOC_GRID")
+    auto = G.associate(t["truth_poses"], po_, obs, map_xy, map_type, 1.2)
+    ref = frontend.associate(t["truth_poses"], po_, obs, map_xy, map_type, 1.2)
+    assert np.array_equal(outs["0"], ref) and np.array_equal(outs["1"], ref) and np.array_equal(auto, ref)
+    assert ref[7] == -1 and ref[11] == -1 and (ref >= 0).mean() > 0.9
+
+
 # ---------------------------------------------------------------- A5-A7
 @pytest.mark.parametrize("N,M", [(50, 30), (1000, 200)])
 def test_linearize_blocks_match_oracle(pkg, po, bench_graphs, N, M):
