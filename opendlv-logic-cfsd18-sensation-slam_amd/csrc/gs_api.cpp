@@ -409,19 +409,29 @@ static int upload_graph(gs_graph *g) {
       if (v == 4) v = 0;                                              // device-side code for the block-per-front kernel
       d.factor_variant = v;
       if (const char *e = std::getenv("GS_DBG")) d.dbg = std::atoi(e);
-      if (v == 2 || v == 3) { AL(Uimg, (size_t)P.fronts.size() * 2568); ZERO(Uimg, (size_t)P.fronts.size() * 2568); }   // 2560-double tile image + 8 zero doubles
+      if (v == 2) { AL(Uimg, (size_t)P.fronts.size() * 2568); ZERO(Uimg, (size_t)P.fronts.size() * 2568); }   // 2560-double tile images
       if (v == 3) {
           std::vector<int32_t> lf = P.level_fronts_owned;
           lf.insert(lf.end(), P.level_fronts_shared.begin(), P.level_fronts_shared.end());
-          constexpr int F3W = 160;                           // 32 descriptor ints + the row tables of the first two children
+          constexpr int F3W = 224;                           // 32 descriptor ints + the row tables of the first two children + the front's own store table
           std::vector<int32_t> fd(lf.size() * F3W, 0);
+          // update matrices, packed: row r' (0 .. nbnd, the last = rhs) of the boundary block holds columns 0 .. min(r', nbnd - 1)
+          // at r'(r'+1)/2; then one double that stays zero (clamped gathers land on it) and one that collects clamped stores
+          std::vector<int32_t> u3_off(P.fronts.size()), u3_size(P.fronts.size());
+          { int64_t tot = 0;
+            for (size_t f0 = 0; f0 < P.fronts.size(); ++f0) { const int nb = P.fronts[f0].nbnd;
+                u3_off[f0] = (int32_t)tot; u3_size[f0] = (nb * (nb + 1)) / 2 + nb; tot += ((u3_size[f0] + 2 + 1) & ~1);
+                if (tot >= ((int64_t)1 << 31)) return fail(GS_ERR_INVALID, "update-matrix arena beyond 32-bit offsets"); }
+            AL(Uimg, (size_t)tot + 2); ZERO(Uimg, (size_t)tot + 2); }
+          UP(u3_off, u3_off); UP(u3_size, u3_size);
           for (size_t q = 0; q < lf.size(); ++q) { const int sidx = lf[q]; const Front &F = P.fronts[sidx]; int32_t *r = &fd[F3W * q];
               r[0] = sidx; r[1] = F.npiv; r[2] = F.nbnd; r[3] = F.asm_off; r[4] = F.asm_cnt - F.asm_dup; r[5] = F.asm_dup;
               r[6] = F.child_cnt; r[7] = F.child_off; r[8] = (int32_t)(F.L_off & 0xffffffffLL); r[9] = (int32_t)(F.L_off >> 32);
               r[10] = F.piv0; r[11] = (int32_t)F.bnd_off;
               for (int k = 0; k < 2; ++k) { r[12 + k] = -1; r[14 + k] = 0; r[16 + k] = 0;
                   if (k < F.child_cnt) { const int c = P.children[F.child_off + k]; const Front &C = P.fronts[c];
-                      r[12 + k] = c; r[14 + k] = C.npiv | (C.nbnd << 16); r[16 + k] = C.owner; } }
+                      r[12 + k] = c; r[14 + k] = C.npiv | (C.nbnd << 16); r[16 + k] = C.owner; r[26 + k] = u3_off[c]; r[28 + k] = u3_size[c]; } }
+              r[24] = u3_off[sidx]; r[25] = u3_size[sidx];
               const int64_t xo = (P.world > 1 && (size_t)sidx < P.x_off.size()) ? P.x_off[sidx] : 0;
               r[18] = (int32_t)(xo & 0xffffffffLL); r[19] = (int32_t)(xo >> 32); }
           std::vector<int32_t> recs(P.asm_recs.size() * 4);
@@ -436,14 +446,15 @@ static int upload_graph(gs_graph *g) {
           // into a row part (low 16 bits) and a column part (high 16 bits); -30000 = no such row (sum goes negative)
           std::vector<int32_t> pinv(P.fronts.size() * 64);
           const int32_t pinv_none = (int32_t)((uint32_t)((-30000) & 0xffff) | ((uint32_t)(-30000) << 16));
-          { auto pack = [](int cr) -> int32_t { const int Ic = cr >> 4;
-                const int ro8 = (((Ic * (Ic + 1)) >> 1) * 256 + (cr & 15) * 16) * 8, co8 = ((cr >> 4) * 256 + (cr & 15)) * 8;
-                return (int32_t)((uint32_t)(ro8 & 0xffff) | ((uint32_t)co8 << 16)); };
-            std::fill(pinv.begin(), pinv.end(), pinv_none);
+          // pack(i, col_ok): boundary row i of a front inside its packed update matrix: row part i(i+1)/2, column part i (bytes)
+          auto pack = [pinv_none](int i, bool col_ok) -> int32_t {
+              const int ro8 = ((i * (i + 1)) >> 1) * 8, co8 = col_ok ? i * 8 : -30000;
+              return (int32_t)((uint32_t)(ro8 & 0xffff) | ((uint32_t)(co8 & 0xffff) << 16)); };
+          { std::fill(pinv.begin(), pinv.end(), pinv_none);
             for (size_t c = 0; c < P.fronts.size(); ++c) { const Front &C = P.fronts[c]; if (C.parent < 0) continue;
                 const Front &Pa = P.fronts[C.parent]; int32_t *row = &pinv[64 * c];
-                for (int i = 0; i < C.nbnd; ++i) row[P.child_map[C.map_off + i]] = pack(C.npiv + i);
-                row[Pa.npiv + Pa.nbnd] = pack(C.npiv + C.nbnd); } }
+                for (int i = 0; i < C.nbnd; ++i) row[P.child_map[C.map_off + i]] = pack(i, true);
+                row[Pa.npiv + Pa.nbnd] = pack(C.nbnd, false); } }
           UP(pinv, pinv);
           // scalar assembly records {offset in H_arena, offset in the staging image}, padded per front to a multiple of
           // 64 with (0 -> image offset 1, a don't-care upper-triangle slot); fused landmark diagonals go to lm3
@@ -479,7 +490,10 @@ static int upload_graph(gs_graph *g) {
             UP(sc3, sc); UP(lm3, lm); }
           for (size_t q = 0; q < lf.size(); ++q) { int32_t *r = &fd[F3W * q];
               for (int k = 0; k < 2; ++k) { const int c = r[12 + k];
-                  for (int R = 0; R < 64; ++R) r[32 + 64 * k + R] = c >= 0 ? pinv[64 * (size_t)c + R] : pinv_none; } }
+                  for (int R = 0; R < 64; ++R) r[32 + 64 * k + R] = c >= 0 ? pinv[64 * (size_t)c + R] : pinv_none; }
+              // the front's own store table: row of the front -> its place in the front's packed update matrix
+              const int np = r[1], nb = r[2];
+              for (int R = 0; R < 64; ++R) r[160 + R] = (R >= np && R <= np + nb) ? pack(R - np, R < np + nb) : pinv_none; }
           UP(f3_desc, fd);
       } }
     AL(dbg_ts, 64); ZERO(dbg_ts, 64);

@@ -61,10 +61,10 @@ struct DevGraph {
     long long *dbg_ts = nullptr;                                // [64] phase timestamps (100 MHz) of one front, GS_DBG = 8 | level_count << 8
     int32_t dbg = 0;                                            // GS_DBG ablation bits (timing experiments only)
     int32_t factor_variant = 0;                                 // 0 block-per-front VALU, 1 wave-per-front VALU, 2 wave-per-front MFMA, 3 MFMA LDL^T gather (default)
-    double *Uimg = nullptr;                                     // MFMA variant: update matrices as 16x16 tile images
+    double *Uimg = nullptr;                                     // variant 2: update matrices as 16x16 tile images; variant 3: packed lower triangles (u3_off, u3_size)
     // variant 3 (latency-shaped MFMA/LDL^T kernels): flat per-level descriptors, value-ready assembly records,
     // per-front inverse row maps into the parent (formats: gs_kernels.hip, "variant 3")
-    int32_t *f3_desc = nullptr, *asm3 = nullptr, *pinv = nullptr, *sc3 = nullptr, *lm3 = nullptr;
+    int32_t *f3_desc = nullptr, *asm3 = nullptr, *pinv = nullptr, *sc3 = nullptr, *lm3 = nullptr, *u3_off = nullptr, *u3_size = nullptr;
     double *H_arena = nullptr;                                  // Hpp_diag | b_pose | Hpp_off | Hpl | lm_part | Hll_diag | b_lm, one allocation
     // pose-window shards (world == 1: everything is "own", no exchange)
     int32_t rank = 0, wt_lo = 0, wt_hi = 0;                     // this shard sweeps wave tiles [wt_lo, wt_hi)

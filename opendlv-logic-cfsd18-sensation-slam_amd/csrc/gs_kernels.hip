@@ -1099,17 +1099,21 @@ __global__ void __launch_bounds__(256, 2) k_factor_mfma(DevGraph d, int level_of
 //      per-wave-tile partial slots, in slot order)
 //   asm3 [record][4]: kind | count << 8, src, r0, c0 — as asm_recs, except that a landmark diagonal record carries its
 //      partial-sum slot range (src = first slot, count = #slots) so that no index load precedes the value loads
-//   pinv [front][64] int32: for row R of the PARENT, where THIS front's matching row sits in its tile image: byte offset
-//      split into a row part (low 16 bits, signed) and a column part (high 16 bits); -30000 in both = no such row.
-//      The tables of a front's first two children sit right behind its descriptor (f3_desc stride 160 ints), so the
-//      gathers can be issued after the FIRST round trip.
+//   update matrices are PACKED lower triangles: boundary row r' (0 .. nbnd, the last one = rhs) holds its columns
+//      0 .. min(r', nbnd - 1) at r'(r'+1)/2 — half the bytes of 16 x 16 tile images, and a parent row's columns are
+//      contiguous (fewer cache lines per gather).  Behind each: one double that stays zero (clamped gathers read it)
+//      and one that swallows clamped stores.  offset(r', c') = rowpart(r') + colpart(c'), so both the child's store and
+//      the parent's gather address an element with one add:
+//   pinv [front][64] int32: for row R of the PARENT, the boundary row of THIS front that lands on it, as byte offsets
+//      {rowpart = r'(r'+1)/2 * 8 (low 16 bits), colpart = r' * 8 (high 16 bits)}; -30000 = none (the sum goes negative).
+//      The tables of a front's first two children and the front's own store table (row of the front -> {rowpart,
+//      colpart}) sit right behind its descriptor (f3_desc stride 224 ints): known after the FIRST round trip.
 struct F3 {
     int s, npiv, nbnd, asm_off, asm_uniq, asm_dup, nchild, child_off, piv0, bnd_off, c_id[2], c_info[2], c_owner[2];
-    int sc_off, sc_cnt, lm_off, lm_cnt;
+    int sc_off, sc_cnt, lm_off, lm_cnt, u_off, u_size, c_uoff[2], c_usize[2];
     int64_t L_off, x_off;
 };
-static constexpr int F3_INTS = 32, F3_STRIDE = 160;   // 32 descriptor ints, then pinv of child 0 and of child 1 (64 ints each)
-static constexpr int MF_SLOT = MF_IMG + 8;         // HBM stride of a tile image: 8 always-zero doubles behind it (target of clamped gathers)
+static constexpr int F3_INTS = 32, F3_STRIDE = 224;   // 32 descriptor ints, pinv of child 0, pinv of child 1, own store table (64 ints each)
 __device__ __forceinline__ F3 f3_load(const int32_t *desc, int idx, int lane) {
     const int v = (lane < F3_INTS) ? desc[(int64_t)idx * F3_STRIDE + lane] : 0;
     auto g = [&](int i) { return __builtin_amdgcn_readlane(v, i); };
@@ -1119,6 +1123,7 @@ __device__ __forceinline__ F3 f3_load(const int32_t *desc, int idx, int lane) {
     r.c_id[0] = g(12); r.c_id[1] = g(13); r.c_info[0] = g(14); r.c_info[1] = g(15); r.c_owner[0] = g(16); r.c_owner[1] = g(17);
     r.x_off = (int64_t)(uint32_t)g(18) | ((int64_t)g(19) << 32);
     r.sc_off = g(20); r.sc_cnt = g(21); r.lm_off = g(22); r.lm_cnt = g(23);
+    r.u_off = g(24); r.u_size = g(25); r.c_uoff[0] = g(26); r.c_uoff[1] = g(27); r.c_usize[0] = g(28); r.c_usize[1] = g(29);
     return r;
 }
 
@@ -1193,9 +1198,9 @@ __device__ __forceinline__ void asm3_put(const StageFront &P, int kind_cnt, int 
 
 // gather one child's update matrix by destination: pv = pinv[child][lane]; accumulator element (R, C) of the parent
 // reads byte offset rowpart(R) + colpart(C) of the child's tile image.  A missing row makes the sum negative, which
-// the unsigned min clamps to the zero padding behind the image: three instructions per element, no branches.
+// the unsigned min clamps to the zero double behind the packed matrix: three instructions per element, no branches.
 // (Upper-triangle elements of the diagonal tiles read some other, finite, element: they are don't-care everywhere.)
-__device__ __forceinline__ void f3_gather_child(const double *Uc, int pv, int lane, double (&u)[10][4]) {
+__device__ __forceinline__ void f3_gather_child(const double *Uc, int usize, int pv, int lane, double (&u)[10][4]) {
     const int lc = lane & 15, lr = lane >> 4;
     int co[4];
 #pragma unroll
@@ -1207,7 +1212,7 @@ __device__ __forceinline__ void f3_gather_child(const double *Uc, int pv, int la
             const int ro = (int)(short)(__shfl(pv, 16 * I + lr + 4 * q, WAVE) & 0xffff);
 #pragma unroll
             for (int J = 0; J <= I; ++J)
-                u[mf_tile(I, J)][q] = ld_off(Uc, min((uint32_t)(ro + co[J]), (uint32_t)(MF_IMG * 8)));
+                u[mf_tile(I, J)][q] = ld_off(Uc, min((uint32_t)(ro + co[J]), (uint32_t)usize * 8u));
         }
 }
 
@@ -1280,6 +1285,7 @@ __global__ void __launch_bounds__(256, 2) k_factor3(DevGraph d, int level_off, i
     int pv[2];                                                       // the children's row tables ride behind the descriptor
     pv[0] = d.f3_desc[(int64_t)(level_off + fi) * F3_STRIDE + F3_INTS + lane];
     pv[1] = d.f3_desc[(int64_t)(level_off + fi) * F3_STRIDE + F3_INTS + 64 + lane];
+    const int sv = d.f3_desc[(int64_t)(level_off + fi) * F3_STRIDE + F3_INTS + 128 + lane];     // own store table
     const F3 fr = f3_load(d.f3_desc, level_off + fi, lane);
     const int npiv = fr.npiv, f = npiv + fr.nbnd;
     StageFront P{smem + (int64_t)wave * MF_IMG, f};
@@ -1292,8 +1298,8 @@ __global__ void __launch_bounds__(256, 2) k_factor3(DevGraph d, int level_off, i
     for (int k = 0; k < 2; ++k)
         use[k] = fr.c_id[k] >= 0 && !(mode == FRONT_CONTRIB && fr.c_owner[k] != d.rank) && !(top && fr.c_owner[k] >= 0);   // uniform
     double u0[10][4], u1[10][4];
-    if (use[0]) f3_gather_child(d.Uimg + (int64_t)fr.c_id[0] * MF_SLOT, pv[0], lane, u0);
-    if (use[1]) f3_gather_child(d.Uimg + (int64_t)fr.c_id[1] * MF_SLOT, pv[1], lane, u1);
+    if (use[0]) f3_gather_child(d.Uimg + fr.c_uoff[0], fr.c_usize[0], pv[0], lane, u0);
+    if (use[1]) f3_gather_child(d.Uimg + fr.c_uoff[1], fr.c_usize[1], pv[1], lane, u1);
     // ---- round trip 2b: scalar assembly records (eight per lane up front), landmark records
     const int nsc = top ? 0 : fr.sc_cnt, nlm = top ? 0 : fr.lm_cnt;
     const int2 *sc3 = reinterpret_cast<const int2 *>(d.sc3) + fr.sc_off;
@@ -1377,7 +1383,7 @@ __global__ void __launch_bounds__(256, 2) k_factor3(DevGraph d, int level_off, i
         if (mode == FRONT_CONTRIB && dc.z != d.rank) continue;
         if (top && dc.z >= 0) continue;
         const int pvx = d.pinv[(int64_t)dc.x * 64 + lane];
-        f3_gather_child(d.Uimg + (int64_t)dc.x * MF_SLOT, pvx, lane, u0);
+        f3_gather_child(d.Uimg + d.u3_off[dc.x], d.u3_size[dc.x], pvx, lane, u0);
 #pragma unroll
         for (int t = 0; t < 10; ++t)
 #pragma unroll
@@ -1409,16 +1415,31 @@ __global__ void __launch_bounds__(256, 2) k_factor3(DevGraph d, int level_off, i
     go = go && f3_panel_step<14>(bad, acc, Pn, L, npiv, f, lane);  go = go && f3_panel_step<15>(bad, acc, Pn, L, npiv, f, lane);
     if (bad && lane == 0) atomicExch(d.fail, 1);
     F3_TS(7);
-    // ---- Schur complement out as a tile image (only tiles that hold entries with row, col >= npiv)
-    double *U = d.Uimg + (int64_t)fr.s * MF_SLOT;
+    // ---- Schur complement out, packed: element (row, col) -> rowpart(row) + colpart(col) from the front's own table; pivot
+    // rows / columns make the sum negative and the upper-triangle lanes of the diagonal tiles are forced there: the
+    // unsigned min sends all of those to the spare double behind the matrix
+    {
+        double *U = d.Uimg + fr.u_off;
+        const uint32_t dump = (uint32_t)(fr.u_size + 1) * 8u;
+        int co[4];
 #pragma unroll
-    for (int I = 0; I < 4; ++I)
+        for (int J = 0; J < 4; ++J) co[J] = __shfl(sv, 16 * J + lc, WAVE) >> 16;
 #pragma unroll
-        for (int J = 0; J <= I; ++J) {
-            if (16 * I + 15 < npiv || 16 * J + 15 < npiv) continue;   // uniform
+        for (int I = 0; I < 4; ++I) {
+            if (16 * I + 15 < npiv || 16 * I > f) continue;         // uniform
 #pragma unroll
-            for (int q = 0; q < 4; ++q) U[(mf_tile(I, J) * 4 + q) * 64 + lane] = acc[mf_tile(I, J)][q];
+            for (int q = 0; q < 4; ++q) {
+                const int ro = (int)(short)(__shfl(sv, 16 * I + lr + 4 * q, WAVE) & 0xffff);
+#pragma unroll
+                for (int J = 0; J <= I; ++J) {
+                    if (16 * J + 15 < npiv) continue;                // uniform
+                    int off = ro + co[J];
+                    if (I == J) off = (lr + 4 * q < lc) ? -1 : off;
+                    st_off(U, min((uint32_t)off, dump), acc[mf_tile(I, J)][q]);
+                }
+            }
         }
+    }
     F3_TS(8);
 }
 
