@@ -424,6 +424,9 @@ static int upload_graph(gs_graph *g) {
                 if (tot >= ((int64_t)1 << 31)) return fail(GS_ERR_INVALID, "update-matrix arena beyond 32-bit offsets"); }
             AL(Uimg, (size_t)tot + 2); ZERO(Uimg, (size_t)tot + 2); }
           UP(u3_off, u3_off); UP(u3_size, u3_size);
+          AL(done_f, P.fronts.size()); ZERO(done_f, P.fronts.size()); AL(done_b, P.fronts.size()); ZERO(done_b, P.fronts.size());
+          d.epoch = 0; d.tree = (P.world == 1) ? 1 : 0;              // whole-tree launches: single-GPU graphs (GS_TREE=0: one launch per level)
+          if (const char *e = std::getenv("GS_TREE")) d.tree = (std::atoi(e) != 0 && P.world == 1) ? 1 : 0;
           for (size_t q = 0; q < lf.size(); ++q) { const int sidx = lf[q]; const Front &F = P.fronts[sidx]; int32_t *r = &fd[F3W * q];
               r[0] = sidx; r[1] = F.npiv; r[2] = F.nbnd; r[3] = F.asm_off; r[4] = F.asm_cnt - F.asm_dup; r[5] = F.asm_dup;
               r[6] = F.child_cnt; r[7] = F.child_off; r[8] = (int32_t)(F.L_off & 0xffffffffLL); r[9] = (int32_t)(F.L_off >> 32);
@@ -431,7 +434,7 @@ static int upload_graph(gs_graph *g) {
               for (int k = 0; k < 2; ++k) { r[12 + k] = -1; r[14 + k] = 0; r[16 + k] = 0;
                   if (k < F.child_cnt) { const int c = P.children[F.child_off + k]; const Front &C = P.fronts[c];
                       r[12 + k] = c; r[14 + k] = C.npiv | (C.nbnd << 16); r[16 + k] = C.owner; r[26 + k] = u3_off[c]; r[28 + k] = u3_size[c]; } }
-              r[24] = u3_off[sidx]; r[25] = u3_size[sidx];
+              r[24] = u3_off[sidx]; r[25] = u3_size[sidx]; r[30] = F.parent;
               const int64_t xo = (P.world > 1 && (size_t)sidx < P.x_off.size()) ? P.x_off[sidx] : 0;
               r[18] = (int32_t)(xo & 0xffffffffLL); r[19] = (int32_t)(xo >> 32); }
           std::vector<int32_t> recs(P.asm_recs.size() * 4);
@@ -592,11 +595,16 @@ static int ensure_ready(gs_graph *g) {
 // own fronts bottom-up (mode 0), shared top bottom-up from the all-reduced exchange buffer (mode 2)
 static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int base, int mode) {
     const int nlev = (int)ls.start.size() - 1;
+    if (g->d.factor_variant == 3 && g->d.tree && mode == 0 && base == 0 && nlev > 0) {     // every own level in one launch
+        ++g->d.epoch; launch_factor_tree(g->d, ls.start[nlev], g->stream); return; }
     for (int l = 0; l < nlev; ++l)
         launch_factor_level(g->d, base + ls.start[l], ls.start[l + 1] - ls.start[l], ls.max_f[l], mode, g->stream);
 }
 static void enqueue_backsolve_levels(gs_graph *g, const gs_graph::LevelSet &ls, int base) {
     const int nlev = (int)ls.start.size() - 1;
+    if (g->d.factor_variant == 3 && g->d.tree && base == 0 && nlev > 0) {
+        int mn = 0, mf = 0; for (int l = 0; l < nlev; ++l) { mn = std::max(mn, ls.max_npiv[l]); mf = std::max(mf, ls.max_f[l]); }
+        launch_backsolve_tree(g->d, ls.start[nlev], mn, mf, g->stream); return; }
     for (int l = nlev - 1; l >= 0; --l)
         launch_backsolve_level(g->d, base + ls.start[l], ls.start[l + 1] - ls.start[l], ls.max_npiv[l], ls.max_nbnd[l], g->stream);
 }

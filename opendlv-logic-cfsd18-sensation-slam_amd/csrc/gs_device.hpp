@@ -65,6 +65,7 @@ struct DevGraph {
     // variant 3 (latency-shaped MFMA/LDL^T kernels): flat per-level descriptors, value-ready assembly records,
     // per-front inverse row maps into the parent (formats: gs_kernels.hip, "variant 3")
     int32_t *f3_desc = nullptr, *asm3 = nullptr, *pinv = nullptr, *sc3 = nullptr, *lm3 = nullptr, *u3_off = nullptr, *u3_size = nullptr;
+    int32_t *done_f = nullptr, *done_b = nullptr; int32_t epoch = 0, tree = 0;   // whole-tree launches: per-front completion flags (= epoch when done)
     double *H_arena = nullptr;                                  // Hpp_diag | b_pose | Hpp_off | Hpl | lm_part | Hll_diag | b_lm, one allocation
     // pose-window shards (world == 1: everything is "own", no exchange)
     int32_t rank = 0, wt_lo = 0, wt_hi = 0;                     // this shard sweeps wave tiles [wt_lo, wt_hi)
@@ -80,6 +81,8 @@ void launch_linearize_finalize(const DevGraph &d, hipStream_t st);   // H_ll, b_
 void launch_chi2_only(const DevGraph &d, hipStream_t st);
 // mode: 0 own front, 1 contribution of this rank to a shared front (-> exchange), 2 shared front from the exchange
 void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f, int mode, hipStream_t st);
+void launch_factor_tree(const DevGraph &d, int count, hipStream_t st);                       // variant 3, every own level in one launch
+void launch_backsolve_tree(const DevGraph &d, int count, int max_npiv, int max_f, hipStream_t st);
 void launch_backsolve_level(const DevGraph &d, int level_off, int count, int max_npiv, int max_nbnd, hipStream_t st);
 void launch_update(const DevGraph &d, hipStream_t st);
 void launch_pose_trig(const DevGraph &d, hipStream_t st);       // pose_cs from pose_est (after every host -> device estimate copy)

@@ -1110,7 +1110,7 @@ __global__ void __launch_bounds__(256, 2) k_factor_mfma(DevGraph d, int level_of
 //      colpart}) sit right behind its descriptor (f3_desc stride 224 ints): known after the FIRST round trip.
 struct F3 {
     int s, npiv, nbnd, asm_off, asm_uniq, asm_dup, nchild, child_off, piv0, bnd_off, c_id[2], c_info[2], c_owner[2];
-    int sc_off, sc_cnt, lm_off, lm_cnt, u_off, u_size, c_uoff[2], c_usize[2];
+    int sc_off, sc_cnt, lm_off, lm_cnt, u_off, u_size, c_uoff[2], c_usize[2], parent;
     int64_t L_off, x_off;
 };
 static constexpr int F3_INTS = 32, F3_STRIDE = 224;   // 32 descriptor ints, pinv of child 0, pinv of child 1, own store table (64 ints each)
@@ -1123,7 +1123,7 @@ __device__ __forceinline__ F3 f3_load(const int32_t *desc, int idx, int lane) {
     r.c_id[0] = g(12); r.c_id[1] = g(13); r.c_info[0] = g(14); r.c_info[1] = g(15); r.c_owner[0] = g(16); r.c_owner[1] = g(17);
     r.x_off = (int64_t)(uint32_t)g(18) | ((int64_t)g(19) << 32);
     r.sc_off = g(20); r.sc_cnt = g(21); r.lm_off = g(22); r.lm_cnt = g(23);
-    r.u_off = g(24); r.u_size = g(25); r.c_uoff[0] = g(26); r.c_uoff[1] = g(27); r.c_usize[0] = g(28); r.c_usize[1] = g(29);
+    r.u_off = g(24); r.u_size = g(25); r.c_uoff[0] = g(26); r.c_uoff[1] = g(27); r.c_usize[0] = g(28); r.c_usize[1] = g(29); r.parent = g(30);
     return r;
 }
 
@@ -1200,6 +1200,11 @@ __device__ __forceinline__ void asm3_put(const StageFront &P, int kind_cnt, int 
 // reads byte offset rowpart(R) + colpart(C) of the child's tile image.  A missing row makes the sum negative, which
 // the unsigned min clamps to the zero double behind the packed matrix: three instructions per element, no branches.
 // (Upper-triangle elements of the diagonal tiles read some other, finite, element: they are don't-care everywhere.)
+// device-scope (sc1) load: fetched from the memory side, not from this XCD's L2 — data another XCD wrote during THIS kernel
+__device__ __forceinline__ double ld_off_coh(const double *base, uint32_t byte_off) {
+    return __hip_atomic_load(reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool COH>
 __device__ __forceinline__ void f3_gather_child(const double *Uc, int usize, int pv, int lane, double (&u)[10][4]) {
     const int lc = lane & 15, lr = lane >> 4;
     int co[4];
@@ -1212,7 +1217,8 @@ __device__ __forceinline__ void f3_gather_child(const double *Uc, int usize, int
             const int ro = (int)(short)(__shfl(pv, 16 * I + lr + 4 * q, WAVE) & 0xffff);
 #pragma unroll
             for (int J = 0; J <= I; ++J)
-                u[mf_tile(I, J)][q] = ld_off(Uc, min((uint32_t)(ro + co[J]), (uint32_t)usize * 8u));
+            { const uint32_t o = min((uint32_t)(ro + co[J]), (uint32_t)usize * 8u);
+                u[mf_tile(I, J)][q] = COH ? ld_off_coh(Uc, o) : ld_off(Uc, o); }
         }
 }
 
@@ -1274,6 +1280,27 @@ __device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[10], double 
     return true;
 }
 
+// ---- whole-tree launches (single GPU).  One launch factorises every level: wave w takes level position w, so a
+// front's children always sit in EARLIER workgroups.  Dispatch is in workgroup order per XCD, hence whatever a resident
+// wave waits for is resident too or already done — no level barrier, no kernel boundary between levels, and a front's
+// descriptor / record / value round trips run while its children still work.  A front publishes its update matrix
+// with device-scope (sc1, write-through) stores, drains them (s_waitcnt), then sets done[front] = epoch; the parent
+// polls that flag and gathers with device-scope loads (the XCDs' L2s are not coherent with each other inside a kernel).
+// The poll is bounded: on expiry the front carries on, reports through d.fail, and the grid still drains.
+__device__ __forceinline__ bool f3_wait_flag(const int32_t *flag, int epoch) {
+    for (int it = 0; it < (1 << 18); ++it) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); return true; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return false;
+}
+__device__ __forceinline__ void f3_publish(int32_t *flag, int epoch, int lane) {
+    __builtin_amdgcn_s_waitcnt(0);                                  // this wave's write-through stores have been acknowledged
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (lane == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool TREE>
 __global__ void __launch_bounds__(256, 2) k_factor3(DevGraph d, int level_off, int count, int mode) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1298,8 +1325,10 @@ __global__ void __launch_bounds__(256, 2) k_factor3(DevGraph d, int level_off, i
     for (int k = 0; k < 2; ++k)
         use[k] = fr.c_id[k] >= 0 && !(mode == FRONT_CONTRIB && fr.c_owner[k] != d.rank) && !(top && fr.c_owner[k] >= 0);   // uniform
     double u0[10][4], u1[10][4];
-    if (use[0]) f3_gather_child(d.Uimg + fr.c_uoff[0], fr.c_usize[0], pv[0], lane, u0);
-    if (use[1]) f3_gather_child(d.Uimg + fr.c_uoff[1], fr.c_usize[1], pv[1], lane, u1);
+    if (!TREE) {
+        if (use[0]) f3_gather_child<false>(d.Uimg + fr.c_uoff[0], fr.c_usize[0], pv[0], lane, u0);
+        if (use[1]) f3_gather_child<false>(d.Uimg + fr.c_uoff[1], fr.c_usize[1], pv[1], lane, u1);
+    }
     // ---- round trip 2b: scalar assembly records (eight per lane up front), landmark records
     const int nsc = top ? 0 : fr.sc_cnt, nlm = top ? 0 : fr.lm_cnt;
     const int2 *sc3 = reinterpret_cast<const int2 *>(d.sc3) + fr.sc_off;
@@ -1360,6 +1389,14 @@ __global__ void __launch_bounds__(256, 2) k_factor3(DevGraph d, int level_off, i
     }
     wave_lds_sync();
     F3_TS(5);
+    if (TREE) {                                                      // everything above ran while the children were still working
+        bool okw = true;
+        if (use[0]) okw = f3_wait_flag(d.done_f + fr.c_id[0], d.epoch) && okw;
+        if (use[1]) okw = f3_wait_flag(d.done_f + fr.c_id[1], d.epoch) && okw;
+        if (!okw && lane == 0) atomicExch(d.fail, 2);
+        if (use[0]) f3_gather_child<true>(d.Uimg + fr.c_uoff[0], fr.c_usize[0], pv[0], lane, u0);
+        if (use[1]) f3_gather_child<true>(d.Uimg + fr.c_uoff[1], fr.c_usize[1], pv[1], lane, u1);
+    }
     // ---- accumulators = originals + child 0 + child 1 (+ further children, rare)
     v4d acc[10];
 #pragma unroll
@@ -1383,7 +1420,8 @@ __global__ void __launch_bounds__(256, 2) k_factor3(DevGraph d, int level_off, i
         if (mode == FRONT_CONTRIB && dc.z != d.rank) continue;
         if (top && dc.z >= 0) continue;
         const int pvx = d.pinv[(int64_t)dc.x * 64 + lane];
-        f3_gather_child(d.Uimg + d.u3_off[dc.x], d.u3_size[dc.x], pvx, lane, u0);
+        if (TREE && !f3_wait_flag(d.done_f + dc.x, d.epoch) && lane == 0) atomicExch(d.fail, 2);
+        f3_gather_child<TREE>(d.Uimg + d.u3_off[dc.x], d.u3_size[dc.x], pvx, lane, u0);
 #pragma unroll
         for (int t = 0; t < 10; ++t)
 #pragma unroll
@@ -1435,15 +1473,17 @@ __global__ void __launch_bounds__(256, 2) k_factor3(DevGraph d, int level_off, i
                     if (16 * J + 15 < npiv) continue;                // uniform
                     int off = ro + co[J];
                     if (I == J) off = (lr + 4 * q < lc) ? -1 : off;
-                    st_off(U, min((uint32_t)off, dump), acc[mf_tile(I, J)][q]);
+                    if (TREE) st_off_wt(U, min((uint32_t)off, dump), (double)acc[mf_tile(I, J)][q]); else st_off(U, min((uint32_t)off, dump), (double)acc[mf_tile(I, J)][q]);
                 }
             }
         }
     }
+    if (TREE) f3_publish(d.done_f + fr.s, d.epoch, lane);
     F3_TS(8);
 }
 
 // backward solve of variant 3's LDL^T panels (unit diagonal): x_piv = L11^-T (y - L21^T x_bnd), one wave per front
+template <bool TREE>      // TREE: one launch, root first (wave w takes level position count - 1 - w), a front waits for its parent's flag
 __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, int count, int slot_doubles) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1451,7 +1491,8 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
     if (fi >= count) return;
     const bool ts_on = (d.dbg & 8) && count == (d.dbg >> 8) && fi == 0;
     F3_TS(32);
-    const F3 fr = f3_load(d.f3_desc, level_off + fi, lane);
+    const int pos = TREE ? count - 1 - fi : level_off + fi;
+    const F3 fr = f3_load(d.f3_desc, pos, lane);
     const int npiv = fr.npiv, nbnd = fr.nbnd, f = npiv + nbnd, ldl = f + 1, lds = (f + 1) | 1;
     F3_TS(33);
     double *S = smem + (int64_t)wave * slot_doubles;
@@ -1467,7 +1508,8 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
         for (int j = 0; j < 32; ++j) if (c0 + j < npiv && lane <= f) S[(c0 + j) * lds + lane] = t[j];
     }
     F3_TS(34);
-    const double xb = (row >= 0) ? d.xe[row] : 0.0;
+    if (TREE && fr.parent >= 0 && !f3_wait_flag(d.done_b + fr.parent, d.epoch) && lane == 0) atomicExch(d.fail, 2);   // L is in LDS by now
+    const double xb = (row >= 0) ? (TREE ? ld_off_coh(d.xe, (uint32_t)row * 8u) : d.xe[row]) : 0.0;
     wave_lds_sync();
     F3_TS(35);
     const int me = min(lane, npiv - 1);                              // lanes >= npiv compute on a valid column and drop the result
@@ -1489,16 +1531,32 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
             if (cc > 0) { const double xcc = lane_bcast(w, cc); if (lane < cc) w -= l4[j] * xcc; } }
     }
     F3_TS(37);
-    if (lane < npiv) d.xe[fr.piv0 + lane] = w;
+    if (lane < npiv) { if (TREE) st_off_wt(d.xe, (uint32_t)(fr.piv0 + lane) * 8u, w); else d.xe[fr.piv0 + lane] = w; }
+    if (TREE) f3_publish(d.done_b + fr.s, d.epoch, lane);
     F3_TS(38);
+}
+
+// whole-tree launches of variant 3 (own fronts of a single-GPU graph): every level in one kernel each
+void launch_factor_tree(const DevGraph &d, int count, hipStream_t st) {
+    if (count <= 0) return;
+    static bool attr_set_t = false;
+    if (!attr_set_t) { (void)hipFuncSetAttribute((const void *)k_factor3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_t = true; }
+    hipLaunchKernelGGL(k_factor3<true>, dim3((count + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, 0, count, FRONT_OWN);
+}
+void launch_backsolve_tree(const DevGraph &d, int count, int max_npiv, int max_f, hipStream_t st) {
+    if (count <= 0) return;
+    const int slot = ((((max_f + 1) | 1) * max_npiv) + 1) & ~1;
+    static bool attr_set_bt = false;
+    if (!attr_set_bt) { (void)hipFuncSetAttribute((const void *)k_backsolve3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_bt = true; }
+    hipLaunchKernelGGL(k_backsolve3<true>, dim3((count + 3) / 4), dim3(256), (size_t)slot * 4 * sizeof(double), st, d, 0, count, slot);
 }
 
 void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f, int mode, hipStream_t st) {
     if (count <= 0) return;
     if (max_f <= 63 && d.factor_variant == 3) {
         static bool attr_set_3 = false;
-        if (!attr_set_3) { hipFuncSetAttribute((const void *)k_factor3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_3 = true; }
-        hipLaunchKernelGGL(k_factor3, dim3((count + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, level_off, count, mode);
+        if (!attr_set_3) { hipFuncSetAttribute((const void *)k_factor3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_3 = true; }
+        hipLaunchKernelGGL(k_factor3<false>, dim3((count + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, level_off, count, mode);
         return;
     }
     if (max_f <= 63 && d.factor_variant == 2) {
@@ -1597,8 +1655,8 @@ void launch_backsolve_level(const DevGraph &d, int level_off, int count, int max
     if (d.factor_variant == 3) {                                     // LDL^T panels: unit-diagonal backward solve
         const int f = max_npiv + max_nbnd, slot = ((((f + 1) | 1) * max_npiv) + 1) & ~1;
         static bool attr_set_b3 = false;
-        if (!attr_set_b3) { hipFuncSetAttribute((const void *)k_backsolve3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_b3 = true; }
-        hipLaunchKernelGGL(k_backsolve3, dim3((count + 3) / 4), dim3(256), (size_t)slot * 4 * sizeof(double), st, d, level_off, count, slot);
+        if (!attr_set_b3) { hipFuncSetAttribute((const void *)k_backsolve3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_b3 = true; }
+        hipLaunchKernelGGL(k_backsolve3<false>, dim3((count + 3) / 4), dim3(256), (size_t)slot * 4 * sizeof(double), st, d, level_off, count, slot);
         return;
     }
     if (max_npiv + max_nbnd <= 63) {
