@@ -425,8 +425,8 @@ static int upload_graph(gs_graph *g) {
             AL(Uimg, (size_t)tot + 2); ZERO(Uimg, (size_t)tot + 2); }
           UP(u3_off, u3_off); UP(u3_size, u3_size);
           AL(done_f, P.fronts.size()); ZERO(done_f, P.fronts.size()); AL(done_b, P.fronts.size()); ZERO(done_b, P.fronts.size());
-          d.epoch = 0; d.tree = (P.world == 1) ? 1 : 0;              // whole-tree launches: single-GPU graphs (GS_TREE=0: one launch per level)
-          if (const char *e = std::getenv("GS_TREE")) d.tree = (std::atoi(e) != 0 && P.world == 1) ? 1 : 0;
+          d.epoch = 0; d.tree = 1;                                    // whole-tree launches for this rank's own subtrees (GS_TREE=0: one launch per level)
+          if (const char *e = std::getenv("GS_TREE")) d.tree = std::atoi(e) != 0 ? 1 : 0;
           for (size_t q = 0; q < lf.size(); ++q) { const int sidx = lf[q]; const Front &F = P.fronts[sidx]; int32_t *r = &fd[F3W * q];
               r[0] = sidx; r[1] = F.npiv; r[2] = F.nbnd; r[3] = F.asm_off; r[4] = F.asm_cnt - F.asm_dup; r[5] = F.asm_dup;
               r[6] = F.child_cnt; r[7] = F.child_off; r[8] = (int32_t)(F.L_off & 0xffffffffLL); r[9] = (int32_t)(F.L_off >> 32);
@@ -434,7 +434,8 @@ static int upload_graph(gs_graph *g) {
               for (int k = 0; k < 2; ++k) { r[12 + k] = -1; r[14 + k] = 0; r[16 + k] = 0;
                   if (k < F.child_cnt) { const int c = P.children[F.child_off + k]; const Front &C = P.fronts[c];
                       r[12 + k] = c; r[14 + k] = C.npiv | (C.nbnd << 16); r[16 + k] = C.owner; r[26 + k] = u3_off[c]; r[28 + k] = u3_size[c]; } }
-              r[24] = u3_off[sidx]; r[25] = u3_size[sidx]; r[30] = F.parent;
+              r[24] = u3_off[sidx]; r[25] = u3_size[sidx];
+              r[30] = (F.parent >= 0 && P.fronts[F.parent].owner == F.owner && F.owner >= 0) || (P.world == 1) ? F.parent : -1;   // whole-tree backward solve waits for an OWN parent only (the shared top ran in earlier launches)
               const int64_t xo = (P.world > 1 && (size_t)sidx < P.x_off.size()) ? P.x_off[sidx] : 0;
               r[18] = (int32_t)(xo & 0xffffffffLL); r[19] = (int32_t)(xo >> 32); }
           std::vector<int32_t> recs(P.asm_recs.size() * 4);
