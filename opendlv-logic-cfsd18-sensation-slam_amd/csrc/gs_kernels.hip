@@ -435,11 +435,28 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
     const bool live = p < d.N;
     const int64_t L = d.ell_len, S = (int64_t)T * d.N;
     const int R = d.ell_R;
-    // ---- pose state, incidence range, landmark-sum item descriptors, the tile's position list
+    // ---- first round trip: pose state, incidence range, tile descriptor AND the streams of slots 0-1 — none of these
+    // addresses depends on a loaded value, so everything is issued before the first wait
+    const uint32_t off8 = (uint32_t)(T * p + h) * 8u;             // byte offset of this lane's edge inside one ELL slot plane (< 4 GiB: host-checked)
+    const uint32_t plane8 = (uint32_t)S * 8u;
+    struct Slots { int l[2]; uint32_t dst[2]; double zx[2], zy[2], w00[2], w01[2], w11[2]; };
+    auto load_slots = [&](int c, Slots &e) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int i = c + j;
+            e.l[j] = -1; e.dst[j] = 0xFFFFu; e.zx[j] = e.zy[j] = e.w00[j] = e.w01[j] = e.w11[j] = 0.0;
+            if (live && i < R) { const uint32_t o = off8 + (uint32_t)i * plane8;      // SGPR base + 32-bit lane offset addressing
+                e.l[j] = LD_S(d.ell_l, o >> 1); e.dst[j] = LD_S(d.ell_dst, o >> 2); e.zx[j] = LD_S(d.ell_z, o); e.zy[j] = LD_S(d.ell_z + L, o);
+                e.w00[j] = LD_S(d.ell_w, o); e.w01[j] = LD_S(d.ell_w + L, o); e.w11[j] = LD_S(d.ell_w + 2 * L, o); } }
+    };
     double px = 0, py = 0, th = 0; bool fp = true; int q0 = 0, q1 = 0;
     if (live) { px = d.pose_est[3 * p]; py = d.pose_est[3 * p + 1]; th = d.pose_est[3 * p + 2]; fp = d.pose_fixed[p];
                 q0 = d.ppadj_start[p]; q1 = d.ppadj_start[p + 1]; }
     const int4 wd = reinterpret_cast<const int4 *>(d.wt_desc)[wt];        // {first group, #groups, first position, #positions}
+    double sn = 0.0, cs = 1.0;                                     // cos/sin of theta are kept per pose (k_update): no sincos here
+    if (live) { const double2 t2 = reinterpret_cast<const double2 *>(d.pose_cs)[p]; cs = t2.x; sn = t2.y; }
+    Slots e0; load_slots(0, e0);
+    // ---- second round trip: what needs a loaded index — first odometry incidence, landmark-sum item descriptors (and,
+    // inside the chunk, the landmark estimates of slots 0-1)
     int4 inc0 = make_int4(-1, 0, 0, 0);                           // this lane's first odometry incidence, fetched now, used after the edges
     if (q0 + h < q1) inc0 = reinterpret_cast<const int4 *>(d.ppinc)[q0 + h];
     const int g0 = wd.x, ng = wd.y, pos_off = wd.z, nitems = ng * 5;
@@ -447,36 +464,23 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
 #pragma unroll
     for (int u = 0; u < 2; ++u) { const int item = lane + 64 * u;
         if (item < nitems) { const int gl = item % ng; it_s[u] = d.grp_pos_start[g0 + gl] - pos_off; it_e[u] = d.grp_pos_start[g0 + gl + 1] - pos_off; it_slot[u] = d.grp_slot[g0 + gl]; } }
-    double sn = 0.0, cs = 1.0;                                     // cos/sin of theta are kept per pose (k_update): no sincos here
-    if (live) { const double2 t2 = reinterpret_cast<const double2 *>(d.pose_cs)[p]; cs = t2.x; sn = t2.y; }
     // ---- observation edges, two slots at a time: loads of both slots, both landmark gathers, then the arithmetic.
     // (All four slots at once need ~170 VGPRs = 3 waves per SIMD, and 100k poses are 3125 waves for 3072 slots: a
     // second round for 53 waves.  Two at a time fit 128 VGPRs = 4 waves per SIMD: one round, and the other three
     // waves of the SIMD cover the shorter per-thread load queue.)
     double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, chi = 0.0;
-    const uint32_t off8 = (uint32_t)(T * p + h) * 8u;             // byte offset of this lane's edge inside one ELL slot plane (< 4 GiB: host-checked)
-    const uint32_t plane8 = (uint32_t)S * 8u;
-#pragma unroll 1
-    for (int c = 0; c < LIN_R; c += 2) {
-        if (c >= R) break;                                          // uniform
-        LTS(1 + c / 2);
-        int l[2]; uint32_t dst[2]; double zx[2], zy[2], w00[2], w01[2], w11[2], lx[2], ly[2]; bool fl[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { const int i = c + j;
-            l[j] = -1; dst[j] = 0xFFFFu; zx[j] = zy[j] = w00[j] = w01[j] = w11[j] = 0.0;
-            if (live && i < R) { const uint32_t o = off8 + (uint32_t)i * plane8;      // SGPR base + 32-bit lane offset addressing
-                l[j] = LD_S(d.ell_l, o >> 1); dst[j] = LD_S(d.ell_dst, o >> 2); zx[j] = LD_S(d.ell_z, o); zy[j] = LD_S(d.ell_z + L, o);
-                w00[j] = LD_S(d.ell_w, o); w01[j] = LD_S(d.ell_w + L, o); w11[j] = LD_S(d.ell_w + 2 * L, o); } }
+    auto do_slots = [&](int c, const Slots &e) {
+        double lx[2], ly[2]; bool fl[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) { lx[j] = ly[j] = 0.0; fl[j] = true;
-            if (l[j] >= 0) { lx[j] = d.lm_est[2 * l[j]]; ly[j] = d.lm_est[2 * l[j] + 1]; fl[j] = d.lm_fixed[l[j]]; } }
+            if (e.l[j] >= 0) { lx[j] = d.lm_est[2 * e.l[j]]; ly[j] = d.lm_est[2 * e.l[j] + 1]; fl[j] = d.lm_fixed[e.l[j]]; } }
 #pragma unroll
         for (int j = 0; j < 2; ++j) { const int i = c + j;
             double hl0 = 0, hl1 = 0, hl2 = 0, bl0 = 0, bl1 = 0;
-            if (l[j] >= 0) {
+            if (e.l[j] >= 0) {
                 const uint32_t o = off8 + (uint32_t)i * plane8;
                 PlQuad q;
-                quad_pl(px, py, cs, sn, lx[j], ly[j], zx[j], zy[j], w00[j], w01[j], w11[j], q);
+                quad_pl(px, py, cs, sn, lx[j], ly[j], e.zx[j], e.zy[j], e.w00[j], e.w01[j], e.w11[j], q);
                 if (!(fp && fl[j])) chi += q.chi;
                 const bool both = !fp && !fl[j];
 #pragma unroll
@@ -487,10 +491,14 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
                 for (int k = 0; k < 3; ++k) b[k] += q.bp[k];
                 hl0 = q.Hl[0]; hl1 = q.Hl[1]; hl2 = q.Hl[2]; bl0 = q.bl[0]; bl1 = q.bl[1];
             }
-            if (dst[j] != 0xFFFFu) { const int pos = dst[j];          // an edge another shard evaluates (l < 0) still owns its position: zeros
+            if (e.dst[j] != 0xFFFFu) { const int pos = e.dst[j];      // an edge another shard evaluates (l < 0) still owns its position: zeros
                 s_lc[wave][0][pos] = hl0; s_lc[wave][1][pos] = hl1; s_lc[wave][2][pos] = hl2; s_lc[wave][3][pos] = bl0; s_lc[wave][4][pos] = bl1; }
         }
-    }
+    };
+    LTS(1);
+    do_slots(0, e0);
+    LTS(2);
+    if (R > 2) { Slots e1; load_slots(2, e1); do_slots(2, e1); }     // uniform (prefetching these under slots 0-1: measured, no change)
     LTS(3);
     // ---- odometry incidences: lane h takes incidences q0+h, q0+h+T, ... of its pose
     if (q0 + h < q1) chi += pp_incidence_rec<true>(d, inc0, H, b, p, cs, sn);
