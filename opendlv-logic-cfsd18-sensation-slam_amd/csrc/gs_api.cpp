@@ -319,6 +319,7 @@ static int upload_graph(gs_graph *g) {
     const HostGraph &h = g->h; const Plan &P = g->plan; DevGraph &d = g->d;
     const int N = h.n_poses(), M = h.n_lms(), Epp = h.n_pp(), Epl = h.n_pl();
     d.N = N; d.M = M; d.Epp = Epp; d.Epl = Epl; d.n_scalar = P.n_scalar;
+    g->leaf_n = -1;
     int rc;
 #define UP(dst, vec) if ((rc = dev_upload(g, &d.dst, vec)) != GS_OK) return rc
     UP(pose_est, h.pose_est); UP(lm_est, h.lm_est); UP(pose_fixed, h.pose_fixed); UP(lm_fixed, h.lm_fixed);
@@ -538,6 +539,7 @@ static int upload_graph(gs_graph *g) {
 
 static int build_plan_host(gs_graph *g) {
     PlanOptions o; o.leaf_poses = g->cfg.leaf_poses; o.world = g->world; o.rank = g->rank;
+    if (const char *e = std::getenv("GS_LEAF_POSES")) o.leaf_poses = std::atoi(e);       // tuning override
     if (const char *e = std::getenv("GS_ELL_LANES")) o.ell_lanes = std::atoi(e);       // tuning knob: lanes per pose of the ELL layout
     std::string err;
     if (!build_plan(g->h, o, g->plan, err)) { g->plan_version = ~0ull; return fail(GS_ERR_EMPTY, "plan: " + err); }
@@ -597,7 +599,16 @@ static int ensure_ready(gs_graph *g) {
 static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int base, int mode) {
     const int nlev = (int)ls.start.size() - 1;
     if (g->d.factor_variant == 3 && g->d.tree && mode == 0 && base == 0 && nlev > 0) {     // every own level in one launch
-        ++g->d.epoch; launch_factor_tree(g->d, ls.start[nlev], g->stream); return; }
+        ++g->d.epoch;
+        // leaf instance: level 0 only if its fronts really have no children (always true for an elimination tree's level 0)
+        if (g->leaf_n < 0) {                                          // once per plan
+            int n_leaf = ls.start[1], slot = 256;
+            for (int q = 0; q < n_leaf; ++q) { const Front &F = g->plan.fronts[g->plan.level_fronts_owned[q]];
+                if (F.child_cnt != 0) { n_leaf = 0; break; }
+                slot = std::max(slot, (((F.npiv + F.nbnd + 1) | 1) * F.npiv + 1) & ~1); }
+            if (const char *e = std::getenv("GS_LEAF_KERNEL")) if (std::atoi(e) == 0) n_leaf = 0;
+            g->leaf_n = n_leaf; g->leaf_slot = slot; }
+        launch_factor_tree(g->d, g->leaf_n, g->leaf_slot, ls.start[nlev], g->stream); return; }
     for (int l = 0; l < nlev; ++l)
         launch_factor_level(g->d, base + ls.start[l], ls.start[l + 1] - ls.start[l], ls.max_f[l], mode, g->stream);
 }

@@ -29,6 +29,7 @@ struct gs_graph {
     hipEvent_t ev[8]{};
     LevelSet own, shared;                   // this rank's fronts / the shared top (pose-window shards)
     int shared_base = 0;                    // offset of the shared list inside d.level_fronts
+    int leaf_n = -1, leaf_slot = 0;             // level-0 fronts handled by the leaf instance of the factor kernel, its LDS slot (doubles per wave)
     double ms_structure = 0;
     int rank = 0, world = 1;
     double *exchange = nullptr; bool exchange_external = false;   // caller-provided exchange buffer (e.g. a torch tensor)

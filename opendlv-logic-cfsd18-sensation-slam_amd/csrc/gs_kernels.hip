@@ -1169,9 +1169,21 @@ __device__ __forceinline__ void asm3_load(const DevGraph &d, int kind_cnt, int s
             for (int k = 0; k < 6; ++k) v[k] = d.Hpl[k * S + src]; } break;
     }
 }
+// staging of a front's original entries before they go to the accumulators.  StageT<false>: the 64 x 64 tile image
+// (20 KB).  StageT<true>: only the pivot columns, column-major (f+1) x npiv with an odd leading dimension (~9 KB) —
+// leaves have nothing else to stage, and the smaller footprint is what lets three workgroups share a CU.
+template <bool PANEL> struct StageT;
+template <> struct StageT<false> { double *F; int f, ld;
+    __device__ __forceinline__ double &at(int r, int c) const { return F[mf_tile(r >> 4, c >> 4) * 256 + (r & 15) * 16 + (c & 15)]; }
+    __device__ __forceinline__ int img(int off) const { return off; } };
+template <> struct StageT<true> { double *F; int f, ld;
+    __device__ __forceinline__ double &at(int r, int c) const { return F[c * ld + r]; }
+    __device__ __forceinline__ int img(int off) const {            // tile-image offset (the records' format) -> panel offset
+        const int t = off >> 8, I = t >= 6 ? 3 : (t >= 3 ? 2 : (t >= 1 ? 1 : 0)), J = t - ((I * (I + 1)) >> 1);
+        return (16 * J + (off & 15)) * ld + 16 * I + ((off >> 4) & 15); } };
 // phase B: the values into the staging image
-template <bool ADD>
-__device__ __forceinline__ void asm3_put(const StageFront &P, int kind_cnt, int r0, int c0, const double (&v)[9]) {
+template <bool ADD, class St>
+__device__ __forceinline__ void asm3_put(const St &P, int kind_cnt, int r0, int c0, const double (&v)[9]) {
     const int kind = kind_cnt & 0xff, f = P.f;
     auto put = [&](int r, int c, double x) { if (ADD) P.at(r, c) += x; else P.at(r, c) = x; };
     switch (kind) {
@@ -1308,8 +1320,11 @@ __device__ __forceinline__ void f3_publish(int32_t *flag, int epoch, int lane) {
     if (lane == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <bool TREE>
-__global__ void __launch_bounds__(256, 2) k_factor3(DevGraph d, int level_off, int count, int mode) {
+// LEAF: fronts without children (level 0 of a rank's own subtrees, mode OWN only): no gather registers, pivot-column
+// staging => 3 waves per SIMD and 3 workgroups per CU instead of 2 (halving the resident waves was measured to cost
+// the leaf level x1.67: it is bound by resident waves x front latency, not yet by bandwidth)
+template <bool TREE, bool LEAF>
+__global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int level_off, int count, int mode, int leaf_slot) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int fi = blockIdx.x * 4 + wave;
@@ -1323,7 +1338,7 @@ __global__ void __launch_bounds__(256, 2) k_factor3(DevGraph d, int level_off, i
     const int sv = d.f3_desc[(int64_t)(level_off + fi) * F3_STRIDE + F3_INTS + 128 + lane];     // own store table
     const F3 fr = f3_load(d.f3_desc, level_off + fi, lane);
     const int npiv = fr.npiv, f = npiv + fr.nbnd;
-    StageFront P{smem + (int64_t)wave * MF_IMG, f};
+    StageT<LEAF> P{smem + (int64_t)wave * (LEAF ? leaf_slot : MF_IMG), f, (f + 1) | 1};
     const int lc = lane & 15, lr = lane >> 4;
     F3_TS(1);
     const bool top = mode == FRONT_TOP;
@@ -1331,7 +1346,7 @@ __global__ void __launch_bounds__(256, 2) k_factor3(DevGraph d, int level_off, i
     bool use[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k)
-        use[k] = fr.c_id[k] >= 0 && !(mode == FRONT_CONTRIB && fr.c_owner[k] != d.rank) && !(top && fr.c_owner[k] >= 0);   // uniform
+        use[k] = !LEAF && fr.c_id[k] >= 0 && !(mode == FRONT_CONTRIB && fr.c_owner[k] != d.rank) && !(top && fr.c_owner[k] >= 0);   // uniform
     double u0[10][4], u1[10][4];
     if (!TREE) {
         if (use[0]) f3_gather_child<false>(d.Uimg + fr.c_uoff[0], fr.c_usize[0], pv[0], lane, u0);
@@ -1348,12 +1363,15 @@ __global__ void __launch_bounds__(256, 2) k_factor3(DevGraph d, int level_off, i
     F3_TS(2);
     // the staging image: originals only touch pivot columns, i.e. tile columns 0 .. (npiv - 1) / 16
     const int Jmax = top ? 3 : ((npiv - 1) >> 4);
+    if (LEAF) { for (int idx = lane; idx < P.ld * npiv; idx += 64) P.F[idx] = 0.0; }
+    else {
 #pragma unroll
-    for (int I = 0; I < 4; ++I)
+        for (int I = 0; I < 4; ++I)
 #pragma unroll
-        for (int J = 0; J <= I; ++J) if (J <= Jmax) {
+            for (int J = 0; J <= I; ++J) if (J <= Jmax) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) P.F[mf_tile(I, J) * 256 + q * 64 + lane] = 0.0; }
+                for (int q = 0; q < 4; ++q) P.F[mf_tile(I, J) * 256 + q * 64 + lane] = 0.0; }
+    }
     wave_lds_sync();
     F3_TS(3);
     // ---- round trip 3: the original values
@@ -1378,8 +1396,8 @@ __global__ void __launch_bounds__(256, 2) k_factor3(DevGraph d, int level_off, i
 #pragma unroll
                     for (int k = 0; k < 5; ++k) lv[k] += (q0 + j < lmr.x) ? t[j][k] : 0.0; } }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (64 * u < nsc) P.F[sc[u].y] = val[u];
-        for (int base = 512; base < nsc; base += 64) { const int2 r = sc3[base + lane]; P.F[r.y] = ld_off(d.H_arena, (uint32_t)r.x * 8u); }   // fronts with > 512 scalars
+        for (int u = 0; u < 8; ++u) if (64 * u < nsc) P.F[P.img(sc[u].y)] = val[u];
+        for (int base = 512; base < nsc; base += 64) { const int2 r = sc3[base + lane]; P.F[P.img(r.y)] = ld_off(d.H_arena, (uint32_t)r.x * 8u); }   // fronts with > 512 scalars
         if (lane < nlm) { const int r0 = lmr.z, c0 = lmr.w;
             P.at(r0, c0) = lv[0]; P.at(r0 + 1, c0) = lv[1]; P.at(r0 + 1, c0 + 1) = lv[2]; P.at(f, c0) = lv[3]; P.at(f, c0 + 1) = lv[4]; }
         for (int t = 64 + lane; t < nlm; t += 64) {                  // fronts with > 64 landmark pivots (not on f <= 63 fronts; kept for safety)
@@ -1412,7 +1430,10 @@ __global__ void __launch_bounds__(256, 2) k_factor3(DevGraph d, int level_off, i
 #pragma unroll
         for (int J = 0; J <= I; ++J) { const int t = mf_tile(I, J);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[t][q] = (J <= Jmax) ? P.F[t * 256 + q * 64 + lane] : 0.0; }
+            for (int q = 0; q < 4; ++q) {
+                if (LEAF) { const int row = 16 * I + lr + 4 * q, col = 16 * J + lc;       // pivot-column panel: (row, col) at col * ld + row
+                    acc[t][q] = (J <= Jmax && col < npiv && row <= f) ? P.F[min(col, npiv - 1) * P.ld + min(row, f)] : 0.0; }
+                else acc[t][q] = (J <= Jmax) ? P.F[t * 256 + q * 64 + lane] : 0.0; } }
     if (use[0]) {
 #pragma unroll
         for (int t = 0; t < 10; ++t)
@@ -1423,7 +1444,7 @@ __global__ void __launch_bounds__(256, 2) k_factor3(DevGraph d, int level_off, i
         for (int t = 0; t < 10; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[t][q] += u1[t][q]; }
-    for (int ci = 2; ci < fr.nchild; ++ci) {
+    for (int ci = 2; !LEAF && ci < fr.nchild; ++ci) {
         const int4 dc = reinterpret_cast<const int4 *>(d.child_desc)[fr.child_off + ci];    // {front, npiv | nbnd << 16, owner, map offset}
         if (mode == FRONT_CONTRIB && dc.z != d.rank) continue;
         if (top && dc.z >= 0) continue;
@@ -1436,7 +1457,7 @@ __global__ void __launch_bounds__(256, 2) k_factor3(DevGraph d, int level_off, i
             for (int q = 0; q < 4; ++q) acc[t][q] += u0[t][q];
     }
     wave_lds_sync();
-    if (mode == FRONT_CONTRIB) {                                     // this rank's share of a shared front -> exchange slot
+    if (!LEAF && mode == FRONT_CONTRIB) {                            // this rank's share of a shared front -> exchange slot
 #pragma unroll
         for (int t = 0; t < 10; ++t)
 #pragma unroll
@@ -1545,11 +1566,14 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
 }
 
 // whole-tree launches of variant 3 (own fronts of a single-GPU graph): every level in one kernel each
-void launch_factor_tree(const DevGraph &d, int count, hipStream_t st) {
+void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int count, hipStream_t st) {
     if (count <= 0) return;
     static bool attr_set_t = false;
-    if (!attr_set_t) { (void)hipFuncSetAttribute((const void *)k_factor3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_t = true; }
-    hipLaunchKernelGGL(k_factor3<true>, dim3((count + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, 0, count, FRONT_OWN);
+    if (!attr_set_t) { (void)hipFuncSetAttribute((const void *)k_factor3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_factor3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_t = true; }
+    // level 0 (no children) through the high-occupancy leaf instance, everything above in one launch whose fronts wait on flags
+    if (n_leaf > 0) hipLaunchKernelGGL((k_factor3<true, true>), dim3((n_leaf + 3) / 4), dim3(256), (size_t)leaf_slot * 4 * sizeof(double), st, d, 0, n_leaf, FRONT_OWN, leaf_slot);
+    if (count > n_leaf) hipLaunchKernelGGL((k_factor3<true, false>), dim3((count - n_leaf + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, n_leaf, count - n_leaf, FRONT_OWN, 0);
 }
 void launch_backsolve_tree(const DevGraph &d, int count, int max_npiv, int max_f, hipStream_t st) {
     if (count <= 0) return;
@@ -1563,8 +1587,10 @@ void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f,
     if (count <= 0) return;
     if (max_f <= 63 && d.factor_variant == 3) {
         static bool attr_set_3 = false;
-        if (!attr_set_3) { hipFuncSetAttribute((const void *)k_factor3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_3 = true; }
-        hipLaunchKernelGGL(k_factor3<false>, dim3((count + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, level_off, count, mode);
+        if (!attr_set_3) { hipFuncSetAttribute((const void *)k_factor3<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_3 = true; }
+        static size_t lds3 = 0;                                      // GS_F3_LDS_KB: occupancy experiments (more LDS per block = fewer resident blocks)
+        if (lds3 == 0) { lds3 = (size_t)MF_IMG * 4 * sizeof(double); if (const char *e = getenv("GS_F3_LDS_KB")) lds3 = std::max(lds3, (size_t)atoi(e) * 1024); }
+        hipLaunchKernelGGL((k_factor3<false, false>), dim3((count + 3) / 4), dim3(256), lds3, st, d, level_off, count, mode, 0);
         return;
     }
     if (max_f <= 63 && d.factor_variant == 2) {
