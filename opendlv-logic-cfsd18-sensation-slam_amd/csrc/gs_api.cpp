@@ -615,8 +615,13 @@ static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int
 static void enqueue_backsolve_levels(gs_graph *g, const gs_graph::LevelSet &ls, int base) {
     const int nlev = (int)ls.start.size() - 1;
     if (g->d.factor_variant == 3 && g->d.tree && base == 0 && nlev > 0) {
-        int mn = 0, mf = 0; for (int l = 0; l < nlev; ++l) { mn = std::max(mn, ls.max_npiv[l]); mf = std::max(mf, ls.max_f[l]); }
-        launch_backsolve_tree(g->d, ls.start[nlev], mn, mf, g->stream); return; }
+        // levels >= 1 in one launch (fronts wait for their parent's flag), then the leaf level on its own: by then every
+        // parent is done, so it needs no flags, and its LDS slot is sized for the leaves alone (more resident waves)
+        const int l0 = (nlev > 1 && g->leaf_n != 0) ? 1 : 0;
+        int mn = 0, mf = 0; for (int l = l0; l < nlev; ++l) { mn = std::max(mn, ls.max_npiv[l]); mf = std::max(mf, ls.max_f[l]); }
+        launch_backsolve_tree(g->d, ls.start[l0], ls.start[nlev] - ls.start[l0], mn, mf, g->stream);
+        if (l0 == 1) launch_backsolve_level(g->d, 0, ls.start[1], ls.max_npiv[0], ls.max_nbnd[0], g->stream);
+        return; }
     for (int l = nlev - 1; l >= 0; --l)
         launch_backsolve_level(g->d, base + ls.start[l], ls.start[l + 1] - ls.start[l], ls.max_npiv[l], ls.max_nbnd[l], g->stream);
 }

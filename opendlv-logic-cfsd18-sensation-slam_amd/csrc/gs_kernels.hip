@@ -1520,7 +1520,7 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
     if (fi >= count) return;
     const bool ts_on = (d.dbg & 8) && count == (d.dbg >> 8) && fi == 0;
     F3_TS(32);
-    const int pos = TREE ? count - 1 - fi : level_off + fi;
+    const int pos = TREE ? level_off + (count - 1 - fi) : level_off + fi;
     const F3 fr = f3_load(d.f3_desc, pos, lane);
     const int npiv = fr.npiv, nbnd = fr.nbnd, f = npiv + nbnd, ldl = f + 1, lds = (f + 1) | 1;
     F3_TS(33);
@@ -1575,12 +1575,12 @@ void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int count,
     if (n_leaf > 0) hipLaunchKernelGGL((k_factor3<true, true>), dim3((n_leaf + 3) / 4), dim3(256), (size_t)leaf_slot * 4 * sizeof(double), st, d, 0, n_leaf, FRONT_OWN, leaf_slot);
     if (count > n_leaf) hipLaunchKernelGGL((k_factor3<true, false>), dim3((count - n_leaf + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, n_leaf, count - n_leaf, FRONT_OWN, 0);
 }
-void launch_backsolve_tree(const DevGraph &d, int count, int max_npiv, int max_f, hipStream_t st) {
-    if (count <= 0) return;
+void launch_backsolve_tree(const DevGraph &d, int first, int count, int max_npiv, int max_f, hipStream_t st) {
+    if (count <= 0) return;                                          // positions [first, first + count), root first
     const int slot = ((((max_f + 1) | 1) * max_npiv) + 1) & ~1;
     static bool attr_set_bt = false;
     if (!attr_set_bt) { (void)hipFuncSetAttribute((const void *)k_backsolve3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_bt = true; }
-    hipLaunchKernelGGL(k_backsolve3<true>, dim3((count + 3) / 4), dim3(256), (size_t)slot * 4 * sizeof(double), st, d, 0, count, slot);
+    hipLaunchKernelGGL(k_backsolve3<true>, dim3((count + 3) / 4), dim3(256), (size_t)slot * 4 * sizeof(double), st, d, first, count, slot);
 }
 
 void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f, int mode, hipStream_t st) {
