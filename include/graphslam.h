@@ -267,6 +267,22 @@ int  gs_slam_loop_closed(gs_slam *s);
 int  gs_slam_current_cone_index(gs_slam *s);
 int  gs_slam_get_send_pose(gs_slam *s, double out_xytheta[3]);
 gs_graph *gs_slam_graph(gs_slam *s);
+/* ---- frame collector and output encoders (row f-2) ---------------------------
+ * gs_slam_collect_direction / _distance / _type <- Slam::nextCone (src/slam.cpp:67-152): one field of column objectId of
+ *      the 4 x 1000 collector; returns 1 when the message opened a new frame, 0 otherwise, < 0 on error
+ *      (objectId >= 1000 is refused; the reference indexes unchecked).
+ * gs_slam_collect_flush <- Slam::initializeCollection (src/slam.cpp:221-257) after its wait, without the keyframe gate:
+ *      extracts the leftmost lastObjectId + 1 columns (also copied to cones_out_4xk when not NULL, count in *k_out),
+ *      resets the collector and runs gs_slam_perform on them with the given odometry pose.
+ * gs_slam_encode_cones <- Slam::sendCones + Cone::getDirection / getDistance (src/slam.cpp:656-677, src/cone.cpp:34-53):
+ *      conesPerPacket cones from currentConeIndex on, wrapping around the map, seen from the send pose; float32 fields
+ *      as in the messages (azimuth in degrees, zenith is always 0).  cfg.reference_quirks keeps the reference's heading
+ *      unit slip. */
+int  gs_slam_collect_direction(gs_slam *s, uint32_t object_id, double azimuth_deg, double zenith_deg);
+int  gs_slam_collect_distance(gs_slam *s, uint32_t object_id, double distance);
+int  gs_slam_collect_type(gs_slam *s, uint32_t object_id, uint32_t type);
+int  gs_slam_collect_flush(gs_slam *s, const double pose_xytheta[3], int32_t *k_out, double *cones_out_4xk);
+int  gs_slam_encode_cones(gs_slam *s, int32_t cones_per_packet, float *azimuth_deg, float *distance, int32_t *type);
 
 #ifdef __cplusplus
 }

@@ -144,6 +144,11 @@ def lib():
     L.gs_slam_perform.argtypes = [vp, _dp, _dp, C.c_int32]
     L.gs_slam_get_map.argtypes = [vp, C.c_int32, _dp, _ip]
     L.gs_slam_get_send_pose.argtypes = [vp, _dp]
+    L.gs_slam_collect_direction.argtypes = [vp, C.c_uint32, C.c_double, C.c_double]
+    L.gs_slam_collect_distance.argtypes = [vp, C.c_uint32, C.c_double]
+    L.gs_slam_collect_type.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.gs_slam_collect_flush.argtypes = [vp, _dp, C.POINTER(C.c_int32), _dp]
+    L.gs_slam_encode_cones.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     _lib = L
     return L
 
@@ -461,3 +466,24 @@ class Slam:
 
     def send_pose(self):
         o = np.zeros(3); self._check(self.L.gs_slam_get_send_pose(self.h, _d(o))); return o
+
+    # ---- frame collector and output encoders (reference Slam::nextCone / initializeCollection / sendCones)
+    def collect_direction(self, object_id, azimuth_deg, zenith_deg):
+        return self._check(self.L.gs_slam_collect_direction(self.h, int(object_id), float(azimuth_deg), float(zenith_deg)))
+
+    def collect_distance(self, object_id, distance):
+        return self._check(self.L.gs_slam_collect_distance(self.h, int(object_id), float(distance)))
+
+    def collect_type(self, object_id, cone_type):
+        return self._check(self.L.gs_slam_collect_type(self.h, int(object_id), int(cone_type)))
+
+    def collect_flush(self, pose):
+        """Extracts the collected frame ([K,4] rows az, zen, dist, type), resets the collector, runs perform_slam on it."""
+        pose = _f64(pose); k = C.c_int32(0); buf = np.zeros((1000, 4))
+        self._check(self.L.gs_slam_collect_flush(self.h, _d(pose), C.byref(k), _d(buf)))
+        return buf[:k.value].copy()
+
+    def encode_cones(self, cones_per_packet):
+        n = int(cones_per_packet); az = np.zeros(n, dtype=np.float32); di = np.zeros(n, dtype=np.float32); ty = np.zeros(n, dtype=np.int32)
+        self._check(self.L.gs_slam_encode_cones(self.h, n, az.ctypes.data_as(C.POINTER(C.c_float)), di.ctypes.data_as(C.POINTER(C.c_float)), _i(ty)))
+        return az, di, ty

@@ -25,6 +25,10 @@ struct gs_slam {
     uint32_t current_cone_index = 0;                         // m_currentConeIndex
     double send_pose[3] = {0, 0, 0};                         // m_sendPose
     int optimise_calls = 0;
+    // frame collector (m_coneCollector, m_lastObjectId, m_newFrame; reference src/slam.cpp:46, 67-152, 221-257)
+    std::vector<double> collector = std::vector<double>(4 * 1000, 0.0);   // 4 x 1000, column-major: (az, zen, dist, type) per objectId
+    uint32_t last_object_id = 0;
+    bool new_frame = true;
 };
 
 using gs::fail;
@@ -201,6 +205,60 @@ extern "C" int gs_slam_perform(gs_slam *s, const double pose[3], const double *c
         if (reobserved > 0) s->current_cone_index = current;
         // updatePoseFromGraph (:416-422): the raw estimate of the last pose vertex; no re-optimisation (:403)
         if ((rc = gs_get_pose(s->g, s->pose_id - 1, s->send_pose)) != GS_OK) return rc;
+    }
+    return GS_OK;
+}
+
+// ------------------------------------------------------------------ f-2: frame collector and output encoders
+// Slam::nextCone (reference src/slam.cpp:67-152): one message = one field of column objectId of the 4 x 1000 collector;
+// m_lastObjectId = max; the first message after a flush opens the frame (m_newFrame true -> false), which in the
+// reference starts the waiting thread that ends in initializeCollection.  Return value: 1 if this message opened a
+// frame, 0 otherwise, < 0 on error.  objectId >= 1000 is an error here (the reference indexes unchecked).
+static int collect(gs_slam *s, uint32_t id, int row0, const double *vals, int nvals) {
+    if (!s) return fail(GS_ERR_INVALID, "null handle");
+    if (id >= 1000) return fail(GS_ERR_INVALID, "objectId beyond the 4 x 1000 collector");
+    for (int r = 0; r < nvals; ++r) s->collector[4 * (size_t)id + row0 + r] = vals[r];
+    s->last_object_id = std::max(s->last_object_id, id);
+    const int opened = s->new_frame ? 1 : 0;
+    s->new_frame = false;
+    return opened;
+}
+extern "C" int gs_slam_collect_direction(gs_slam *s, uint32_t object_id, double azimuth_deg, double zenith_deg) {
+    const double v[2] = {azimuth_deg, zenith_deg}; return collect(s, object_id, 0, v, 2);
+}
+extern "C" int gs_slam_collect_distance(gs_slam *s, uint32_t object_id, double distance) { return collect(s, object_id, 2, &distance, 1); }
+extern "C" int gs_slam_collect_type(gs_slam *s, uint32_t object_id, uint32_t type) { const double v = (double)type; return collect(s, object_id, 3, &v, 1); }
+// Slam::initializeCollection (reference src/slam.cpp:221-257) after its wait and without the keyframe gate (both are
+// transport timing, out of scope): take the leftmost m_lastObjectId + 1 columns, reset the collector, run performSLAM.
+extern "C" int gs_slam_collect_flush(gs_slam *s, const double pose_xytheta[3], int32_t *k_out, double *cones_out_4xk) {
+    if (!s || !pose_xytheta) return fail(GS_ERR_INVALID, "null argument");
+    const int k = (int)s->last_object_id + 1;
+    std::vector<double> extracted(s->collector.begin(), s->collector.begin() + 4 * (size_t)k);
+    s->new_frame = true; s->last_object_id = 0;
+    std::fill(s->collector.begin(), s->collector.end(), 0.0);
+    if (k_out) *k_out = k;
+    if (cones_out_4xk) std::memcpy(cones_out_4xk, extracted.data(), extracted.size() * sizeof(double));
+    return gs_slam_perform(s, pose_xytheta, extracted.data(), k);      // extractedCones.cols() > 0 always holds (:245)
+}
+// Slam::sendCones + Cone::getDirection / getDistance (reference src/slam.cpp:656-677, src/cone.cpp:34-53): the
+// conesPerPacket map cones starting at m_currentConeIndex, wrapping around the map, seen from m_sendPose; message
+// fields are float32.  Quirk 8-B.7 (the radian heading scaled by 1/RAD2DEG before it is subtracted from degrees) is
+// reproduced under cfg.reference_quirks, otherwise the heading is converted to degrees.
+extern "C" int gs_slam_encode_cones(gs_slam *s, int32_t cones_per_packet, float *azimuth_deg, float *distance, int32_t *type) {
+    if (!s || cones_per_packet < 0 || (cones_per_packet > 0 && (!azimuth_deg || !distance || !type))) return fail(GS_ERR_INVALID, "bad argument");
+    if (cones_per_packet > 0 && s->map.empty()) return fail(GS_ERR_INVALID, "empty map");
+    const double RAD2DEG = 57.295779513082325;                       // reference src/slam.hpp:135
+    const size_t n = s->map.size();
+    for (int i = 0; i < cones_per_packet; ++i) {
+        size_t index = s->current_cone_index + (size_t)i;
+        if (index >= n) index -= n;                                  // the reference's single wrap (:666-667) ...
+        if (index >= n) index %= n;                                  // ... made safe for conesPerPacket > map size (reference: out of bounds)
+        const MapCone &c = s->map[index];
+        const double x = c.x - s->send_pose[0], y = c.y - s->send_pose[1];
+        const double heading = s->cfg.reference_quirks ? s->send_pose[2] * (1 / RAD2DEG) : s->send_pose[2] * RAD2DEG;
+        azimuth_deg[i] = (float)(std::atan2(y, x) * RAD2DEG - heading);
+        distance[i] = (float)std::sqrt(x * x + y * y);
+        type[i] = c.type;
     }
     return GS_OK;
 }

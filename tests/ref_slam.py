@@ -1,5 +1,6 @@
 """Test-only restatement, in Python over the CPU oracle, of the graph side of the reference's class Slam:
-performSLAM (reference src/slam.cpp:298-338), addPoseToGraph/addOdometryMeasurement (:433-459), addConesToMap
+frame collector nextCone / initializeCollection (reference src/slam.cpp:67-152, 221-257), output encoders sendCones +
+Cone::getDirection / getDistance (src/slam.cpp:656-677, src/cone.cpp:34-53), performSLAM (reference src/slam.cpp:298-338), addPoseToGraph/addOdometryMeasurement (:433-459), addConesToMap
 (:552-635), addConeToGraph/addConeMeasurement (:525-550), loopClosing (:697-706), optimizeGraph (:461-484),
 updateMap (:713-732), localizer (:340-414), updatePoseFromGraph (:416-422).
 
@@ -22,6 +23,38 @@ class RefSlam:
         self.current_cone_index = 0
         self.send_pose = np.zeros(3)
         self.optimise_calls = 0
+        self.collector = np.zeros((4, 1000)); self.last_object_id = 0; self.new_frame = True
+
+    # --- frame collector (reference src/slam.cpp:67-152, 221-257; the wait and the keyframe gate are transport timing)
+    def _collect(self, object_id, rows, vals):
+        self.collector[rows, object_id] = vals
+        self.last_object_id = max(self.last_object_id, object_id)
+        opened = self.new_frame; self.new_frame = False
+        return int(opened)
+
+    def collect_direction(self, object_id, az, zen): return self._collect(object_id, [0, 1], [az, zen])
+    def collect_distance(self, object_id, dist): return self._collect(object_id, [2], [dist])
+    def collect_type(self, object_id, ty): return self._collect(object_id, [3], [float(ty)])
+
+    def collect_flush(self, pose):
+        extracted = self.collector[:, :self.last_object_id + 1].T.copy()
+        self.new_frame = True; self.last_object_id = 0; self.collector[:] = 0.0
+        self.perform(pose, extracted)
+        return extracted
+
+    # --- output encoders (reference src/slam.cpp:656-677, src/cone.cpp:34-53); float32 message fields
+    def encode_cones(self, cones_per_packet):
+        RAD2DEG = 57.295779513082325
+        n = len(self.map); az = np.zeros(cones_per_packet, np.float32); di = np.zeros(cones_per_packet, np.float32); ty = np.zeros(cones_per_packet, np.int32)
+        for i in range(cones_per_packet):
+            idx = self.current_cone_index + i
+            if idx >= n: idx -= n
+            if idx >= n: idx %= n
+            c = self.map[idx]
+            x, y = c[0] - self.send_pose[0], c[1] - self.send_pose[1]
+            heading = self.send_pose[2] * (1 / RAD2DEG) if self.quirks else self.send_pose[2] * RAD2DEG
+            az[i] = np.float32(np.arctan2(y, x) * RAD2DEG - heading); di[i] = np.float32(np.sqrt(x * x + y * y)); ty[i] = c[2]
+        return az, di, ty
 
     # --- helpers on the oracle graph (indices: pose k = id 1000 + k)
     def _add_measurement(self, cone_id, z):

@@ -390,3 +390,44 @@ def test_cfg4_properties(pkg, frontend):
     assert rmse_truth < 100.0                                   # the 25 km lap stays near the truth (ML uncertainty ~25 m)
     assert np.array_equal(G.poses()[:2], g["pose_est"][:2])
     G.close()
+
+
+# ---------------------------------------------------------------- f-2: frame collector + output encoders
+@pytest.mark.parametrize("quirks", [0, 1])
+def test_frame_collector_and_cone_encoders_match_reference_logic(pkg, quirks):
+    """Message-in / message-out around the back-end: per-field collector writes (Slam::nextCone, reference
+    src/slam.cpp:67-152) in scrambled arrival order, frame extraction + reset (initializeCollection :221-257), then the
+    conesPerPacket window that sendCones encodes (:656-677, Cone::getDirection / getDistance src/cone.cpp:34-53) with
+    its wrap-around and float32 fields.  Product: csrc/gs_slam.cpp over the HIP C-ABI; checker: tests/ref_slam.py."""
+    from ref_slam import RefSlam
+    N, M = 120, 60
+    t = pkg.track.generate(N, M)
+    S = pkg.Slam(same_cone_threshold=1.2, cone_mapping_threshold=67.0, reference_quirks=quirks)
+    R = RefSlam(same_cone_threshold=1.2, cone_mapping_threshold=67.0, quirks=bool(quirks))
+    rng = np.random.default_rng(5)
+    frames = list(range(N)) + list(range(8))
+    for n, k in enumerate(frames):
+        obs = t["obs"][k]                                     # [K, 4]
+        msgs = [(f, i) for i in range(len(obs)) for f in range(3)]
+        order = rng.permutation(len(msgs))                    # direction / distance / type messages arrive interleaved
+        opened = []
+        for q in order:
+            f, i = msgs[q]
+            for X in (S, R):
+                if f == 0: o = X.collect_direction(i, obs[i, 0], obs[i, 1])
+                elif f == 1: o = X.collect_distance(i, obs[i, 2])
+                else: o = X.collect_type(i, int(obs[i, 3]))
+                opened.append(o)
+        assert opened[0] == 1 and opened[1] == 1 and sum(opened) == 2          # exactly the first message opens the frame, on both
+        es, er = S.collect_flush(t["odom_poses"][k]), R.collect_flush(t["odom_poses"][k])
+        assert np.array_equal(es, er) and np.array_equal(es, obs)
+        assert S.map_size == len(R.map) and S.loop_closed == R.loop_closing_complete and S.current_cone_index == R.current_cone_index
+        if S.map_size:
+            for cpp in (1, 10, S.map_size, S.map_size + 3):   # includes windows that wrap around the map
+                a, b = S.encode_cones(cpp), R.encode_cones(cpp)
+                assert np.array_equal(a[2], b[2])
+                assert np.allclose(a[0], b[0], rtol=0, atol=2e-5) and np.allclose(a[1], b[1], rtol=1e-6, atol=0)     # float32 fields of values that agree to 1e-7
+    assert S.loop_closed
+    with pytest.raises(Exception):
+        S.collect_type(1000, 1)                               # beyond the 4 x 1000 collector: refused, not written
+    S.close()
