@@ -1083,6 +1083,30 @@ __global__ void __launch_bounds__(256, 2) k_factor_mfma(DevGraph d, int level_of
         }
 }
 
+// F3_NT: bit 0 = the L panels (written once by the factor kernel, read once by the backward solve) move with
+// non-temporal stores / loads, so that 2 x 141 MB per iteration do not sweep the caches the update matrices and the
+// original values live in.  Measured at cfg4 (factor phase, us / GN iterations per s): 0: 281 / 2310, 1: 255 / 2480,
+// 3 (+ records): 256 / 2485, 5 (+ original values): 267 / 2410, 7: 268 / 2415.
+#ifndef F3_NT
+#define F3_NT 1
+#endif
+#if F3_NT & 1
+#define F3_ST_L(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#define F3_LD_L(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define F3_ST_L(ptr, v) (*(ptr) = (v))
+#define F3_LD_L(ptr) (*(ptr))
+#endif
+#if F3_NT & 2      // bit 1: the scalar assembly records (read once per iteration)
+#define F3_LD_REC(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define F3_LD_REC(ptr) (*(ptr))
+#endif
+#if F3_NT & 4      // bit 2: the original H values (written by the linearisation pass, read once here)
+#define F3_LD_VAL(base, off) ld_off_nt(base, off)
+#else
+#define F3_LD_VAL(base, off) ld_off(base, off)
+#endif
 // ---- variant 3: latency-shaped wave-per-front kernels (f <= 63).  The time of a level is the latency of ONE front
 // (the top of the tree has fewer fronts than the chip has wave slots, and the leaf level is a few rounds of that
 // latency), so these kernels are built around the number of dependent memory round trips per front:
@@ -1280,7 +1304,7 @@ __device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[10], double 
             for (int j2 = j + 1; j2 < 4; ++j2) { const double c2 = lane_bcast(p[j], k0 + j2); p[j2] -= lj * c2; }
             p[j] = (lane == col) ? piv : lj;
             dd[j] = piv;
-            if (lane <= f) L[(int64_t)col * (f + 1) + lane] = p[j];   // column `col` of the L panel (rows < col are 0, row col = d)
+            if (lane <= f) F3_ST_L(&L[(int64_t)col * (f + 1) + lane], p[j]);   // column `col` of the L panel (rows < col are 0, row col = d)
         } else p[j] = 0.0;                                          // not a pivot: contributes nothing to the update
     }
 #pragma unroll
@@ -1357,7 +1381,8 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
     const int2 *sc3 = reinterpret_cast<const int2 *>(d.sc3) + fr.sc_off;
     int2 sc[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) sc[u] = (64 * u < nsc) ? sc3[64 * u + lane] : make_int2(0, 1);        // uniform predicate
+    for (int u = 0; u < 8; ++u) { sc[u] = make_int2(0, 1);
+        if (64 * u < nsc) { const long long v = F3_LD_REC(reinterpret_cast<const long long *>(sc3 + 64 * u + lane)); sc[u] = make_int2((int)(v & 0xffffffffLL), (int)(v >> 32)); } }   // uniform predicate
     int4 lmr = make_int4(0, 0, 0, 0);
     if (lane < nlm) lmr = reinterpret_cast<const int4 *>(d.lm3)[fr.lm_off + lane];
     F3_TS(2);
@@ -1382,7 +1407,7 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
     } else {
         double val[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (64 * u < nsc) val[u] = ld_off(d.H_arena, (uint32_t)sc[u].x * 8u);
+        for (int u = 0; u < 8; ++u) if (64 * u < nsc) val[u] = F3_LD_VAL(d.H_arena, (uint32_t)sc[u].x * 8u);
         double lv[5] = {0, 0, 0, 0, 0};
         if (lane < nlm) { const int64_t G = d.n_groups;
             for (int q0 = 0; q0 < lmr.x; q0 += 4) {                  // four slots' loads in flight, added in slot order
@@ -1532,7 +1557,7 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
     for (int c0 = 0; c0 < npiv; c0 += 32) {                          // 32 column loads in flight per lane: one round trip for npiv <= 32
         double t[32];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) t[j] = L[(int64_t)min(c0 + j, npiv - 1) * ldl + lrow];
+        for (int j = 0; j < 32; ++j) t[j] = F3_LD_L(&L[(int64_t)min(c0 + j, npiv - 1) * ldl + lrow]);
 #pragma unroll
         for (int j = 0; j < 32; ++j) if (c0 + j < npiv && lane <= f) S[(c0 + j) * lds + lane] = t[j];
     }
