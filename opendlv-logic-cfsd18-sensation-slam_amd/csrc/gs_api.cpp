@@ -435,7 +435,7 @@ static int upload_graph(gs_graph *g) {
               for (int k = 0; k < 2; ++k) { r[12 + k] = -1; r[14 + k] = 0; r[16 + k] = 0;
                   if (k < F.child_cnt) { const int c = P.children[F.child_off + k]; const Front &C = P.fronts[c];
                       r[12 + k] = c; r[14 + k] = C.npiv | (C.nbnd << 16); r[16 + k] = C.owner; r[26 + k] = u3_off[c]; r[28 + k] = u3_size[c]; } }
-              r[24] = u3_off[sidx]; r[25] = u3_size[sidx];
+              r[24] = u3_off[sidx]; r[25] = u3_size[sidx]; r[31] = F.level;
               r[30] = (F.parent >= 0 && P.fronts[F.parent].owner == F.owner && F.owner >= 0) || (P.world == 1) ? F.parent : -1;   // whole-tree backward solve waits for an OWN parent only (the shared top ran in earlier launches)
               const int64_t xo = (P.world > 1 && (size_t)sidx < P.x_off.size()) ? P.x_off[sidx] : 0;
               r[18] = (int32_t)(xo & 0xffffffffLL); r[19] = (int32_t)(xo >> 32); }

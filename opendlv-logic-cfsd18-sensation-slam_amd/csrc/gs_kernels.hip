@@ -1142,7 +1142,7 @@ __global__ void __launch_bounds__(256, 2) k_factor_mfma(DevGraph d, int level_of
 //      colpart}) sit right behind its descriptor (f3_desc stride 224 ints): known after the FIRST round trip.
 struct F3 {
     int s, npiv, nbnd, asm_off, asm_uniq, asm_dup, nchild, child_off, piv0, bnd_off, c_id[2], c_info[2], c_owner[2];
-    int sc_off, sc_cnt, lm_off, lm_cnt, u_off, u_size, c_uoff[2], c_usize[2], parent;
+    int sc_off, sc_cnt, lm_off, lm_cnt, u_off, u_size, c_uoff[2], c_usize[2], parent, level;
     int64_t L_off, x_off;
 };
 static constexpr int F3_INTS = 32, F3_STRIDE = 224;   // 32 descriptor ints, pinv of child 0, pinv of child 1, own store table (64 ints each)
@@ -1155,7 +1155,7 @@ __device__ __forceinline__ F3 f3_load(const int32_t *desc, int idx, int lane) {
     r.c_id[0] = g(12); r.c_id[1] = g(13); r.c_info[0] = g(14); r.c_info[1] = g(15); r.c_owner[0] = g(16); r.c_owner[1] = g(17);
     r.x_off = (int64_t)(uint32_t)g(18) | ((int64_t)g(19) << 32);
     r.sc_off = g(20); r.sc_cnt = g(21); r.lm_off = g(22); r.lm_cnt = g(23);
-    r.u_off = g(24); r.u_size = g(25); r.c_uoff[0] = g(26); r.c_uoff[1] = g(27); r.c_usize[0] = g(28); r.c_usize[1] = g(29); r.parent = g(30);
+    r.u_off = g(24); r.u_size = g(25); r.c_uoff[0] = g(26); r.c_uoff[1] = g(27); r.c_usize[0] = g(28); r.c_usize[1] = g(29); r.parent = g(30); r.level = g(31);
     return r;
 }
 
@@ -1441,12 +1441,19 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
     wave_lds_sync();
     F3_TS(5);
     if (TREE) {                                                      // everything above ran while the children were still working
-        bool okw = true;
-        if (use[0]) okw = f3_wait_flag(d.done_f + fr.c_id[0], d.epoch) && okw;
-        if (use[1]) okw = f3_wait_flag(d.done_f + fr.c_id[1], d.epoch) && okw;
-        if (!okw && lane == 0) atomicExch(d.fail, 2);
-        if (use[0]) f3_gather_child<true>(d.Uimg + fr.c_uoff[0], fr.c_usize[0], pv[0], lane, u0);
-        if (use[1]) f3_gather_child<true>(d.Uimg + fr.c_uoff[1], fr.c_usize[1], pv[1], lane, u1);
+        if (fr.level == 1 && leaf_slot != 0) {
+            // children = leaves of the PREVIOUS launch: complete and visible — no flags, and ordinary (cached) loads: the
+            // gather touches every line from several instructions, device-scope loads would refetch it each time
+            if (use[0]) f3_gather_child<false>(d.Uimg + fr.c_uoff[0], fr.c_usize[0], pv[0], lane, u0);
+            if (use[1]) f3_gather_child<false>(d.Uimg + fr.c_uoff[1], fr.c_usize[1], pv[1], lane, u1);
+        } else {
+            bool okw = true;
+            if (use[0]) okw = f3_wait_flag(d.done_f + fr.c_id[0], d.epoch) && okw;
+            if (use[1]) okw = f3_wait_flag(d.done_f + fr.c_id[1], d.epoch) && okw;
+            if (!okw && lane == 0) atomicExch(d.fail, 2);
+            if (use[0]) f3_gather_child<true>(d.Uimg + fr.c_uoff[0], fr.c_usize[0], pv[0], lane, u0);
+            if (use[1]) f3_gather_child<true>(d.Uimg + fr.c_uoff[1], fr.c_usize[1], pv[1], lane, u1);
+        }
     }
     // ---- accumulators = originals + child 0 + child 1 (+ further children, rare)
     v4d acc[10];
@@ -1527,12 +1534,14 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
                     if (16 * J + 15 < npiv) continue;                // uniform
                     int off = ro + co[J];
                     if (I == J) off = (lr + 4 * q < lc) ? -1 : off;
-                    if (TREE) st_off_wt(U, min((uint32_t)off, dump), (double)acc[mf_tile(I, J)][q]); else st_off(U, min((uint32_t)off, dump), (double)acc[mf_tile(I, J)][q]);
+                    if (TREE && !LEAF) st_off_wt(U, min((uint32_t)off, dump), (double)acc[mf_tile(I, J)][q]);      // consumed inside this launch: write through
+                    else st_off(U, min((uint32_t)off, dump), (double)acc[mf_tile(I, J)][q]);                        // consumed by a later launch
                 }
             }
         }
     }
-    if (TREE) f3_publish(d.done_f + fr.s, d.epoch, lane);
+    if (TREE && !LEAF) f3_publish(d.done_f + fr.s, d.epoch, lane);
+    if (TREE && LEAF && lane == 0) d.done_f[fr.s] = d.epoch;        // read by the next launch only (third and later children of a front)
     F3_TS(8);
 }
 
@@ -1598,7 +1607,7 @@ void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int count,
         (void)hipFuncSetAttribute((const void *)k_factor3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_t = true; }
     // level 0 (no children) through the high-occupancy leaf instance, everything above in one launch whose fronts wait on flags
     if (n_leaf > 0) hipLaunchKernelGGL((k_factor3<true, true>), dim3((n_leaf + 3) / 4), dim3(256), (size_t)leaf_slot * 4 * sizeof(double), st, d, 0, n_leaf, FRONT_OWN, leaf_slot);
-    if (count > n_leaf) hipLaunchKernelGGL((k_factor3<true, false>), dim3((count - n_leaf + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, n_leaf, count - n_leaf, FRONT_OWN, 0);
+    if (count > n_leaf) hipLaunchKernelGGL((k_factor3<true, false>), dim3((count - n_leaf + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, n_leaf, count - n_leaf, FRONT_OWN, n_leaf > 0 ? 1 : 0);   // last argument: a leaf launch preceded
 }
 void launch_backsolve_tree(const DevGraph &d, int first, int count, int max_npiv, int max_f, hipStream_t st) {
     if (count <= 0) return;                                          // positions [first, first + count), root first
