@@ -295,6 +295,23 @@ def test_factor_kernel_variants_match_oracle(pkg, po, bench_graphs, variant):
     G.close()
 
 
+@pytest.mark.parametrize("env", [{"GS_TREE": "0"}, {"GS_LEAF_KERNEL": "0"}, {"GS_TREE": "0", "GS_FACTOR_VARIANT": "3"}])
+def test_solver_launch_modes_give_the_same_answer(pkg, po, bench_graphs, monkeypatch, env):
+    """The default solver runs one flagged launch for all levels above the leaves plus leaf-instance launches; the
+    same kernels also run one launch per level (GS_TREE=0, what the shared top of a sharded graph uses) and without
+    the leaf instances (GS_LEAF_KERNEL=0).  Every mode must agree with the oracle and, bit for bit, with the default."""
+    _, g = bench_graphs(10000, 2000)
+    og = make_oracle_graph(po, g); og.optimize(4, ordering=1)
+    A = fresh(pkg, g); A.optimize(4)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    B = fresh(pkg, g); done, st = B.optimize(4)
+    assert done == 4 and st.numeric_failure == 0
+    assert rel(B.poses(), og.poses()) < 1e-9 and rel(B.landmarks(), og.landmarks()) < 1e-9
+    assert np.array_equal(A.poses(), B.poses()) and np.array_equal(A.landmarks(), B.landmarks())     # same arithmetic, same order
+    A.close(); B.close()
+
+
 # ---------------------------------------------------------------- f-1: the Slam host mirror (performSLAM graph side)
 @pytest.mark.parametrize("quirks", [0, 1])
 def test_slam_mirror_frame_by_frame_matches_reference_logic(pkg, quirks):
