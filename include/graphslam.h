@@ -100,6 +100,8 @@ typedef struct gs_stats {
     double  ms_total;           /* whole call, events                                       */
     int64_t factor_flops;       /* model flops of one factorisation                         */
     int64_t factor_bytes;       /* L + update-matrix storage, bytes                         */
+    double  ms_event_overhead;  /* gs_time_iterations: an empty event-to-event interval on the
+                                   stream, i.e. the share of every phase time that is measurement */
 } gs_stats;
 
 int  gs_version(void);                               /* major*100+minor */

@@ -803,15 +803,27 @@ extern "C" int gs_time_iterations(gs_graph *g, int32_t reps, gs_stats *s) {
     const bool newer = g->dev_estimates_newer;
     std::memset(s, 0, sizeof(*s)); s->struct_size = (int32_t)sizeof(*s); fill_plan_stats(g, s);
     enqueue_iteration(g, false);                                 // warm
+    // all repetitions are enqueued back to back like the iterations of gs_optimize (no host round trip in between);
+    // every repetition has its own five phase events plus a sixth right behind the fifth: that empty interval is what
+    // one event boundary costs on this stream (ms_event_overhead), i.e. how much of each phase time is the measurement
+    std::vector<hipEvent_t> evs((size_t)reps * 6);
+    for (auto &e : evs) HIP_TRY(hipEventCreate(&e));
+    hipEvent_t saved[5]; for (int k = 0; k < 5; ++k) saved[k] = g->ev[k];
     for (int r = 0; r < reps; ++r) {
+        for (int k = 0; k < 5; ++k) g->ev[k] = evs[(size_t)r * 6 + k];
         enqueue_iteration(g, true);
-        hipEventSynchronize(g->ev[4]);
-        float a = 0, b = 0, c = 0, dd = 0;
-        hipEventElapsedTime(&a, g->ev[0], g->ev[1]); hipEventElapsedTime(&b, g->ev[1], g->ev[2]);
-        hipEventElapsedTime(&c, g->ev[2], g->ev[3]); hipEventElapsedTime(&dd, g->ev[3], g->ev[4]);
-        s->ms_linearize += a; s->ms_factor += b; s->ms_backsolve += c; s->ms_update += dd;
+        hipEventRecord(evs[(size_t)r * 6 + 5], g->stream);
     }
-    s->ms_linearize /= reps; s->ms_factor /= reps; s->ms_backsolve /= reps; s->ms_update /= reps;
+    for (int k = 0; k < 5; ++k) g->ev[k] = saved[k];
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    double ovh = 0.0;
+    for (int r = 0; r < reps; ++r) { const hipEvent_t *e = &evs[(size_t)r * 6];
+        float a = 0, b = 0, c = 0, dd = 0, o = 0;
+        hipEventElapsedTime(&a, e[0], e[1]); hipEventElapsedTime(&b, e[1], e[2]);
+        hipEventElapsedTime(&c, e[2], e[3]); hipEventElapsedTime(&dd, e[3], e[4]); hipEventElapsedTime(&o, e[4], e[5]);
+        s->ms_linearize += a; s->ms_factor += b; s->ms_backsolve += c; s->ms_update += dd; ovh += o; }
+    for (auto &e : evs) hipEventDestroy(e);
+    s->ms_linearize /= reps; s->ms_factor /= reps; s->ms_backsolve /= reps; s->ms_update /= reps; s->ms_event_overhead = ovh / reps;
     s->ms_total = s->ms_linearize + s->ms_factor + s->ms_backsolve + s->ms_update; s->iterations = reps;
     hipMemcpyAsync(g->d.pose_est, sp, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToDevice, g->stream);
     launch_pose_trig(g->d, g->stream);
