@@ -708,6 +708,10 @@ extern "C" int gs_optimize(gs_graph *g, int32_t iterations, gs_stats *stats) {
     if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->struct_size = (int32_t)sizeof(*stats);
         fill_plan_stats(g, stats); stats->iterations = failflag[0] ? 0 : iterations; stats->numeric_failure = failflag[0];
         stats->chi2_initial = iterations > 0 ? hist[1] : hist[1 + nh]; stats->chi2_final = hist[1 + nh]; stats->ms_total = ms; }
+    if (failflag[0] == 2) {          // a whole-tree launch gave up waiting for a front (workgroups not dispatched in order?): never again on this handle
+        g->d.tree = 0;
+        g_last_error = "whole-tree launch: a front's completion flag did not arrive in time; the handle now uses one launch per level — restore the estimates and optimise again";
+        return 0; }
     if (failflag[0]) { g_last_error = "non-positive pivot: H is not positive definite"; return 0; }
     return iterations;
 }
