@@ -1447,12 +1447,10 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
             if (use[0]) f3_gather_child<false>(d.Uimg + fr.c_uoff[0], fr.c_usize[0], pv[0], lane, u0);
             if (use[1]) f3_gather_child<false>(d.Uimg + fr.c_uoff[1], fr.c_usize[1], pv[1], lane, u1);
         } else {
-            bool okw = true;
-            if (use[0]) okw = f3_wait_flag(d.done_f + fr.c_id[0], d.epoch) && okw;
-            if (use[1]) okw = f3_wait_flag(d.done_f + fr.c_id[1], d.epoch) && okw;
+            bool okw = true;                                         // child 0's gather is issued while child 1 may still be working
+            if (use[0]) { okw = f3_wait_flag(d.done_f + fr.c_id[0], d.epoch) && okw; f3_gather_child<true>(d.Uimg + fr.c_uoff[0], fr.c_usize[0], pv[0], lane, u0); }
+            if (use[1]) { okw = f3_wait_flag(d.done_f + fr.c_id[1], d.epoch) && okw; f3_gather_child<true>(d.Uimg + fr.c_uoff[1], fr.c_usize[1], pv[1], lane, u1); }
             if (!okw && lane == 0) atomicExch(d.fail, 2);
-            if (use[0]) f3_gather_child<true>(d.Uimg + fr.c_uoff[0], fr.c_usize[0], pv[0], lane, u0);
-            if (use[1]) f3_gather_child<true>(d.Uimg + fr.c_uoff[1], fr.c_usize[1], pv[1], lane, u1);
         }
     }
     // ---- accumulators = originals + child 0 + child 1 (+ further children, rare)
@@ -1571,27 +1569,55 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
         for (int j = 0; j < 32; ++j) if (c0 + j < npiv && lane <= f) S[(c0 + j) * lds + lane] = t[j];
     }
     F3_TS(34);
-    if (TREE && fr.parent >= 0 && !f3_wait_flag(d.done_b + fr.parent, d.epoch) && lane == 0) atomicExch(d.fail, 2);   // L is in LDS by now
-    const double xb = (row >= 0) ? (TREE ? ld_off_coh(d.xe, (uint32_t)row * 8u) : d.xe[row]) : 0.0;
-    wave_lds_sync();
-    F3_TS(35);
     const int me = min(lane, npiv - 1);                              // lanes >= npiv compute on a valid column and drop the result
-    double w = S[me * lds + f];
-    for (int r0 = 0; r0 < nbnd; r0 += 16) {                          // 16 LDS reads in flight, then the FMAs in row order
-        double l16[16];
+    double w;
+    if (TREE) {
+        // Everything that does not depend on the parent happens BEFORE the wait: the panel is in LDS, and this lane's
+        // share of it — its column of L21 (the boundary mat-vec) and of L11 (the substitution) — goes on into registers,
+        // so that after the flag only the gather of x_bnd and two chains of (readlane, fma) remain.
+        wave_lds_sync();
+        double l21[64], lcol[32];
+        const int nb1 = max(nbnd - 1, 0);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) l16[j] = S[me * lds + npiv + min(r0 + j, nbnd - 1)];
+        for (int r = 0; r < 64; ++r) l21[r] = S[me * lds + npiv + min(r, nb1)];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) w -= ((r0 + j < nbnd) ? l16[j] : 0.0) * lane_bcast(xb, min(r0 + j, 63));
-    }
-    F3_TS(36);
-    for (int c1 = npiv - 1; c1 > 0; c1 -= 4) {                       // the L11 entries of four steps are read ahead of the chain
-        double l4[4];
+        for (int cc = 1; cc < 32; ++cc) lcol[cc] = S[min(min(lane, cc - 1), npiv - 1) * lds + min(cc, f)];
+        w = S[me * lds + f];
+        if (fr.parent >= 0 && !f3_wait_flag(d.done_b + fr.parent, d.epoch) && lane == 0) atomicExch(d.fail, 2);
+        const double xb = (row >= 0) ? ld_off_coh(d.xe, (uint32_t)row * 8u) : 0.0;        // 0 beyond the boundary: those terms vanish
+        F3_TS(35);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const int cc = max(c1 - j, 1); l4[j] = S[min(lane, cc - 1) * lds + cc]; }
+        for (int r0 = 0; r0 < 64; r0 += 16) if (r0 < nbnd) {         // uniform
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const int cc = c1 - j;
-            if (cc > 0) { const double xcc = lane_bcast(w, cc); if (lane < cc) w -= l4[j] * xcc; } }
+            for (int j = 0; j < 16; ++j) w -= l21[r0 + j] * lane_bcast(xb, r0 + j); }
+        F3_TS(36);
+        for (int cc = npiv - 1; cc >= 32; --cc) {                    // fronts with more than 32 pivots: the upper steps from LDS
+            const double lv = S[min(lane, cc - 1) * lds + cc]; const double xcc = lane_bcast(w, cc);
+            if (lane < cc) w -= lv * xcc; }
+#pragma unroll
+        for (int cc = 31; cc >= 1; --cc) if (cc < npiv) {            // uniform
+            const double xcc = lane_bcast(w, cc); if (lane < cc) w -= lcol[cc] * xcc; }
+    } else {
+        const double xb = (row >= 0) ? d.xe[row] : 0.0;
+        wave_lds_sync();
+        F3_TS(35);
+        w = S[me * lds + f];
+        for (int r0 = 0; r0 < nbnd; r0 += 16) {                      // 16 LDS reads in flight, then the FMAs in row order
+            double l16[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) l16[j] = S[me * lds + npiv + min(r0 + j, nbnd - 1)];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w -= ((r0 + j < nbnd) ? l16[j] : 0.0) * lane_bcast(xb, min(r0 + j, 63));
+        }
+        F3_TS(36);
+        for (int c1 = npiv - 1; c1 > 0; c1 -= 4) {                   // the L11 entries of four steps are read ahead of the chain
+            double l4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int cc = max(c1 - j, 1); l4[j] = S[min(lane, cc - 1) * lds + cc]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int cc = c1 - j;
+                if (cc > 0) { const double xcc = lane_bcast(w, cc); if (lane < cc) w -= l4[j] * xcc; } }
+        }
     }
     F3_TS(37);
     if (lane < npiv) { if (TREE) st_off_wt(d.xe, (uint32_t)(fr.piv0 + lane) * 8u, w); else d.xe[fr.piv0 + lane] = w; }
