@@ -436,7 +436,7 @@ static int upload_graph(gs_graph *g) {
                   if (k < F.child_cnt) { const int c = P.children[F.child_off + k]; const Front &C = P.fronts[c];
                       r[12 + k] = c; r[14 + k] = C.npiv | (C.nbnd << 16); r[16 + k] = C.owner; r[26 + k] = u3_off[c]; r[28 + k] = u3_size[c]; } }
               r[24] = u3_off[sidx]; r[25] = u3_size[sidx]; r[31] = F.level;
-              r[30] = (F.parent >= 0 && P.fronts[F.parent].owner == F.owner && F.owner >= 0) || (P.world == 1) ? F.parent : -1;   // whole-tree backward solve waits for an OWN parent only (the shared top ran in earlier launches)
+              r[30] = (F.parent >= 0 && P.fronts[F.parent].owner == F.owner) ? F.parent : -1;   // whole-tree backward solve: wait for a parent of the SAME launch only (own in own, shared in shared; a subtree root's shared parent ran earlier)
               const int64_t xo = (P.world > 1 && (size_t)sidx < P.x_off.size()) ? P.x_off[sidx] : 0;
               r[18] = (int32_t)(xo & 0xffffffffLL); r[19] = (int32_t)(xo >> 32); }
           std::vector<int32_t> recs(P.asm_recs.size() * 4);
@@ -609,6 +609,8 @@ static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int
             if (const char *e = std::getenv("GS_LEAF_KERNEL")) if (std::atoi(e) == 0) n_leaf = 0;
             g->leaf_n = n_leaf; g->leaf_slot = slot; }
         launch_factor_tree(g->d, g->leaf_n, g->leaf_slot, ls.start[nlev], g->stream); return; }
+    if (g->d.factor_variant == 3 && g->d.tree && mode == 2 && nlev > 0 && ls.start[nlev] > 0) {     // the shared top of a sharded graph, one flagged launch
+        launch_factor_tree_top(g->d, base, ls.start[nlev], g->stream); return; }
     for (int l = 0; l < nlev; ++l)
         launch_factor_level(g->d, base + ls.start[l], ls.start[l + 1] - ls.start[l], ls.max_f[l], mode, g->stream);
 }
@@ -622,6 +624,9 @@ static void enqueue_backsolve_levels(gs_graph *g, const gs_graph::LevelSet &ls, 
         launch_backsolve_tree(g->d, ls.start[l0], ls.start[nlev] - ls.start[l0], mn, mf, g->stream);
         if (l0 == 1) launch_backsolve_level(g->d, 0, ls.start[1], ls.max_npiv[0], ls.max_nbnd[0], g->stream);
         return; }
+    if (g->d.factor_variant == 3 && g->d.tree && base != 0 && nlev > 0 && ls.start[nlev] > 0) {      // shared top: one flagged launch, root first
+        int mn = 0, mf = 0; for (int l = 0; l < nlev; ++l) { mn = std::max(mn, ls.max_npiv[l]); mf = std::max(mf, ls.max_f[l]); }
+        launch_backsolve_tree(g->d, base, ls.start[nlev], mn, mf, g->stream); return; }
     for (int l = nlev - 1; l >= 0; --l)
         launch_backsolve_level(g->d, base + ls.start[l], ls.start[l + 1] - ls.start[l], ls.max_npiv[l], ls.max_nbnd[l], g->stream);
 }

@@ -1635,6 +1635,14 @@ void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int count,
     if (n_leaf > 0) hipLaunchKernelGGL((k_factor3<true, true>), dim3((n_leaf + 3) / 4), dim3(256), (size_t)leaf_slot * 4 * sizeof(double), st, d, 0, n_leaf, FRONT_OWN, leaf_slot);
     if (count > n_leaf) hipLaunchKernelGGL((k_factor3<true, false>), dim3((count - n_leaf + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, n_leaf, count - n_leaf, FRONT_OWN, n_leaf > 0 ? 1 : 0);   // last argument: a leaf launch preceded
 }
+// the shared top of a sharded graph (mode TOP: fronts start from the all-reduced exchange slots and gather their shared
+// children only): one flagged launch as well
+void launch_factor_tree_top(const DevGraph &d, int first, int count, hipStream_t st) {
+    if (count <= 0) return;
+    static bool attr_set_tt = false;
+    if (!attr_set_tt) { (void)hipFuncSetAttribute((const void *)k_factor3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_tt = true; }
+    hipLaunchKernelGGL((k_factor3<true, false>), dim3((count + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, first, count, FRONT_TOP, 0);
+}
 void launch_backsolve_tree(const DevGraph &d, int first, int count, int max_npiv, int max_f, hipStream_t st) {
     if (count <= 0) return;                                          // positions [first, first + count), root first
     const int slot = ((((max_f + 1) | 1) * max_npiv) + 1) & ~1;
