@@ -344,7 +344,7 @@ def test_slam_mirror_frame_by_frame_matches_reference_logic(pkg, quirks):
 
 
 # ---------------------------------------------------------------- pose-window shards through the HIP kernels
-@pytest.mark.parametrize("world,N,M", [(2, 1000, 200), (4, 10000, 2000)])
+@pytest.mark.parametrize("world,N,M", [(2, 1000, 200), (4, 10000, 2000), (8, 10000, 2000)])
 def test_sharded_iterations_match_oracle(pkg, po, bench_graphs, world, N, M):
     """`world` rank handles share this one GPU; the exchange buffers are summed in-process exactly where the
     multi-GPU run all-reduces them over RCCL.  After 5 Gauss-Newton iterations the merged estimates must match
