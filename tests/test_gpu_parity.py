@@ -312,6 +312,23 @@ def test_solver_launch_modes_give_the_same_answer(pkg, po, bench_graphs, monkeyp
     A.close(); B.close()
 
 
+@pytest.mark.parametrize("shape", [dict(n_poses=40, n_lms=25), dict(n_poses=150, n_lms=12, obs_per_pose=3, extra_pp=25),
+                                   dict(n_poses=400, n_lms=60, obs_per_pose=2, extra_pp=3, dup_edges=9),
+                                   dict(n_poses=12, n_lms=12, obs_per_pose=7, extra_pp=2)])
+def test_irregular_graphs_one_step_matches_oracle(pkg, po, shape):
+    """Graphs that are no track: random loop-closure edges (fronts with more than two children, fat separators), few
+    landmarks seen from everywhere, parallel edges, anisotropic information.  One Gauss-Newton step of the default solver
+    (whole-tree launches, leaf instances) against the oracle's LDL^T, several seeds per shape."""
+    for seed in range(6):
+        g = random_graph(100 + seed, **shape)
+        og = make_oracle_graph(po, g); og.build_system(); og.apply_update(og.solve_ldlt(0)); dp_o, dl_o = og.delta()
+        G = fresh(pkg, g); done, st = G.optimize(1); dp, dl = G.export_delta()
+        assert done == 1 and st.numeric_failure == 0
+        scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
+        assert np.abs(dp - dp_o).max() / scale < 1e-9 and np.abs(dl - dl_o).max() / scale < 1e-9, (shape, seed, st.max_front)
+        G.close()
+
+
 # ---------------------------------------------------------------- f-1: the Slam host mirror (performSLAM graph side)
 @pytest.mark.parametrize("quirks", [0, 1])
 def test_slam_mirror_frame_by_frame_matches_reference_logic(pkg, quirks):
