@@ -394,6 +394,9 @@ template <class Tp> __device__ __forceinline__ void st_off_wt(Tp *base, uint32_t
 //   back-to-back launches  nt=0 26.1  nt=1 30.4  nt=2 26.8  nt=3 29.8   (streams still cached from the last launch)
 //   inside a GN iteration  nt=0 37.5  nt=1 33.0  nt=2 38.7  nt=3 33.8   (streams cold: the solver moved ~1 GB since)
 // and cfg5 (1 GB per pass) back to back: nt=0 230, nt=3 210.  The iteration is what ships: loads non-temporal.
+// Re-measured with the final solver (L panels non-temporal): nt=0 30.7 us in-iteration but the factor phase after it
+// 252 us and 2540 it/s; nt=1 31.7 us, factor 244 us, 2600 it/s — streaming the read-once inputs past the caches is
+// worth more to the kernels that follow than to this one.
 #ifndef LIN_NT
 #define LIN_NT 1
 #endif
@@ -1655,7 +1658,7 @@ void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f,
     if (count <= 0) return;
     if (max_f <= 63 && d.factor_variant == 3) {
         static bool attr_set_3 = false;
-        if (!attr_set_3) { hipFuncSetAttribute((const void *)k_factor3<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_3 = true; }
+        if (!attr_set_3) { (void)hipFuncSetAttribute((const void *)k_factor3<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_3 = true; }
         static size_t lds3 = 0;                                      // GS_F3_LDS_KB: occupancy experiments (more LDS per block = fewer resident blocks)
         if (lds3 == 0) { lds3 = (size_t)MF_IMG * 4 * sizeof(double); if (const char *e = getenv("GS_F3_LDS_KB")) lds3 = std::max(lds3, (size_t)atoi(e) * 1024); }
         hipLaunchKernelGGL((k_factor3<false, false>), dim3((count + 3) / 4), dim3(256), lds3, st, d, level_off, count, mode, 0);
@@ -1663,21 +1666,21 @@ void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f,
     }
     if (max_f <= 63 && d.factor_variant == 2) {
         static bool attr_set_m = false;
-        if (!attr_set_m) { hipFuncSetAttribute((const void *)k_factor_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_m = true; }
+        if (!attr_set_m) { (void)hipFuncSetAttribute((const void *)k_factor_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_m = true; }
         hipLaunchKernelGGL(k_factor_mfma, dim3((count + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double) + 8 * 64 * sizeof(int32_t), st, d, level_off, count, mode);
         return;
     }
     if (max_f <= 63 && d.factor_variant == 1) {   // VALU wave-per-front variant: measured SLOWER than the block kernel, kept for A/B only
         const int slot = ((max_f * (max_f + 1)) / 2 + max_f + 1) & ~1;                // doubles per wave, 16-B aligned
         static bool attr_set_w = false;
-        if (!attr_set_w) { hipFuncSetAttribute((const void *)k_factor_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_w = true; }
+        if (!attr_set_w) { (void)hipFuncSetAttribute((const void *)k_factor_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_w = true; }
         hipLaunchKernelGGL(k_factor_wave, dim3((count + 3) / 4), dim3(256), (size_t)slot * 4 * sizeof(double), st, d, level_off, count, mode, slot);
         return;
     }
     int64_t bytes = (int64_t)((max_f + 1) | 1) * max_f * 8;
     if (bytes <= LDS_LIMIT_BYTES) {
         static bool attr_set = false;
-        if (!attr_set) { hipFuncSetAttribute((const void *)k_factor_level<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES); attr_set = true; }
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_factor_level<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES); attr_set = true; }
         hipLaunchKernelGGL(k_factor_level<true>, dim3(count), dim3(256), (size_t)bytes, st, d, level_off, mode);
     } else {
         hipLaunchKernelGGL(k_factor_level<false>, dim3(count), dim3(256), 0, st, d, level_off, mode);
@@ -1757,14 +1760,14 @@ void launch_backsolve_level(const DevGraph &d, int level_off, int count, int max
     if (d.factor_variant == 3) {                                     // LDL^T panels: unit-diagonal backward solve
         const int f = max_npiv + max_nbnd, slot = ((((f + 1) | 1) * max_npiv) + 1) & ~1;
         static bool attr_set_b3 = false;
-        if (!attr_set_b3) { hipFuncSetAttribute((const void *)k_backsolve3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_b3 = true; }
+        if (!attr_set_b3) { (void)hipFuncSetAttribute((const void *)k_backsolve3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_b3 = true; }
         hipLaunchKernelGGL(k_backsolve3<false>, dim3((count + 3) / 4), dim3(256), (size_t)slot * 4 * sizeof(double), st, d, level_off, count, slot);
         return;
     }
     if (max_npiv + max_nbnd <= 63) {
         const int f = max_npiv + max_nbnd, slot = ((((f + 1) | 1) * max_npiv) + 1) & ~1;
         static bool attr_set_b = false;
-        if (!attr_set_b) { hipFuncSetAttribute((const void *)k_backsolve_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_b = true; }
+        if (!attr_set_b) { (void)hipFuncSetAttribute((const void *)k_backsolve_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_b = true; }
         hipLaunchKernelGGL(k_backsolve_wave, dim3((count + 3) / 4), dim3(256), (size_t)slot * 4 * sizeof(double), st, d, level_off, count, slot);
         return;
     }
