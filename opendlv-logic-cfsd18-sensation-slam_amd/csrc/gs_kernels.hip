@@ -451,8 +451,8 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
                 e.l[j] = LD_S(d.ell_l, o >> 1); e.dst[j] = LD_S(d.ell_dst, o >> 2); e.zx[j] = LD_S(d.ell_z, o); e.zy[j] = LD_S(d.ell_z + L, o);
                 e.w00[j] = LD_S(d.ell_w, o); e.w01[j] = LD_S(d.ell_w + L, o); e.w11[j] = LD_S(d.ell_w + 2 * L, o); } }
     };
-    double px = 0, py = 0, th = 0; bool fp = true; int q0 = 0, q1 = 0;
-    if (live) { px = d.pose_est[3 * p]; py = d.pose_est[3 * p + 1]; th = d.pose_est[3 * p + 2]; fp = d.pose_fixed[p];
+    double px = 0, py = 0; bool fp = true; int q0 = 0, q1 = 0;       // theta itself is not needed: its cos/sin are cached per pose
+    if (live) { px = d.pose_est[3 * p]; py = d.pose_est[3 * p + 1]; fp = d.pose_fixed[p];
                 q0 = d.ppadj_start[p]; q1 = d.ppadj_start[p + 1]; }
     const int4 wd = reinterpret_cast<const int4 *>(d.wt_desc)[wt];        // {first group, #groups, first position, #positions}
     double sn = 0.0, cs = 1.0;                                     // cos/sin of theta are kept per pose (k_update): no sincos here
