@@ -285,6 +285,26 @@ int  gs_slam_collect_distance(gs_slam *s, uint32_t object_id, double distance);
 int  gs_slam_collect_type(gs_slam *s, uint32_t object_id, uint32_t type);
 int  gs_slam_collect_flush(gs_slam *s, const double pose_xytheta[3], int32_t *k_out, double *cones_out_4xk);
 int  gs_slam_encode_cones(gs_slam *s, int32_t cones_per_packet, float *azimuth_deg, float *distance, int32_t *type);
+/* ---- odometry intake and pose output (row f-4), host side -------------------------
+ * gs_wgs84_to_cartesian / gs_wgs84_from_cartesian <- wgs84::toCartesian / fromCartesian (src/WGS84toCartesian.hpp:39-113,
+ *      119-146): ellipsoidal polyconic projection about the reference point and its step-search inverse; arrays are
+ *      {latitude, longitude} in degrees and {x, y} in metres.
+ * gs_slam_set_gps_reference       <- m_gpsReference (command line of the microservice)
+ * gs_slam_next_wgs84 / _heading   <- Slam::nextSplitPose (src/slam.cpp:154-185; heading wrapped with the float PI)
+ * gs_slam_next_geolocation        <- Slam::nextPose (src/slam.cpp:187-209)
+ * gs_slam_next_yaw_rate           <- Slam::nextYawRate (src/slam.cpp:211-219)
+ * gs_slam_get_odometry            -> m_odometryData (x, y, heading) and m_yawRate: the pose gs_slam_perform is fed
+ * gs_slam_encode_pose             <- Slam::sendPose (src/slam.cpp:679-695): {longitude, latitude, heading} as float32;
+ *      cfg.reference_quirks keeps the reference's swapped latitude / longitude fields. */
+int  gs_wgs84_to_cartesian(const double ref_latlon_deg[2], const double pos_latlon_deg[2], double out_xy[2]);
+int  gs_wgs84_from_cartesian(const double ref_latlon_deg[2], const double xy[2], double out_latlon_deg[2]);
+int  gs_slam_set_gps_reference(gs_slam *s, double latitude_deg, double longitude_deg);
+int  gs_slam_next_wgs84(gs_slam *s, double latitude_deg, double longitude_deg);
+int  gs_slam_next_heading(gs_slam *s, double north_heading);
+int  gs_slam_next_geolocation(gs_slam *s, double latitude_deg, double longitude_deg, double heading);
+int  gs_slam_next_yaw_rate(gs_slam *s, double angular_velocity_z);
+int  gs_slam_get_odometry(gs_slam *s, double out_xy_heading_yawrate[4]);
+int  gs_slam_encode_pose(gs_slam *s, float out_lon_lat_heading[3]);
 
 #ifdef __cplusplus
 }

@@ -149,6 +149,15 @@ def lib():
     L.gs_slam_collect_type.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.gs_slam_collect_flush.argtypes = [vp, _dp, C.POINTER(C.c_int32), _dp]
     L.gs_slam_encode_cones.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    L.gs_wgs84_to_cartesian.argtypes = [_dp, _dp, _dp]
+    L.gs_wgs84_from_cartesian.argtypes = [_dp, _dp, _dp]
+    L.gs_slam_set_gps_reference.argtypes = [vp, C.c_double, C.c_double]
+    L.gs_slam_next_wgs84.argtypes = [vp, C.c_double, C.c_double]
+    L.gs_slam_next_heading.argtypes = [vp, C.c_double]
+    L.gs_slam_next_geolocation.argtypes = [vp, C.c_double, C.c_double, C.c_double]
+    L.gs_slam_next_yaw_rate.argtypes = [vp, C.c_double]
+    L.gs_slam_get_odometry.argtypes = [vp, _dp]
+    L.gs_slam_encode_pose.argtypes = [vp, C.POINTER(C.c_float)]
     _lib = L
     return L
 
@@ -483,7 +492,33 @@ class Slam:
         self._check(self.L.gs_slam_collect_flush(self.h, _d(pose), C.byref(k), _d(buf)))
         return buf[:k.value].copy()
 
+    # ---- odometry intake and pose output (reference Slam::nextSplitPose / nextPose / nextYawRate / sendPose)
+    def set_gps_reference(self, lat, lon): self._check(self.L.gs_slam_set_gps_reference(self.h, float(lat), float(lon)))
+    def next_wgs84(self, lat, lon): self._check(self.L.gs_slam_next_wgs84(self.h, float(lat), float(lon)))
+    def next_heading(self, north_heading): self._check(self.L.gs_slam_next_heading(self.h, float(north_heading)))
+    def next_geolocation(self, lat, lon, heading): self._check(self.L.gs_slam_next_geolocation(self.h, float(lat), float(lon), float(heading)))
+    def next_yaw_rate(self, wz): self._check(self.L.gs_slam_next_yaw_rate(self.h, float(wz)))
+
+    def odometry(self):
+        o = np.zeros(4); self._check(self.L.gs_slam_get_odometry(self.h, _d(o))); return o
+
+    def encode_pose(self):
+        o = np.zeros(3, dtype=np.float32); self._check(self.L.gs_slam_encode_pose(self.h, o.ctypes.data_as(C.POINTER(C.c_float)))); return o
+
     def encode_cones(self, cones_per_packet):
         n = int(cones_per_packet); az = np.zeros(n, dtype=np.float32); di = np.zeros(n, dtype=np.float32); ty = np.zeros(n, dtype=np.int32)
         self._check(self.L.gs_slam_encode_cones(self.h, n, az.ctypes.data_as(C.POINTER(C.c_float)), di.ctypes.data_as(C.POINTER(C.c_float)), _i(ty)))
         return az, di, ty
+
+
+def wgs84_to_cartesian(ref_latlon, pos_latlon):
+    """Product implementation of the reference's wgs84::toCartesian (host side, no device needed)."""
+    L = lib(); o = np.zeros(2); r = _f64(ref_latlon); p = _f64(pos_latlon)
+    if L.gs_wgs84_to_cartesian(_d(r), _d(p), _d(o)) != 0: raise GsError("gs_wgs84_to_cartesian failed")
+    return o
+
+
+def wgs84_from_cartesian(ref_latlon, xy):
+    L = lib(); o = np.zeros(2); r = _f64(ref_latlon); p = _f64(xy)
+    if L.gs_wgs84_from_cartesian(_d(r), _d(p), _d(o)) != 0: raise GsError("gs_wgs84_from_cartesian failed")
+    return o

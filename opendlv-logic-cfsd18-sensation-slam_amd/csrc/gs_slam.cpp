@@ -29,6 +29,10 @@ struct gs_slam {
     std::vector<double> collector = std::vector<double>(4 * 1000, 0.0);   // 4 x 1000, column-major: (az, zen, dist, type) per objectId
     uint32_t last_object_id = 0;
     bool new_frame = true;
+    // odometry intake (m_gpsReference, m_odometryData, m_yawRate; reference src/slam.cpp:154-219)
+    double gps_reference[2] = {0, 0};                        // latitude, longitude (degrees)
+    double odometry[3] = {0, 0, 0};                          // x, y (metres from the reference), heading
+    double yaw_rate = 0;
 };
 
 using gs::fail;
@@ -260,5 +264,63 @@ extern "C" int gs_slam_encode_cones(gs_slam *s, int32_t cones_per_packet, float 
         distance[i] = (float)std::sqrt(x * x + y * y);
         type[i] = c.type;
     }
+    return GS_OK;
+}
+
+// ------------------------------------------------------------------ f-4: odometry intake and pose output
+// m_gpsReference comes from the command line in the reference (src/opendlv-logic-cfsd18-sensation-slam.cpp, keys
+// refLatitude / refLongitude); latitude first, as wgs84::toCartesian takes it.
+extern "C" int gs_slam_set_gps_reference(gs_slam *s, double latitude_deg, double longitude_deg) {
+    if (!s) return fail(GS_ERR_INVALID, "null handle");
+    s->gps_reference[0] = latitude_deg; s->gps_reference[1] = longitude_deg;
+    return GS_OK;
+}
+// Slam::nextSplitPose, GeodeticWgs84Reading branch (reference src/slam.cpp:156-176): position only
+extern "C" int gs_slam_next_wgs84(gs_slam *s, double latitude_deg, double longitude_deg) {
+    if (!s) return fail(GS_ERR_INVALID, "null handle");
+    const double p[2] = {latitude_deg, longitude_deg};
+    return gs_wgs84_to_cartesian(s->gps_reference, p, s->odometry);
+}
+// Slam::nextSplitPose, GeodeticHeadingReading branch (:177-184): north heading -> [-PI, PI] with the reference's
+// float-literal PI (src/slam.hpp:136)
+extern "C" int gs_slam_next_heading(gs_slam *s, double north_heading) {
+    if (!s) return fail(GS_ERR_INVALID, "null handle");
+    const double PI = 3.14159265f;
+    double h = north_heading - PI;
+    h = (h > PI) ? (h - 2 * PI) : h;
+    h = (h < -PI) ? (h + 2 * PI) : h;
+    s->odometry[2] = h;
+    return GS_OK;
+}
+// Slam::nextPose (:187-209): a Geolocation message carries position and heading together (heading taken as is)
+extern "C" int gs_slam_next_geolocation(gs_slam *s, double latitude_deg, double longitude_deg, double heading) {
+    int rc = gs_slam_next_wgs84(s, latitude_deg, longitude_deg);
+    if (rc != GS_OK) return rc;
+    s->odometry[2] = heading;
+    return GS_OK;
+}
+// Slam::nextYawRate (:211-219)
+extern "C" int gs_slam_next_yaw_rate(gs_slam *s, double angular_velocity_z) {
+    if (!s) return fail(GS_ERR_INVALID, "null handle");
+    s->yaw_rate = angular_velocity_z / 4;
+    return GS_OK;
+}
+extern "C" int gs_slam_get_odometry(gs_slam *s, double out_xy_heading_yawrate[4]) {
+    if (!s || !out_xy_heading_yawrate) return fail(GS_ERR_INVALID, "null argument");
+    std::memcpy(out_xy_heading_yawrate, s->odometry, 3 * sizeof(double)); out_xy_heading_yawrate[3] = s->yaw_rate;
+    return GS_OK;
+}
+// Slam::sendPose (:679-695): the send pose back to WGS84, float32 message fields {longitude, latitude, heading}.
+// fromCartesian returns {latitude, longitude}; the reference writes element 0 into `longitude` and element 1 into
+// `latitude` — kept under cfg.reference_quirks, put right otherwise.
+extern "C" int gs_slam_encode_pose(gs_slam *s, float out_lon_lat_heading[3]) {
+    if (!s || !out_lon_lat_heading) return fail(GS_ERR_INVALID, "null argument");
+    double latlon[2];
+    int rc = gs_wgs84_from_cartesian(s->gps_reference, s->send_pose, latlon);
+    if (rc != GS_OK) return rc;
+    const bool q = s->cfg.reference_quirks != 0;
+    out_lon_lat_heading[0] = (float)(q ? latlon[0] : latlon[1]);
+    out_lon_lat_heading[1] = (float)(q ? latlon[1] : latlon[0]);
+    out_lon_lat_heading[2] = (float)s->send_pose[2];
     return GS_OK;
 }

@@ -268,3 +268,30 @@ class OracleFrontend:
         self.L.orc_associate_fixed_map(len(obs), _d(poses), _i(pose_of_obs), _d(obs), len(map_xy),
                                        _d(map_xy), _i(map_type), float(thr), float(type_tol), self.lidar, _i(out))
         return out
+
+
+_ref_wgs84 = None
+
+
+def ref_wgs84():
+    """The reference's own WGS84 <-> Cartesian header, compiled into oracle/_ref/libref_wgs84.so (None if not built)."""
+    global _ref_wgs84
+    if _ref_wgs84 is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_wgs84.so")
+        if not os.path.exists(path):
+            return None
+        R = C.CDLL(path)
+        dp = C.POINTER(C.c_double)
+        R.ref_wgs84_to_cartesian.argtypes = [dp, dp, dp]; R.ref_wgs84_from_cartesian.argtypes = [dp, dp, dp]
+        _ref_wgs84 = R
+    return _ref_wgs84
+
+
+def ref_to_cartesian(ref_latlon, pos_latlon):
+    R = ref_wgs84(); o = np.zeros(2)
+    R.ref_wgs84_to_cartesian(_d(np.ascontiguousarray(ref_latlon, dtype=np.float64)), _d(np.ascontiguousarray(pos_latlon, dtype=np.float64)), _d(o)); return o
+
+
+def ref_from_cartesian(ref_latlon, xy):
+    R = ref_wgs84(); o = np.zeros(2)
+    R.ref_wgs84_from_cartesian(_d(np.ascontiguousarray(ref_latlon, dtype=np.float64)), _d(np.ascontiguousarray(xy, dtype=np.float64)), _d(o)); return o
