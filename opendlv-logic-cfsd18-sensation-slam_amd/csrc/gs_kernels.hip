@@ -1380,7 +1380,18 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
         if (use[1]) f3_gather_child<false>(d.Uimg + fr.c_uoff[1], fr.c_usize[1], pv[1], lane, u1);
     }
     // ---- round trip 2b: scalar assembly records (eight per lane up front), landmark records
-    const int nsc = top ? 0 : fr.sc_cnt, nlm = top ? 0 : fr.lm_cnt;
+#ifndef F3_LEAF_BLOCKS
+#define F3_LEAF_BLOCKS 1
+#endif
+    // leaves (F3_LEAF_BLOCKS): their level is bound by bytes, not by a lone wave's instruction count, and a block record
+    // (16 bytes for the 5-9 scalars of one H block) is a quarter of the scalar records' bytes
+    constexpr bool BLK = LEAF && F3_LEAF_BLOCKS;
+    const int nsc = (top || BLK) ? 0 : fr.sc_cnt, nlm = (top || BLK) ? 0 : fr.lm_cnt;
+    int4 brec[2];
+    if (BLK) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int t = lane + 64 * u;
+            brec[u] = (t < fr.asm_uniq) ? reinterpret_cast<const int4 *>(d.asm3)[fr.asm_off + t] : make_int4(-1, 0, 0, 0); } }
     const int2 *sc3 = reinterpret_cast<const int2 *>(d.sc3) + fr.sc_off;
     int2 sc[8];
 #pragma unroll
@@ -1408,6 +1419,16 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
         const double *X = d.exchange + fr.x_off;                     // slot layout: (f+1) x f column-major, ld = f+1
         for (int c = 0; c < f; ++c) if (lane >= c && lane <= f) P.at(lane, c) = X[c * (f + 1) + lane];
     } else {
+        if (BLK) {
+            double bv[2][9];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) if (brec[u].x >= 0) asm3_load(d, brec[u].x, brec[u].y, bv[u]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) if (brec[u].x >= 0) asm3_put<false>(P, brec[u].x, brec[u].z, brec[u].w, bv[u]);
+            for (int t = lane + 128; t < fr.asm_uniq; t += 64) {
+                const int4 r = reinterpret_cast<const int4 *>(d.asm3)[fr.asm_off + t];
+                double w[9]; asm3_load(d, r.x, r.y, w); asm3_put<false>(P, r.x, r.z, r.w, w); }
+        }
         double val[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) if (64 * u < nsc) val[u] = F3_LD_VAL(d.H_arena, (uint32_t)sc[u].x * 8u);
