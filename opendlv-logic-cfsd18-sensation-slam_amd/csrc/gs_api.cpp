@@ -452,7 +452,7 @@ static int upload_graph(gs_graph *g) {
           std::vector<int32_t> pinv(P.fronts.size() * 64);
           const int32_t pinv_none = (int32_t)((uint32_t)((-30000) & 0xffff) | ((uint32_t)(-30000) << 16));
           // pack(i, col_ok): boundary row i of a front inside its packed update matrix: row part i(i+1)/2, column part i (bytes)
-          auto pack = [pinv_none](int i, bool col_ok) -> int32_t {
+          auto pack = [](int i, bool col_ok) -> int32_t {
               const int ro8 = ((i * (i + 1)) >> 1) * 8, co8 = col_ok ? i * 8 : -30000;
               return (int32_t)((uint32_t)(ro8 & 0xffff) | ((uint32_t)(co8 & 0xffff) << 16)); };
           { std::fill(pinv.begin(), pinv.end(), pinv_none);
