@@ -19,6 +19,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace gs {
@@ -130,6 +132,8 @@ struct Builder {
 
 bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::string &err) {
     auto t0 = std::chrono::steady_clock::now();
+    const bool pt_on = std::getenv("GS_PLAN_TIMING") != nullptr; auto pt_prev = t0;      // GS_PLAN_TIMING: phase times on stderr
+#define GS_PT(i) do { if (pt_on) { auto n_ = std::chrono::steady_clock::now(); std::fprintf(stderr, "plan phase %d: %.2f ms\n", (i), std::chrono::duration<double, std::milli>(n_ - pt_prev).count()); pt_prev = n_; } } while (0)
     plan = Plan();
     PlanOptions opt = opt_in;
     if (opt.leaf_poses <= 0) opt.leaf_poses = 8;
@@ -138,6 +142,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     if (B.nv == 0) { err = "no free vertex"; return false; }
     const int N = g.n_poses(), M = g.n_lms(), Epl = g.n_pl(), Epp = g.n_pp();
 
+    GS_PT(0);
     // ---- device layout of the observation edges: ELL, T lanes per pose -------------------------------
     // pl_start/pl_order: edges grouped by pose (stable) on the host.  On the device the s-th edge of pose p
     // sits at  idx = (s / T) * (T*N) + T*p + (s % T):  the T lanes of a pose each own up to R = ceil(Kmax/T)
@@ -192,6 +197,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     for (size_t q = 0; q < plan.ppadj.size(); ++q) { const int code = plan.ppadj[q], k = code >> 1;
         plan.ppinc[4 * q] = k; plan.ppinc[4 * q + 1] = code & 1; plan.ppinc[4 * q + 2] = g.pp_i[k]; plan.ppinc[4 * q + 3] = g.pp_j[k]; }
 
+    GS_PT(1);
     // ---- wave tiles of the fused A5-A7 kernel: one wave = 64/T consecutive poses.  Per wave tile the distinct
     // landmarks it touches ("groups") with the wave-local positions (slot*64 + lane) of their edges.  Partial-sum
     // slots are ordered by (landmark, wave tile): the finalize pass reads one contiguous run per landmark and the
@@ -230,6 +236,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         for (int q = 0; q < G; ++q) plan.grp_slot[q] = fill[plan.grp_lm[q]]++;
     }
 
+    GS_PT(2);
     // ---- elimination order by nested dissection ----
     B.build_adjacency(plan.ell_of_ins);
     B.assigned.assign(B.nfp, 0);
@@ -245,6 +252,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     for (int i = 0; i < B.nfp; ++i) plan.pose_gidx[B.pose_of_fp[i]] = gidx[i];
     for (int l = 0; l < B.nfl; ++l) plan.lm_gidx[B.lm_of_fl[l]] = gidx[B.nfp + l];
 
+    GS_PT(3);
     // ---- symbolic factorisation over supernodes ----
     std::vector<std::vector<int32_t>> bndv(S), kids(S);
     std::vector<int32_t> parent(S, -1), stamp(B.nv, -1);
@@ -257,6 +265,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         if (!bd.empty()) { parent[s] = sn_of[bd[0]]; kids[parent[s]].push_back(s); }
     }
 
+    GS_PT(4);
     // ---- fronts ----
     plan.fronts.resize(S);
     std::vector<int32_t> loc(B.nv, -1);
@@ -312,6 +321,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         F.U_off = plan.u_doubles; plan.u_doubles += (int64_t)(F.nbnd + 1) * F.nbnd;
         for (int k = 0; k < F.npiv; ++k) { int64_t r2 = F.npiv + F.nbnd + 1 - k; plan.factor_flops += r2 * r2; }
     }
+    GS_PT(5);
     // ---- levels ----
     int nlev = 0;
     for (auto &F : plan.fronts) nlev = std::max(nlev, F.level + 1);
@@ -321,6 +331,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     plan.level_fronts.resize(S);
     { std::vector<int32_t> fill(plan.level_start.begin(), plan.level_start.end() - 1);
       for (int s = 0; s < S; ++s) plan.level_fronts[fill[plan.fronts[s].level]++] = s; }
+    GS_PT(6);
     // ---- pose-window shards: rank r owns the subtrees whose poses all lie in the r-th contiguous
     // window of the free-pose sequence; every front above them is "shared" (owner -1): the window-boundary
     // separator poses and the landmarks seen from more than one window.  An edge is evaluated by exactly one rank,
@@ -378,6 +389,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
             plan.x_off[s] = plan.exchange_doubles; plan.exchange_doubles += (f + 1) * f; }
     }
     plan.valid = true;
+    GS_PT(7);
     plan.ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return true;
 }
