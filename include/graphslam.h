@@ -194,6 +194,9 @@ int  gs_time_linearize(gs_graph *g, int32_t reps, double *out_ms_per_pass);
  * holds `count` fronts record 100 MHz timestamps at their phase boundaries for that level's first front
  * (factor: slots 0.., backsolve: slots 32..).  Copies the 64 slots out.  No reference counterpart. */
 int gs_debug_timestamps(gs_graph *g, int64_t *out64);
+/* Tuning aid (F3_DONE_TS builds of the library only, zeros otherwise): 100 MHz completion time of every front in the
+ * last factor launch ([0, n)) and the last backward-solve launch ([n, 2n)); returns n.  No reference counterpart. */
+int gs_debug_front_times(gs_graph *g, int64_t *out, int64_t capacity);
 
 int64_t gs_linearize_bytes(gs_graph *g);
 int  gs_export_system(gs_graph *g, double *Hpp_diag, double *Hll_diag, double *Hpp_off,

@@ -103,6 +103,7 @@ def lib():
         getattr(L, name).argtypes = [vp]
     L.gs_linearize_bytes.argtypes = [vp]
     L.gs_debug_timestamps.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.gs_debug_front_times.argtypes = [vp, C.POINTER(C.c_int64), C.c_int64]
     L.gs_dist_exchange_doubles.argtypes = [vp]
     L.gs_slam_graph.argtypes = [vp]
     L.gs_set_stream.argtypes = [vp, vp]
@@ -327,6 +328,11 @@ class Graph:
 
     def linearize_bytes(self):
         return int(self.L.gs_linearize_bytes(self.h))
+
+    def debug_front_times(self):
+        """[2, n_fronts] completion times (100 MHz ticks) of the last factor / backward-solve launches (F3_DONE_TS builds)."""
+        n = self.stats().n_fronts; buf = (C.c_int64 * (2 * n))()
+        self._check(self.L.gs_debug_front_times(self.h, buf, 2 * n)); return np.array(buf[:], dtype=np.int64).reshape(2, n)
 
     def debug_timestamps(self):
         """100 MHz phase timestamps of one front (tuning aid, see include/graphslam.h gs_debug_timestamps)."""

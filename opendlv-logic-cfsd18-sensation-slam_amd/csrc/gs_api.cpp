@@ -502,6 +502,7 @@ static int upload_graph(gs_graph *g) {
           UP(f3_desc, fd);
       } }
     AL(dbg_ts, 64); ZERO(dbg_ts, 64);
+    AL(done_ts, 2 * P.fronts.size() + 2); ZERO(done_ts, 2 * P.fronts.size() + 2);
     AL(Lbuf, P.l_doubles); AL(Ubuf, P.u_doubles); AL(xe, P.n_scalar); AL(dpose, (size_t)N * 3); AL(dlm, (size_t)M * 2); AL(fail, 4);
     HIP_TRY(hipMemsetAsync(d.fail, 0, 4 * sizeof(int32_t), g->stream));
     HIP_TRY(hipMemsetAsync(d.chi2, 0, 80 * sizeof(double), g->stream));
@@ -619,10 +620,17 @@ static void enqueue_backsolve_levels(gs_graph *g, const gs_graph::LevelSet &ls, 
     if (g->d.factor_variant == 3 && g->d.tree && base == 0 && nlev > 0) {
         // levels >= 1 in one launch (fronts wait for their parent's flag), then the leaf level on its own: by then every
         // parent is done, so it needs no flags, and its LDS slot is sized for the leaves alone (more resident waves)
-        const int l0 = (nlev > 1 && g->leaf_n != 0) ? 1 : 0;
+        // The flagged launch is register-heavy (each lane preloads its L columns: 2 waves per SIMD) — right for the chain
+        // of the upper levels (2.2 us per level), wrong for the wide levels at the bottom, which are bound by resident
+        // waves x bytes: levels of more than GS_BS_WIDE (2048) fronts run one light launch each, like the leaves
+        // (measured per-level completion times: scripts/level_times.py).
+        int wide = 2048; if (const char *e = std::getenv("GS_BS_WIDE")) wide = std::atoi(e);
+        int l0 = 0;
+        if (g->leaf_n != 0) while (l0 + 1 < nlev && ls.start[l0 + 1] - ls.start[l0] > wide) ++l0;
+        if (l0 == 0 && nlev > 1 && g->leaf_n != 0) l0 = 1;
         int mn = 0, mf = 0; for (int l = l0; l < nlev; ++l) { mn = std::max(mn, ls.max_npiv[l]); mf = std::max(mf, ls.max_f[l]); }
         launch_backsolve_tree(g->d, ls.start[l0], ls.start[nlev] - ls.start[l0], mn, mf, g->stream);
-        if (l0 == 1) launch_backsolve_level(g->d, 0, ls.start[1], ls.max_npiv[0], ls.max_nbnd[0], g->stream);
+        for (int l = l0 - 1; l >= 0; --l) launch_backsolve_level(g->d, ls.start[l], ls.start[l + 1] - ls.start[l], ls.max_npiv[l], ls.max_nbnd[l], g->stream);
         return; }
     if (g->d.factor_variant == 3 && g->d.tree && base != 0 && nlev > 0 && ls.start[nlev] > 0) {      // shared top: one flagged launch, root first
         int mn = 0, mf = 0; for (int l = 0; l < nlev; ++l) { mn = std::max(mn, ls.max_npiv[l]); mf = std::max(mf, ls.max_f[l]); }
@@ -751,6 +759,15 @@ extern "C" int gs_time_linearize(gs_graph *g, int32_t reps, double *out_ms) {
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, g->ev[0], g->ev[1]));
     *out_ms = (double)ms / reps;
     return GS_OK;
+}
+extern "C" int gs_debug_front_times(gs_graph *g, int64_t *out, int64_t capacity) {
+    if (!g || !out) return fail(GS_ERR_INVALID, "null argument");
+    if (!g->dev_valid) return fail(GS_ERR_NOT_INITIALIZED, "nothing on the device yet");
+    const int64_t n = 2 * (int64_t)g->plan.fronts.size();
+    if (capacity < n) return fail(GS_ERR_CAPACITY, "buffer too small");
+    HIP_TRY(hipMemcpyAsync(out, g->d.done_ts, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return (int)(n / 2);
 }
 extern "C" int gs_debug_timestamps(gs_graph *g, int64_t *out64) {
     if (!g || !out64) return fail(GS_ERR_INVALID, "null argument");

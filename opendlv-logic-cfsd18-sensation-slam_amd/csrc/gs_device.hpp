@@ -58,6 +58,7 @@ struct DevGraph {
     double *dpose = nullptr, *dlm = nullptr;                    // last increment per vertex
     int32_t *fail = nullptr;                                    // [0] != 0 : non-positive pivot met
     double *front_ws = nullptr; int64_t front_ws_stride = 0;    // global workspace for fronts too big for LDS
+    long long *done_ts = nullptr;                               // [2][n_fronts] F3_DONE_TS tuning builds: 100 MHz completion time of every front (factor, backsolve)
     long long *dbg_ts = nullptr;                                // [64] phase timestamps (100 MHz) of one front, GS_DBG = 8 | level_count << 8
     int32_t dbg = 0;                                            // GS_DBG ablation bits (timing experiments only)
     int32_t factor_variant = 0;                                 // 0 block-per-front VALU, 1 wave-per-front VALU, 2 wave-per-front MFMA, 3 MFMA LDL^T gather (default)

@@ -1562,6 +1562,12 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
             }
         }
     }
+#ifndef F3_DONE_TS
+#define F3_DONE_TS 0
+#endif
+#if F3_DONE_TS
+    if (lane == 0) d.done_ts[fr.s] = wall_clock64();
+#endif
     if (TREE && !LEAF) f3_publish(d.done_f + fr.s, d.epoch, lane);
     if (TREE && LEAF && lane == 0) d.done_f[fr.s] = d.epoch;        // read by the next launch only (third and later children of a front)
     F3_TS(8);
@@ -1645,6 +1651,9 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
     }
     F3_TS(37);
     if (lane < npiv) { if (TREE) st_off_wt(d.xe, (uint32_t)(fr.piv0 + lane) * 8u, w); else d.xe[fr.piv0 + lane] = w; }
+#if F3_DONE_TS
+    if (lane == 0) d.done_ts[d.n_fronts + fr.s] = wall_clock64();
+#endif
     if (TREE) f3_publish(d.done_b + fr.s, d.epoch, lane);
     F3_TS(38);
 }

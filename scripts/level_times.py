@@ -1,0 +1,23 @@
+"""Per-level completion times inside the whole-tree launches (needs a library built with -DF3_DONE_TS=1: GS_LIB=...)."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from plan_exec import Plan
+pkg = importlib.import_module("opendlv-logic-cfsd18-sensation-slam_amd")
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
+N, M = pkg.track.CONFIGS[name]
+t = pkg.track.generate(N, M); fe = pkg.Graph(); g = pkg.track.bench_graph(t, fe)
+G = pkg.Graph(); G.load_bench_graph(g); G.initialize_optimization()
+P = Plan(G.plan_export())
+for _ in range(5):
+    G.iterate()
+G.synchronize()
+ts = G.debug_front_times().astype(np.float64) / 100.0          # us
+for phase, name2 in ((0, "factor"), (1, "backward solve")):
+    t0 = ts[phase][ts[phase] > 0].min()
+    print(name2, "(us after the first front of the launch sequence finished): level  #fronts  first done  last done")
+    for l in range(P.n_levels):
+        fr = P.level_fronts[P.level_start[l]:P.level_start[l + 1]]
+        v = ts[phase][fr]
+        print("   level %2d  %6d  %8.1f  %8.1f" % (l, len(fr), v.min() - t0, v.max() - t0))
