@@ -1269,10 +1269,15 @@ __device__ __forceinline__ void f3_gather_child(const double *Uc, int usize, int
         }
 }
 
-__device__ __forceinline__ double rcp_f64(double x) {             // reciprocal to ~1 ulp: hardware seed + two Newton steps
+#ifndef F3_RCP_NEWTON
+#define F3_RCP_NEWTON 2
+#endif
+__device__ __forceinline__ double rcp_f64(double x) {             // reciprocal to ~1 ulp: hardware seed + Newton steps
     double r = __builtin_amdgcn_rcp(x);
     double e = fma(-x, r, 1.0); r = fma(r, e, r);
+#if F3_RCP_NEWTON >= 2
     e = fma(-x, r, 1.0); r = fma(r, e, r);
+#endif
     return r;
 }
 
@@ -1356,7 +1361,7 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int fi = blockIdx.x * 4 + wave;
     if (fi >= count) return;                                        // whole wave leaves; no block barrier below
-    const bool ts_on = (d.dbg & 8) && count == (d.dbg >> 8) && fi == 0;
+    const bool ts_on = ((d.dbg & 8) && count == (d.dbg >> 8) && fi == 0) || ((d.dbg & 16) && level_off + fi == (d.dbg >> 8));   // 16: probe the front at a level POSITION
 #define F3_TS(i) do { if (ts_on) { __builtin_amdgcn_s_waitcnt(0); if (lane == 0) d.dbg_ts[i] = wall_clock64(); } } while (0)
     F3_TS(0);
     int pv[2];                                                       // the children's row tables ride behind the descriptor

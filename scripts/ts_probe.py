@@ -6,7 +6,13 @@ pkg = importlib.import_module("opendlv-logic-cfsd18-sensation-slam_amd")
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
 N, M = pkg.track.CONFIGS[name]
 t = pkg.track.generate(N, M); fe = pkg.Graph(); g = pkg.track.bench_graph(t, fe)
-G = pkg.Graph(); G.load_bench_graph(g); G.initialize_optimization()
+G = pkg.Graph(); G.load_bench_graph(g)
+if len(sys.argv) > 2:                                            # probe the first front of tree level argv[2] (whole-tree launch): GS_DBG is set here
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from plan_exec import Plan
+    H = pkg.Graph(device=-2); H.load_bench_graph(g); H.plan_build_host(); P = Plan(H.plan_export()); H.close()
+    os.environ["GS_DBG"] = str(16 | (int(P.level_start[int(sys.argv[2])]) << 8))
+G.initialize_optimization()
 for _ in range(4):
     G.iterate()
 G.synchronize()
