@@ -269,6 +269,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     // ---- fronts ----
     plan.fronts.resize(S);
     std::vector<int32_t> loc(B.nv, -1);
+    std::vector<AsmRec> recs, uniq, dup;                             // reused across fronts (no per-front allocation)
     for (int s = 0; s < S; ++s) {
         Front &F = plan.fronts[s];
         F.parent = parent[s]; F.piv0 = gidx[B.sn[s][0]];
@@ -290,7 +291,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
             for (int w : bndv[c]) for (int t = 0; t < B.dim(w); ++t) plan.child_map.push_back(loc[w] + t); }
         // original entries
         F.asm_off = (int32_t)plan.asm_recs.size();
-        std::vector<AsmRec> recs;
+        recs.clear();
         for (int v : B.sn[s]) {
             if (v < B.nfp) recs.push_back({ASM_POSE_DIAG, B.pose_of_fp[v], loc[v], loc[v]});
             else recs.push_back({ASM_LM_DIAG, B.lm_of_fl[v - B.nfp], loc[v], loc[v]});
@@ -309,7 +310,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         // duplicates (parallel edges between the same two vertices) go to the tail
         std::stable_sort(recs.begin(), recs.end(), [](const AsmRec &x, const AsmRec &y) {
             return x.r0 != y.r0 ? x.r0 < y.r0 : x.c0 < y.c0; });
-        std::vector<AsmRec> uniq, dup;
+        uniq.clear(); dup.clear();
         for (size_t t = 0; t < recs.size(); ++t) {
             if (t > 0 && recs[t].r0 == recs[t - 1].r0 && recs[t].c0 == recs[t - 1].c0) dup.push_back(recs[t]);
             else uniq.push_back(recs[t]);
