@@ -1298,11 +1298,12 @@ __device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[10], double 
     double p[4], dd[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[j] = Pn[lane * 4 + j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    // one pivot of the panel; FULL = every column of this panel is a pivot (all panels of a front but possibly the
+    // last): then there are no uniform branches between the pivots and no merges of the p[] registers after them
+    auto pivot = [&](int j, bool is_pivot) {
         const int col = k0 + j;
         dd[j] = 0.0;
-        if (col < npiv) {                                           // uniform
+        if (is_pivot) {
             double piv = lane_bcast(p[j], col);
             const bool ok = piv > 0.0;                              // a non-positive pivot is reported once, at the end of the front
             bad = bad || !ok; piv = ok ? piv : 1.0;
@@ -1314,6 +1315,13 @@ __device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[10], double 
             dd[j] = piv;
             if (lane <= f) F3_ST_L(&L[(int64_t)col * (f + 1) + lane], p[j]);   // column `col` of the L panel (rows < col are 0, row col = d)
         } else p[j] = 0.0;                                          // not a pivot: contributes nothing to the update
+    };
+    if (k0 + 4 <= npiv) {                                           // uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pivot(j, true);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pivot(j, k0 + j < npiv);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) Pn[lane * 4 + j] = p[j];
