@@ -1308,12 +1308,12 @@ __device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[10], double 
             const bool ok = piv > 0.0;                              // a non-positive pivot is reported once, at the end of the front
             bad = bad || !ok; piv = ok ? piv : 1.0;
             const double inv = rcp_f64(piv);
-            const double lj = (lane > col) ? p[j] * inv : 0.0;
+            const double lj = (lane >= col) ? p[j] * inv : 0.0;    // row col itself gets d / d = 1: a dead row in every later use
 #pragma unroll
             for (int j2 = j + 1; j2 < 4; ++j2) { const double c2 = lane_bcast(p[j], k0 + j2); p[j2] -= lj * c2; }
-            p[j] = (lane == col) ? piv : lj;
+            p[j] = lj;
             dd[j] = piv;
-            if (lane <= f) F3_ST_L(&L[(int64_t)col * (f + 1) + lane], p[j]);   // column `col` of the L panel (rows < col are 0, row col = d)
+            if (lane <= f) F3_ST_L(&L[(int64_t)col * (f + 1) + lane], lj);   // column `col` of the L panel (rows < col are 0, the diagonal is 1)
         } else p[j] = 0.0;                                          // not a pivot: contributes nothing to the update
     };
     if (k0 + 4 <= npiv) {                                           // uniform
