@@ -1286,34 +1286,36 @@ __device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[10], double 
     constexpr int k0 = 4 * B, J0 = B / 4, jc = (B % 4) * 4;
     if (k0 >= npiv) return false;                                   // uniform
     const int lc = lane & 15, lr = lane >> 4;
-    // 1. the panel's four columns (rows of tiles J0..3) to LDS, row-major 64 x 4
+    // The wide levels of the tree are bound by instruction issue, so this function is written for few instructions:
+    // one exec-mask region for the spill and one for the L stores, no uniform branches inside them, the positivity
+    // test as one compare per pivot into a flag that is looked at once per front (no protective select: a front with a
+    // bad pivot produces garbage, the solve is reported as failed).
+    // 1. the panel's four columns (rows of tiles J0..3) to LDS, row-major 64 x 4 (tile rows beyond f hold zeros)
     if (lc >= jc && lc < jc + 4) {
 #pragma unroll
-        for (int I = J0; I < 4; ++I) if (16 * I <= f) {              // uniform: tile rows beyond the rhs row hold nothing
+        for (int I = J0; I < 4; ++I)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) Pn[(16 * I + lr + 4 * q) * 4 + (lc - jc)] = acc[mf_tile(I, J0)][q]; }
+            for (int q = 0; q < 4; ++q) Pn[(16 * I + lr + 4 * q) * 4 + (lc - jc)] = acc[mf_tile(I, J0)][q];
     }
     wave_lds_sync();
-    // 2. factorise the panel, lane r = row r:  l = c / d below the diagonal, d on it, 0 above
+    // 2. factorise the panel, lane r = row r:  l = c / d from the diagonal down (the diagonal itself becomes 1), 0 above
     double p[4], dd[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[j] = Pn[lane * 4 + j];
-    // one pivot of the panel; FULL = every column of this panel is a pivot (all panels of a front but possibly the
-    // last): then there are no uniform branches between the pivots and no merges of the p[] registers after them
+    // one pivot of the panel.  If every column of this panel is a pivot (all panels of a front but possibly the last)
+    // there are no uniform branches between the pivots and no merges of the p[] registers after them.
     auto pivot = [&](int j, bool is_pivot) {
         const int col = k0 + j;
         dd[j] = 0.0;
         if (is_pivot) {
-            double piv = lane_bcast(p[j], col);
-            const bool ok = piv > 0.0;                              // a non-positive pivot is reported once, at the end of the front
-            bad = bad || !ok; piv = ok ? piv : 1.0;
+            const double piv = lane_bcast(p[j], col);
+            bad = bad || !(piv > 0.0);                              // a non-positive (or NaN) pivot is reported once, at the end of the front
             const double inv = rcp_f64(piv);
             const double lj = (lane >= col) ? p[j] * inv : 0.0;    // row col itself gets d / d = 1: a dead row in every later use
 #pragma unroll
             for (int j2 = j + 1; j2 < 4; ++j2) { const double c2 = lane_bcast(p[j], k0 + j2); p[j2] -= lj * c2; }
             p[j] = lj;
             dd[j] = piv;
-            if (lane <= f) F3_ST_L(&L[(int64_t)col * (f + 1) + lane], lj);   // column `col` of the L panel (rows < col are 0, the diagonal is 1)
         } else p[j] = 0.0;                                          // not a pivot: contributes nothing to the update
     };
     if (k0 + 4 <= npiv) {                                           // uniform
@@ -1322,6 +1324,11 @@ __device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[10], double 
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) pivot(j, k0 + j < npiv);
+    }
+    if (lane <= f) {                                                // the panel's columns of L (rows < col are 0, the diagonal is 1), one masked region
+        double *Lc = L + (int64_t)k0 * (f + 1) + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (k0 + j < npiv) F3_ST_L(Lc + (int64_t)j * (f + 1), p[j]);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) Pn[lane * 4 + j] = p[j];
