@@ -147,6 +147,12 @@ def main():
         dt = float(tt.item())
     ms_per_step = dt * 1e3 / args.steps
     value = world * args.steps / dt                # 100k-pose-window iterations per second over the whole job
+    # the handle that was timed must have WORKED: a zero pivot or a solver launch that gave up on a front applies no
+    # update and is reported here (GsError -> non-zero exit, no JSON line), on every rank
+    G.sync_estimates()
+    timed_poses, timed_lms = G.poses(), G.landmarks()
+    if not (np.isfinite(timed_poses).all() and np.isfinite(timed_lms).all()):
+        raise SystemExit("bench: the timed handle holds non-finite estimates")
 
     # ---- roofline of the edge-linearisation kernel (HIP events on the library's stream, this process)
     lin_ms = G.time_linearize(50)                  # this rank's window when sharded
@@ -208,6 +214,16 @@ def main():
         out["landmark_rmse_vs_oracle_rel"] = float(np.sqrt(((Lm - og.landmarks()) ** 2).sum(1).mean()) / rms)
         out["heading_max_abs_diff_vs_oracle"] = float(np.abs(P[:, 2] - og.poses()[:, 2]).max())
         out["parity_iterations"] = int(done)
+        # ... and the handle that was TIMED ran exactly that arithmetic: the same number of iterations through
+        # gs_optimize on the second handle must reproduce its estimates bit for bit (every sum has a fixed order)
+        more = args.warmup + args.steps - int(done)
+        if more > 0:
+            G2.optimize(more)
+        same = bool(np.array_equal(G2.poses(), timed_poses) and np.array_equal(G2.landmarks(), timed_lms))
+        out["timed_handle_bitwise_equals_optimize"] = same
+        out["timed_handle_iterations"] = args.warmup + args.steps
+        if not same:
+            raise SystemExit("bench: the timed handle's estimates differ from gs_optimize(%d) on a second handle" % (args.warmup + args.steps))
         G2.close()
     else:
         out["cpu_baseline"] = None

@@ -44,8 +44,9 @@ extern "C" {
 #define GS_ERR_HIP              -5  /* a HIP call failed (see gs_last_error)    */
 #define GS_ERR_NOT_INITIALIZED  -6  /* gs_iterate before gs_initialize_optimization */
 #define GS_ERR_EMPTY            -7  /* nothing to optimise (no free vertex)     */
-#define GS_ERR_NUMERIC          -8  /* non-positive pivot: H not SPD            */
+#define GS_ERR_NUMERIC          -8  /* zero pivot: H singular (see gs_optimize) */
 #define GS_ERR_CAPACITY         -9  /* output buffer too small                  */
+#define GS_ERR_TIMEOUT         -10  /* a whole-tree solver launch gave up waiting for a front (see gs_stream_synchronize) */
 
 typedef struct gs_graph gs_graph;   /* replaces g2o::SparseOptimizer (src/slam.hpp:98) */
 typedef struct gs_slam  gs_slam;    /* replaces the graph-side state of class Slam     */
@@ -85,11 +86,11 @@ typedef struct gs_config {
  * the handle's stream, milliseconds, summed over the iterations of the call) */
 typedef struct gs_stats {
     int32_t struct_size;
-    int32_t iterations;         /* iterations actually performed                            */
+    int32_t iterations;         /* iterations whose update was applied (== requested unless the solve failed) */
     int32_t n_free_poses, n_free_landmarks;
     int32_t n_odometry_edges, n_observation_edges;
     int32_t n_fronts, n_levels, max_front;   /* multifrontal plan                          */
-    int32_t numeric_failure;    /* 1 if a non-positive pivot was met                        */
+    int32_t numeric_failure;    /* 0 ok; 1 zero pivot; 2 front-flag timeout; 3 failure reported by another rank */
     double  chi2_initial;       /* chi2 at the linearisation point of the first iteration   */
     double  chi2_final;         /* chi2 at the linearisation point of the last iteration    */
     double  ms_structure;       /* host: ordering + symbolic + upload (iteration-0 work)   */
@@ -162,12 +163,27 @@ int  gs_get_landmarks(gs_graph *g, int32_t capacity, int32_t *out_ids, double *o
  *      + g2o BlockSolver::buildStructure: index maps, ordering, symbolic plan, upload to HBM.
  * gs_optimize                <- m_optimizer.optimize(10)                          (src/slam.cpp:481)
  *      runs `iterations` x (computeActiveErrors, buildSystem, solve, update) on the device,
- *      no damping, no line search, no convergence test; returns iterations done, 0 if the
- *      factorisation met a non-positive pivot (g2o returns 0 when the solver fails).
+ *      no damping, no line search, no convergence test; returns iterations done.
+ *      Failure semantics are g2o's: when the factorisation of an iteration fails, that iteration's
+ *      update and all later ones are NOT applied — the estimates stay at the last good iterate —
+ *      and the call returns 0 (stats->iterations = updates applied, stats->numeric_failure = code).
+ *      The default solver is an LDL^T like the Eigen 3.3.4 SimplicialLDLT behind g2o's
+ *      LinearSolverEigen and fails like it on a pivot d == 0 only
+ *      (thirdparty/Eigen/src/SparseCholesky/SimplicialCholesky_impl.h:172-176), plus on NaN;
+ *      the Cholesky fallback kernels (factor_variant 1, 2, 4) fail on d <= 0 like SimplicialLLT.
  * gs_iterate                 one Gauss-Newton iteration, asynchronous on the handle's stream
- *      (the bench's "step"); estimates stay in HBM until gs_sync_estimates / gs_optimize. */
+ *      (the bench's "step"); estimates stay in HBM until gs_sync_estimates / gs_optimize.
+ *      A failed iteration applies no update either; gs_stream_synchronize / gs_sync_estimates
+ *      report it (GS_ERR_NUMERIC, or GS_ERR_TIMEOUT when a whole-tree launch gave up waiting for
+ *      a front: the handle then switches to one launch per level) once and clear the condition.
+ * gs_optimize_until          config 2 of BASELINE.json ("optimise to convergence"): the reference has no
+ *      stop rule, this is the build-defined one.  Iterates until the chi2 at two
+ *      consecutive linearisation points differs by <= rel_chi2_tol * chi2 (checked on the device
+ *      value every iteration), at most max_iterations; returns the iterations whose update
+ *      was applied, 0 on failure as gs_optimize. */
 int  gs_initialize_optimization(gs_graph *g);
 int  gs_optimize(gs_graph *g, int32_t iterations, gs_stats *stats /* may be NULL */);
+int  gs_optimize_until(gs_graph *g, int32_t max_iterations, double rel_chi2_tol, gs_stats *stats /* may be NULL */);
 int  gs_iterate(gs_graph *g);
 int  gs_sync_estimates(gs_graph *g);      /* device -> host estimates, waits for the stream   */
 int  gs_stream_synchronize(gs_graph *g);
@@ -197,6 +213,9 @@ int gs_debug_timestamps(gs_graph *g, int64_t *out64);
 /* Tuning aid (F3_DONE_TS builds of the library only, zeros otherwise): 100 MHz completion time of every front in the
  * last factor launch ([0, n)) and the last backward-solve launch ([n, 2n)); returns n.  No reference counterpart. */
 int gs_debug_front_times(gs_graph *g, int64_t *out, int64_t capacity);
+/* Fault injection (tests of the failure semantics; the reference has none): the k-th iteration enqueued after
+ * this call reports `code` (1 = zero pivot, 2 = front-flag timeout) from its first front; k = 0 disarms. */
+int gs_debug_fail_at_iteration(gs_graph *g, int32_t k, int32_t code);
 
 int64_t gs_linearize_bytes(gs_graph *g);
 int  gs_export_system(gs_graph *g, double *Hpp_diag, double *Hll_diag, double *Hpp_off,
@@ -261,11 +280,13 @@ int  gs_dist_write_exchange(gs_graph *g, const double *host_in);
 int  gs_dist_known(gs_graph *g, uint8_t *pose_known, uint8_t *lm_known, uint8_t *pose_primary, uint8_t *lm_primary);
 
 /* ---- Slam-level host mirror (rows f-1/f-2 of SURVEY §8f) ----------------------
- * gs_slam_perform <- Slam::performSLAM graph part (src/slam.cpp:298-338): addPoseToGraph,
- *      addConesToMap / localizer, loop-closure trigger, optimizeGraph, updateMap. */
+ * gs_slam_perform <- Slam::performSLAM (src/slam.cpp:298-338): the 200 m odometry guard, the heading compensated by
+ *      yawRate * dt (0 < dt < 1 s, dt from gs_slam_set_sample_times), addPoseToGraph, then — two independent ifs as in
+ *      the reference (:329-334) — addConesToMap (loop-closure trigger, optimizeGraph, updateMap) while the loop is open
+ *      and the localizer once it is closed, i.e. BOTH in the frame that closes it. */
 int  gs_slam_create(const gs_config *cfg, gs_slam **out);
 int  gs_slam_destroy(gs_slam *s);
-int  gs_slam_perform(gs_slam *s, const double pose_xytheta[3], const double *cones_4xk, int32_t k);
+int  gs_slam_perform(gs_slam *s, const double odometry_xytheta[3], const double *cones_4xk, int32_t k);
 int  gs_slam_map_size(gs_slam *s);
 int  gs_slam_get_map(gs_slam *s, int32_t capacity, double *out_xy, int32_t *out_type);
 int  gs_slam_loop_closed(gs_slam *s);
@@ -306,6 +327,9 @@ int  gs_slam_next_wgs84(gs_slam *s, double latitude_deg, double longitude_deg);
 int  gs_slam_next_heading(gs_slam *s, double north_heading);
 int  gs_slam_next_geolocation(gs_slam *s, double latitude_deg, double longitude_deg, double heading);
 int  gs_slam_next_yaw_rate(gs_slam *s, double angular_velocity_z);
+/* m_yawReceivedTime / m_lastTimeStamp (src/slam.cpp:216; :73,102,129): sample times (microseconds) of the last yaw-rate
+ * message and the last cone message; performSLAM's dt = |difference| / 1e6 (src/slam.cpp:309) */
+int  gs_slam_set_sample_times(gs_slam *s, int64_t yaw_received_us, int64_t last_cone_us);
 int  gs_slam_get_odometry(gs_slam *s, double out_xy_heading_yawrate[4]);
 int  gs_slam_encode_pose(gs_slam *s, float out_lon_lat_heading[3]);
 

@@ -21,7 +21,7 @@ _ip = C.POINTER(C.c_int32)
 GS_OK = 0
 ERRORS = {-1: "GS_ERR_INVALID", -2: "GS_ERR_DUPLICATE_ID", -3: "GS_ERR_UNKNOWN_ID", -4: "GS_ERR_NO_DEVICE",
           -5: "GS_ERR_HIP", -6: "GS_ERR_NOT_INITIALIZED", -7: "GS_ERR_EMPTY", -8: "GS_ERR_NUMERIC",
-          -9: "GS_ERR_CAPACITY"}
+          -9: "GS_ERR_CAPACITY", -10: "GS_ERR_TIMEOUT"}
 
 
 class GsError(RuntimeError):
@@ -126,6 +126,8 @@ def lib():
     L.gs_get_poses.argtypes = [vp, C.c_int32, _ip, _dp]
     L.gs_get_landmarks.argtypes = [vp, C.c_int32, _ip, _dp]
     L.gs_optimize.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
+    L.gs_optimize_until.argtypes = [vp, C.c_int32, C.c_double, C.POINTER(Stats)]
+    L.gs_debug_fail_at_iteration.argtypes = [vp, C.c_int32, C.c_int32]
     L.gs_chi2.argtypes = [vp, _dp]
     L.gs_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.gs_time_linearize.argtypes = [vp, C.c_int32, _dp]
@@ -158,6 +160,7 @@ def lib():
     L.gs_slam_next_geolocation.argtypes = [vp, C.c_double, C.c_double, C.c_double]
     L.gs_slam_next_yaw_rate.argtypes = [vp, C.c_double]
     L.gs_slam_get_odometry.argtypes = [vp, _dp]
+    L.gs_slam_set_sample_times.argtypes = [vp, C.c_int64, C.c_int64]
     L.gs_slam_encode_pose.argtypes = [vp, C.POINTER(C.c_float)]
     _lib = L
     return L
@@ -300,6 +303,14 @@ class Graph:
         st = Stats(); st.struct_size = C.sizeof(Stats)
         done = self._check(self.L.gs_optimize(self.h, int(iterations), C.byref(st)))
         return done, st
+
+    def optimize_until(self, max_iterations, rel_chi2_tol):
+        st = Stats(); st.struct_size = C.sizeof(Stats)
+        done = self._check(self.L.gs_optimize_until(self.h, int(max_iterations), float(rel_chi2_tol), C.byref(st)))
+        return done, st
+
+    def debug_fail_at_iteration(self, k, code=1):
+        self._check(self.L.gs_debug_fail_at_iteration(self.h, int(k), int(code)))
 
     def iterate(self):
         return self._check(self.L.gs_iterate(self.h))
@@ -504,6 +515,9 @@ class Slam:
     def next_heading(self, north_heading): self._check(self.L.gs_slam_next_heading(self.h, float(north_heading)))
     def next_geolocation(self, lat, lon, heading): self._check(self.L.gs_slam_next_geolocation(self.h, float(lat), float(lon), float(heading)))
     def next_yaw_rate(self, wz): self._check(self.L.gs_slam_next_yaw_rate(self.h, float(wz)))
+
+    def set_sample_times(self, yaw_received_us, last_cone_us):
+        self._check(self.L.gs_slam_set_sample_times(self.h, int(yaw_received_us), int(last_cone_us)))
 
     def odometry(self):
         o = np.zeros(4); self._check(self.L.gs_slam_get_odometry(self.h, _d(o))); return o

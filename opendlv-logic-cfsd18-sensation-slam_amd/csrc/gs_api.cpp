@@ -260,14 +260,49 @@ static int pull_estimates_if_needed(gs_graph *g) {
     g->dev_estimates_newer = false;
     return GS_OK;
 }
+// The device-side failure state: fail[0] = code (1 zero pivot, 2 a whole-tree launch gave up on a front's flag, 3 a
+// failure another rank reported), fail[1] = updates applied since the last reset.  k_update applies nothing once the
+// code is non-zero, so the estimates in HBM are those of the last good iterate, as in g2o after a failed solve.
+static int read_failure(gs_graph *g, int32_t out[2]) {
+    out[0] = out[1] = 0;
+    if (!g->dev_valid || !g->d.fail) return GS_OK;
+    HIP_TRY(hipMemcpyAsync(out, g->d.fail, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return GS_OK;
+}
+static int reset_failure(gs_graph *g) {
+    g->d.inject_iter = 0; g->d.inject_code = 0;
+    HIP_TRY(hipMemsetAsync(g->d.fail, 0, 4 * sizeof(int32_t), g->stream));
+    return GS_OK;
+}
+// After gs_iterate / gs_dist_iterate_*: report a failure of the iterations run since the last report (once), apply the
+// one-launch-per-level fallback after a flag timeout.  The estimates stay at the last good iterate either way.
+static int surface_failure(gs_graph *g) {
+    int32_t st[2]; int rc = read_failure(g, st); if (rc != GS_OK) return rc;
+    if (st[0] == 0) return GS_OK;
+    rc = reset_failure(g); if (rc != GS_OK) return rc;
+    if (st[0] == 2) { g->d.tree = 0;
+        return fail(GS_ERR_TIMEOUT, "whole-tree launch: a front's completion flag did not arrive in time; no update was applied from that "
+                                    "iteration on (estimates = last good iterate); the handle now uses one launch per level"); }
+    return fail(GS_ERR_NUMERIC, st[0] == 3 ? "another rank met a zero pivot: no update applied from that iteration on (estimates = last good iterate)"
+                                           : "zero pivot: H is singular; no update applied from that iteration on (estimates = last good iterate)");
+}
 extern "C" int gs_sync_estimates(gs_graph *g) {
     if (!g) return fail(GS_ERR_INVALID, "null graph");
-    return pull_estimates_if_needed(g);
+    int rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
+    if (g->host_only || !g->dev_valid) return GS_OK;
+    return surface_failure(g);
 }
 extern "C" int gs_stream_synchronize(gs_graph *g) {
     if (!g) return fail(GS_ERR_INVALID, "null graph");
     int rc = ensure_device(g); if (rc != GS_OK) return rc;
     HIP_TRY(hipStreamSynchronize(g->stream));
+    return surface_failure(g);
+}
+extern "C" int gs_debug_fail_at_iteration(gs_graph *g, int32_t k, int32_t code) {
+    if (!g || k < 0 || (code != 1 && code != 2)) return fail(GS_ERR_INVALID, "bad argument");
+    if (!g->dev_valid) return fail(GS_ERR_NOT_INITIALIZED, "call gs_initialize_optimization first");
+    g->d.inject_iter = k > 0 ? g->d.iter + k : 0; g->d.inject_code = code;
     return GS_OK;
 }
 extern "C" int gs_get_pose(gs_graph *g, int32_t id, double out[3]) {
@@ -393,7 +428,9 @@ static int upload_graph(gs_graph *g) {
     { std::vector<int32_t> lf = P.level_fronts_owned; g->shared_base = (int)lf.size();
       lf.insert(lf.end(), P.level_fronts_shared.begin(), P.level_fronts_shared.end());
       UP(level_fronts, lf); }
+    d.xfail_off = -1; d.iter = 0; d.inject_iter = 0; d.inject_code = 0;
     if (P.world > 1) { UP(x_off, P.x_off);
+        d.xfail_off = P.exchange_doubles - 2;                             // the ranks' failure flags ride at the tail of the exchange buffer
         if (!g->exchange_external) { AL(exchange, P.exchange_doubles); ZERO(exchange, P.exchange_doubles); }
         else d.exchange = g->exchange; }
     { std::vector<int32_t> recs(P.asm_recs.size() * 4);
@@ -641,6 +678,7 @@ static void enqueue_backsolve_levels(gs_graph *g, const gs_graph::LevelSet &ls, 
 // pose-window shards, first half: linearise this shard's edges, factorise its own subtrees, write its contribution
 // to every shared front into the exchange buffer (the caller all-reduces that buffer: RCCL sum, fp64)
 static void enqueue_local(gs_graph *g, bool timed) {
+    ++g->d.iter;                                                     // kernels see the iteration they belong to (fault injection, gs_debug_fail_at_iteration)
     if (timed) hipEventRecord(g->ev[0], g->stream);
     launch_linearize(g->d, g->stream);
     if (timed) hipEventRecord(g->ev[1], g->stream);
@@ -691,42 +729,72 @@ extern "C" int gs_get_stats(gs_graph *g, gs_stats *s) {
     return GS_OK;
 }
 
-extern "C" int gs_optimize(gs_graph *g, int32_t iterations, gs_stats *stats) {
+// gs_optimize (rel_tol < 0: the reference's fixed iteration count) and gs_optimize_until (rel_tol >= 0: the stop rule)
+static int optimize_impl(gs_graph *g, int32_t iterations, double rel_tol, gs_stats *stats) {
     if (!g) return fail(GS_ERR_INVALID, "null graph");
     if (iterations < 0) return fail(GS_ERR_INVALID, "negative iteration count");
     if (g->world > 1) return fail(GS_ERR_INVALID, "sharded graph: drive gs_dist_iterate_local / all-reduce / gs_dist_iterate_finish");
     // g2o: optimize() is always preceded by initializeOptimization() (reference src/slam.cpp:480-481);
     // the plan is rebuilt only when the structure changed since the last call.
     int rc = ensure_ready(g); if (rc != GS_OK) return rc;
-    HIP_TRY(hipMemsetAsync(g->d.fail, 0, 4 * sizeof(int32_t), g->stream));
+    { const int ii = g->d.inject_iter, ic = g->d.inject_code;       // an armed fault injection survives the reset below
+      HIP_TRY(hipMemsetAsync(g->d.fail, 0, 4 * sizeof(int32_t), g->stream)); g->d.inject_iter = ii; g->d.inject_code = ic; }
+    const bool until = rel_tol >= 0.0;
+    g->d.conv_tol = until ? rel_tol : -1.0;
+    if (until) { const double none = -1.0; HIP_TRY(hipMemcpyAsync(g->d.chi2 + 70, &none, sizeof(double), hipMemcpyHostToDevice, g->stream)); }
     hipEventRecord(g->ev[5], g->stream);
     const int nh = std::min(iterations, 64);
-    for (int it = 0; it < iterations; ++it) {
-        enqueue_iteration(g, false);
-        if (it < nh) hipMemcpyAsync(g->d.chi2 + 1 + it, g->d.chi2, sizeof(double), hipMemcpyDeviceToDevice, g->stream);
+    // All iterations are enqueued up front (no host round trip between them).  g2o leaves its loop at the first failed
+    // solve and keeps the previous iterate: k_update applies nothing once the failure flag is up, and fail[1] says how
+    // many updates went in.  A flag timeout of a whole-tree launch (code 2) is not a property of H: the handle falls
+    // back to one launch per level and runs the remaining iterations again from the last good iterate.
+    // Stop rule (gs_optimize_until): k_update compares the chi2 of consecutive linearisation points on the device and
+    // raises fail[2]; later updates are skipped like after a failure.  The host enqueues chunks of 4 iterations and
+    // looks at the flags in between, so at most 3 enqueued iterations run as no-ops after convergence.
+    int applied = 0, enq = 0; int32_t ff[4] = {0, 0, 0, 0}; bool fell_back = false;
+    while (enq < iterations) {
+        const int upto = until ? std::min(iterations, enq + 4) : iterations;
+        for (int it = enq; it < upto; ++it) {
+            enqueue_iteration(g, false);
+            if (it < nh) hipMemcpyAsync(g->d.chi2 + 1 + it, g->d.chi2, sizeof(double), hipMemcpyDeviceToDevice, g->stream);
+        }
+        enq = upto;
+        HIP_TRY(hipMemcpyAsync(ff, g->d.fail, sizeof(ff), hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        applied = ff[1];
+        if (ff[0] == 2 && g->d.tree && !fell_back) {
+            g->d.tree = 0; fell_back = true; g->d.inject_iter = 0;
+            HIP_TRY(hipMemsetAsync(g->d.fail, 0, sizeof(int32_t), g->stream));      // the code only: the update count goes on
+            enq = applied; ff[0] = 0; continue; }
+        if (ff[0] != 0 || ff[2] != 0) break;
     }
+    g->d.conv_tol = -1.0;
+    if (until) HIP_TRY(hipMemsetAsync(g->d.fail + 2, 0, sizeof(int32_t), g->stream));     // the stop flag must not gate later gs_iterate calls
+    const int nshow = std::min(applied, nh);
     if (g->cfg.verbose || stats) { launch_chi2_only(g->d, g->stream);
         hipMemcpyAsync(g->d.chi2 + 1 + nh, g->d.chi2, sizeof(double), hipMemcpyDeviceToDevice, g->stream); }
     hipEventRecord(g->ev[6], g->stream);
-    int32_t failflag[4] = {0, 0, 0, 0}; double hist[80];
-    HIP_TRY(hipMemcpyAsync(failflag, g->d.fail, sizeof(failflag), hipMemcpyDeviceToHost, g->stream));
+    double hist[80];
     HIP_TRY(hipMemcpyAsync(hist, g->d.chi2, sizeof(hist), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("iteration: ") + hipGetErrorString(e));
-    rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
+    rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;   // on failure: the last good iterate (what g2o's vertices hold)
     float ms = 0; hipEventElapsedTime(&ms, g->ev[5], g->ev[6]);
-    if (g->cfg.verbose) for (int it = 0; it < nh; ++it)     // g2o prints the chi2 AFTER the update of iteration it
-        std::fprintf(stderr, "iteration= %d\t chi2= %.6f\t edges= %d\t schur= 0\n", it, hist[2 + it], g->h.n_pp() + g->h.n_pl());
+    if (g->cfg.verbose) for (int it = 0; it < nshow; ++it)  // g2o prints the chi2 AFTER the update of iteration it
+        std::fprintf(stderr, "iteration= %d\t chi2= %.6f\t edges= %d\t schur= 0\n", it, it + 1 < applied ? hist[2 + it] : hist[1 + nh], g->h.n_pp() + g->h.n_pl());
     if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->struct_size = (int32_t)sizeof(*stats);
-        fill_plan_stats(g, stats); stats->iterations = failflag[0] ? 0 : iterations; stats->numeric_failure = failflag[0];
+        fill_plan_stats(g, stats); stats->iterations = applied; stats->numeric_failure = ff[0];
         stats->chi2_initial = iterations > 0 ? hist[1] : hist[1 + nh]; stats->chi2_final = hist[1 + nh]; stats->ms_total = ms; }
-    if (failflag[0] == 2) {          // a whole-tree launch gave up waiting for a front (workgroups not dispatched in order?): never again on this handle
-        g->d.tree = 0;
-        g_last_error = "whole-tree launch: a front's completion flag did not arrive in time; the handle now uses one launch per level — restore the estimates and optimise again";
-        return 0; }
-    if (failflag[0]) { g_last_error = "non-positive pivot: H is not positive definite"; return 0; }
-    return iterations;
+    if (ff[0]) { rc = reset_failure(g); if (rc != GS_OK) return rc; }
+    if (ff[0] == 2) { g_last_error = "a front's completion flag did not arrive in time, with one launch per level as well"; return 0; }
+    if (ff[0]) { g_last_error = "zero pivot: H is singular (g2o: optimize() returns 0, the vertices keep the last good iterate)"; return 0; }
+    return applied;
+}
+extern "C" int gs_optimize(gs_graph *g, int32_t iterations, gs_stats *stats) { return optimize_impl(g, iterations, -1.0, stats); }
+extern "C" int gs_optimize_until(gs_graph *g, int32_t max_iterations, double rel_chi2_tol, gs_stats *stats) {
+    if (!(rel_chi2_tol >= 0.0)) return fail(GS_ERR_INVALID, "rel_chi2_tol must be >= 0");
+    return optimize_impl(g, max_iterations, rel_chi2_tol, stats);
 }
 
 extern "C" int gs_chi2(gs_graph *g, double *out) {

@@ -665,6 +665,13 @@ __device__ __forceinline__ void apply_asm(const DevGraph &d, const int32_t *rec,
 //         matrices of the children it owns, written to the front's slot of the exchange buffer; no factorisation.
 // mode 2: a shared front after the all-reduce: start from the summed slot, add the shared children, factorise.
 enum { FRONT_OWN = 0, FRONT_CONTRIB = 1, FRONT_TOP = 2 };
+// pose-window shards: a rank's failure flag travels with its contribution (one extra double behind the shared fronts'
+// slots, summed by the same all-reduce), so that EVERY rank skips the update of an iteration in which ANY rank met a
+// zero pivot — g2o stops the whole optimisation at that iteration and keeps the previous iterate.  The local phase
+// (linearise, own subtrees) has completed on this stream when the contribution launch starts.
+__device__ __forceinline__ void contrib_publish_fail(const DevGraph &d) {
+    if (d.xfail_off >= 0) d.exchange[d.xfail_off] = (d.fail[0] != 0) ? 1.0 : 0.0;
+}
 template <bool USE_LDS>
 __global__ void __launch_bounds__(256) k_factor_level(DevGraph d, int level_off, int mode) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -708,13 +715,14 @@ __global__ void __launch_bounds__(256) k_factor_level(DevGraph d, int level_off,
     if (mode == FRONT_CONTRIB) {
         double *X = d.exchange + d.x_off[s];
         for (int idx = tid; idx < (f + 1) * f; idx += 256) { int c = idx / (f + 1), r = idx - c * (f + 1); X[idx] = (r >= c) ? F[c * ld + r] : 0.0; }
+        if (blockIdx.x == 0 && tid == 0) contrib_publish_fail(d);
         return;
     }
     // right-looking partial Cholesky
     const int tx = tid & 15, ty = tid >> 4;
     for (int k = 0; k < npiv; ++k) {
         double piv = F[k * ld + k];
-        if (!(piv > 0.0)) { if (tid == 0) atomicExch(d.fail, 1); piv = 1.0; }
+        if (!(piv > 0.0)) { if (tid == 0) atomicMax(d.fail, 1); piv = 1.0; }        // Cholesky (sqrt): fails on d <= 0 like Eigen's SimplicialLLT
         const double dd = sqrt(piv), inv = 1.0 / dd;
         __syncthreads();
         for (int r = k + 1 + tid; r <= f; r += 256) F[k * ld + r] *= inv;
@@ -887,13 +895,14 @@ __global__ void __launch_bounds__(256) k_factor_wave(DevGraph d, int level_off, 
     if (mode == FRONT_CONTRIB) {
         double *X = d.exchange + d.x_off[s];
         for (int c = 0; c < f; ++c) if (lane <= f) X[c * (f + 1) + lane] = (lane >= c) ? P.at(lane, c) : 0.0;
+        if (fi == 0 && lane == 0) contrib_publish_fail(d);
         return;
     }
     // right-looking partial Cholesky, lane r = row r
     double *L = d.Lbuf + fr.L_off; const int ldl = f + 1;
     for (int k = 0; k < npiv; ++k) {
         double piv = P.at(k, k);                                      // same address in every lane: LDS broadcast
-        if (!(piv > 0.0)) { if (lane == 0) atomicExch(d.fail, 1); piv = 1.0; }
+        if (!(piv > 0.0)) { if (lane == 0) atomicMax(d.fail, 1); piv = 1.0; }
         const double dd = sqrt(piv), inv = 1.0 / dd;
         double Lr = 0.0;
         if (lane > k && lane <= f) Lr = P.at(lane, k) * inv;
@@ -984,7 +993,7 @@ __device__ __forceinline__ bool mf_panel_step(const DevGraph &d, v4d (&acc)[10],
         const int col = k0 + j;
         if (col < npiv) {                                           // uniform
             double piv = lane_bcast(p[j], col);
-            if (!(piv > 0.0)) { if (lane == 0) atomicExch(d.fail, 1); piv = 1.0; }
+            if (!(piv > 0.0)) { if (lane == 0) atomicMax(d.fail, 1); piv = 1.0; }
             const double s = sqrt(piv), inv = 1.0 / s;
             p[j] = (lane > col) ? p[j] * inv : (lane == col ? s : 0.0);
 #pragma unroll
@@ -1053,6 +1062,7 @@ __global__ void __launch_bounds__(256, 2) k_factor_mfma(DevGraph d, int level_of
     if (mode == FRONT_CONTRIB) {
         double *X = d.exchange + d.x_off[s];
         for (int c = 0; c < f; ++c) if (lane <= f) X[c * (f + 1) + lane] = (lane >= c) ? P.at(lane, c) : 0.0;
+        if (fi == 0 && lane == 0) contrib_publish_fail(d);
         return;
     }
     // ---- tiles -> accumulators
@@ -1309,7 +1319,7 @@ __device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[10], double 
         dd[j] = 0.0;
         if (is_pivot) {
             const double piv = lane_bcast(p[j], col);
-            bad = bad || !(piv > 0.0);                              // a non-positive (or NaN) pivot is reported once, at the end of the front
+            bad = bad || !(fabs(piv) > 0.0);                        // LDL^T: a ZERO pivot fails (Eigen 3.3.4 SimplicialCholesky_impl.h:172-176: d == 0), a negative one does not; NaN is reported too
             const double inv = rcp_f64(piv);
             const double lj = (lane >= col) ? p[j] * inv : 0.0;    // row col itself gets d / d = 1: a dead row in every later use
 #pragma unroll
@@ -1494,7 +1504,7 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
             bool okw = true;                                         // child 0's gather is issued while child 1 may still be working
             if (use[0]) { okw = f3_wait_flag(d.done_f + fr.c_id[0], d.epoch) && okw; f3_gather_child<true>(d.Uimg + fr.c_uoff[0], fr.c_usize[0], pv[0], lane, u0); }
             if (use[1]) { okw = f3_wait_flag(d.done_f + fr.c_id[1], d.epoch) && okw; f3_gather_child<true>(d.Uimg + fr.c_uoff[1], fr.c_usize[1], pv[1], lane, u1); }
-            if (!okw && lane == 0) atomicExch(d.fail, 2);
+            if (!okw && lane == 0) atomicMax(d.fail, 2);
         }
     }
     // ---- accumulators = originals + child 0 + child 1 (+ further children, rare)
@@ -1523,7 +1533,7 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
         if (mode == FRONT_CONTRIB && dc.z != d.rank) continue;
         if (top && dc.z >= 0) continue;
         const int pvx = d.pinv[(int64_t)dc.x * 64 + lane];
-        if (TREE && !f3_wait_flag(d.done_f + dc.x, d.epoch) && lane == 0) atomicExch(d.fail, 2);
+        if (TREE && !f3_wait_flag(d.done_f + dc.x, d.epoch) && lane == 0) atomicMax(d.fail, 2);
         f3_gather_child<TREE>(d.Uimg + d.u3_off[dc.x], d.u3_size[dc.x], pvx, lane, u0);
 #pragma unroll
         for (int t = 0; t < 10; ++t)
@@ -1539,6 +1549,7 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
         wave_lds_sync();
         double *X = d.exchange + fr.x_off;
         for (int c = 0; c < f; ++c) if (lane <= f) X[c * (f + 1) + lane] = (lane >= c) ? P.at(lane, c) : 0.0;
+        if (fi == 0 && lane == 0) contrib_publish_fail(d);
         return;
     }
     F3_TS(6);
@@ -1554,7 +1565,8 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
     go = go && f3_panel_step<10>(bad, acc, Pn, L, npiv, f, lane);  go = go && f3_panel_step<11>(bad, acc, Pn, L, npiv, f, lane);
     go = go && f3_panel_step<12>(bad, acc, Pn, L, npiv, f, lane);  go = go && f3_panel_step<13>(bad, acc, Pn, L, npiv, f, lane);
     go = go && f3_panel_step<14>(bad, acc, Pn, L, npiv, f, lane);  go = go && f3_panel_step<15>(bad, acc, Pn, L, npiv, f, lane);
-    if (bad && lane == 0) atomicExch(d.fail, 1);
+    if (d.inject_iter != 0 && d.iter == d.inject_iter && level_off + fi == 0 && lane == 0) atomicMax(d.fail, d.inject_code);   // gs_debug_fail_at_iteration (fault injection for tests)
+    if (bad && lane == 0) atomicMax(d.fail, 1);
     F3_TS(7);
     // ---- Schur complement out, packed: element (row, col) -> rowpart(row) + colpart(col) from the front's own table; pivot
     // rows / columns make the sum negative and the upper-triangle lanes of the diagonal tiles are forced there: the
@@ -1633,7 +1645,7 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
 #pragma unroll
         for (int cc = 1; cc < 32; ++cc) lcol[cc] = S[min(min(lane, cc - 1), npiv - 1) * lds + min(cc, f)];
         w = S[me * lds + f];
-        if (fr.parent >= 0 && !f3_wait_flag(d.done_b + fr.parent, d.epoch) && lane == 0) atomicExch(d.fail, 2);
+        if (fr.parent >= 0 && !f3_wait_flag(d.done_b + fr.parent, d.epoch) && lane == 0) atomicMax(d.fail, 2);
         const double xb = (row >= 0) ? ld_off_coh(d.xe, (uint32_t)row * 8u) : 0.0;        // 0 beyond the boundary: those terms vanish
         F3_TS(35);
 #pragma unroll
@@ -1840,8 +1852,17 @@ void launch_pose_trig(const DevGraph &d, hipStream_t st) {
 // ------------------------------------------------------------------ A9
 __global__ void __launch_bounds__(256) k_update(DevGraph d) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
+    // g2o: when the linear solve fails, OptimizationAlgorithmGaussNewton::solve returns Fail BEFORE update() and
+    // SparseOptimizer::optimize leaves its loop: the vertices keep the previous iterate (call site reference
+    // src/slam.cpp:481).  The iterations of a gs_optimize call are all enqueued up front, so the rule lives here: once
+    // the failure flag is up (zero pivot, a whole-tree launch that gave up on a flag, or — pose-window shards — a
+    // failure any rank reported with its contribution) no update is applied any more.  fail[1] counts applied updates.
+    const bool peer_failed = d.xfail_off >= 0 && d.exchange[d.xfail_off] != 0.0;
+    const bool stop = d.fail[0] != 0 || peer_failed || d.fail[2] != 0;       // fail[2]: gs_optimize_until's stop rule fired in an earlier iteration
+    if (t == 0) { if (stop) { if (peer_failed) atomicMax(d.fail, 3); } else atomicAdd(d.fail + 1, 1); }
     // pose-window shards: a rank only tracks the vertices of its own subtrees and of the shared top
-    if (t < d.N) {
+    if (stop) { }
+    else if (t < d.N) {
         int g = d.pose_known[t] ? d.pose_gidx[t] : -1;
         double dx = 0, dy = 0, dt = 0;
         if (g >= 0) { dx = d.xe[g]; dy = d.xe[g + 1]; dt = d.xe[g + 2];
@@ -1857,12 +1878,22 @@ __global__ void __launch_bounds__(256) k_update(DevGraph d) {
         d.dlm[2 * l] = dx; d.dlm[2 * l + 1] = dy;
     }
     // fused linearisation leaves one chi2 partial per wave tile: total them here (fixed order), no extra launch
-    if (blockIdx.x == gridDim.x - 1 && d.n_wtiles > 0) {
+    if (blockIdx.x == gridDim.x - 1) {
         __shared__ double red[8];
-        double s = 0.0;
-        for (int k = threadIdx.x; k < d.n_wtiles; k += 256) s += d.chi2_partial[k];
-        const double tot = block_sum(s, red);
-        if (threadIdx.x == 0) d.chi2[0] = tot;
+        double tot = 0.0;
+        if (d.n_wtiles > 0) {
+            double s = 0.0;
+            for (int k = threadIdx.x; k < d.n_wtiles; k += 256) s += d.chi2_partial[k];
+            tot = block_sum(s, red);
+            if (threadIdx.x == 0) d.chi2[0] = tot;
+        } else if (threadIdx.x == 0) tot = d.chi2[0];              // gather kernels: k_reduce_chi2 totalled it already
+        // stop rule of gs_optimize_until: this iteration's update has been applied; if the chi2 of its linearisation point
+        // is within conv_tol (relative) of the previous one, no later update is applied
+        if (threadIdx.x == 0 && d.conv_tol >= 0.0 && !stop) {
+            const double prev = d.chi2[70];
+            if (prev >= 0.0 && fabs(prev - tot) <= d.conv_tol * tot) d.fail[2] = 1;
+            d.chi2[70] = tot;
+        }
     }
 }
 void launch_update(const DevGraph &d, hipStream_t st) {

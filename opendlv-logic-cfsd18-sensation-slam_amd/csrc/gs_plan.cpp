@@ -388,6 +388,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         plan.x_off.assign(S, -1);
         for (int s : plan.level_fronts_shared) { const Front &F = plan.fronts[s]; const int64_t f = F.npiv + F.nbnd;
             plan.x_off[s] = plan.exchange_doubles; plan.exchange_doubles += (f + 1) * f; }
+        plan.exchange_doubles += 2;                // tail: [0] the ranks' failure flags (summed by the same all-reduce), [1] spare
     }
     plan.valid = true;
     GS_PT(7);

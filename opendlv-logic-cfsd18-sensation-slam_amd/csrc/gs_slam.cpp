@@ -32,7 +32,8 @@ struct gs_slam {
     // odometry intake (m_gpsReference, m_odometryData, m_yawRate; reference src/slam.cpp:154-219)
     double gps_reference[2] = {0, 0};                        // latitude, longitude (degrees)
     double odometry[3] = {0, 0, 0};                          // x, y (metres from the reference), heading
-    double yaw_rate = 0;
+    float yaw_rate = 0;                                      // m_yawRate is a float in the reference (src/slam.hpp:128)
+    int64_t yaw_received_us = 0, last_cone_us = 0;           // m_yawReceivedTime, m_lastTimeStamp (sample times, microseconds)
 };
 
 using gs::fail;
@@ -109,9 +110,97 @@ static double cone_distance(const MapCone &c, double x, double y) {     // dista
     return std::sqrt((c.x - x) * (c.x - x) + (c.y - y) * (c.y - y));
 }
 
-extern "C" int gs_slam_perform(gs_slam *s, const double pose[3], const double *cones, int32_t k) {
-    if (!s || !pose || k < 0 || (k > 0 && !cones)) return fail(GS_ERR_INVALID, "bad argument");
-    if (std::fabs(pose[0]) > 200 || std::fabs(pose[1]) > 200) return GS_OK;      // :300-303
+// the frame's A0 results: CoG-frame XY of every observation (edge measurement) and its global XY (association query)
+struct FrameXY { std::vector<double> zxy, gxy; };
+
+// addConesToMap, reference src/slam.cpp:552-635
+static int add_cones_to_map(gs_slam *s, const double pose[3], const double *cones, int k, const FrameXY &fx) {
+    int rc;
+    const std::vector<double> &zxy = fx.zxy, &gxy = fx.gxy;
+    std::vector<int32_t> pose_of(k, 0), idx(k, -1);
+    const bool quirks = s->cfg.reference_quirks != 0;
+    int first = 0;
+    if (s->map.empty()) {                                            // :554-567
+        MapCone c{gxy[0], gxy[1], (int)cones[3], 0};
+        s->map.push_back(c);
+        if ((rc = add_cone_to_graph(s, c, &zxy[0])) != GS_OK) return rc;
+        if (!quirks) first = 1;                     // the reference re-matches i = 0 and adds the edge twice
+    }
+    // A1 against the map as it stands at the start of the frame, on the device
+    const int m0 = (int)s->map.size();
+    { std::vector<double> mxy(2 * (size_t)m0); std::vector<int32_t> mty(m0);
+      for (int j = 0; j < m0; ++j) { mxy[2 * j] = s->map[j].x; mxy[2 * j + 1] = s->map[j].y; mty[j] = s->map[j].type; }
+      if ((rc = gs_associate_batch(s->g, k, pose, 1, pose_of.data(), cones, m0, mxy.data(), mty.data(),
+                                   s->cfg.same_cone_threshold, 1e-4, idx.data())) != GS_OK) return rc; }
+    double min_distance = 100;
+    bool optimise_pending = false;
+    for (int i = first; i < k; ++i) {                                // :570-634
+        const double d2car = cones[4 * i + 2], type_i = cones[4 * i + 3];
+        bool found = false; int j = -1;
+        if (!s->loop_closing) {                                      // the while loop's guard, :575
+            if (idx[i] >= 0) { found = true; j = idx[i]; }
+            else for (int t = m0; t < (int)s->map.size(); ++t)       // cones appended earlier in this frame
+                if (std::fabs(s->map[t].type - type_i) < 1e-4 && cone_distance(s->map[t], gxy[2 * i], gxy[2 * i + 1]) < s->cfg.same_cone_threshold) { found = true; j = t; break; }
+        }
+        if (found) {
+            if ((rc = add_cone_measurement(s, s->map[j].id, &zxy[2 * i])) != GS_OK) return rc;      // :591
+            // loopClosing(), :697-706, asked with m_currentConeIndex as it was BEFORE this match (:593 precedes :598)
+            if (cone_distance(s->map[0], s->map[j].x, s->map[j].y) < s->cfg.loop_closing_radius &&
+                s->current_cone_index > (uint32_t)s->cfg.loop_closing_min_index && d2car < s->cfg.cone_mapping_threshold && !s->loop_closing)
+                s->loop_closing = true;
+            if (d2car < min_distance) { s->current_cone_index = (uint32_t)j; min_distance = d2car; }
+        }
+        if (d2car < s->cfg.cone_mapping_threshold && !found && !s->loop_closing) {                 // :608-623
+            MapCone c{gxy[2 * i], gxy[2 * i + 1], (int)type_i, (int)s->map.size()};
+            s->map.push_back(c);
+            if ((rc = add_cone_to_graph(s, c, &zxy[2 * i])) != GS_OK) return rc;
+        }
+        if (s->loop_closing) {                                       // :625-633
+            if (quirks) { if ((rc = optimize_and_update_map(s)) != GS_OK) return rc; s->loop_closing_complete = true; }   // §8-B.2: once per remaining observation
+            else optimise_pending = true;
+        }
+    }
+    if (optimise_pending) { if ((rc = optimize_and_update_map(s)) != GS_OK) return rc; s->loop_closing_complete = true; }
+    return GS_OK;
+}
+
+// localizer, reference src/slam.cpp:340-414: re-associate against the frozen map, one more edge per re-observed cone,
+// the send pose is the raw estimate of the newest pose vertex (optimizeGraph is commented out there, :403)
+static int localizer(gs_slam *s, const double pose[3], const double *cones, int k, const FrameXY &fx) {
+    int rc;
+    const std::vector<double> &zxy = fx.zxy, &gxy = fx.gxy;
+    const bool quirks = s->cfg.reference_quirks != 0;
+    uint32_t current = s->current_cone_index; double min_distance = 100; int reobserved = 0;
+    for (int i = 0; i < k; ++i) {
+        const double d2car = cones[4 * i + 2]; const int type_i = (int)cones[4 * i + 3];          // static_cast<int>, :357
+        for (size_t j = 0; j < s->map.size(); ++j) {
+            // the reference omits fabs on the (integer) type difference (:360); kept only under reference_quirks
+            const double dt = (double)(s->map[j].type - type_i);
+            const bool type_ok = quirks ? (dt < 1e-4) : (std::fabs(dt) < 1e-4);
+            if (cone_distance(s->map[j], gxy[2 * i], gxy[2 * i + 1]) < s->cfg.same_cone_threshold && type_ok) {
+                ++reobserved;
+                double z[2] = {zxy[2 * i], zxy[2 * i + 1]};
+                if (quirks) {   // §8-B.4: the reference passes the POSE where (az, zen, dist) is expected (:373)
+                    if ((rc = gs_polar_to_xy_batch(s->g, 1, &pose[0], &pose[1], &pose[2], z)) != GS_OK) return rc;
+                }
+                if ((rc = add_cone_measurement(s, s->map[j].id, z)) != GS_OK) return rc;
+                if (d2car < min_distance) { current = (uint32_t)j; min_distance = d2car; }
+                break;
+            }
+        }
+    }
+    if (reobserved > 0) s->current_cone_index = current;            // :387 (uninitialised in the reference when nothing matched)
+    // updatePoseFromGraph (:416-422)
+    return gs_get_pose(s->g, s->pose_id - 1, s->send_pose);
+}
+
+extern "C" int gs_slam_perform(gs_slam *s, const double odometry[3], const double *cones, int32_t k) {
+    if (!s || !odometry || k < 0 || (k > 0 && !cones)) return fail(GS_ERR_INVALID, "bad argument");
+    if (std::fabs(odometry[0]) > 200 || std::fabs(odometry[1]) > 200) return GS_OK;      // :300-303
+    // heading compensated by the yaw rate over the time between the last yaw-rate and the last cone message (:306-318)
+    double pose[3] = {odometry[0], odometry[1], odometry[2]};
+    const double elapsed = std::fabs((double)(s->yaw_received_us - s->last_cone_us)) / 1000000.0;
+    if (elapsed > 0 && elapsed < 1) pose[2] = pose[2] - (double)s->yaw_rate * elapsed;
     s->poses.push_back({pose[0], pose[1], pose[2]});
     int rc;
     // ---- addPoseToGraph + addOdometryMeasurement (:433-459)
@@ -127,89 +216,19 @@ extern "C" int gs_slam_perform(gs_slam *s, const double pose[3], const double *c
         if ((rc = gs_add_odometry_edge(s->g, s->pose_id - 1, s->pose_id, z, info)) != GS_OK) return rc;
     }
     s->pose_id++;
-    if (k == 0) return GS_OK;
+    if (k == 0) return GS_OK;          // initializeCollection never passes an empty frame (:245)
 
     // ---- A0 for the whole frame on the device
-    std::vector<double> az(k), zen(k), dist(k), zxy(2 * (size_t)k), gxy(2 * (size_t)k);
-    std::vector<int32_t> pose_of(k, 0), idx(k, -1);
-    for (int i = 0; i < k; ++i) { az[i] = cones[4 * i]; zen[i] = cones[4 * i + 1]; dist[i] = cones[4 * i + 2]; }
-    if ((rc = gs_polar_to_xy_batch(s->g, k, az.data(), zen.data(), dist.data(), zxy.data())) != GS_OK) return rc;
-    if ((rc = gs_cone_to_global_batch(s->g, k, pose, 1, pose_of.data(), cones, gxy.data())) != GS_OK) return rc;
+    FrameXY fx; fx.zxy.resize(2 * (size_t)k); fx.gxy.resize(2 * (size_t)k);
+    { std::vector<double> az(k), zen(k), dist(k); std::vector<int32_t> pose_of(k, 0);
+      for (int i = 0; i < k; ++i) { az[i] = cones[4 * i]; zen[i] = cones[4 * i + 1]; dist[i] = cones[4 * i + 2]; }
+      if ((rc = gs_polar_to_xy_batch(s->g, k, az.data(), zen.data(), dist.data(), fx.zxy.data())) != GS_OK) return rc;
+      if ((rc = gs_cone_to_global_batch(s->g, k, pose, 1, pose_of.data(), cones, fx.gxy.data())) != GS_OK) return rc; }
 
-    if (!s->loop_closing_complete) {
-        // ---- addConesToMap (:552-635)
-        const bool quirks = s->cfg.reference_quirks != 0;
-        int first = 0;
-        if (s->map.empty()) {
-            MapCone c{gxy[0], gxy[1], (int)cones[3], 0};
-            s->map.push_back(c);
-            if ((rc = add_cone_to_graph(s, c, &zxy[0])) != GS_OK) return rc;
-            if (!quirks) first = 1;                     // the reference re-matches i = 0 and adds the edge twice
-        }
-        // A1 against the map as it stands at the start of the frame, on the device
-        const int m0 = (int)s->map.size();
-        { std::vector<double> mxy(2 * (size_t)m0); std::vector<int32_t> mty(m0);
-          for (int j = 0; j < m0; ++j) { mxy[2 * j] = s->map[j].x; mxy[2 * j + 1] = s->map[j].y; mty[j] = s->map[j].type; }
-          if ((rc = gs_associate_batch(s->g, k, pose, 1, pose_of.data(), cones, m0, mxy.data(), mty.data(),
-                                       s->cfg.same_cone_threshold, 1e-4, idx.data())) != GS_OK) return rc; }
-        double min_distance = 100;
-        bool optimise_pending = false;
-        for (int i = first; i < k; ++i) {
-            const double d2car = cones[4 * i + 2], type_i = cones[4 * i + 3];
-            bool found = false; int j = -1;
-            if (!s->loop_closing) {
-                if (idx[i] >= 0) { found = true; j = idx[i]; }
-                else for (int t = m0; t < (int)s->map.size(); ++t)       // cones appended earlier in this frame
-                    if (std::fabs(s->map[t].type - type_i) < 1e-4 && cone_distance(s->map[t], gxy[2 * i], gxy[2 * i + 1]) < s->cfg.same_cone_threshold) { found = true; j = t; break; }
-            }
-            if (found) {
-                if ((rc = add_cone_measurement(s, s->map[j].id, &zxy[2 * i])) != GS_OK) return rc;
-                // loopClosing(), :697-706
-                if (cone_distance(s->map[0], s->map[j].x, s->map[j].y) < s->cfg.loop_closing_radius &&
-                    s->current_cone_index > (uint32_t)s->cfg.loop_closing_min_index && d2car < s->cfg.cone_mapping_threshold && !s->loop_closing)
-                    s->loop_closing = true;
-                if (d2car < min_distance) { s->current_cone_index = (uint32_t)j; min_distance = d2car; }
-            }
-            if (d2car < s->cfg.cone_mapping_threshold && !found && !s->loop_closing) {
-                MapCone c{gxy[2 * i], gxy[2 * i + 1], (int)type_i, (int)s->map.size()};
-                s->map.push_back(c);
-                if ((rc = add_cone_to_graph(s, c, &zxy[2 * i])) != GS_OK) return rc;
-            }
-            if (s->loop_closing) {
-                if (quirks) { if ((rc = optimize_and_update_map(s)) != GS_OK) return rc; s->loop_closing_complete = true; }   // §8-B.2: once per remaining observation
-                else optimise_pending = true;
-            }
-        }
-        if (optimise_pending) { if ((rc = optimize_and_update_map(s)) != GS_OK) return rc; s->loop_closing_complete = true; }
-        return GS_OK;
-    }
-
-    // ---- localizer (:340-414), only with at least two cones (:332)
-    if (k > 1) {
-        const bool quirks = s->cfg.reference_quirks != 0;
-        uint32_t current = s->current_cone_index; double min_distance = 100; int reobserved = 0;
-        for (int i = 0; i < k; ++i) {
-            const double d2car = cones[4 * i + 2]; const int type_i = (int)cones[4 * i + 3];
-            for (size_t j = 0; j < s->map.size(); ++j) {
-                // the reference omits fabs on the type difference (:360); kept only under reference_quirks
-                const double dt = (double)(s->map[j].type - type_i);
-                const bool type_ok = quirks ? (dt < 1e-4) : (std::fabs(dt) < 1e-4);
-                if (cone_distance(s->map[j], gxy[2 * i], gxy[2 * i + 1]) < s->cfg.same_cone_threshold && type_ok) {
-                    ++reobserved;
-                    double z[2] = {zxy[2 * i], zxy[2 * i + 1]};
-                    if (quirks) {   // §8-B.4: the reference passes the POSE where (az, zen, dist) is expected (:373)
-                        if ((rc = gs_polar_to_xy_batch(s->g, 1, &pose[0], &pose[1], &pose[2], z)) != GS_OK) return rc;
-                    }
-                    if ((rc = add_cone_measurement(s, s->map[j].id, z)) != GS_OK) return rc;
-                    if (d2car < min_distance) { current = (uint32_t)j; min_distance = d2car; }
-                    break;
-                }
-            }
-        }
-        if (reobserved > 0) s->current_cone_index = current;
-        // updatePoseFromGraph (:416-422): the raw estimate of the last pose vertex; no re-optimisation (:403)
-        if ((rc = gs_get_pose(s->g, s->pose_id - 1, s->send_pose)) != GS_OK) return rc;
-    }
+    // two independent ifs in the reference (:329-334): the frame that completes the loop closure ALSO runs the localizer,
+    // against the map updateMap has just rewritten
+    if (!s->loop_closing_complete) { if ((rc = add_cones_to_map(s, pose, cones, k, fx)) != GS_OK) return rc; }
+    if (s->loop_closing_complete && k > 1) { if ((rc = localizer(s, pose, cones, k, fx)) != GS_OK) return rc; }
     return GS_OK;
 }
 
@@ -302,7 +321,14 @@ extern "C" int gs_slam_next_geolocation(gs_slam *s, double latitude_deg, double 
 // Slam::nextYawRate (:211-219)
 extern "C" int gs_slam_next_yaw_rate(gs_slam *s, double angular_velocity_z) {
     if (!s) return fail(GS_ERR_INVALID, "null handle");
-    s->yaw_rate = angular_velocity_z / 4;
+    s->yaw_rate = (float)angular_velocity_z / 4;              // float arithmetic as in the reference (:214)
+    return GS_OK;
+}
+// m_yawReceivedTime (:216) and m_lastTimeStamp (:73,102,129): sample times of the last yaw-rate message and of the last
+// cone message, microseconds.  performSLAM turns their distance into the heading compensation (:306-318).
+extern "C" int gs_slam_set_sample_times(gs_slam *s, int64_t yaw_received_us, int64_t last_cone_us) {
+    if (!s) return fail(GS_ERR_INVALID, "null handle");
+    s->yaw_received_us = yaw_received_us; s->last_cone_us = last_cone_us;
     return GS_OK;
 }
 extern "C" int gs_slam_get_odometry(gs_slam *s, double out_xy_heading_yawrate[4]) {

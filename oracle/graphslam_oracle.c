@@ -552,17 +552,20 @@ void orc_get_delta(const orc_graph *g, double *dpose, double *dlm) {
 }
 
 /* A10: g2o SparseOptimizer::optimize + OptimizationAlgorithmGaussNewton::solve, §8-A.7 */
-int orc_optimize(orc_graph *g, int iterations, int ordering, orc_solver_fn solver, void *ctx,
-                 double *chi2_out, double *tm) {
+int orc_optimize_until(orc_graph *g, int iterations, double rel_tol, int ordering, orc_solver_fn solver, void *ctx,
+                       double *chi2_out, double *tm, int *failed) {
     double t_all = now_ms();
-    int done = 0, analyze = !g->structure_valid;
+    int done = 0, analyze;
+    if (failed) *failed = 0;
     if (!g->structure_valid) build_structure(g);
     if (g->n == 0) return 0;
     analyze = 1;                                   /* initializeOptimization precedes every optimize() */
     double *x = (double *)calloc((size_t)g->n + 1, sizeof(double));
+    double prev = -1.0;
     for (int it = 0; it < iterations; ++it) {
         double t0 = now_ms();
-        if (chi2_out) chi2_out[it] = orc_chi2(g);
+        const double chi = orc_chi2(g);
+        if (chi2_out) chi2_out[it] = chi;
         orc_build_system(g);
         double t1 = now_ms();
         int rc;
@@ -570,13 +573,19 @@ int orc_optimize(orc_graph *g, int iterations, int ordering, orc_solver_fn solve
         else { if (analyze) g->ldlt_valid = 0; rc = orc_solve_ldlt(g, ordering, x); }
         analyze = 0;
         double t2 = now_ms();
-        if (rc != 0) break;
+        if (rc != 0) { if (failed) *failed = 1; break; }   /* g2o: Fail before update(); the previous iterate stays */
         orc_apply_update(g, x);
         double t3 = now_ms();
         if (tm) { tm[0] += t1 - t0; tm[2] += t2 - t1; tm[3] += t3 - t2; }
         ++done;
+        if (rel_tol >= 0.0 && prev >= 0.0 && fabs(prev - chi) <= rel_tol * chi) break;
+        prev = chi;
     }
     free(x);
     if (tm) tm[4] += now_ms() - t_all;
     return done;
+}
+int orc_optimize(orc_graph *g, int iterations, int ordering, orc_solver_fn solver, void *ctx,
+                 double *chi2_out, double *tm) {
+    return orc_optimize_until(g, iterations, -1.0, ordering, solver, ctx, chi2_out, tm, NULL);
 }

@@ -104,9 +104,16 @@ void orc_get_delta(const orc_graph *g, double *dpose, double *dlm);
 /* A10: iterations x (errors, build, solve, update); chi2_out[it] = chi2 at the linearisation
  * point of iteration it (may be NULL); solver==NULL -> own LDLT with `ordering`.
  * timings_ms[5] (may be NULL) accumulates linearise+assemble / analyse / factor+solve / update / total.
- * returns iterations performed (0 if the first factorisation fails). */
+ * returns the iterations whose update was applied.  g2o's SparseOptimizer::optimize leaves its loop at the first
+ * failed solve, BEFORE that iteration's update, and returns 0 then (reference call site src/slam.cpp:481); the
+ * vertices keep the previous iterate.  *failed (may be NULL) tells the two outcomes apart. */
 int  orc_optimize(orc_graph *g, int iterations, int ordering, orc_solver_fn solver, void *solver_ctx,
                   double *chi2_out, double *timings_ms);
+/* the same with the build-defined stop rule of BASELINE config 2 ("optimise to convergence"; the reference has none,
+ * SURVEY §0.5): after the update of iteration it >= 1, stop if |chi2[it-1] - chi2[it]| <= rel_chi2_tol * chi2[it]
+ * (chi2 at the linearisation points).  rel_chi2_tol < 0: no stop rule. */
+int  orc_optimize_until(orc_graph *g, int max_iterations, double rel_chi2_tol, int ordering, orc_solver_fn solver,
+                        void *solver_ctx, double *chi2_out, double *timings_ms, int *failed);
 
 #ifdef __cplusplus
 }

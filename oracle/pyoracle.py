@@ -59,6 +59,7 @@ def lib():
         L.orc_associate_fixed_map.argtypes =[C.c_int, _dp, _ip, _dp, C.c_int, _dp, _ip,
                                               C.c_double, C.c_double, C.c_double, _ip]
         L.orc_optimize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, _dp, _dp]
+        L.orc_optimize_until.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, _dp, _dp, _ip]
         for f in ("orc_destroy", "orc_add_poses", "orc_add_landmarks", "orc_add_odometry_edges",
                   "orc_add_observation_edges", "orc_set_fixed_pose", "orc_set_fixed_landmark",
                   "orc_num_poses", "orc_num_landmarks", "orc_num_odometry_edges",
@@ -235,6 +236,15 @@ class OracleGraph:
         ctx = solver.ctx if solver is not None else None
         done = self.L.orc_optimize(self.g, iterations, ordering, fn, ctx, _d(chi), _d(tm))
         return done, chi[:iterations], tm
+
+    def optimize_until(self, max_iterations, rel_chi2_tol, ordering=1, solver=None):
+        """The stop rule of BASELINE config 2 (rel_chi2_tol < 0: none).  Returns (updates_applied, chi2[it], failed)."""
+        chi = np.zeros(max(max_iterations, 1)); tm = np.zeros(5); failed = C.c_int(0)
+        fn = solver.fn if solver is not None else None
+        ctx = solver.ctx if solver is not None else None
+        done = self.L.orc_optimize_until(self.g, max_iterations, float(rel_chi2_tol), ordering, fn, ctx, _d(chi), _d(tm),
+                                         C.byref(failed))
+        return done, chi[:max_iterations], bool(failed.value)
 
 
 class OracleFrontend:

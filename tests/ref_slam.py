@@ -4,8 +4,10 @@ Cone::getDirection / getDistance (src/slam.cpp:656-677, src/cone.cpp:34-53), per
 (:552-635), addConeToGraph/addConeMeasurement (:525-550), loopClosing (:697-706), optimizeGraph (:461-484),
 updateMap (:713-732), localizer (:340-414), updatePoseFromGraph (:416-422).
 
-It is the checker for the product's host mirror csrc/gs_slam.cpp (C++ over the HIP C-ABI): two independent
-implementations of the same control flow, one on the oracle, one on the GPU path.  `quirks=False` is the
+It is the checker for the product's host mirror csrc/gs_slam.cpp (C++ over the HIP C-ABI).  perform / _add_cones_to_map /
+_localizer follow the reference's text statement by statement (line numbers in the comments), with the oracle's A0 and
+the oracle's optimiser underneath; tests/test_gpu_parity.py additionally asserts facts read off the reference directly
+(edges added in the loop-closing frame, the pose published there) so that the product is not only compared with this twin.  `quirks=False` is the
 documented clean mode (SURVEY §8-B items 1, 2, 4 off); `quirks=True` keeps them."""
 import numpy as np
 
@@ -24,6 +26,9 @@ class RefSlam:
         self.send_pose = np.zeros(3)
         self.optimise_calls = 0
         self.collector = np.zeros((4, 1000)); self.last_object_id = 0; self.new_frame = True
+        self.poses = []                    # m_poses
+        self.yaw_rate = np.float32(0.0); self.yaw_received_us = 0; self.last_cone_us = 0
+        self.localizer_calls = 0
 
     # --- frame collector (reference src/slam.cpp:67-152, 221-257; the wait and the keyframe gate are transport timing)
     def _collect(self, object_id, rows, vals):
@@ -74,71 +79,102 @@ class RefSlam:
         for c in self.map:
             c[0], c[1] = L[c[3]]
 
-    def perform(self, pose, cones):
-        pose = np.asarray(pose, dtype=np.float64); cones = np.asarray(cones, dtype=np.float64).reshape(-1, 4)
-        if abs(pose[0]) > 200 or abs(pose[1]) > 200:
+    # --- odometry side inputs of performSLAM (reference src/slam.cpp:211-219, :73,102,129)
+    def next_yaw_rate(self, wz):
+        self.yaw_rate = np.float32(np.float32(wz) / np.float32(4))        # float m_yawRate (src/slam.hpp:128)
+
+    def set_sample_times(self, yaw_received_us, last_cone_us):
+        self.yaw_received_us, self.last_cone_us = int(yaw_received_us), int(last_cone_us)
+
+    # --- performSLAM, reference src/slam.cpp:298-338, statement by statement
+    def perform(self, odometry, cones):
+        odometry = np.asarray(odometry, dtype=np.float64); cones = np.asarray(cones, dtype=np.float64).reshape(-1, 4)
+        if abs(odometry[0]) > 200 or abs(odometry[1]) > 200:              # :300-303
             return
+        pose = odometry.copy()                                            # :307
+        elapsed = abs(float(self.yaw_received_us - self.last_cone_us)) / 1000000.0     # :309
+        if 0 < elapsed < 1:                                               # :315-317
+            pose[2] = pose[2] - float(self.yaw_rate) * elapsed
+        self.poses.append(pose.copy())                                    # :319
+        self._add_pose_to_graph(pose)                                     # :325
+        if len(cones) == 0:                                               # never happens in the reference (:245)
+            return
+        if not self.loop_closing_complete:                                # :329-331
+            self._add_cones_to_map(cones, pose)
+        if self.loop_closing_complete and len(cones) > 1:                 # :332-334 — a second, independent if
+            self._localizer(pose, cones)
+
+    # addPoseToGraph + addOdometryMeasurement, :433-459
+    def _add_pose_to_graph(self, pose):
         self.g.add_poses([pose])
-        if self.n_poses > 0:
+        if self.n_poses > 0:                                              # m_poseId > 1000
             prev = self.g.poses()[self.n_poses - 1]
-            L = po.lib()
-            inv = np.zeros(3); z = np.zeros(3)
+            L = po.lib(); inv = np.zeros(3); z = np.zeros(3)
             L.orc_se2_inverse(po._d(np.ascontiguousarray(prev)), po._d(inv)); L.orc_se2_compose(po._d(inv), po._d(pose.copy()), po._d(z))
             self.g.add_odometry_edges([self.n_poses - 1], [self.n_poses], [z], (5 * np.eye(3)).reshape(1, 9))
         self.n_poses += 1
+
+    # addConesToMap, :552-635
+    def _add_cones_to_map(self, cones, pose):
         K = len(cones)
-        if K == 0:
-            return
+        zxy = self.fe.polar_to_xy(cones[:, 0], cones[:, 1], cones[:, 2])          # Spherical2Cartesian of (az, zen, dist), :539
+        gxy = self.fe.cone_to_global(pose[None], np.zeros(K, dtype=np.int32), cones)   # coneToGlobal, :572
+        first = 0
+        if not self.map:                                                  # :554-567
+            self._add_cone(gxy[0], int(cones[0, 3]), zxy[0])
+            if not self.quirks:
+                first = 1                                                 # clean mode drops the duplicate edge (§8-B.1)
+        min_distance = 100.0; pending = False
+        for i in range(first, K):                                         # :570
+            d2car, ty = cones[i, 2], cones[i, 3]
+            found, j = False, 0
+            while not found and j < len(self.map) and not self.loop_closing:      # :575
+                c = self.map[j]
+                if abs(c[2] - ty) < 0.0001:                               # :576
+                    if np.sqrt((c[0] - gxy[i, 0]) ** 2 + (c[1] - gxy[i, 1]) ** 2) < self.thr:       # :579, :584
+                        found = True
+                        self._add_measurement(c[3], zxy[i])               # :591
+                        if self._loop_closing_candidate(c, d2car) and not self.loop_closing:       # :593
+                            self.loop_closing = True
+                        if d2car < min_distance:                          # :598
+                            self.current_cone_index = j; min_distance = d2car
+                j += 1
+            if d2car < self.map_thr and not found and not self.loop_closing:      # :608
+                self._add_cone(gxy[i], int(ty), zxy[i])
+            if self.loop_closing:                                         # :625
+                if self.quirks:
+                    self._optimise(); self.loop_closing_complete = True   # once per remaining observation (§8-B.2)
+                else:
+                    pending = True
+        if pending:
+            self._optimise(); self.loop_closing_complete = True
+
+    def _loop_closing_candidate(self, c, d2car):                          # loopClosing, :697-706
+        d = np.sqrt((self.map[0][0] - c[0]) ** 2 + (self.map[0][1] - c[1]) ** 2)
+        return d < 1 and self.current_cone_index > 20 and d2car < self.map_thr
+
+    # localizer, :340-414
+    def _localizer(self, pose, cones):
+        K = len(cones)
         zxy = self.fe.polar_to_xy(cones[:, 0], cones[:, 1], cones[:, 2])
         gxy = self.fe.cone_to_global(pose[None], np.zeros(K, dtype=np.int32), cones)
-        if not self.loop_closing_complete:
-            first = 0
-            if not self.map:
-                self._add_cone(gxy[0], cones[0, 3], zxy[0])
-                if not self.quirks:
-                    first = 1
-            min_distance = 100.0; pending = False
-            for i in range(first, K):
-                d2car, ty = cones[i, 2], cones[i, 3]
-                found, j = False, -1
-                if not self.loop_closing:
-                    for t, c in enumerate(self.map):
-                        if abs(c[2] - ty) < 1e-4 and np.hypot(c[0] - gxy[i, 0], c[1] - gxy[i, 1]) < self.thr:
-                            found, j = True, t
-                            break
-                if found:
-                    self._add_measurement(self.map[j][3], zxy[i])
-                    if (np.hypot(self.map[0][0] - self.map[j][0], self.map[0][1] - self.map[j][1]) < 1.0 and
-                            self.current_cone_index > 20 and d2car < self.map_thr and not self.loop_closing):
-                        self.loop_closing = True
-                    if d2car < min_distance:
-                        self.current_cone_index = j; min_distance = d2car
-                if d2car < self.map_thr and not found and not self.loop_closing:
-                    self._add_cone(gxy[i], ty, zxy[i])
-                if self.loop_closing:
-                    if self.quirks:
-                        self._optimise(); self.loop_closing_complete = True
-                    else:
-                        pending = True
-            if pending:
-                self._optimise(); self.loop_closing_complete = True
-            return
-        if K > 1:
-            current, min_distance, reobserved = self.current_cone_index, 100.0, 0
-            for i in range(K):
-                d2car, ty = cones[i, 2], int(cones[i, 3])
-                for j, c in enumerate(self.map):
-                    dt = c[2] - ty
-                    type_ok = (dt < 1e-4) if self.quirks else (abs(dt) < 1e-4)
-                    if np.hypot(c[0] - gxy[i, 0], c[1] - gxy[i, 1]) < self.thr and type_ok:
-                        reobserved += 1
-                        z = zxy[i]
-                        if self.quirks:
-                            z = self.fe.polar_to_xy([pose[0]], [pose[1]], [pose[2]])[0]
-                        self._add_measurement(c[3], z)
-                        if d2car < min_distance:
-                            current, min_distance = j, d2car
-                        break
-            if reobserved > 0:
-                self.current_cone_index = current
-            self.send_pose = self.g.poses()[self.n_poses - 1].copy()
+        reobserved, min_distance, current = 0, 100.0, None                # currentConeIndex is uninitialised at :348
+        for i in range(K):
+            d2car, ty = cones[i, 2], int(cones[i, 3])                     # static_cast<int>(coneObservedGlobal(2)), :357
+            j, found = 0, False
+            while not found and j < len(self.map):                        # :355
+                c = self.map[j]
+                dt = c[2] - ty                                            # int - int, no fabs in the reference (:360)
+                type_ok = (dt < 0.0001) if self.quirks else (abs(dt) < 0.0001)
+                if np.sqrt((c[0] - gxy[i, 0]) ** 2 + (c[1] - gxy[i, 1]) ** 2) < self.thr and type_ok:
+                    reobserved += 1; found = True
+                    # addConeMeasurement(m_map[j], pose), :373: the POSE goes where (az, zen, dist) is expected (§8-B.4)
+                    z = self.fe.polar_to_xy([pose[0]], [pose[1]], [pose[2]])[0] if self.quirks else zxy[i]
+                    self._add_measurement(c[3], z)
+                    if d2car < min_distance:                              # :375-378
+                        current = j; min_distance = d2car
+                j += 1
+        if reobserved > 0:                                                # :387
+            self.current_cone_index = current
+        self.send_pose = self.g.poses()[self.n_poses - 1].copy()          # updatePoseFromGraph, :404-408, :416-422
+        self.localizer_calls += 1

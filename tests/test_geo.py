@@ -58,7 +58,7 @@ def test_slam_intake_and_pose_encoding(pkg, ref):
         assert np.allclose(S.odometry()[:2], ref.ref_to_cartesian(r, (r[0] + 0.001, r[1] - 0.002)), rtol=0, atol=1e-8)
         S.next_geolocation(r[0] - 0.0005, r[1] + 0.0007, 1.25); S.next_yaw_rate(0.8)
         o = S.odometry()
-        assert np.allclose(o[:2], ref.ref_to_cartesian(r, (r[0] - 0.0005, r[1] + 0.0007)), rtol=0, atol=1e-8) and o[2] == 1.25 and o[3] == 0.2
+        assert np.allclose(o[:2], ref.ref_to_cartesian(r, (r[0] - 0.0005, r[1] + 0.0007)), rtol=0, atol=1e-8) and o[2] == 1.25 and o[3] == float(np.float32(0.8) / np.float32(4))    # float m_yawRate, src/slam.hpp:128
         enc = S.encode_pose()                                          # send pose is still (0, 0, 0): the reference point itself
         latlon = ref.ref_from_cartesian(r, (0.0, 0.0))
         want = (latlon[0], latlon[1]) if quirks else (latlon[1], latlon[0])

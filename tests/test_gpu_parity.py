@@ -227,14 +227,90 @@ def test_gauge_and_fixed_vertices_untouched(pkg, bench_graphs):
     G.close()
 
 
-def test_not_positive_definite_returns_zero_like_g2o(pkg):
-    # no gauge at all and a lone pose chain: H is singular -> a pivot is not positive -> 0 iterations
+def test_singular_system_returns_zero_and_leaves_the_estimates_like_g2o(pkg):
+    # no gauge at all, no information on theta: H has exact zero rows -> a pivot is exactly 0 -> Eigen's LDLT reports
+    # failure (SimplicialCholesky_impl.h:172-176), g2o's optimize() returns 0 and never calls update()
     G = pkg.Graph()
-    G.add_poses([0, 1, 2], np.zeros((3, 3)))
-    z = np.zeros((2, 3)); info = np.tile((np.diag([1.0, 1.0, 0.0])).reshape(1, 9), (2, 1))
+    P0 = np.array([[0.0, 0, 0], [1.1, 0.2, 0.1], [2.3, -0.1, 0.2]])
+    G.add_poses([0, 1, 2], P0)
+    z = np.array([[1.0, 0, 0], [1.0, 0, 0]]); info = np.tile((np.diag([1.0, 1.0, 0.0])).reshape(1, 9), (2, 1))
     G.add_odometry_edges([0, 1], [1, 2], z, info)
-    done, st = G.optimize(2)
-    assert done == 0 and st.numeric_failure == 1
+    done, st = G.optimize(3)
+    assert done == 0 and st.numeric_failure == 1 and st.iterations == 0
+    assert np.array_equal(G.poses(), P0)                        # not one update applied
+    G.close()
+
+
+def test_failed_iteration_keeps_the_last_good_iterate_like_g2o(pkg, po, bench_graphs):
+    """g2o: `ok = solver->solve(); if (!ok) return Fail;` comes BEFORE `update()`, and SparseOptimizer::optimize leaves
+    its loop and returns 0 (call site reference src/slam.cpp:481): after a failure in iteration 3 of 5 the vertices hold
+    the iterate of iteration 2.  Here all five iterations are enqueued up front, so the rule has to hold on the device."""
+    _, g = bench_graphs(1000, 200)
+    og = make_oracle_graph(po, g); og.optimize(2, ordering=1)
+    G = fresh(pkg, g); G.initialize_optimization()
+    G.debug_fail_at_iteration(3, 1)                             # fault injection: the third iteration reports a zero pivot
+    done, st = G.optimize(5)
+    assert done == 0 and st.numeric_failure == 1 and st.iterations == 2
+    assert rel(G.poses(), og.poses()) < 1e-9 and rel(G.landmarks(), og.landmarks()) < 1e-9
+    done, st = G.optimize(3); og.optimize(3, ordering=1)       # the handle is usable again: 2 + 3 iterations
+    assert done == 3 and st.numeric_failure == 0
+    assert rel(G.poses(), og.poses()) < 1e-9 and rel(G.landmarks(), og.landmarks()) < 1e-9
+    G.close()
+
+
+def test_front_flag_timeout_falls_back_to_level_launches_and_finishes(pkg, po, bench_graphs):
+    """A whole-tree launch that gives up on a front's flag (code 2) applies no update either; gs_optimize then switches the
+    handle to one launch per level and runs the remaining iterations from the last good iterate."""
+    _, g = bench_graphs(1000, 200)
+    og = make_oracle_graph(po, g); og.optimize(5, ordering=1)
+    G = fresh(pkg, g); G.initialize_optimization()
+    G.debug_fail_at_iteration(3, 2)
+    done, st = G.optimize(5)
+    assert done == 5 and st.numeric_failure == 0 and st.iterations == 5
+    assert rel(G.poses(), og.poses()) < 1e-9 and rel(G.landmarks(), og.landmarks()) < 1e-9
+    G.close()
+
+
+def test_iterate_path_surfaces_a_failure_once_and_keeps_the_last_good_iterate(pkg, po, bench_graphs):
+    _, g = bench_graphs(1000, 200)
+    og = make_oracle_graph(po, g); og.optimize(1, ordering=1)
+    G = fresh(pkg, g); G.initialize_optimization()
+    G.debug_fail_at_iteration(2, 1)
+    for _ in range(4):
+        G.iterate()                                            # asynchronous: nothing to report yet
+    with pytest.raises(pkg.GsError) as e:
+        G.sync_estimates()
+    assert e.value.code == -8                                   # GS_ERR_NUMERIC
+    assert rel(G.poses(), og.poses()) < 1e-9 and rel(G.landmarks(), og.landmarks()) < 1e-9      # iteration 1 only
+    G.synchronize()                                            # reported once, cleared
+    for _ in range(2):
+        G.iterate()
+    G.sync_estimates(); og.optimize(2, ordering=1)
+    assert rel(G.poses(), og.poses()) < 1e-9 and rel(G.landmarks(), og.landmarks()) < 1e-9
+    G.debug_fail_at_iteration(1, 2); G.iterate()               # flag timeout: its own error code
+    with pytest.raises(pkg.GsError) as e:
+        G.synchronize()
+    assert e.value.code == -10                                  # GS_ERR_TIMEOUT
+    G.iterate(); G.sync_estimates(); og.optimize(1, ordering=1)
+    assert rel(G.poses(), og.poses()) < 1e-9
+    G.close()
+
+
+@pytest.mark.parametrize("N,M,tol", [(1000, 200, 1e-9), (1000, 200, 1e-4), (50, 30, 1e-12)])
+def test_optimize_until_stops_where_the_oracle_stops(pkg, po, bench_graphs, N, M, tol):
+    """BASELINE config 2, "1k poses / 200 cones, optimise to convergence": the reference has no stop rule (SURVEY §0.5);
+    the build-defined one (relative chi2 change between consecutive linearisation points) is evaluated on the device
+    and restated in the oracle — both must stop after the same iteration with the same estimates."""
+    _, g = bench_graphs(N, M)
+    og = make_oracle_graph(po, g); done_o, chi_o, failed = og.optimize_until(40, tol, ordering=1)
+    G = fresh(pkg, g); done, st = G.optimize_until(40, tol)
+    assert not failed and st.numeric_failure == 0
+    assert done == done_o and 2 <= done < 40, (done, done_o)
+    rms = np.sqrt((og.poses()[:, :2] ** 2).sum(1).mean())
+    assert np.abs(G.poses() - og.poses()).max() / rms < 1e-9 and np.abs(G.landmarks() - og.landmarks()).max() / rms < 1e-9
+    assert abs(st.chi2_final - og.chi2()) <= 1e-6 * og.chi2()
+    G.iterate(); G.sync_estimates(); og.optimize(1, ordering=1)                # the stop flag does not linger
+    assert np.abs(G.poses() - og.poses()).max() / rms < 1e-9
     G.close()
 
 
@@ -332,9 +408,10 @@ def test_irregular_graphs_one_step_matches_oracle(pkg, po, shape):
 # ---------------------------------------------------------------- f-1: the Slam host mirror (performSLAM graph side)
 @pytest.mark.parametrize("quirks", [0, 1])
 def test_slam_mirror_frame_by_frame_matches_reference_logic(pkg, quirks):
-    """csrc/gs_slam.cpp (C++ over the HIP C-ABI) against tests/ref_slam.py (Python over the CPU oracle), fed the same
-    keyframes: odometry pose + 4 x K cone collector matrix per frame, through loop closure (optimizeGraph + updateMap,
-    reference src/slam.cpp:625-633) and a few localizer frames after it (reference src/slam.cpp:340-414)."""
+    """csrc/gs_slam.cpp (C++ over the HIP C-ABI) against tests/ref_slam.py (the reference's performSLAM / addConesToMap /
+    localizer restated statement by statement over the CPU oracle), fed the same keyframes: odometry pose + yaw rate +
+    sample times + 4 x K cone collector matrix per frame, through loop closure (optimizeGraph + updateMap, reference
+    src/slam.cpp:625-633), the localizer call of that same frame (:332-334) and a few localizer frames after it."""
     from ref_slam import RefSlam
     N, M = 120, 60
     t = pkg.track.generate(N, M)
@@ -342,21 +419,63 @@ def test_slam_mirror_frame_by_frame_matches_reference_logic(pkg, quirks):
     R = RefSlam(same_cone_threshold=1.2, cone_mapping_threshold=67.0, quirks=bool(quirks))
     frames = list(range(N)) + list(range(6))               # one lap, then re-drive the first frames (localizer mode)
     closed_at = None
+    rng = np.random.default_rng(11)
     for n, k in enumerate(frames):
+        # yaw-rate heading compensation (:306-318): dt = 0 (none), inside (0, 1) s (applied), beyond 1 s (none)
+        wz = float(np.float32(rng.normal(0, 0.3))); dt_us = [0, 40000, 250000, 1500000][n % 4]
+        for X in (S, R):
+            X.next_yaw_rate(wz); X.set_sample_times(10_000_000 + 100_000 * n + dt_us, 10_000_000 + 100_000 * n)
         S.perform_slam(t["odom_poses"][k], t["obs"][k]); R.perform(t["odom_poses"][k], t["obs"][k])
         assert S.map_size == len(R.map), (n, S.map_size, len(R.map))
         assert S.loop_closed == R.loop_closing_complete, n
         assert S.current_cone_index == R.current_cone_index, n
+        assert S.graph.n_pl == R.g.n_pl and S.graph.n_pp == R.g.n_pp, n
+        assert np.abs(S.send_pose() - R.send_pose).max() < 1e-7, n
         if closed_at is None and S.loop_closed:
             closed_at = n
+            assert R.localizer_calls == 1                   # the closing frame itself ran the localizer
     assert closed_at is not None and closed_at < N          # the lap closes on re-observing the first cone
+    assert R.localizer_calls == len(frames) - closed_at
     xy, ty = S.map()
     Rm = np.array([[c[0], c[1]] for c in R.map]); Rt = np.array([c[2] for c in R.map])
     assert np.array_equal(ty, Rt)
     assert np.abs(xy - Rm).max() < 1e-7                     # optimised map, GPU vs oracle
-    assert np.abs(S.send_pose() - R.send_pose).max() < 1e-7
-    assert S.graph.n_poses == R.n_poses and S.graph.n_pl == R.g.n_pl and S.graph.n_pp == R.g.n_pp
+    assert S.graph.n_poses == R.n_poses
     assert np.abs(S.graph.poses() - R.g.poses()).max() < 1e-7
+    # the compensated heading is what entered the graph and m_poses: frames with 0 < dt < 1 differ from the raw odometry
+    P0 = np.array(R.poses)
+    assert np.abs(P0[1, 2] - (t["odom_poses"][1][2])) > 0 and P0[0, 2] == t["odom_poses"][0][2] and P0[3, 2] == t["odom_poses"][3][2]
+    S.close()
+
+
+def test_loop_closing_frame_runs_the_localizer_too_like_the_reference(pkg, frontend):
+    """Facts read off the reference, not off the twin: `if(!m_loopClosingComplete) addConesToMap(...)` and
+    `if(m_loopClosingComplete && cones.cols() > 1) localizer(...)` are two separate ifs (src/slam.cpp:329-334), so the
+    frame in which addConesToMap completes the loop closure ALSO (a) adds one edge per observation that re-matches the map
+    updateMap has just rewritten (:360-373), (b) publishes m_sendPose = the estimate of the newest pose vertex, which that
+    frame's optimizeGraph moved (:404-408, :416-422), (c) sets m_currentConeIndex to the nearest re-observed cone (:375-387)."""
+    N, M = 120, 60
+    t = pkg.track.generate(N, M)
+    S = pkg.Slam(same_cone_threshold=1.2, cone_mapping_threshold=67.0, reference_quirks=0)
+    k = 0
+    while not S.loop_closed:
+        assert np.array_equal(S.send_pose(), np.zeros(3))            # m_sendPose << 0,0,0 until the first localizer call (:49)
+        before = S.graph.n_pl
+        S.perform_slam(t["odom_poses"][k], t["obs"][k]); k += 1
+        assert k <= N
+    k -= 1                                                            # the closing frame
+    obs, pose = np.asarray(t["obs"][k]), np.asarray(t["odom_poses"][k])
+    xy, ty = S.map()                                                  # the map AFTER updateMap
+    idx = frontend.associate(pose[None], np.zeros(len(obs), dtype=np.int32), obs, xy, ty, 1.2)
+    n_loc = int((idx >= 0).sum())
+    assert n_loc >= 2
+    added = S.graph.n_pl - before
+    assert n_loc + 1 <= added <= n_loc + len(obs)                     # localizer edges + the addConesToMap edges up to the closing match
+    last = S.graph.get_pose(1000 + k)
+    assert np.array_equal(S.send_pose(), last)                        # (b)
+    assert np.abs(last - pose).max() > 1e-9                           # the optimised estimate, not the raw odometry
+    matched = np.where(idx >= 0)[0]
+    assert S.current_cone_index == int(idx[matched[np.argmin(obs[matched, 2])]])      # (c)
     S.close()
 
 
@@ -389,6 +508,34 @@ def test_sharded_iterations_match_oracle(pkg, po, bench_graphs, world, N, M):
     assert np.sqrt(((L - og.landmarks()) ** 2).sum(1).mean()) / rms < 1e-6
     assert np.abs(P[:, 2] - og.poses()[:, 2]).max() < 1e-6
     # every rank evaluated only its own share of the edges
+    for G in ranks:
+        G.close()
+
+
+def test_sharded_failure_on_one_rank_stops_every_rank(pkg, po, bench_graphs):
+    """A zero pivot in ONE rank's own subtree: its flag travels with the contribution through the all-reduce, every
+    rank skips that iteration's update and all later ones — the merged estimates are the oracle's after iteration 1."""
+    world, (N, M) = 2, (1000, 200)
+    _, g = bench_graphs(N, M)
+    ranks = []
+    for r in range(world):
+        G = fresh(pkg, g); G.dist_configure(r, world); G.initialize_optimization(); ranks.append(G)
+    ranks[1].debug_fail_at_iteration(2, 1)
+    for _ in range(3):
+        for G in ranks:
+            G.dist_iterate_local()
+        total = sum(G.dist_read_exchange() for G in ranks)
+        for G in ranks:
+            G.dist_write_exchange(total); G.dist_iterate_finish()
+    P = np.zeros((N, 3)); L = np.zeros((len(g["lm_est"]), 2))
+    for G in ranks:
+        with pytest.raises(pkg.GsError) as e:
+            G.sync_estimates()
+        assert e.value.code == -8
+        pk, lk, pprim, lprim = G.dist_known()
+        P += G.poses() * pprim[:, None]; L += G.landmarks() * lprim[:, None]
+    og = make_oracle_graph(po, g); og.optimize(1, ordering=1)
+    assert rel(P, og.poses()) < 1e-9 and rel(L, og.landmarks()) < 1e-9
     for G in ranks:
         G.close()
 

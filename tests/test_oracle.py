@@ -238,3 +238,21 @@ def test_golden_fixture_config1(po, pkg):
     # the generator is deterministic: the committed inputs are what the track source produces today
     t = pkg.track.generate(50, 30)
     assert np.array_equal(t["obs"], z["track_obs"]) and np.array_equal(t["odom_poses"], z["track_odom"])
+
+
+def test_optimize_until_stop_rule_and_failure_semantics(po, pkg, frontend):
+    """The build-defined stop rule (the reference has none) and g2o's failure rule in the oracle."""
+    t = pkg.track.generate(50, 30); g = pkg.track.bench_graph(t, frontend)
+    og = make_oracle_graph(po, g)
+    done, chi, failed = og.optimize_until(40, 1e-9)
+    assert not failed and 2 <= done < 40
+    assert abs(chi[done - 2] - chi[done - 1]) <= 1e-9 * chi[done - 1]           # the rule fired at the last iteration ...
+    assert all(abs(chi[k - 1] - chi[k]) > 1e-9 * chi[k] for k in range(1, done - 1))   # ... and not before
+    og2 = make_oracle_graph(po, g); d2, _, _ = og2.optimize_until(done, -1.0)   # no rule: same iterate after the same count
+    assert d2 == done and np.array_equal(og.poses(), og2.poses())
+    # singular system: the first solve fails, no update is applied (g2o returns 0, vertices untouched)
+    s = po.OracleGraph(); P0 = np.array([[0.0, 0, 0], [1.1, 0.2, 0.1], [2.3, -0.1, 0.2]]); s.add_poses(P0)
+    info = np.tile(np.diag([1.0, 1.0, 0.0]).reshape(1, 9), (2, 1))
+    s.add_odometry_edges([0, 1], [1, 2], np.array([[1.0, 0, 0], [1.0, 0, 0]]), info)
+    done, _, failed = s.optimize_until(3, -1.0, ordering=0)
+    assert done == 0 and failed and np.array_equal(s.poses(), P0)
