@@ -469,9 +469,9 @@ static int upload_graph(gs_graph *g) {
               r[0] = sidx; r[1] = F.npiv; r[2] = F.nbnd; r[3] = F.asm_off; r[4] = F.asm_cnt - F.asm_dup; r[5] = F.asm_dup;
               r[6] = F.child_cnt; r[7] = F.child_off; r[8] = (int32_t)(F.L_off & 0xffffffffLL); r[9] = (int32_t)(F.L_off >> 32);
               r[10] = F.piv0; r[11] = (int32_t)F.bnd_off;
-              for (int k = 0; k < 2; ++k) { r[12 + k] = -1; r[14 + k] = 0; r[16 + k] = 0;
+              for (int k = 0; k < 2; ++k) { r[12 + k] = -1; r[16 + k] = 0;
                   if (k < F.child_cnt) { const int c = P.children[F.child_off + k]; const Front &C = P.fronts[c];
-                      r[12 + k] = c; r[14 + k] = C.npiv | (C.nbnd << 16); r[16 + k] = C.owner; r[26 + k] = u3_off[c]; r[28 + k] = u3_size[c]; } }
+                      r[12 + k] = c; r[16 + k] = C.owner; r[26 + k] = u3_off[c]; r[28 + k] = u3_size[c]; } }
               r[24] = u3_off[sidx]; r[25] = u3_size[sidx]; r[31] = F.level;
               r[30] = (F.parent >= 0 && P.fronts[F.parent].owner == F.owner) ? F.parent : -1;   // whole-tree backward solve: wait for a parent of the SAME launch only (own in own, shared in shared; a subtree root's shared parent ran earlier)
               const int64_t xo = (P.world > 1 && (size_t)sidx < P.x_off.size()) ? P.x_off[sidx] : 0;
@@ -530,6 +530,16 @@ static int upload_graph(gs_graph *g) {
             for (size_t q = 0; q < lf.size(); ++q) { int32_t *r = &fd[F3W * q]; const int sidx = lf[q];
                 r[20] = sc_off[sidx]; r[21] = sc_cnt[sidx]; r[22] = lm_off[sidx]; r[23] = lm_cnt[sidx]; }
             UP(sc3, sc); UP(lm3, lm); }
+          std::vector<int32_t> xtab;                          // third and later children: [row table 64 | front, u offset, u size, owner, 0 0 0 0] each
+          for (size_t q = 0; q < lf.size(); ++q) { int32_t *r = &fd[F3W * q]; const Front &F = P.fronts[lf[q]];
+              r[14] = (int32_t)xtab.size();
+              for (int k = 2; k < F.child_cnt; ++k) { const int c = P.children[F.child_off + k];
+                  xtab.insert(xtab.end(), pinv.begin() + 64 * (size_t)c, pinv.begin() + 64 * (size_t)c + 64);
+                  const int32_t hdr[8] = {c, u3_off[c], u3_size[c], P.fronts[c].owner, 0, 0, 0, 0};
+                  xtab.insert(xtab.end(), hdr, hdr + 8); }
+              if (xtab.size() >= ((size_t)1 << 30)) return fail(GS_ERR_INVALID, "extra-children table too large"); }
+          xtab.resize(xtab.size() + 72, 0);
+          UP(f3_x, xtab);
           for (size_t q = 0; q < lf.size(); ++q) { int32_t *r = &fd[F3W * q];
               for (int k = 0; k < 2; ++k) { const int c = r[12 + k];
                   for (int R = 0; R < 64; ++R) r[32 + 64 * k + R] = c >= 0 ? pinv[64 * (size_t)c + R] : pinv_none; }
@@ -578,6 +588,7 @@ static int upload_graph(gs_graph *g) {
 static int build_plan_host(gs_graph *g) {
     PlanOptions o; o.leaf_poses = g->cfg.leaf_poses; o.world = g->world; o.rank = g->rank;
     if (const char *e = std::getenv("GS_LEAF_POSES")) o.leaf_poses = std::atoi(e);       // tuning override
+    if (const char *e = std::getenv("GS_CLUSTER_WAYS")) o.cluster_ways = std::atoi(e);   // tuning override: 2 = binary dissection down to the leaves
     if (const char *e = std::getenv("GS_ELL_LANES")) o.ell_lanes = std::atoi(e);       // tuning knob: lanes per pose of the ELL layout
     std::string err;
     if (!build_plan(g->h, o, g->plan, err)) { g->plan_version = ~0ull; return fail(GS_ERR_EMPTY, "plan: " + err); }

@@ -69,6 +69,7 @@ struct DevGraph {
     double *Uimg = nullptr;                                     // variant 2: update matrices as 16x16 tile images; variant 3: packed lower triangles (u3_off, u3_size)
     // variant 3 (latency-shaped MFMA/LDL^T kernels): flat per-level descriptors, value-ready assembly records,
     // per-front inverse row maps into the parent (formats: gs_kernels.hip, "variant 3")
+    int32_t *f3_x = nullptr;                                    // row tables + headers of the third and later children of a front (72 ints per child)
     int32_t *f3_desc = nullptr, *asm3 = nullptr, *pinv = nullptr, *sc3 = nullptr, *lm3 = nullptr, *u3_off = nullptr, *u3_size = nullptr;
     int32_t *done_f = nullptr, *done_b = nullptr; int32_t epoch = 0, tree = 0;   // whole-tree launches: per-front completion flags (= epoch when done)
     double *H_arena = nullptr;                                  // Hpp_diag | b_pose | Hpp_off | Hpl | lm_part | Hll_diag | b_lm, one allocation

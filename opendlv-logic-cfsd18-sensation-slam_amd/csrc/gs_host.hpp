@@ -102,7 +102,8 @@ struct Plan {
     double ms_build = 0;
 };
 
-struct PlanOptions { int leaf_poses = 8; int world = 1; int rank = 0; int ell_lanes = 0; };
+struct PlanOptions { int leaf_poses = 8; int world = 1; int rank = 0; int ell_lanes = 0;
+                     int cluster_ways = 0; };      // fan-out of the multi-way split above the leaves (0 = default 8, <= 2 = binary all the way down)
 
 constexpr int LIN_R = 4;               // observation slots per lane handled by the fused linearisation kernel
 

@@ -1136,7 +1136,8 @@ __global__ void __launch_bounds__(256, 2) k_factor_mfma(DevGraph d, int level_of
 //      backward solve has a unit diagonal (no division there either).
 // Record formats (built in gs_api.cpp upload_graph):
 //   f3_desc [level position][24] int32: 0 front, 1 npiv, 2 nbnd, 3 asm_off, 4 #unique records, 5 #duplicate records,
-//      6 #children, 7 child_off, 8-9 L_off, 10 piv0, 11 bnd_off, 12-13 child front (-1 none), 14-15 child npiv | nbnd << 16,
+//      6 #children, 7 child_off, 8-9 L_off, 10 piv0, 11 bnd_off, 12-13 child front (-1 none), 14 offset of the front's table of third and later children in f3_x (F3X ints per child:
+//      its 64-entry row table, then {front, update-matrix offset, size, owner}), 15 unused,
 //      16-17 child owner, 18-19 exchange slot offset, 20 sc_off, 21 #scalar records (multiple of 64), 22 lm_off, 23 #landmark records
 //   sc3 [scalar][2]: {offset of the value in H_arena, offset in the staging image}: the original blocks flattened to
 //      scalars, so the assembly is branch-free (load record, load value, one LDS store)
@@ -1154,18 +1155,18 @@ __global__ void __launch_bounds__(256, 2) k_factor_mfma(DevGraph d, int level_of
 //      The tables of a front's first two children and the front's own store table (row of the front -> {rowpart,
 //      colpart}) sit right behind its descriptor (f3_desc stride 224 ints): known after the FIRST round trip.
 struct F3 {
-    int s, npiv, nbnd, asm_off, asm_uniq, asm_dup, nchild, child_off, piv0, bnd_off, c_id[2], c_info[2], c_owner[2];
+    int s, npiv, nbnd, asm_off, asm_uniq, asm_dup, nchild, child_off, piv0, bnd_off, c_id[2], x_tab, c_owner[2];
     int sc_off, sc_cnt, lm_off, lm_cnt, u_off, u_size, c_uoff[2], c_usize[2], parent, level;
     int64_t L_off, x_off;
 };
-static constexpr int F3_INTS = 32, F3_STRIDE = 224;   // 32 descriptor ints, pinv of child 0, pinv of child 1, own store table (64 ints each)
+static constexpr int F3_INTS = 32, F3_STRIDE = 224, F3X = 72;   // 32 descriptor ints, pinv of child 0, pinv of child 1, own store table (64 ints each)
 __device__ __forceinline__ F3 f3_load(const int32_t *desc, int idx, int lane) {
     const int v = (lane < F3_INTS) ? desc[(int64_t)idx * F3_STRIDE + lane] : 0;
     auto g = [&](int i) { return __builtin_amdgcn_readlane(v, i); };
     F3 r;
     r.s = g(0); r.npiv = g(1); r.nbnd = g(2); r.asm_off = g(3); r.asm_uniq = g(4); r.asm_dup = g(5); r.nchild = g(6); r.child_off = g(7);
     r.L_off = (int64_t)(uint32_t)g(8) | ((int64_t)g(9) << 32); r.piv0 = g(10); r.bnd_off = g(11);
-    r.c_id[0] = g(12); r.c_id[1] = g(13); r.c_info[0] = g(14); r.c_info[1] = g(15); r.c_owner[0] = g(16); r.c_owner[1] = g(17);
+    r.c_id[0] = g(12); r.c_id[1] = g(13); r.x_tab = g(14); r.c_owner[0] = g(16); r.c_owner[1] = g(17);
     r.x_off = (int64_t)(uint32_t)g(18) | ((int64_t)g(19) << 32);
     r.sc_off = g(20); r.sc_cnt = g(21); r.lm_off = g(22); r.lm_cnt = g(23);
     r.u_off = g(24); r.u_size = g(25); r.c_uoff[0] = g(26); r.c_uoff[1] = g(27); r.c_usize[0] = g(28); r.c_usize[1] = g(29); r.parent = g(30); r.level = g(31);
@@ -1528,17 +1529,31 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
         for (int t = 0; t < 10; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[t][q] += u1[t][q]; }
-    for (int ci = 2; !LEAF && ci < fr.nchild; ++ci) {
-        const int4 dc = reinterpret_cast<const int4 *>(d.child_desc)[fr.child_off + ci];    // {front, npiv | nbnd << 16, owner, map offset}
-        if (mode == FRONT_CONTRIB && dc.z != d.rank) continue;
-        if (top && dc.z >= 0) continue;
-        const int pvx = d.pinv[(int64_t)dc.x * 64 + lane];
-        if (TREE && !f3_wait_flag(d.done_f + dc.x, d.epoch) && lane == 0) atomicMax(d.fail, 2);
-        f3_gather_child<TREE>(d.Uimg + d.u3_off[dc.x], d.u3_size[dc.x], pvx, lane, u0);
+    // third and later children (the multi-way splits above the leaves have up to 8), one at a time through the first
+    // child's gather registers (acc + two gather sets is all the register file holds at two waves per SIMD); a child's
+    // row table and {front, offset, size, owner} header come from one table per front (f3_x) and are fetched while the
+    // previous child's gather is in flight — one round trip per extra child, no descriptor / pinv / offset lookups
+    if (!LEAF && fr.nchild > 2) {
+        const int ne = fr.nchild - 2;
+        const int32_t *xt = d.f3_x + fr.x_tab;
+        const bool plain = !TREE || (fr.level == 1 && leaf_slot != 0);     // children complete and visible: no flags, cached loads
+        int pa = xt[lane], ha = xt[64 + (lane & 7)];
+        for (int e = 0; e < ne; ++e) {
+            const int a_id = __builtin_amdgcn_readlane(ha, 0), a_uoff = __builtin_amdgcn_readlane(ha, 1), a_usz = __builtin_amdgcn_readlane(ha, 2), a_own = __builtin_amdgcn_readlane(ha, 3);
+            const bool ua = !(mode == FRONT_CONTRIB && a_own != d.rank) && !(top && a_own >= 0);
+            if (ua) {
+                if (plain) f3_gather_child<false>(d.Uimg + a_uoff, a_usz, pa, lane, u0);
+                else { if (!f3_wait_flag(d.done_f + a_id, d.epoch) && lane == 0) atomicMax(d.fail, 2);
+                       f3_gather_child<true>(d.Uimg + a_uoff, a_usz, pa, lane, u0); }
+            }
+            const int en = min(e + 1, ne - 1);                             // the next child's table (the last one re-reads its own)
+            pa = xt[en * F3X + lane]; ha = xt[en * F3X + 64 + (lane & 7)];
+            if (ua) {
 #pragma unroll
-        for (int t = 0; t < 10; ++t)
+                for (int t = 0; t < 10; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[t][q] += u0[t][q];
+                    for (int q = 0; q < 4; ++q) acc[t][q] += u0[t][q]; }
+        }
     }
     wave_lds_sync();
     if (!LEAF && mode == FRONT_CONTRIB) {                            // this rank's share of a shared front -> exchange slot

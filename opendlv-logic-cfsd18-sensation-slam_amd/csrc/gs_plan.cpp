@@ -90,6 +90,50 @@ struct Builder {
 
     void emit(std::vector<int32_t> &&verts) { if (!verts.empty()) sn.push_back(std::move(verts)); }
 
+    // Multi-way split at the bottom of the tree.  Binary dissection down to the leaves leaves three levels of
+    // separators that are ONE pose each (3 pivots: the cones around them are seen from far outside such a short range
+    // and belong to separators higher up) — 14 336 of cfg4's 32 767 fronts, each paying a whole front's latency (child
+    // gather, one panel, update matrix out) for three pivots.  A range of up to `cluster_ways` leaves is therefore cut
+    // by all its split poses AT ONCE: they form one separator supernode (3 (p - 1) pivots) whose p children are the
+    // leaves.  Bounded so that neither the cluster front nor a leaf can exceed the 63 scalars of the wave-per-front
+    // kernels: rows <= separator poses + cones alive in the range + the two poses outside it.
+    bool nd_multi(int a, int b, int un, std::vector<int32_t> &cones) {
+        const int ways = opt.cluster_ways;
+        if (ways <= 2) return false;
+        int p = std::min(ways, (un + 1 + opt.leaf_poses) / (opt.leaf_poses + 1));       // ceil((un + 1) / (leaf + 1)) parts
+        if (p <= 2 || un > ways * (opt.leaf_poses + 1) - 1) return false;
+        while (p > 2 && 3 * (p - 1) + 2 * (int)cones.size() + 6 > 60) --p;
+        if (p <= 2) return false;
+        // split poses: the unassigned ones at ranks (un * k) / p, k = 1 .. p - 1
+        std::vector<int32_t> un_pos; un_pos.reserve(un);
+        for (int i = a; i < b; ++i) if (!assigned[i]) un_pos.push_back(i);
+        std::vector<int32_t> sep_poses;
+        std::vector<int32_t> cut;                                        // part k = positions (cut[k], cut[k + 1])
+        cut.push_back(a - 1);
+        for (int k = 1; k < p; ++k) { const int m = un_pos[(size_t)((int64_t)un * k / p)];
+            if (assigned[m]) continue; assigned[m] = 1; sep_poses.push_back(m); cut.push_back(m); }
+        cut.push_back(b);
+        const int np = (int)cut.size() - 1;
+        auto part_of = [&](int i) { int k = 0; while (k + 1 < np && i > cut[k + 1]) ++k; return k; };
+        // pose-pose edges that still span two parts pull their later endpoint into the separator
+        for (int i : un_pos) { if (assigned[i]) continue;
+            for (int q = inc_start[i]; q < inc_start[i + 1]; ++q) { if (inc[q].kind > 1) continue;
+                const int j = inc[q].other; if (j <= i || j < a || j >= b || assigned[j]) continue;
+                if (part_of(j) != part_of(i)) { assigned[j] = 1; sep_poses.push_back(j); } } }
+        std::vector<std::vector<int32_t>> part_cones(np);
+        std::vector<int32_t> sep_cones, orphans;
+        for (int l : cones) { int hit = -1, n = 0;
+            for (int k = 0; k < np && n < 2; ++k) if (has_observer(l, cut[k] + 1, cut[k + 1])) { hit = k; ++n; }
+            if (n >= 2) sep_cones.push_back(l); else if (n == 1) part_cones[hit].push_back(l); else orphans.push_back(l); }
+        cones.clear(); cones.shrink_to_fit();
+        if (!orphans.empty()) { std::vector<int32_t> v; for (int l : orphans) v.push_back(nfp + l); emit(std::move(v)); }
+        for (int k = 0; k < np; ++k) nd(cut[k] + 1, cut[k + 1], part_cones[k]);
+        std::vector<int32_t> verts(sep_poses.begin(), sep_poses.end());
+        for (int l : sep_cones) verts.push_back(nfp + l);
+        emit(std::move(verts));
+        return true;
+    }
+
     // nested dissection over free-pose positions [a, b); `cones` = free landmarks alive in this range
     void nd(int a, int b, std::vector<int32_t> &cones) {
         int un = 0;
@@ -101,6 +145,7 @@ struct Builder {
             emit(std::move(verts));
             return;
         }
+        if (nd_multi(a, b, un, cones)) return;
         // split pose: the middle unassigned one
         int m = -1, seen = 0;
         for (int i = a; i < b; ++i) if (!assigned[i]) { if (seen == un / 2) { m = i; break; } ++seen; }
@@ -137,6 +182,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     plan = Plan();
     PlanOptions opt = opt_in;
     if (opt.leaf_poses <= 0) opt.leaf_poses = 8;
+    if (opt.cluster_ways <= 0) opt.cluster_ways = 8;
     Builder B(g, opt);
     B.index_vertices();
     if (B.nv == 0) { err = "no free vertex"; return false; }
