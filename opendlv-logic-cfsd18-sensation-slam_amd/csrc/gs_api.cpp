@@ -352,6 +352,8 @@ static void se2_inverse_host(const double *a, double *out) {
 
 static int upload_graph(gs_graph *g) {
     const HostGraph &h = g->h; const Plan &P = g->plan; DevGraph &d = g->d;
+    const bool ut_on = std::getenv("GS_PLAN_TIMING") != nullptr; auto ut_prev = std::chrono::steady_clock::now();
+#define GS_UT(name) do { if (ut_on) { auto n_ = std::chrono::steady_clock::now(); std::fprintf(stderr, "upload %-18s %.2f ms\n", (name), std::chrono::duration<double, std::milli>(n_ - ut_prev).count()); ut_prev = n_; } } while (0)
     const int N = h.n_poses(), M = h.n_lms(), Epp = h.n_pp(), Epl = h.n_pl();
     d.N = N; d.M = M; d.Epp = Epp; d.Epl = Epl; d.n_scalar = P.n_scalar;
     g->leaf_n = -1;
@@ -375,6 +377,7 @@ static int upload_graph(gs_graph *g) {
           double *o = &zi[5 * (size_t)pos]; o[0] = inv[0]; o[1] = inv[1]; o[2] = inv[2]; o[3] = std::cos(inv[2]); o[4] = std::sin(inv[2]);
           for (int t = 0; t < 6; ++t) w[6 * (size_t)pos + t] = h.pp_info[6 * (size_t)k + t]; }
       UP(pp_zinv, zi); UP(pp_info, w); }
+    GS_UT("estimates+edges");
     UP(lm_start, P.lm_start); UP(lm_edges, P.lm_edges); UP(ppadj_start, P.ppadj_start);
     { std::vector<int32_t> inc = P.ppinc;                                 // incidences of edges another rank evaluates: edge = -1
       if (P.world > 1) for (size_t q = 0; q * 4 < inc.size(); ++q) if (P.pp_rank[inc[4 * q]] != P.rank) inc[4 * q] = -1;
@@ -412,6 +415,7 @@ static int upload_graph(gs_graph *g) {
     d.n_chi2_partial = std::max((N + 255) / 256, d.n_wtiles);
     AL(chi2_partial, d.n_chi2_partial); AL(chi2, 80); ZERO(chi2_partial, d.n_chi2_partial);
     UP(pose_known, P.pose_known); UP(lm_known, P.lm_known);
+    GS_UT("tiles+arena");
     // plan
     { std::vector<DevFront> df(P.fronts.size());
       for (size_t s = 0; s < P.fronts.size(); ++s) { const Front &F = P.fronts[s]; DevFront &o = df[s];
@@ -437,6 +441,7 @@ static int upload_graph(gs_graph *g) {
       for (size_t t = 0; t < P.asm_recs.size(); ++t) { recs[4 * t] = P.asm_recs[t].kind; recs[4 * t + 1] = P.asm_recs[t].src;
           recs[4 * t + 2] = P.asm_recs[t].r0; recs[4 * t + 3] = P.asm_recs[t].c0; }
       UP(asm_recs, recs); }
+    GS_UT("plan arrays");
     // factor kernel variant (gs_config.factor_variant, GS_FACTOR_VARIANT overrides): 0 = default = 3 when every front
     // fits 63 scalars, else 4.  3 = wave-per-front LDL^T on the fp64 matrix cores, latency-shaped; 2 = wave-per-front
     // Cholesky on the matrix cores (first version); 1 = wave-per-front VALU; 4 = block-per-front VALU (any front size).
@@ -498,6 +503,7 @@ static int upload_graph(gs_graph *g) {
                 for (int i = 0; i < C.nbnd; ++i) row[P.child_map[C.map_off + i]] = pack(i, true);
                 row[Pa.npiv + Pa.nbnd] = pack(C.nbnd, false); } }
           UP(pinv, pinv);
+          GS_UT("f3 desc+asm3+pinv");
           // scalar assembly records {offset in H_arena, offset in the staging image}, padded per front to a multiple of
           // 64 with (0 -> image offset 1, a don't-care upper-triangle slot); fused landmark diagonals go to lm3
           { std::vector<int32_t> sc, lm; std::vector<int32_t> sc_off(P.fronts.size()), sc_cnt(P.fronts.size()), lm_off(P.fronts.size()), lm_cnt(P.fronts.size());
@@ -529,7 +535,9 @@ static int upload_graph(gs_graph *g) {
             if (sc.size() / 2 >= ((size_t)1 << 31)) return fail(GS_ERR_INVALID, "too many assembly scalars");
             for (size_t q = 0; q < lf.size(); ++q) { int32_t *r = &fd[F3W * q]; const int sidx = lf[q];
                 r[20] = sc_off[sidx]; r[21] = sc_cnt[sidx]; r[22] = lm_off[sidx]; r[23] = lm_cnt[sidx]; }
+            GS_UT("sc3 build");
             UP(sc3, sc); UP(lm3, lm); }
+          GS_UT("sc3 upload");
           std::vector<int32_t> xtab;                          // third and later children: [row table 64 | front, u offset, u size, owner, 0 0 0 0] each
           for (size_t q = 0; q < lf.size(); ++q) { int32_t *r = &fd[F3W * q]; const Front &F = P.fronts[lf[q]];
               r[14] = (int32_t)xtab.size();
@@ -548,6 +556,7 @@ static int upload_graph(gs_graph *g) {
               for (int R = 0; R < 64; ++R) r[160 + R] = (R >= np && R <= np + nb) ? pack(R - np, R < np + nb) : pinv_none; }
           UP(f3_desc, fd);
       } }
+    GS_UT("f3 x+desc upload");
     AL(dbg_ts, 64); ZERO(dbg_ts, 64);
     AL(done_ts, 2 * P.fronts.size() + 2); ZERO(done_ts, 2 * P.fronts.size() + 2);
     AL(Lbuf, P.l_doubles); AL(Ubuf, P.u_doubles); AL(xe, P.n_scalar); AL(dpose, (size_t)N * 3); AL(dlm, (size_t)M * 2); AL(fail, 4);
@@ -579,7 +588,9 @@ static int upload_graph(gs_graph *g) {
 #undef UP
 #undef AL
 #undef ZERO
+    GS_UT("arenas+levels");
     HIP_TRY(hipStreamSynchronize(g->stream));
+    GS_UT("final sync");
     g->dev_valid = true; g->dev_estimates_newer = false;
     g->dev_estimate_version = h.estimate_version;
     return GS_OK;

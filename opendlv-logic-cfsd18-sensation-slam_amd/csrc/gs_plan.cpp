@@ -102,29 +102,44 @@ struct Builder {
         if (ways <= 2) return false;
         int p = std::min(ways, (un + 1 + opt.leaf_poses) / (opt.leaf_poses + 1));       // ceil((un + 1) / (leaf + 1)) parts
         if (p <= 2 || un > ways * (opt.leaf_poses + 1) - 1) return false;
-        while (p > 2 && 3 * (p - 1) + 2 * (int)cones.size() + 6 > 60) --p;
-        if (p <= 2) return false;
-        // split poses: the unassigned ones at ranks (un * k) / p, k = 1 .. p - 1
         std::vector<int32_t> un_pos; un_pos.reserve(un);
         for (int i = a; i < b; ++i) if (!assigned[i]) un_pos.push_back(i);
-        std::vector<int32_t> sep_poses;
-        std::vector<int32_t> cut;                                        // part k = positions (cut[k], cut[k + 1])
-        cut.push_back(a - 1);
-        for (int k = 1; k < p; ++k) { const int m = un_pos[(size_t)((int64_t)un * k / p)];
-            if (assigned[m]) continue; assigned[m] = 1; sep_poses.push_back(m); cut.push_back(m); }
-        cut.push_back(b);
+        // boundary of the cluster front = what the subtree (these poses + the cones alive here) touches outside itself:
+        // poses across pose-pose edges (the separators of the ranges around it) and cones that already belong to a
+        // separator higher up.  Exact, whatever p is.
+        int nb = 0;
+        { std::vector<int32_t> seen_p, seen_c;
+          auto alive = [&](int l) { return std::find(cones.begin(), cones.end(), l) != cones.end(); };
+          for (int i : un_pos) for (int q = inc_start[i]; q < inc_start[i + 1]; ++q) { const int o = inc[q].other;
+              if (inc[q].kind <= 1) { if ((o < a || o >= b || assigned[o]) && std::find(seen_p.begin(), seen_p.end(), o) == seen_p.end()) seen_p.push_back(o); }
+              else { const int l = o - nfp; if (std::find(seen_c.begin(), seen_c.end(), l) == seen_c.end()) seen_c.push_back(l); } }
+          int bc = 0; for (int l : seen_c) bc += !alive(l);
+          nb = 3 * (int)seen_p.size() + 2 * bc; }
+        std::vector<int32_t> sep_poses, cut, sep_cones, orphans;
+        std::vector<std::vector<int32_t>> part_cones;
+        for (;; --p) {
+            if (p <= 2) return false;
+            sep_poses.clear(); cut.clear(); sep_cones.clear(); orphans.clear();
+            // split poses: the unassigned ones at ranks (un * k) / p, k = 1 .. p - 1; part k = positions (cut[k], cut[k + 1])
+            cut.push_back(a - 1);
+            for (int k = 1; k < p; ++k) { const int m = un_pos[(size_t)((int64_t)un * k / p)];
+                if (assigned[m]) continue; assigned[m] = 1; sep_poses.push_back(m); cut.push_back(m); }
+            cut.push_back(b);
+            const int np = (int)cut.size() - 1;
+            auto part_of = [&](int i) { int k = 0; while (k + 1 < np && i > cut[k + 1]) ++k; return k; };
+            // pose-pose edges that still span two parts pull their later endpoint into the separator
+            for (int i : un_pos) { if (assigned[i]) continue;
+                for (int q = inc_start[i]; q < inc_start[i + 1]; ++q) { if (inc[q].kind > 1) continue;
+                    const int j = inc[q].other; if (j <= i || j < a || j >= b || assigned[j]) continue;
+                    if (part_of(j) != part_of(i)) { assigned[j] = 1; sep_poses.push_back(j); } } }
+            part_cones.assign(np, {});
+            for (int l : cones) { int hit = -1, n = 0;
+                for (int k = 0; k < np && n < 2; ++k) if (has_observer(l, cut[k] + 1, cut[k + 1])) { hit = k; ++n; }
+                if (n >= 2) sep_cones.push_back(l); else if (n == 1) part_cones[hit].push_back(l); else orphans.push_back(l); }
+            if (3 * (int)sep_poses.size() + 2 * (int)sep_cones.size() + nb <= 63) break;       // the cluster front fits a wave
+            for (int m : sep_poses) assigned[m] = 0;                // too big: fewer parts (their larger pieces are dissected further)
+        }
         const int np = (int)cut.size() - 1;
-        auto part_of = [&](int i) { int k = 0; while (k + 1 < np && i > cut[k + 1]) ++k; return k; };
-        // pose-pose edges that still span two parts pull their later endpoint into the separator
-        for (int i : un_pos) { if (assigned[i]) continue;
-            for (int q = inc_start[i]; q < inc_start[i + 1]; ++q) { if (inc[q].kind > 1) continue;
-                const int j = inc[q].other; if (j <= i || j < a || j >= b || assigned[j]) continue;
-                if (part_of(j) != part_of(i)) { assigned[j] = 1; sep_poses.push_back(j); } } }
-        std::vector<std::vector<int32_t>> part_cones(np);
-        std::vector<int32_t> sep_cones, orphans;
-        for (int l : cones) { int hit = -1, n = 0;
-            for (int k = 0; k < np && n < 2; ++k) if (has_observer(l, cut[k] + 1, cut[k + 1])) { hit = k; ++n; }
-            if (n >= 2) sep_cones.push_back(l); else if (n == 1) part_cones[hit].push_back(l); else orphans.push_back(l); }
         cones.clear(); cones.shrink_to_fit();
         if (!orphans.empty()) { std::vector<int32_t> v; for (int l : orphans) v.push_back(nfp + l); emit(std::move(v)); }
         for (int k = 0; k < np; ++k) nd(cut[k] + 1, cut[k + 1], part_cones[k]);
