@@ -5,6 +5,7 @@
 #include "gs_device.hpp"
 #include "gs_host.hpp"
 #include "gs_internal.hpp"
+#include "gs_parallel.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -366,16 +367,18 @@ static int upload_graph(gs_graph *g) {
     d.ell_T = P.ell_T; d.ell_R = P.ell_R; d.ell_len = P.ell_len;
     { const size_t L = (size_t)P.ell_len;                                                                    // ELL streams
       std::vector<int32_t> l(L, -1); std::vector<double> z(L * 2, 0.0), w(L * 3, 0.0);
-      for (size_t e = 0; e < L; ++e) { const int k = P.ell_ins[e]; if (k < 0) continue;
+      parallel_chunks((int64_t)L, 1 << 15, [&](int64_t b, int64_t e1, int) {
+      for (size_t e = (size_t)b; e < (size_t)e1; ++e) { const int k = P.ell_ins[e]; if (k < 0) continue;
           if (P.world > 1 && P.pl_rank[k] != P.rank) continue;          // pose-window shards: evaluated by another rank
           l[e] = h.pl_l[k]; z[e] = h.pl_z[2 * (size_t)k]; z[L + e] = h.pl_z[2 * (size_t)k + 1];
-          for (int t = 0; t < 3; ++t) w[t * L + e] = h.pl_info[3 * (size_t)k + t]; }
+          for (int t = 0; t < 3; ++t) w[t * L + e] = h.pl_info[3 * (size_t)k + t]; } });
       UP(ell_l, l); UP(ell_z, z); UP(ell_w, w); }
     { std::vector<double> zi((size_t)Epp * 5), w((size_t)Epp * 6);
-      for (int pos = 0; pos < Epp; ++pos) { int k = P.pp_order[pos];
+      parallel_chunks((int64_t)Epp, 1 << 13, [&](int64_t b, int64_t e1, int) {
+      for (int pos = (int)b; pos < (int)e1; ++pos) { int k = P.pp_order[pos];
           double inv[3]; se2_inverse_host(&h.pp_z[3 * (size_t)k], inv);
           double *o = &zi[5 * (size_t)pos]; o[0] = inv[0]; o[1] = inv[1]; o[2] = inv[2]; o[3] = std::cos(inv[2]); o[4] = std::sin(inv[2]);
-          for (int t = 0; t < 6; ++t) w[6 * (size_t)pos + t] = h.pp_info[6 * (size_t)k + t]; }
+          for (int t = 0; t < 6; ++t) w[6 * (size_t)pos + t] = h.pp_info[6 * (size_t)k + t]; } });
       UP(pp_zinv, zi); UP(pp_info, w); }
     GS_UT("estimates+edges");
     UP(lm_start, P.lm_start); UP(lm_edges, P.lm_edges); UP(ppadj_start, P.ppadj_start);
@@ -506,37 +509,27 @@ static int upload_graph(gs_graph *g) {
           GS_UT("f3 desc+asm3+pinv");
           // scalar assembly records {offset in H_arena, offset in the staging image}, padded per front to a multiple of
           // 64 with (0 -> image offset 1, a don't-care upper-triangle slot); fused landmark diagonals go to lm3
-          { std::vector<int32_t> sc, lm; std::vector<int32_t> sc_off(P.fronts.size()), sc_cnt(P.fronts.size()), lm_off(P.fronts.size()), lm_cnt(P.fronts.size());
-            auto img = [](int r, int c) { const int I = r >> 4, J = c >> 4; return (((I * (I + 1)) >> 1) + J) * 256 + (r & 15) * 16 + (c & 15); };
-            const int64_t L = P.ell_len;
-            for (size_t sidx = 0; sidx < P.fronts.size(); ++sidx) { const Front &F = P.fronts[sidx]; const int f = F.npiv + F.nbnd;
-                sc_off[sidx] = (int32_t)(sc.size() / 2); lm_off[sidx] = (int32_t)(lm.size() / 4);
-                auto add = [&](int64_t src, int r, int c) { sc.push_back((int32_t)src); sc.push_back(img(r, c)); };
-                for (int t = F.asm_off; t < F.asm_off + F.asm_cnt - F.asm_dup; ++t) { const AsmRec &R = P.asm_recs[t]; const int r0 = R.r0, c0 = R.c0; const int64_t src = R.src;
-                    switch (R.kind) {
-                        case 0: { const int64_t H = arena_off[0], B = arena_off[1];
-                            add(H + src, r0, c0); add(H + N + src, r0 + 1, c0); add(H + 2 * (int64_t)N + src, r0 + 2, c0);
-                            add(H + 3 * (int64_t)N + src, r0 + 1, c0 + 1); add(H + 4 * (int64_t)N + src, r0 + 2, c0 + 1); add(H + 5 * (int64_t)N + src, r0 + 2, c0 + 2);
-                            for (int k = 0; k < 3; ++k) add(B + k * (int64_t)N + src, f, c0 + k); } break;
-                        case 1:
-                            if (fused) { const int q0 = P.lm_grp_start[src], q1 = P.lm_grp_start[src + 1];
-                                lm.push_back(q1 - q0); lm.push_back(q0); lm.push_back(r0); lm.push_back(c0); }
-                            else { const int64_t H = arena_off[5], B = arena_off[6];
-                                add(H + src, r0, c0); add(H + M + src, r0 + 1, c0); add(H + 2 * (int64_t)M + src, r0 + 1, c0 + 1);
-                                add(B + src, f, c0); add(B + M + src, f, c0 + 1); }
-                            break;
-                        case 2: for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) add(arena_off[2] + (3 * a + b) * (int64_t)Epp + src, r0 + a, c0 + b); break;
-                        case 3: for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) add(arena_off[2] + (3 * b + a) * (int64_t)Epp + src, r0 + a, c0 + b); break;
-                        case 4: for (int a = 0; a < 3; ++a) for (int b = 0; b < 2; ++b) add(arena_off[3] + (2 * a + b) * L + src, r0 + a, c0 + b); break;
-                        default: for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b) add(arena_off[3] + (2 * b + a) * L + src, r0 + a, c0 + b); break;
-                    } }
-                while ((sc.size() / 2 - (size_t)sc_off[sidx]) % 64) { sc.push_back(0); sc.push_back(1); }
-                sc_cnt[sidx] = (int32_t)(sc.size() / 2) - sc_off[sidx]; lm_cnt[sidx] = (int32_t)(lm.size() / 4) - lm_off[sidx]; }
-            if (sc.size() / 2 >= ((size_t)1 << 31)) return fail(GS_ERR_INVALID, "too many assembly scalars");
+          // (expanded ON THE DEVICE from the block records: the host only counts them per front)
+          { const size_t S = P.fronts.size();
+            std::vector<int32_t> sc_off(S), sc_cnt(S), lm_off(S), lm_cnt(S), bf(6 * S);
+            parallel_chunks((int64_t)S, 2048, [&](int64_t b, int64_t e, int) {
+                for (int64_t sidx = b; sidx < e; ++sidx) { const Front &F = P.fronts[sidx]; int ns = 0, nl = 0;
+                    for (int t = F.asm_off; t < F.asm_off + F.asm_cnt - F.asm_dup; ++t) { const int k = P.asm_recs[t].kind;
+                        if (k == 0) ns += 9; else if (k == 1) { if (fused) ++nl; else ns += 5; } else if (k <= 3) ns += 9; else ns += 6; }
+                    sc_cnt[sidx] = (ns + 63) & ~63; lm_cnt[sidx] = nl; } });
+            int64_t so = 0, lo = 0;
+            for (size_t sidx = 0; sidx < S; ++sidx) { const Front &F = P.fronts[sidx];
+                if (so >= ((int64_t)1 << 31) - 64) return fail(GS_ERR_INVALID, "too many assembly scalars");
+                sc_off[sidx] = (int32_t)so; lm_off[sidx] = (int32_t)lo; so += sc_cnt[sidx]; lo += lm_cnt[sidx];
+                int32_t *r = &bf[6 * sidx]; r[0] = F.asm_off; r[1] = F.asm_cnt - F.asm_dup; r[2] = F.npiv + F.nbnd; r[3] = sc_off[sidx]; r[4] = sc_cnt[sidx]; r[5] = lm_off[sidx]; }
             for (size_t q = 0; q < lf.size(); ++q) { int32_t *r = &fd[F3W * q]; const int sidx = lf[q];
                 r[20] = sc_off[sidx]; r[21] = sc_cnt[sidx]; r[22] = lm_off[sidx]; r[23] = lm_cnt[sidx]; }
-            GS_UT("sc3 build");
-            UP(sc3, sc); UP(lm3, lm); }
+            AL(sc3, 2 * (size_t)so + 2); AL(lm3, 4 * (size_t)lo + 4);
+            int32_t *bf_dev = nullptr; if ((rc = dev_upload(g, &bf_dev, bf)) != GS_OK) return rc;
+            Sc3Args A; for (int k = 0; k < 8; ++k) A.off[k] = arena_off[k];
+            A.L = P.ell_len; A.N = N; A.M = M; A.Epp = Epp; A.fused = fused ? 1 : 0;
+            launch_build_sc3(bf_dev, d.asm3, d.sc3, d.lm3, (int)S, A, g->stream);
+            GS_UT("sc3 build"); }
           GS_UT("sc3 upload");
           std::vector<int32_t> xtab;                          // third and later children: [row table 64 | front, u offset, u size, owner, 0 0 0 0] each
           for (size_t q = 0; q < lf.size(); ++q) { int32_t *r = &fd[F3W * q]; const Front &F = P.fronts[lf[q]];

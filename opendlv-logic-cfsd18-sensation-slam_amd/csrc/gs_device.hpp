@@ -102,6 +102,9 @@ void launch_associate(int n, const double *poses, const int32_t *pose_of_obs, co
 void launch_associate_grid(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar,
                            const double *map_xy, const int32_t *map_type, double thr, double type_tol, double minx, double miny,
                            double inv_cell, int nx, int ny, const int32_t *cell_start, const int32_t *cell_items, int32_t *out, hipStream_t st);
+// structure phase on the device: expand the block assembly records into scalar / landmark records (k_build_sc3)
+struct Sc3Args { int64_t off[8]; int64_t L; int32_t N, M, Epp, fused; };
+void launch_build_sc3(const int32_t *bf, const int32_t *asm3, int32_t *sc3, int32_t *lm3, int n_fronts, const Sc3Args &A, hipStream_t st);
 int  factor_lds_limit_f();      // largest front dimension that fits the LDS variant
 
 }  // namespace gs

@@ -1705,6 +1705,54 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
     F3_TS(38);
 }
 
+// ---- structure phase on the device: the scalar assembly records (sc3) and the fused landmark records (lm3) of every
+// front, expanded from the block records (asm3) that are in HBM already.  One wave per front; a lane takes a block
+// record, a wave prefix sum places its 5 / 6 / 9 scalars.  (On the host this expansion was 33 of the 110 ms of the
+// structure phase at 100k poses, plus 67 MB over PCIe.)
+__global__ void __launch_bounds__(256) k_build_sc3(const int32_t *__restrict__ bf, const int32_t *__restrict__ asm3, int32_t *__restrict__ sc3,
+                                                   int32_t *__restrict__ lm3, int n_fronts, Sc3Args A) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + wave;
+    if (s >= n_fronts) return;
+    const int asm_off = bf[6 * s], n_uniq = bf[6 * s + 1], f = bf[6 * s + 2], sc_off = bf[6 * s + 3], sc_cnt = bf[6 * s + 4], lm_off = bf[6 * s + 5];
+    int sbase = sc_off, lbase = lm_off;
+    auto img = [](int r, int c) { const int I = r >> 4, J = c >> 4; return (((I * (I + 1)) >> 1) + J) * 256 + (r & 15) * 16 + (c & 15); };
+    for (int t0 = 0; t0 < n_uniq; t0 += 64) {
+        const int t = t0 + lane; const bool on = t < n_uniq;
+        const int4 r = on ? reinterpret_cast<const int4 *>(asm3)[asm_off + t] : make_int4(-1, 0, 0, 0);
+        const int kind = r.x & 0xff;
+        const bool islm = on && kind == 1 && A.fused;
+        int nsc = !on ? 0 : (kind == 0 ? 9 : (kind == 1 ? (A.fused ? 0 : 5) : (kind <= 3 ? 9 : 6)));
+        int ps = nsc, pl = islm ? 1 : 0;                                  // inclusive prefix sums over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int a = __shfl_up(ps, o, WAVE), b = __shfl_up(pl, o, WAVE); if (lane >= o) { ps += a; pl += b; } }
+        const int tot_s = __shfl(ps, 63, WAVE), tot_l = __shfl(pl, 63, WAVE);
+        int q = sbase + ps - nsc;
+        auto add = [&](int64_t src, int rr, int cc) { sc3[2 * (int64_t)q] = (int32_t)src; sc3[2 * (int64_t)q + 1] = img(rr, cc); ++q; };
+        const int64_t src = r.y; const int r0 = r.z, c0 = r.w;
+        if (on) switch (kind) {
+            case 0: { const int64_t H = A.off[0], B = A.off[1], N = A.N;
+                add(H + src, r0, c0); add(H + N + src, r0 + 1, c0); add(H + 2 * N + src, r0 + 2, c0);
+                add(H + 3 * N + src, r0 + 1, c0 + 1); add(H + 4 * N + src, r0 + 2, c0 + 1); add(H + 5 * N + src, r0 + 2, c0 + 2);
+                for (int k = 0; k < 3; ++k) add(B + k * N + src, f, c0 + k); } break;
+            case 1:
+                if (A.fused) { int32_t *o = lm3 + 4 * (int64_t)(lbase + pl - 1); o[0] = r.x >> 8; o[1] = r.y; o[2] = r0; o[3] = c0; }
+                else { const int64_t H = A.off[5], B = A.off[6], M = A.M;
+                    add(H + src, r0, c0); add(H + M + src, r0 + 1, c0); add(H + 2 * M + src, r0 + 1, c0 + 1); add(B + src, f, c0); add(B + M + src, f, c0 + 1); }
+                break;
+            case 2: for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) add(A.off[2] + (3 * a + b) * (int64_t)A.Epp + src, r0 + a, c0 + b); break;
+            case 3: for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) add(A.off[2] + (3 * b + a) * (int64_t)A.Epp + src, r0 + a, c0 + b); break;
+            case 4: for (int a = 0; a < 3; ++a) for (int b = 0; b < 2; ++b) add(A.off[3] + (2 * a + b) * A.L + src, r0 + a, c0 + b); break;
+            default: for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b) add(A.off[3] + (2 * b + a) * A.L + src, r0 + a, c0 + b); break;
+        }
+        sbase += tot_s; lbase += tot_l;
+    }
+    for (int q = sbase + lane; q < sc_off + sc_cnt; q += 64) { sc3[2 * (int64_t)q] = 0; sc3[2 * (int64_t)q + 1] = 1; }      // padding: (value 0 -> a don't-care slot)
+}
+void launch_build_sc3(const int32_t *bf, const int32_t *asm3, int32_t *sc3, int32_t *lm3, int n_fronts, const Sc3Args &A, hipStream_t st) {
+    if (n_fronts > 0) hipLaunchKernelGGL(k_build_sc3, dim3((n_fronts + 3) / 4), dim3(256), 0, st, bf, asm3, sc3, lm3, n_fronts, A);
+}
+
 // whole-tree launches of variant 3 (own fronts of a single-GPU graph): every level in one kernel each
 void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int count, hipStream_t st) {
     if (count <= 0) return;

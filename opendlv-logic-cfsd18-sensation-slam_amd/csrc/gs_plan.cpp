@@ -16,6 +16,7 @@
 // The construction is a heuristic for ORDER only; the symbolic factorisation below is exact for any
 // graph, so every ordering gives the same solution as the reference's joint Cholesky up to rounding.
 #include "gs_host.hpp"
+#include "gs_parallel.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -327,62 +328,79 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     }
 
     GS_PT(4);
-    // ---- fronts ----
+    // ---- fronts ----  (three passes: sizes in parallel, offsets in one sweep, contents in parallel)
     plan.fronts.resize(S);
-    std::vector<int32_t> loc(B.nv, -1);
-    std::vector<AsmRec> recs, uniq, dup;                             // reused across fronts (no per-front allocation)
-    for (int s = 0; s < S; ++s) {
-        Front &F = plan.fronts[s];
-        F.parent = parent[s]; F.piv0 = gidx[B.sn[s][0]];
-        for (int v : B.sn[s]) F.npiv += B.dim(v);
-        for (int w : bndv[s]) F.nbnd += B.dim(w);
-        F.bnd_off = (int64_t)plan.bnd_rows.size();
-        for (int w : bndv[s]) for (int t = 0; t < B.dim(w); ++t) plan.bnd_rows.push_back(gidx[w] + t);
-        F.level = 0;
-        for (int c : kids[s]) F.level = std::max(F.level, plan.fronts[c].level + 1);
-        F.child_off = (int32_t)plan.children.size(); F.child_cnt = (int32_t)kids[s].size();
-        for (int c : kids[s]) plan.children.push_back(c);
-        plan.max_front = std::max(plan.max_front, F.npiv + F.nbnd);
-        // row offsets of this front
-        int r = 0;
-        for (int v : B.sn[s]) { loc[v] = r; r += B.dim(v); }
-        for (int w : bndv[s]) { loc[w] = r; r += B.dim(w); }
-        // extend-add maps of the children into this front
-        for (int c : kids[s]) { plan.fronts[c].map_off = (int64_t)plan.child_map.size();
-            for (int w : bndv[c]) for (int t = 0; t < B.dim(w); ++t) plan.child_map.push_back(loc[w] + t); }
-        // original entries
-        F.asm_off = (int32_t)plan.asm_recs.size();
-        recs.clear();
-        for (int v : B.sn[s]) {
-            if (v < B.nfp) recs.push_back({ASM_POSE_DIAG, B.pose_of_fp[v], loc[v], loc[v]});
-            else recs.push_back({ASM_LM_DIAG, B.lm_of_fl[v - B.nfp], loc[v], loc[v]});
-            for (int q = B.inc_start[v]; q < B.inc_start[v + 1]; ++q) { const auto &e = B.inc[q];
-                if (vpos[e.other] <= vpos[v]) continue;             // the earlier endpoint owns the block
-                int kind;
-                switch (e.kind) {                                    // e.kind describes v's role; `other` is the later vertex
-                    case 0: kind = ASM_PP_T; break;                  // v = i earlier, j later: F = Hpp_off^T
-                    case 1: kind = ASM_PP; break;                    // v = j earlier, i later
-                    case 2: kind = ASM_PL_T; break;                  // v = pose earlier, landmark later
-                    default: kind = ASM_PL; break;                   // v = landmark earlier, pose later
+    std::vector<int32_t> asm_n(S);
+    parallel_chunks(S, 512, [&](int64_t b0, int64_t e0, int) {
+        for (int s = (int)b0; s < (int)e0; ++s) {
+            Front &F = plan.fronts[s];
+            F.parent = parent[s]; F.piv0 = gidx[B.sn[s][0]];
+            for (int v : B.sn[s]) F.npiv += B.dim(v);
+            for (int w : bndv[s]) F.nbnd += B.dim(w);
+            int n = 0;
+            for (int v : B.sn[s]) { ++n;
+                for (int q = B.inc_start[v]; q < B.inc_start[v + 1]; ++q) n += vpos[B.inc[q].other] > vpos[v]; }     // the earlier endpoint owns the block
+            asm_n[s] = n;
+        } });
+    { int64_t nb = 0, nm = 0, na = 0;
+      for (int s = 0; s < S; ++s) {
+          Front &F = plan.fronts[s];
+          F.bnd_off = nb; nb += F.nbnd;
+          F.map_off = nm; nm += F.nbnd;                               // this front's boundary rows -> rows of its parent's front
+          F.level = 0;
+          for (int c : kids[s]) F.level = std::max(F.level, plan.fronts[c].level + 1);
+          F.child_off = (int32_t)plan.children.size(); F.child_cnt = (int32_t)kids[s].size();
+          for (int c : kids[s]) plan.children.push_back(c);
+          plan.max_front = std::max(plan.max_front, F.npiv + F.nbnd);
+          F.asm_off = (int32_t)na; F.asm_cnt = asm_n[s]; na += asm_n[s];
+          F.L_off = plan.l_doubles; plan.l_doubles += (int64_t)(F.npiv + F.nbnd + 1) * F.npiv;
+          F.U_off = plan.u_doubles; plan.u_doubles += (int64_t)(F.nbnd + 1) * F.nbnd;
+          for (int k = 0; k < F.npiv; ++k) { int64_t r2 = F.npiv + F.nbnd + 1 - k; plan.factor_flops += r2 * r2; }
+      }
+      if (na >= ((int64_t)1 << 31)) { err = "too many assembly records"; return false; }
+      plan.bnd_rows.resize((size_t)nb); plan.child_map.resize((size_t)nm); plan.asm_recs.resize((size_t)na); }
+    parallel_chunks(S, 512, [&](int64_t b0, int64_t e0, int) {
+        std::vector<int32_t> loc(B.nv, -1);                          // row of a vertex inside the current front (only entries set below are read)
+        std::vector<AsmRec> recs, uniq, dup;
+        for (int s = (int)b0; s < (int)e0; ++s) {
+            Front &F = plan.fronts[s];
+            { int32_t *o = &plan.bnd_rows[(size_t)F.bnd_off];
+              for (int w : bndv[s]) for (int t = 0; t < B.dim(w); ++t) *o++ = gidx[w] + t; }
+            int r = 0;
+            for (int v : B.sn[s]) { loc[v] = r; r += B.dim(v); }
+            for (int w : bndv[s]) { loc[w] = r; r += B.dim(w); }
+            // extend-add maps of the children into this front
+            for (int c : kids[s]) { int32_t *o = &plan.child_map[(size_t)plan.fronts[c].map_off];
+                for (int w : bndv[c]) for (int t = 0; t < B.dim(w); ++t) *o++ = loc[w] + t; }
+            // original entries
+            recs.clear();
+            for (int v : B.sn[s]) {
+                if (v < B.nfp) recs.push_back({ASM_POSE_DIAG, B.pose_of_fp[v], loc[v], loc[v]});
+                else recs.push_back({ASM_LM_DIAG, B.lm_of_fl[v - B.nfp], loc[v], loc[v]});
+                for (int q = B.inc_start[v]; q < B.inc_start[v + 1]; ++q) { const auto &e = B.inc[q];
+                    if (vpos[e.other] <= vpos[v]) continue;             // the earlier endpoint owns the block
+                    int kind;
+                    switch (e.kind) {                                    // e.kind describes v's role; `other` is the later vertex
+                        case 0: kind = ASM_PP_T; break;                  // v = i earlier, j later: F = Hpp_off^T
+                        case 1: kind = ASM_PP; break;                    // v = j earlier, i later
+                        case 2: kind = ASM_PL_T; break;                  // v = pose earlier, landmark later
+                        default: kind = ASM_PL; break;                   // v = landmark earlier, pose later
+                    }
+                    recs.push_back({kind, e.epos, loc[e.other], loc[v]});
                 }
-                recs.push_back({kind, e.epos, loc[e.other], loc[v]});
             }
-        }
-        // duplicates (parallel edges between the same two vertices) go to the tail
-        std::stable_sort(recs.begin(), recs.end(), [](const AsmRec &x, const AsmRec &y) {
-            return x.r0 != y.r0 ? x.r0 < y.r0 : x.c0 < y.c0; });
-        uniq.clear(); dup.clear();
-        for (size_t t = 0; t < recs.size(); ++t) {
-            if (t > 0 && recs[t].r0 == recs[t - 1].r0 && recs[t].c0 == recs[t - 1].c0) dup.push_back(recs[t]);
-            else uniq.push_back(recs[t]);
-        }
-        F.asm_cnt = (int32_t)recs.size(); F.asm_dup = (int32_t)dup.size();
-        plan.asm_recs.insert(plan.asm_recs.end(), uniq.begin(), uniq.end());
-        plan.asm_recs.insert(plan.asm_recs.end(), dup.begin(), dup.end());
-        F.L_off = plan.l_doubles; plan.l_doubles += (int64_t)(F.npiv + F.nbnd + 1) * F.npiv;
-        F.U_off = plan.u_doubles; plan.u_doubles += (int64_t)(F.nbnd + 1) * F.nbnd;
-        for (int k = 0; k < F.npiv; ++k) { int64_t r2 = F.npiv + F.nbnd + 1 - k; plan.factor_flops += r2 * r2; }
-    }
+            // duplicates (parallel edges between the same two vertices) go to the tail
+            std::stable_sort(recs.begin(), recs.end(), [](const AsmRec &x, const AsmRec &y) {
+                return x.r0 != y.r0 ? x.r0 < y.r0 : x.c0 < y.c0; });
+            uniq.clear(); dup.clear();
+            for (size_t t = 0; t < recs.size(); ++t) {
+                if (t > 0 && recs[t].r0 == recs[t - 1].r0 && recs[t].c0 == recs[t - 1].c0) dup.push_back(recs[t]);
+                else uniq.push_back(recs[t]);
+            }
+            F.asm_dup = (int32_t)dup.size();
+            std::copy(uniq.begin(), uniq.end(), plan.asm_recs.begin() + F.asm_off);
+            std::copy(dup.begin(), dup.end(), plan.asm_recs.begin() + F.asm_off + (int64_t)uniq.size());
+        } });
     GS_PT(5);
     // ---- levels ----
     int nlev = 0;
