@@ -531,14 +531,32 @@ static int upload_graph(gs_graph *g) {
             launch_build_sc3(bf_dev, d.asm3, d.sc3, d.lm3, (int)S, A, g->stream);
             GS_UT("sc3 build"); }
           GS_UT("sc3 upload");
-          std::vector<int32_t> xtab;                          // third and later children: [row table 64 | front, u offset, u size, owner, 0 0 0 0] each
+          // children table of every front: [row table 64 | front, u offset, u size, owner, place in the LDS image, batch, 0 0] per child.
+          // Batches (children whose update matrices are staged in the parent's LDS image together, factor kernel
+          // F3_LDS_GATHER): greedily up to 4 consecutive children, <= 2560 doubles (the image) in all, each <= 895 doubles.
+          std::vector<int32_t> xtab;
           for (size_t q = 0; q < lf.size(); ++q) { int32_t *r = &fd[F3W * q]; const Front &F = P.fronts[lf[q]];
               r[14] = (int32_t)xtab.size();
-              for (int k = 2; k < F.child_cnt; ++k) { const int c = P.children[F.child_off + k];
+              // batch shapes (28 staging doubles per lane either way): 0 = up to four children of <= 447 doubles each,
+              // 1 = up to two of <= 895; a child beyond that is gathered from HBM (batch -1)
+              const size_t x0 = xtab.size();
+              for (int k = 0; k < F.child_cnt; ++k) { const int c = P.children[F.child_off + k];
                   xtab.insert(xtab.end(), pinv.begin() + 64 * (size_t)c, pinv.begin() + 64 * (size_t)c + 64);
-                  const int32_t hdr[8] = {c, u3_off[c], u3_size[c], P.fronts[c].owner, 0, 0, 0, 0};
+                  const int32_t hdr[8] = {c, u3_off[c], u3_size[c], P.fronts[c].owner, 0, -1, 0, 0};
                   xtab.insert(xtab.end(), hdr, hdr + 8); }
-              if (xtab.size() >= ((size_t)1 << 30)) return fail(GS_ERR_INVALID, "extra-children table too large"); }
+              { int batch = 0, k = 0; const int nc = F.child_cnt;
+                auto usz = [&](int kk) { return u3_size[P.children[F.child_off + kk]]; };
+                auto H = [&](int kk) { return &xtab[x0 + 72 * (size_t)kk + 64]; };
+                while (k < nc) {
+                    if (usz(k) + 1 > 14 * 64 - 1) { ++k; continue; }                       // stays batch -1
+                    const int shape = usz(k) + 1 <= 7 * 64 - 1 ? 0 : 1, cap = shape == 0 ? 4 : 2, lim = shape == 0 ? 7 * 64 - 1 : 14 * 64 - 1;
+                    int n = 0, tot = 0;
+                    while (k < nc && n < cap && usz(k) + 1 <= lim && (shape == 1 || usz(k) + 1 <= 7 * 64 - 1)) {
+                        const int need = (usz(k) + 2) & ~1;
+                        if (tot + need > 2560) break;
+                        int32_t *h = H(k); h[4] = tot; h[5] = batch; h[6] = shape; tot += need; ++n; ++k; }
+                    ++batch; } }
+              if (xtab.size() >= ((size_t)1 << 30)) return fail(GS_ERR_INVALID, "children table too large"); }
           xtab.resize(xtab.size() + 72, 0);
           UP(f3_x, xtab);
           for (size_t q = 0; q < lf.size(); ++q) { int32_t *r = &fd[F3W * q];

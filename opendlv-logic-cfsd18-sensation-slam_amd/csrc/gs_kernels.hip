@@ -15,6 +15,7 @@
 //
 // All fp64; every sum has a fixed order (no floating-point atomics) so results are bitwise reproducible.
 #include "gs_device.hpp"
+#include <type_traits>
 
 namespace gs {
 
@@ -1136,8 +1137,8 @@ __global__ void __launch_bounds__(256, 2) k_factor_mfma(DevGraph d, int level_of
 //      backward solve has a unit diagonal (no division there either).
 // Record formats (built in gs_api.cpp upload_graph):
 //   f3_desc [level position][24] int32: 0 front, 1 npiv, 2 nbnd, 3 asm_off, 4 #unique records, 5 #duplicate records,
-//      6 #children, 7 child_off, 8-9 L_off, 10 piv0, 11 bnd_off, 12-13 child front (-1 none), 14 offset of the front's table of third and later children in f3_x (F3X ints per child:
-//      its 64-entry row table, then {front, update-matrix offset, size, owner}), 15 unused,
+//      6 #children, 7 child_off, 8-9 L_off, 10 piv0, 11 bnd_off, 12-13 child front (-1 none), 14 offset of the front's children table in f3_x (F3X ints per child: its 64-entry row
+//      table, then {front, update-matrix offset, size, owner, place in the LDS image, batch (-1: too large to stage)}), 15 unused,
 //      16-17 child owner, 18-19 exchange slot offset, 20 sc_off, 21 #scalar records (multiple of 64), 22 lm_off, 23 #landmark records
 //   sc3 [scalar][2]: {offset of the value in H_arena, offset in the staging image}: the original blocks flattened to
 //      scalars, so the assembly is branch-free (load record, load value, one LDS store)
@@ -1280,6 +1281,32 @@ __device__ __forceinline__ void f3_gather_child(const double *Uc, int usize, int
         }
 }
 
+// The same gather with the child's packed update matrix already staged in LDS (base = its first double, the zero double
+// behind it included): the by-destination reads are LDS reads (~64 cycles) instead of 40 scattered global loads.
+__device__ __forceinline__ void f3_gather_child_lds(const double *base, int usize, int pv, int lane, double (&u)[10][4]) {
+    const int lc = lane & 15, lr = lane >> 4;
+    int co[4];
+#pragma unroll
+    for (int J = 0; J < 4; ++J) co[J] = __shfl(pv, 16 * J + lc, WAVE) >> 16;
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ro = (int)(short)(__shfl(pv, 16 * I + lr + 4 * q, WAVE) & 0xffff);
+#pragma unroll
+            for (int J = 0; J <= I; ++J) { const uint32_t o = min((uint32_t)(ro + co[J]), (uint32_t)usize * 8u);
+                u[mf_tile(I, J)][q] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + o); }
+        }
+}
+// F3_LDS_GATHER (default 1): children's update matrices are fetched with coalesced loads (8 bytes per lane, every cache
+// line used once and fully), staged in the front's LDS image — free once the original entries have moved to the
+// accumulators — and gathered by destination from there; up to four children per batch have their loads in flight
+// together (the batches and each child's place in the image are laid out on the host, x-table header fields 4-5).
+// 0: gather by destination straight from HBM / L2 (two children at a time in registers, further ones one by one).
+#ifndef F3_LDS_GATHER
+#define F3_LDS_GATHER 1
+#endif
+
 #ifndef F3_RCP_NEWTON
 #define F3_RCP_NEWTON 2
 #endif
@@ -1405,11 +1432,19 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
 #pragma unroll
     for (int k = 0; k < 2; ++k)
         use[k] = !LEAF && fr.c_id[k] >= 0 && !(mode == FRONT_CONTRIB && fr.c_owner[k] != d.rank) && !(top && fr.c_owner[k] >= 0);   // uniform
+#if !F3_LDS_GATHER
     double u0[10][4], u1[10][4];
     if (!TREE) {
         if (use[0]) f3_gather_child<false>(d.Uimg + fr.c_uoff[0], fr.c_usize[0], pv[0], lane, u0);
         if (use[1]) f3_gather_child<false>(d.Uimg + fr.c_uoff[1], fr.c_usize[1], pv[1], lane, u1);
     }
+#else
+    // headers {front, offset, size, owner, LDS base, batch} of the first eight children: lane 8 c + field
+    const int32_t *xt = d.f3_x + fr.x_tab;
+    int hx = 0;
+    if (!LEAF && (lane >> 3) < fr.nchild) hx = xt[(lane >> 3) * F3X + 64 + (lane & 7)];
+    (void)use; (void)pv;
+#endif
     // ---- round trip 2b: scalar assembly records (eight per lane up front), landmark records
 #ifndef F3_LEAF_BLOCKS
 #define F3_LEAF_BLOCKS 1
@@ -1495,6 +1530,7 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
     }
     wave_lds_sync();
     F3_TS(5);
+#if !F3_LDS_GATHER
     if (TREE) {                                                      // everything above ran while the children were still working
         if (fr.level == 1 && leaf_slot != 0) {
             // children = leaves of the PREVIOUS launch: complete and visible — no flags, and ordinary (cached) loads: the
@@ -1508,6 +1544,7 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
             if (!okw && lane == 0) atomicMax(d.fail, 2);
         }
     }
+#endif
     // ---- accumulators = originals + child 0 + child 1 (+ further children, rare)
     v4d acc[10];
 #pragma unroll
@@ -1519,6 +1556,7 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
                 if (LEAF) { const int row = 16 * I + lr + 4 * q, col = 16 * J + lc;       // pivot-column panel: (row, col) at col * ld + row
                     acc[t][q] = (J <= Jmax && col < npiv && row <= f) ? P.F[min(col, npiv - 1) * P.ld + min(row, f)] : 0.0; }
                 else acc[t][q] = (J <= Jmax) ? P.F[t * 256 + q * 64 + lane] : 0.0; } }
+#if !F3_LDS_GATHER
     if (use[0]) {
 #pragma unroll
         for (int t = 0; t < 10; ++t)
@@ -1535,7 +1573,7 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
     // previous child's gather is in flight — one round trip per extra child, no descriptor / pinv / offset lookups
     if (!LEAF && fr.nchild > 2) {
         const int ne = fr.nchild - 2;
-        const int32_t *xt = d.f3_x + fr.x_tab;
+        const int32_t *xt = d.f3_x + fr.x_tab + 2 * F3X;                  // the table lists every child; the first two were handled above
         const bool plain = !TREE || (fr.level == 1 && leaf_slot != 0);     // children complete and visible: no flags, cached loads
         int pa = xt[lane], ha = xt[64 + (lane & 7)];
         for (int e = 0; e < ne; ++e) {
@@ -1555,6 +1593,83 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
                     for (int q = 0; q < 4; ++q) acc[t][q] += u0[t][q]; }
         }
     }
+#else
+    if (!LEAF && fr.nchild > 0) {
+        const bool plain = !TREE || (fr.level == 1 && leaf_slot != 0);     // children complete and visible: no flags, cached loads
+        const int nch = fr.nchild;
+        // header field of child ci (uniform): the first eight from the prefetched lane-vector, later ones straight from the table
+        auto hdr = [&](int ci, int field) -> int {
+            return ci < 8 ? __builtin_amdgcn_readlane(hx, 8 * ci + field) : __builtin_amdgcn_readfirstlane(xt[ci * F3X + 64 + field]); };
+        wave_lds_sync();                                                   // every lane has read the original entries out of the image
+        for (int b0 = 0; b0 < nch;) {
+            const int bid = hdr(b0, 5);
+            int cnt = 1;
+            if (bid >= 0) while (cnt < 4 && b0 + cnt < nch && hdr(b0 + cnt, 5) == bid) ++cnt;
+            int bp[4];                                                     // row tables of the batch: in flight while the flags are awaited
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bp[j] = (j < cnt) ? xt[(b0 + j) * F3X + lane] : 0;
+            if (bid < 0) {                                                 // too large to stage (boundary > 40 rows): by destination from HBM
+                const int id = hdr(b0, 0), uoff = hdr(b0, 1), usz = hdr(b0, 2), own = hdr(b0, 3);
+                if (!((mode == FRONT_CONTRIB && own != d.rank) || (top && own >= 0))) {
+                    double ug[10][4];
+                    if (plain) f3_gather_child<false>(d.Uimg + uoff, usz, bp[0], lane, ug);
+                    else { if (!f3_wait_flag(d.done_f + id, d.epoch) && lane == 0) atomicMax(d.fail, 2);
+                           f3_gather_child<true>(d.Uimg + uoff, usz, bp[0], lane, ug); }
+#pragma unroll
+                    for (int t = 0; t < 10; ++t)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[t][q] += ug[t][q];
+                }
+                b0 += 1; continue;
+            }
+            // Two batch shapes, both 28 staging doubles per lane: four small children (<= 447 doubles each: the leaves under a
+            // multi-way split) or two large ones (<= 895: the top of the tree).  Header field 6 says which.
+            auto stage = [&](auto NCc, auto Kc) {
+                constexpr int NC = decltype(NCc)::value, K = decltype(Kc)::value;
+                // phase 1: coalesced loads of every child of the batch (8 bytes per lane), all in flight together
+                double st[NC][K];
+                int c_usz[NC], c_base[NC]; bool c_on[NC];
+                bool okw = true;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) { c_on[j] = false; c_usz[j] = 0; c_base[j] = 0;
+                    if (j < cnt) { const int ci = b0 + j;
+                        const int id = hdr(ci, 0), uoff = hdr(ci, 1), own = hdr(ci, 3);
+                        c_usz[j] = hdr(ci, 2); c_base[j] = hdr(ci, 4);
+                        c_on[j] = !((mode == FRONT_CONTRIB && own != d.rank) || (top && own >= 0));
+                        if (c_on[j]) {
+                            if (!plain) okw = f3_wait_flag(d.done_f + id, d.epoch) && okw;
+                            const double *Uc = d.Uimg + uoff;
+#pragma unroll
+                            for (int k = 0; k < K; ++k) { const int idx = 64 * k + lane;
+                                st[j][k] = 0.0;
+                                if (64 * k <= c_usz[j]) { const uint32_t o = (uint32_t)min(idx, c_usz[j]) * 8u;     // lanes beyond the zero double re-read it
+                                    st[j][k] = plain ? ld_off(Uc, o) : ld_off_coh(Uc, o); } }
+                        } } }
+                if (!okw && lane == 0) atomicMax(d.fail, 2);
+                // phase 2: into the image
+#pragma unroll
+                for (int j = 0; j < NC; ++j) if (c_on[j]) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) { const int idx = 64 * k + lane;
+                        if (64 * k <= c_usz[j] && idx <= c_usz[j]) P.F[c_base[j] + idx] = st[j][k]; } }
+                wave_lds_sync();
+                // phase 3: by destination out of LDS, children in list order (fixed summation order)
+#pragma unroll
+                for (int j = 0; j < NC; ++j) if (c_on[j]) {
+                    double ug[10][4];
+                    f3_gather_child_lds(P.F + c_base[j], c_usz[j], bp[j], lane, ug);
+#pragma unroll
+                    for (int t = 0; t < 10; ++t)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[t][q] += ug[t][q]; }
+            };
+            if (hdr(b0, 6) == 0) stage(std::integral_constant<int, 4>{}, std::integral_constant<int, 7>{});
+            else stage(std::integral_constant<int, 2>{}, std::integral_constant<int, 14>{});
+            wave_lds_sync();                                               // before the next batch (or the panels) overwrite the image
+            b0 += cnt;
+        }
+    }
+#endif
     wave_lds_sync();
     if (!LEAF && mode == FRONT_CONTRIB) {                            // this rank's share of a shared front -> exchange slot
 #pragma unroll

@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace gs {
 
@@ -61,26 +62,40 @@ struct Builder {
         nv = nfp + nfl;
     }
 
-    void build_adjacency(const std::vector<int32_t> &pl_pos_of_ins) {
-        std::vector<int32_t> cnt(nv + 1, 0);
-        auto count = [&](int a, int b) { cnt[a + 1]++; cnt[b + 1]++; };
-        for (int k = 0; k < g.n_pp(); ++k) { int a = fp_of_pose[g.pp_i[k]], b = fp_of_pose[g.pp_j[k]]; if (a >= 0 && b >= 0) count(a, b); }
-        for (int k = 0; k < g.n_pl(); ++k) { int a = fp_of_pose[g.pl_p[k]], b = fl_of_lm[g.pl_l[k]]; if (a >= 0 && b >= 0) count(a, nfp + b); }
+    // Per-vertex incidence lists straight from the CSR arrays of the layout phase (pose -> its odometry incidences
+    // and observation edges, landmark -> its edges): every vertex fills its own range, so the build runs on all host
+    // threads.  Order inside a vertex: odometry edges (insertion order), then observation edges (insertion order for a
+    // pose, pose order for a landmark).
+    void build_adjacency(const Plan &P) {
+        const int N = g.n_poses(); const int T = P.ell_T; const int64_t SN = (int64_t)T * N;
         inc_start.assign(nv + 1, 0);
-        for (int v = 0; v < nv; ++v) inc_start[v + 1] = inc_start[v] + cnt[v + 1];
+        parallel_chunks(nv, 4096, [&](int64_t b0, int64_t e0, int) {
+            for (int v = (int)b0; v < (int)e0; ++v) { int n = 0;
+                if (v < nfp) { const int p = pose_of_fp[v];
+                    for (int q = P.ppadj_start[p]; q < P.ppadj_start[p + 1]; ++q) { const int code = P.ppadj[q], k = code >> 1;
+                        n += fp_of_pose[(code & 1) ? g.pp_i[k] : g.pp_j[k]] >= 0; }
+                    for (int s = P.pl_start[p]; s < P.pl_start[p + 1]; ++s) n += fl_of_lm[g.pl_l[P.pl_order[s]]] >= 0;
+                } else { const int l = lm_of_fl[v - nfp];
+                    for (int q = P.lm_start[l]; q < P.lm_start[l + 1]; ++q) n += fp_of_pose[(int)((P.lm_edges[q] % SN) / T)] >= 0; }
+                inc_start[v + 1] = n; } });
+        for (int v = 0; v < nv; ++v) inc_start[v + 1] += inc_start[v];
         inc.resize(inc_start[nv]);
-        std::vector<int32_t> fill(inc_start.begin(), inc_start.end() - 1);
-        for (int k = 0; k < g.n_pp(); ++k) { int a = fp_of_pose[g.pp_i[k]], b = fp_of_pose[g.pp_j[k]];
-            if (a >= 0 && b >= 0) { inc[fill[a]++] = {b, k, 0}; inc[fill[b]++] = {a, k, 1}; } }
-        for (int k = 0; k < g.n_pl(); ++k) { int a = fp_of_pose[g.pl_p[k]], b = fl_of_lm[g.pl_l[k]];
-            if (a >= 0 && b >= 0) { inc[fill[a]++] = {nfp + b, pl_pos_of_ins[k], 2}; inc[fill[nfp + b]++] = {a, pl_pos_of_ins[k], 3}; } }
-        // landmark observer lists (free-pose positions, ascending)
         cone_obs_start.assign(nfl + 1, 0);
         for (int l = 0; l < nfl; ++l) cone_obs_start[l + 1] = cone_obs_start[l] + (inc_start[nfp + l + 1] - inc_start[nfp + l]);
         cone_obs.resize(cone_obs_start[nfl]);
-        for (int l = 0; l < nfl; ++l) { int o = cone_obs_start[l];
-            for (int q = inc_start[nfp + l]; q < inc_start[nfp + l + 1]; ++q) cone_obs[o++] = inc[q].other;
-            std::sort(cone_obs.begin() + cone_obs_start[l], cone_obs.begin() + cone_obs_start[l + 1]); }
+        parallel_chunks(nv, 4096, [&](int64_t b0, int64_t e0, int) {
+            for (int v = (int)b0; v < (int)e0; ++v) { Inc *o = &inc[inc_start[v]];
+                if (v < nfp) { const int p = pose_of_fp[v];
+                    for (int q = P.ppadj_start[p]; q < P.ppadj_start[p + 1]; ++q) { const int code = P.ppadj[q], k = code >> 1, role = code & 1;
+                        const int other = fp_of_pose[role ? g.pp_i[k] : g.pp_j[k]];
+                        if (other >= 0) *o++ = {other, k, role}; }
+                    for (int s = P.pl_start[p]; s < P.pl_start[p + 1]; ++s) { const int k = P.pl_order[s], fl = fl_of_lm[g.pl_l[k]];
+                        if (fl >= 0) *o++ = {nfp + fl, P.ell_of_ins[k], 2}; }
+                } else { const int lf = v - nfp, l = lm_of_fl[lf]; int32_t *co = &cone_obs[cone_obs_start[lf]];
+                    for (int q = P.lm_start[l]; q < P.lm_start[l + 1]; ++q) { const int e = P.lm_edges[q]; const int fp = fp_of_pose[(int)((e % SN) / T)];
+                        if (fp >= 0) { *o++ = {fp, e, 3}; *co++ = fp; } }
+                    std::sort(&cone_obs[cone_obs_start[lf]], co); }      // landmark observer lists (free-pose positions, ascending)
+            } });
     }
 
     bool has_observer(int l, int lo, int hi) const {   // any unassigned observer position in [lo, hi)
@@ -89,7 +104,8 @@ struct Builder {
         return false;
     }
 
-    void emit(std::vector<int32_t> &&verts) { if (!verts.empty()) sn.push_back(std::move(verts)); }
+    typedef std::vector<std::vector<int32_t>> SnList;
+    static void emit(SnList &out, std::vector<int32_t> &&verts) { if (!verts.empty()) out.push_back(std::move(verts)); }
 
     // Multi-way split at the bottom of the tree.  Binary dissection down to the leaves leaves three levels of
     // separators that are ONE pose each (3 pivots: the cones around them are seen from far outside such a short range
@@ -98,7 +114,7 @@ struct Builder {
     // by all its split poses AT ONCE: they form one separator supernode (3 (p - 1) pivots) whose p children are the
     // leaves.  Bounded so that neither the cluster front nor a leaf can exceed the 63 scalars of the wave-per-front
     // kernels: rows <= separator poses + cones alive in the range + the two poses outside it.
-    bool nd_multi(int a, int b, int un, std::vector<int32_t> &cones) {
+    bool nd_multi(int a, int b, int un, std::vector<int32_t> &cones, SnList &out, int depth) {
         const int ways = opt.cluster_ways;
         if (ways <= 2) return false;
         int p = std::min(ways, (un + 1 + opt.leaf_poses) / (opt.leaf_poses + 1));       // ceil((un + 1) / (leaf + 1)) parts
@@ -142,26 +158,26 @@ struct Builder {
         }
         const int np = (int)cut.size() - 1;
         cones.clear(); cones.shrink_to_fit();
-        if (!orphans.empty()) { std::vector<int32_t> v; for (int l : orphans) v.push_back(nfp + l); emit(std::move(v)); }
-        for (int k = 0; k < np; ++k) nd(cut[k] + 1, cut[k + 1], part_cones[k]);
+        if (!orphans.empty()) { std::vector<int32_t> v; for (int l : orphans) v.push_back(nfp + l); emit(out, std::move(v)); }
+        for (int k = 0; k < np; ++k) nd(cut[k] + 1, cut[k + 1], part_cones[k], out, depth + 1);
         std::vector<int32_t> verts(sep_poses.begin(), sep_poses.end());
         for (int l : sep_cones) verts.push_back(nfp + l);
-        emit(std::move(verts));
+        emit(out, std::move(verts));
         return true;
     }
 
     // nested dissection over free-pose positions [a, b); `cones` = free landmarks alive in this range
-    void nd(int a, int b, std::vector<int32_t> &cones) {
+    void nd(int a, int b, std::vector<int32_t> &cones, SnList &out, int depth) {
         int un = 0;
         for (int i = a; i < b; ++i) un += !assigned[i];
         if (un <= opt.leaf_poses) {
             std::vector<int32_t> verts;
             for (int i = a; i < b; ++i) if (!assigned[i]) { verts.push_back(i); assigned[i] = 1; }
             for (int l : cones) verts.push_back(nfp + l);
-            emit(std::move(verts));
+            emit(out, std::move(verts));
             return;
         }
-        if (nd_multi(a, b, un, cones)) return;
+        if (nd_multi(a, b, un, cones, out, depth)) return;
         // split pose: the middle unassigned one
         int m = -1, seen = 0;
         for (int i = a; i < b; ++i) if (!assigned[i]) { if (seen == un / 2) { m = i; break; } ++seen; }
@@ -180,12 +196,20 @@ struct Builder {
             else orphans.push_back(l);
         }
         cones.clear(); cones.shrink_to_fit();
-        if (!orphans.empty()) { std::vector<int32_t> v; for (int l : orphans) v.push_back(nfp + l); emit(std::move(v)); }
-        nd(a, m, left);
-        nd(m + 1, b, right);
+        if (!orphans.empty()) { std::vector<int32_t> v; for (int l : orphans) v.push_back(nfp + l); emit(out, std::move(v)); }
+        // the two halves touch disjoint pose ranges (and only read the shared tables): the top levels of the recursion
+        // run them on separate host threads, each into its own list, concatenated in elimination order
+        if ((1 << depth) < host_threads() && un > 2048) {
+            SnList lo;
+            std::thread th([&] { nd(a, m, left, lo, depth + 1); });
+            SnList hi; nd(m + 1, b, right, hi, depth + 1);
+            th.join();
+            for (auto &v : lo) out.push_back(std::move(v));
+            for (auto &v : hi) out.push_back(std::move(v));
+        } else { nd(a, m, left, out, depth + 1); nd(m + 1, b, right, out, depth + 1); }
         std::vector<int32_t> verts(sep_poses.begin(), sep_poses.end());
         for (int l : sep_cones) verts.push_back(nfp + l);
-        emit(std::move(verts));
+        emit(out, std::move(verts));
     }
 };
 
@@ -268,22 +292,39 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         const int PW = 64 / T, WT = (N + PW - 1) / PW;
         plan.n_wtiles = WT;
         plan.wt_grp_start.assign(WT + 1, 0);
-        std::vector<std::pair<int32_t, int32_t>> tmp;              // (landmark, local position)
         plan.ell_dst.assign((size_t)plan.ell_len, (uint16_t)0xFFFF);
-        for (int w = 0; w < WT; ++w) {
-            tmp.clear();
-            for (int lane = 0; lane < 64; ++lane) { const int p = w * PW + lane / T, h = lane % T;
-                if (p >= N) break;
-                for (int i = 0; i < R; ++i) { const int s = i * T + h;
-                    if (s < plan.pl_start[p + 1] - plan.pl_start[p]) tmp.emplace_back(g.pl_l[plan.pl_order[plan.pl_start[p] + s]], i * 64 + lane); } }
-            std::sort(tmp.begin(), tmp.end());
-            for (size_t i = 0; i < tmp.size(); ++i) {
-                if (i == 0 || tmp[i].first != tmp[i - 1].first) { plan.grp_lm.push_back(tmp[i].first); plan.grp_pos_start.push_back((int32_t)plan.grp_pos.size()); }
-                plan.grp_pos.push_back(tmp[i].second);
-                plan.ell_dst[(size_t)((int64_t)(tmp[i].second >> 6) * ((int64_t)T * N) + (int64_t)w * 64 + (tmp[i].second & 63))] = (uint16_t)i;
-            }
-            plan.wt_grp_start[w + 1] = (int32_t)plan.grp_lm.size();
-        }
+        // every wave tile is independent: chunks of tiles on the host threads, each into its own lists, stitched afterwards
+        const int C = chunk_count(WT, 256);
+        struct TileOut { std::vector<int32_t> grp_lm, grp_pos_start, grp_pos, tile_groups; };
+        std::vector<TileOut> outs(C);
+        std::vector<int64_t> cb(C + 1, 0);
+        for (int c = 0; c <= C; ++c) cb[c] = (int64_t)WT * c / C;
+        parallel_chunks(C, 1, [&](int64_t c0, int64_t c1, int) {
+            for (int c = (int)c0; c < (int)c1; ++c) { TileOut &O = outs[c];
+                std::vector<std::pair<int32_t, int32_t>> tmp;          // (landmark, local position)
+                for (int w = (int)cb[c]; w < (int)cb[c + 1]; ++w) {
+                    tmp.clear();
+                    for (int lane = 0; lane < 64; ++lane) { const int p = w * PW + lane / T, h = lane % T;
+                        if (p >= N) break;
+                        for (int i = 0; i < R; ++i) { const int s2 = i * T + h;
+                            if (s2 < plan.pl_start[p + 1] - plan.pl_start[p]) tmp.emplace_back(g.pl_l[plan.pl_order[plan.pl_start[p] + s2]], i * 64 + lane); } }
+                    std::sort(tmp.begin(), tmp.end());
+                    int ng = 0;
+                    for (size_t i = 0; i < tmp.size(); ++i) {
+                        if (i == 0 || tmp[i].first != tmp[i - 1].first) { O.grp_lm.push_back(tmp[i].first); O.grp_pos_start.push_back((int32_t)O.grp_pos.size()); ++ng; }
+                        O.grp_pos.push_back(tmp[i].second);
+                        plan.ell_dst[(size_t)((int64_t)(tmp[i].second >> 6) * ((int64_t)T * N) + (int64_t)w * 64 + (tmp[i].second & 63))] = (uint16_t)i;
+                    }
+                    O.tile_groups.push_back(ng);
+                } } });
+        { size_t ng = 0, np2 = 0; for (auto &O : outs) { ng += O.grp_lm.size(); np2 += O.grp_pos.size(); }
+          plan.grp_lm.reserve(ng); plan.grp_pos_start.reserve(ng + 1); plan.grp_pos.reserve(np2);
+          int w = 0;
+          for (auto &O : outs) { const int32_t pos0 = (int32_t)plan.grp_pos.size();
+              plan.grp_lm.insert(plan.grp_lm.end(), O.grp_lm.begin(), O.grp_lm.end());
+              for (int32_t v : O.grp_pos_start) plan.grp_pos_start.push_back(pos0 + v);
+              plan.grp_pos.insert(plan.grp_pos.end(), O.grp_pos.begin(), O.grp_pos.end());
+              for (int n : O.tile_groups) { plan.wt_grp_start[w + 1] = plan.wt_grp_start[w] + n; ++w; } } }
         plan.grp_pos_start.push_back((int32_t)plan.grp_pos.size());
         plan.wt_desc.resize((size_t)WT * 4);
         for (int w = 0; w < WT; ++w) { const int a = plan.wt_grp_start[w], b = plan.wt_grp_start[w + 1];
@@ -300,9 +341,9 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
 
     GS_PT(2);
     // ---- elimination order by nested dissection ----
-    B.build_adjacency(plan.ell_of_ins);
+    B.build_adjacency(plan);
     B.assigned.assign(B.nfp, 0);
-    { std::vector<int32_t> all(B.nfl); for (int l = 0; l < B.nfl; ++l) all[l] = l; B.nd(0, B.nfp, all); }
+    { std::vector<int32_t> all(B.nfl); for (int l = 0; l < B.nfl; ++l) all[l] = l; B.nd(0, B.nfp, all, B.sn, 0); }
     const int S = (int)B.sn.size();
     std::vector<int32_t> sn_of(B.nv, -1), vpos(B.nv, -1), gidx(B.nv, -1);
     { int pos = 0, sc = 0;

@@ -4,6 +4,8 @@ The plan (nested-dissection order, symbolic factorisation, assembly records, ext
 (a) for the invariants any valid multifrontal plan satisfies and (b) numerically: tests/plan_exec.py
 replays the plan in numpy on the oracle's H blocks and must reproduce the oracle's joint-system increment.
 No HIP code runs here."""
+import os
+
 import numpy as np
 import pytest
 
@@ -102,3 +104,22 @@ def test_plan_edge_orders_are_permutations(pkg, bench_graphs):
     assert np.all(np.diff(g["pl_p"][P.pl_order]) >= 0)   # device order: grouped by pose
     assert sorted(P.pp_order.tolist()) == list(range(len(g["pp_i"])))
     G.close()
+
+
+def test_plan_is_the_same_for_any_number_of_host_threads(pkg):
+    """The structure phase runs on several host threads (csrc/gs_parallel.hpp: adjacency, the top levels of the nested
+    dissection, wave tiles, fronts); the plan must not depend on how many: same bytes with GS_THREADS = 1, 3 and 8."""
+    import hashlib
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import importlib, sys, hashlib; sys.path.insert(0, %r); from oracle import pyoracle as po; "
+            "pkg = importlib.import_module('opendlv-logic-cfsd18-sensation-slam_amd'); "
+            "t = pkg.track.generate(10000, 2000); g = pkg.track.bench_graph(t, po.OracleFrontend()); "
+            "H = pkg.Graph(device=-2); H.load_bench_graph(g); H.plan_build_host(); print(hashlib.md5(H.plan_export().tobytes()).hexdigest())" % root)
+    digests = set()
+    for n in ("1", "3", "8"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GS_THREADS=n), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1000:]
+        digests.add(r.stdout.strip().splitlines()[-1])
+    assert len(digests) == 1, digests
