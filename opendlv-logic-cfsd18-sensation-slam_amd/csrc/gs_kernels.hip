@@ -1298,13 +1298,16 @@ __device__ __forceinline__ void f3_gather_child_lds(const double *base, int usiz
                 u[mf_tile(I, J)][q] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + o); }
         }
 }
-// F3_LDS_GATHER (default 1): children's update matrices are fetched with coalesced loads (8 bytes per lane, every cache
-// line used once and fully), staged in the front's LDS image — free once the original entries have moved to the
-// accumulators — and gathered by destination from there; up to four children per batch have their loads in flight
-// together (the batches and each child's place in the image are laid out on the host, x-table header fields 4-5).
-// 0: gather by destination straight from HBM / L2 (two children at a time in registers, further ones one by one).
+// F3_LDS_GATHER = 1 (tuning build; default 0): children's update matrices are fetched with coalesced loads (8 bytes per
+// lane, every cache line used once and fully), staged in the front's LDS image — free once the original entries have
+// moved to the accumulators — and gathered by destination from there; up to four children per batch have their loads in
+// flight together (the batches and each child's place in the image are laid out on the host, children-table header
+// fields 4-6).  Measured at cfg4 on MI355X, same box: factor phase 0.326 ms against 0.194 ms for the default — the
+// staging registers on top of the 80 accumulator registers spill 35 VGPRs to scratch at two waves per SIMD, and the
+// reloads sit in every front's dependent chain.  0: gather by destination straight from HBM / L2 (two children at a
+// time in registers, further ones one by one).
 #ifndef F3_LDS_GATHER
-#define F3_LDS_GATHER 1
+#define F3_LDS_GATHER 0
 #endif
 
 #ifndef F3_RCP_NEWTON
