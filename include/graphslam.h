@@ -262,6 +262,21 @@ int  gs_associate_batch(gs_graph *g, int32_t n, const double *poses_xytheta, int
                         int32_t n_map, const double *map_xy, const int32_t *map_type,
                         double threshold, double type_tol, int32_t *out_index);
 
+/* ---- the per-keyframe front end: A0 + A1 fused, against a map that stays resident in HBM -------------------------
+ * gs_map_clear / gs_map_append / gs_map_set_xy / gs_map_size: the device mirror of Slam::m_map (src/slam.hpp: std::vector<Cone>):
+ *      cones are appended in map order (index = Cone id, src/slam.cpp:556,610) and their positions rewritten after
+ *      updateMap (src/slam.cpp:713-732).  Appends are asynchronous on the handle's stream.
+ * gs_frame_frontend <- the per-frame arithmetic of addConesToMap / localizer (src/slam.cpp:570-607, 350-382): for the k
+ *      observations of ONE frame (collector layout, column-major 4 x k) the CoG-frame XY (edge measurement), the global XY
+ *      seen from `pose`, and the LOWEST map index with a matching type within `threshold` (-1: none) — one launch, one wait,
+ *      no allocation.  signed_type != 0 selects the localizer's test `(type_j - (int)type_i) < type_tol` (no fabs, :360). */
+int  gs_map_clear(gs_graph *g);
+int  gs_map_append(gs_graph *g, int32_t n, const double *xy, const int32_t *type);
+int  gs_map_set_xy(gs_graph *g, int32_t first, int32_t n, const double *xy);
+int  gs_map_size(gs_graph *g);
+int  gs_frame_frontend(gs_graph *g, const double pose_xytheta[3], const double *obs_4xk, int32_t k, double threshold,
+                       double type_tol, int32_t signed_type, double *out_zxy, double *out_gxy, int32_t *out_index);
+
 /* ---- multi-GPU: pose-window shards -----------------------------
  * Each rank owns a contiguous pose window and builds the SAME global plan; it linearises and
  * factorises only its own subtrees, exports the update contributions to the shared top of the

@@ -140,6 +140,10 @@ def lib():
     L.gs_cone_to_global_batch.argtypes = [vp, C.c_int32, _dp, C.c_int32, _ip, _dp, _dp]
     L.gs_associate_batch.argtypes = [vp, C.c_int32, _dp, C.c_int32, _ip, _dp, C.c_int32, _dp, _ip,
                                      C.c_double, C.c_double, _ip]
+    L.gs_map_clear.argtypes = [vp]; L.gs_map_size.argtypes = [vp]
+    L.gs_map_append.argtypes = [vp, C.c_int32, _dp, _ip]
+    L.gs_map_set_xy.argtypes = [vp, C.c_int32, C.c_int32, _dp]
+    L.gs_frame_frontend.argtypes = [vp, _dp, _dp, C.c_int32, C.c_double, C.c_double, C.c_int32, _dp, _dp, _ip]
     L.gs_dist_read_exchange.argtypes = [vp, _dp]
     L.gs_dist_write_exchange.argtypes = [vp, _dp]
     u8 = C.POINTER(C.c_uint8)
@@ -395,6 +399,23 @@ class Graph:
         self._check(self.L.gs_associate_batch(self.h, len(obs), _d(poses), len(poses), _i(po), _d(obs), len(map_xy),
                                               _d(map_xy), _i(map_type), float(thr), float(type_tol), _i(out)))
         return out
+
+    # ---- per-keyframe front end against the resident map
+    def map_clear(self): self._check(self.L.gs_map_clear(self.h))
+    def map_size(self): return self._check(self.L.gs_map_size(self.h))
+
+    def map_append(self, xy, types):
+        xy = _f64(xy, (-1, 2)); ty = _i32(types); self._check(self.L.gs_map_append(self.h, len(ty), _d(xy), _i(ty)))
+
+    def map_set_xy(self, first, xy):
+        xy = _f64(xy, (-1, 2)); self._check(self.L.gs_map_set_xy(self.h, int(first), len(xy), _d(xy)))
+
+    def frame_frontend(self, pose, obs, thr, type_tol=1e-4, signed_type=0):
+        """(zxy [k,2], gxy [k,2], idx [k]) of one frame's observations [k,4] against the resident map."""
+        pose = _f64(pose); obs = _f64(obs, (-1, 4)); k = len(obs)
+        z = np.zeros((k, 2)); gx = np.zeros((k, 2)); idx = np.zeros(k, dtype=np.int32)
+        self._check(self.L.gs_frame_frontend(self.h, _d(pose), _d(obs), k, float(thr), float(type_tol), int(signed_type), _d(z), _d(gx), _i(idx)))
+        return z, gx, idx
 
     # ---- pose-window shards (one handle per rank / GPU)
     def dist_configure(self, rank, world):

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace gs;
@@ -26,6 +27,7 @@ int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
     return fail(GS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
 // ------------------------------------------------------------------ helpers
+void gs_frontend_release(gs_graph *g);       // front-end buffers of the handle (defined with the front end below)
 static int usable_devices() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -115,6 +117,7 @@ extern "C" int gs_destroy(gs_graph *g) {
     hipSetDevice(g->device);
     hipStreamSynchronize(g->stream);
     dev_free_all(g);
+    gs_frontend_release(g);
     for (auto &e : g->ev) hipEventDestroy(e);
     if (g->own_stream) hipStreamDestroy(g->stream);
     delete g;
@@ -351,7 +354,44 @@ static void se2_inverse_host(const double *a, double *out) {
     out[0] = c * (-a[0]) - s * (-a[1]); out[1] = s * (-a[0]) + c * (-a[1]); out[2] = th;
 }
 
-static int upload_graph(gs_graph *g) {
+// Everything that does not depend on the plan goes to HBM on a helper thread WHILE the host builds the plan: estimates,
+// fixed flags, odometry measurements (inverted, with their cos/sin: g2o keeps _inverseMeasurement) and information,
+// and the observation edges as inserted (permuted into the ELL layout on the device afterwards).
+struct RawUpload {
+    std::thread th; int rc = GS_OK; std::string err;
+    int32_t *pl_l = nullptr; double *pl_z = nullptr, *pl_info = nullptr;
+    std::vector<double> zinv;
+};
+static int upload_raw_begin(gs_graph *g, RawUpload &R) {
+    const HostGraph &h = g->h; DevGraph &d = g->d;
+    const size_t N = h.n_poses(), M = h.n_lms(), Epp = h.n_pp(), Epl = h.n_pl();
+    int rc;
+    if ((rc = dev_alloc(g, &d.pose_est, N * 3)) != GS_OK || (rc = dev_alloc(g, &d.lm_est, M * 2)) != GS_OK ||
+        (rc = dev_alloc(g, &d.pose_fixed, N)) != GS_OK || (rc = dev_alloc(g, &d.lm_fixed, M)) != GS_OK ||
+        (rc = dev_alloc(g, &d.pose_cs, N * 2)) != GS_OK || (rc = dev_alloc(g, &d.pp_zinv, Epp * 5)) != GS_OK ||
+        (rc = dev_alloc(g, &d.pp_info, Epp * 6)) != GS_OK || (rc = dev_alloc(g, &R.pl_l, Epl)) != GS_OK ||
+        (rc = dev_alloc(g, &R.pl_z, Epl * 2)) != GS_OK || (rc = dev_alloc(g, &R.pl_info, Epl * 3)) != GS_OK) return rc;
+    R.th = std::thread([g, &R, N, M, Epp, Epl] {
+        const HostGraph &h = g->h; DevGraph &d = g->d;
+        auto cp = [&](void *dst, const void *src, size_t bytes) {
+            if (R.rc != GS_OK || bytes == 0) return;
+            hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g->stream);
+            if (e != hipSuccess) { R.rc = GS_ERR_HIP; R.err = std::string("raw upload: ") + hipGetErrorString(e); } };
+        if (hipSetDevice(g->device) != hipSuccess) { R.rc = GS_ERR_HIP; R.err = "hipSetDevice failed on the upload thread"; return; }
+        cp(d.pose_est, h.pose_est.data(), N * 3 * sizeof(double)); cp(d.lm_est, h.lm_est.data(), M * 2 * sizeof(double));
+        cp(d.pose_fixed, h.pose_fixed.data(), N); cp(d.lm_fixed, h.lm_fixed.data(), M);
+        cp(R.pl_l, h.pl_l.data(), Epl * sizeof(int32_t)); cp(R.pl_z, h.pl_z.data(), Epl * 2 * sizeof(double));
+        cp(R.pl_info, h.pl_info.data(), Epl * 3 * sizeof(double));
+        cp(d.pp_info, h.pp_info.data(), Epp * 6 * sizeof(double));            // odometry edges keep their insertion order on the device
+        R.zinv.resize(Epp * 5);
+        for (size_t k = 0; k < Epp; ++k) { double inv[3]; se2_inverse_host(&h.pp_z[3 * k], inv);
+            double *o = &R.zinv[5 * k]; o[0] = inv[0]; o[1] = inv[1]; o[2] = inv[2]; o[3] = std::cos(inv[2]); o[4] = std::sin(inv[2]); }
+        cp(d.pp_zinv, R.zinv.data(), Epp * 5 * sizeof(double));
+    });
+    return GS_OK;
+}
+
+static int upload_graph(gs_graph *g, RawUpload &raw) {
     const HostGraph &h = g->h; const Plan &P = g->plan; DevGraph &d = g->d;
     const bool ut_on = std::getenv("GS_PLAN_TIMING") != nullptr; auto ut_prev = std::chrono::steady_clock::now();
 #define GS_UT(name) do { if (ut_on) { auto n_ = std::chrono::steady_clock::now(); std::fprintf(stderr, "upload %-18s %.2f ms\n", (name), std::chrono::duration<double, std::milli>(n_ - ut_prev).count()); ut_prev = n_; } } while (0)
@@ -360,26 +400,16 @@ static int upload_graph(gs_graph *g) {
     g->leaf_n = -1;
     int rc;
 #define UP(dst, vec) if ((rc = dev_upload(g, &d.dst, vec)) != GS_OK) return rc
-    UP(pose_est, h.pose_est); UP(lm_est, h.lm_est); UP(pose_fixed, h.pose_fixed); UP(lm_fixed, h.lm_fixed);
-    if ((rc = dev_alloc(g, &d.pose_cs, (size_t)h.n_poses() * 2)) != GS_OK) return rc;
+    // estimates, fixed flags, odometry edges and the insertion-order observation arrays are in HBM already (RawUpload)
     launch_pose_trig(d, g->stream);
     UP(pose_gidx, P.pose_gidx); UP(lm_gidx, P.lm_gidx);
     d.ell_T = P.ell_T; d.ell_R = P.ell_R; d.ell_len = P.ell_len;
-    { const size_t L = (size_t)P.ell_len;                                                                    // ELL streams
-      std::vector<int32_t> l(L, -1); std::vector<double> z(L * 2, 0.0), w(L * 3, 0.0);
-      parallel_chunks((int64_t)L, 1 << 15, [&](int64_t b, int64_t e1, int) {
-      for (size_t e = (size_t)b; e < (size_t)e1; ++e) { const int k = P.ell_ins[e]; if (k < 0) continue;
-          if (P.world > 1 && P.pl_rank[k] != P.rank) continue;          // pose-window shards: evaluated by another rank
-          l[e] = h.pl_l[k]; z[e] = h.pl_z[2 * (size_t)k]; z[L + e] = h.pl_z[2 * (size_t)k + 1];
-          for (int t = 0; t < 3; ++t) w[t * L + e] = h.pl_info[3 * (size_t)k + t]; } });
-      UP(ell_l, l); UP(ell_z, z); UP(ell_w, w); }
-    { std::vector<double> zi((size_t)Epp * 5), w((size_t)Epp * 6);
-      parallel_chunks((int64_t)Epp, 1 << 13, [&](int64_t b, int64_t e1, int) {
-      for (int pos = (int)b; pos < (int)e1; ++pos) { int k = P.pp_order[pos];
-          double inv[3]; se2_inverse_host(&h.pp_z[3 * (size_t)k], inv);
-          double *o = &zi[5 * (size_t)pos]; o[0] = inv[0]; o[1] = inv[1]; o[2] = inv[2]; o[3] = std::cos(inv[2]); o[4] = std::sin(inv[2]);
-          for (int t = 0; t < 6; ++t) w[6 * (size_t)pos + t] = h.pp_info[6 * (size_t)k + t]; } });
-      UP(pp_zinv, zi); UP(pp_info, w); }
+    { const size_t L = (size_t)P.ell_len;                            // ELL streams: permuted on the device (k_build_ell)
+      int32_t *ins = nullptr, *prank = nullptr;
+      if ((rc = dev_upload(g, &ins, P.ell_ins)) != GS_OK) return rc;
+      if (P.world > 1 && (rc = dev_upload(g, &prank, P.pl_rank)) != GS_OK) return rc;
+      if ((rc = dev_alloc(g, &d.ell_l, L)) != GS_OK || (rc = dev_alloc(g, &d.ell_z, 2 * L)) != GS_OK || (rc = dev_alloc(g, &d.ell_w, 3 * L)) != GS_OK) return rc;
+      launch_build_ell((int64_t)L, ins, raw.pl_l, raw.pl_z, raw.pl_info, prank, P.rank, d.ell_l, d.ell_z, d.ell_w, g->stream); }
     GS_UT("estimates+edges");
     UP(lm_start, P.lm_start); UP(lm_edges, P.lm_edges); UP(ppadj_start, P.ppadj_start);
     { std::vector<int32_t> inc = P.ppinc;                                 // incidences of edges another rank evaluates: edge = -1
@@ -486,11 +516,14 @@ static int upload_graph(gs_graph *g) {
               r[18] = (int32_t)(xo & 0xffffffffLL); r[19] = (int32_t)(xo >> 32); }
           std::vector<int32_t> recs(P.asm_recs.size() * 4);
           const bool fused = P.lin_ell_ok && d.n_wtiles > 0;
-          for (size_t t = 0; t < P.asm_recs.size(); ++t) { int kind = P.asm_recs[t].kind, src = P.asm_recs[t].src;
-              if (kind == 1 && fused) { const int q0 = P.lm_grp_start[src], q1 = P.lm_grp_start[src + 1];
-                  if (q1 - q0 >= (1 << 22)) return fail(GS_ERR_INVALID, "landmark seen from too many wave tiles");
-                  kind = 1 | ((q1 - q0) << 8); src = q0; }
-              recs[4 * t] = kind; recs[4 * t + 1] = src; recs[4 * t + 2] = P.asm_recs[t].r0; recs[4 * t + 3] = P.asm_recs[t].c0; }
+          { bool too_many = false;
+            parallel_chunks((int64_t)P.asm_recs.size(), 1 << 14, [&](int64_t b, int64_t e1, int) {
+              for (size_t t = (size_t)b; t < (size_t)e1; ++t) { int kind = P.asm_recs[t].kind, src = P.asm_recs[t].src;
+                  if (kind == 1 && fused) { const int q0 = P.lm_grp_start[src], q1 = P.lm_grp_start[src + 1];
+                      if (q1 - q0 >= (1 << 22)) too_many = true;
+                      kind = 1 | ((q1 - q0) << 8); src = q0; }
+                  recs[4 * t] = kind; recs[4 * t + 1] = src; recs[4 * t + 2] = P.asm_recs[t].r0; recs[4 * t + 3] = P.asm_recs[t].c0; } });
+            if (too_many) return fail(GS_ERR_INVALID, "landmark seen from too many wave tiles"); }
           UP(asm3, recs);
           // per front: where each row R of its PARENT finds this front's row in its tile image, as byte offsets split
           // into a row part (low 16 bits) and a column part (high 16 bits); -30000 = no such row (sum goes negative)
@@ -645,8 +678,13 @@ extern "C" int gs_initialize_optimization(gs_graph *g) {
     rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
     HIP_TRY(hipStreamSynchronize(g->stream));
     dev_free_all(g);
-    rc = build_plan_host(g); if (rc != GS_OK) return rc;
-    rc = upload_graph(g); if (rc != GS_OK) { dev_free_all(g); return rc; }
+    RawUpload raw;
+    rc = upload_raw_begin(g, raw); if (rc != GS_OK) { if (raw.th.joinable()) raw.th.join(); dev_free_all(g); return rc; }
+    rc = build_plan_host(g);                                        // the host threads build the plan while the raw arrays travel
+    raw.th.join();
+    if (rc == GS_OK && raw.rc != GS_OK) rc = fail(raw.rc, raw.err);
+    if (rc != GS_OK) { dev_free_all(g); return rc; }
+    rc = upload_graph(g, raw); if (rc != GS_OK) { dev_free_all(g); return rc; }
     g->ms_structure = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return GS_OK;
 }
@@ -965,20 +1003,46 @@ extern "C" int gs_time_iterations(gs_graph *g, int32_t reps, gs_stats *s) {
 }
 
 // ------------------------------------------------------------------ front end (A0, A1)
+// Device memory of the front end lives on the handle and only ever grows: the batch calls carve a scratch arena, the
+// per-frame path has pinned staging buffers and a device-resident copy of the map.  Nothing is allocated, freed or
+// synchronised beyond the one wait for the results per call.
 namespace {
-struct Scratch {   // device scratch freed on scope exit
-    std::vector<void *> p;
-    ~Scratch() { for (void *q : p) hipFree(q); }
-    template <class T> T *up(const T *h, size_t n, hipStream_t st) { void *d = nullptr; if (hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
-        p.push_back(d); if (h && n) hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, st); return (T *)d; }
+struct Carver {   // carves the handle's grow-only arena (256-byte aligned pieces), valid until the next front-end call
+    gs_graph *g; size_t off = 0;
+    template <class T> T *get(size_t n) { T *p = (T *)(g->fe.arena + off); off += (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255; return p; }
 };
 }
+static int arena_reserve(gs_graph *g, size_t bytes) {
+    if (bytes <= g->fe.arena_bytes) return GS_OK;
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    if (g->fe.arena) { hipFree(g->fe.arena); g->fe.arena = nullptr; g->fe.arena_bytes = 0; }
+    const size_t want = bytes + bytes / 2 + 4096;
+    HIP_TRY(hipMalloc((void **)&g->fe.arena, want));
+    g->fe.arena_bytes = want;
+    return GS_OK;
+}
+static size_t padded(size_t n, size_t elem) { return (std::max<size_t>(n, 1) * elem + 255) & ~(size_t)255; }
+void gs_frontend_release(gs_graph *g) {      // gs_destroy
+    if (g->fe.arena) hipFree(g->fe.arena);
+    if (g->fe.pin_in) hipHostFree(g->fe.pin_in);
+    if (g->fe.pin_out) hipHostFree(g->fe.pin_out);
+    if (g->fe.dev_in) hipFree(g->fe.dev_in);
+    if (g->fe.dev_out) hipFree(g->fe.dev_out);
+    if (g->fe.map_xy) hipFree(g->fe.map_xy);
+    if (g->fe.map_type) hipFree(g->fe.map_type);
+    if (g->fe.pin_map) hipHostFree(g->fe.pin_map);
+    g->fe = gs_graph::FrontEnd();
+}
+
 extern "C" int gs_polar_to_xy_batch(gs_graph *g, int32_t n, const double *az, const double *zen, const double *dist, double *out) {
     if (!g || n < 0 || (n > 0 && (!az || !zen || !dist || !out))) return fail(GS_ERR_INVALID, "bad argument");
     int rc = ensure_device(g); if (rc != GS_OK) return rc;
     if (n == 0) return GS_OK;
-    Scratch s; double *a = s.up(az, n, g->stream), *z = s.up(zen, n, g->stream), *d = s.up(dist, n, g->stream), *o = s.up<double>(nullptr, 2 * (size_t)n, g->stream);
-    if (!a || !z || !d || !o) return fail(GS_ERR_HIP, "hipMalloc failed");
+    if ((rc = arena_reserve(g, 3 * padded(n, 8) + padded(2 * (size_t)n, 8))) != GS_OK) return rc;
+    Carver c{g}; double *a = c.get<double>(n), *z = c.get<double>(n), *d = c.get<double>(n), *o = c.get<double>(2 * (size_t)n);
+    HIP_TRY(hipMemcpyAsync(a, az, (size_t)n * 8, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipMemcpyAsync(z, zen, (size_t)n * 8, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipMemcpyAsync(d, dist, (size_t)n * 8, hipMemcpyHostToDevice, g->stream));
     launch_polar_to_xy(n, a, z, d, g->cfg.lidar_to_cog, o, g->stream);
     HIP_TRY(hipMemcpyAsync(out, o, 2 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
@@ -990,9 +1054,12 @@ extern "C" int gs_cone_to_global_batch(gs_graph *g, int32_t n, const double *pos
     for (int i = 0; i < n; ++i) if (pose_of_obs[i] < 0 || pose_of_obs[i] >= npose) return fail(GS_ERR_INVALID, "pose_of_obs out of range");
     int rc = ensure_device(g); if (rc != GS_OK) return rc;
     if (n == 0) return GS_OK;
-    Scratch s; double *p = s.up(poses, 3 * (size_t)npose, g->stream); int32_t *po = s.up(pose_of_obs, n, g->stream);
-    double *ob = s.up(obs, 4 * (size_t)n, g->stream), *o = s.up<double>(nullptr, 2 * (size_t)n, g->stream);
-    if (!p || !po || !ob || !o) return fail(GS_ERR_HIP, "hipMalloc failed");
+    if ((rc = arena_reserve(g, padded(3 * (size_t)npose, 8) + padded(n, 4) + padded(4 * (size_t)n, 8) + padded(2 * (size_t)n, 8))) != GS_OK) return rc;
+    Carver c{g}; double *p = c.get<double>(3 * (size_t)npose); int32_t *po = c.get<int32_t>(n);
+    double *ob = c.get<double>(4 * (size_t)n), *o = c.get<double>(2 * (size_t)n);
+    HIP_TRY(hipMemcpyAsync(p, poses, 3 * (size_t)npose * 8, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipMemcpyAsync(po, pose_of_obs, (size_t)n * 4, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipMemcpyAsync(ob, obs, 4 * (size_t)n * 8, hipMemcpyHostToDevice, g->stream));
     launch_cone_to_global(n, p, po, ob, g->cfg.lidar_to_cog, o, g->stream);
     HIP_TRY(hipMemcpyAsync(out, o, 2 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
@@ -1005,10 +1072,6 @@ extern "C" int gs_associate_batch(gs_graph *g, int32_t n, const double *poses, i
     for (int i = 0; i < n; ++i) if (pose_of_obs[i] < 0 || pose_of_obs[i] >= npose) return fail(GS_ERR_INVALID, "pose_of_obs out of range");
     int rc = ensure_device(g); if (rc != GS_OK) return rc;
     if (n == 0) return GS_OK;
-    Scratch s; double *p = s.up(poses, 3 * (size_t)npose, g->stream); int32_t *po = s.up(pose_of_obs, n, g->stream);
-    double *ob = s.up(obs, 4 * (size_t)n, g->stream); double *mx = s.up(map_xy, 2 * (size_t)n_map, g->stream);
-    int32_t *mt = s.up(map_type, n_map, g->stream), *o = s.up<int32_t>(nullptr, n, g->stream);
-    if (!p || !po || !ob || !mx || !mt || !o) return fail(GS_ERR_HIP, "hipMalloc failed");
     // maps beyond a few LDS tiles go through a uniform grid (cell edge a hair above the threshold, so that every cone
     // within the threshold sits in the 3 x 3 cells around the query); the brute-force kernel stays for small maps,
     // non-positive thresholds and degenerate extents.  GS_ASSOC_GRID=0/1 forces either (A/B, tests).
@@ -1019,14 +1082,14 @@ extern "C" int gs_associate_batch(gs_graph *g, int32_t n, const double *poses, i
         for (int j = 0; j < n_map; ++j) { const double x = map_xy[2 * (size_t)j], y = map_xy[2 * (size_t)j + 1];
             if (!(std::isfinite(x) && std::isfinite(y))) { grid = false; break; }
             minx = std::min(minx, x); maxx = std::max(maxx, x); miny = std::min(miny, y); maxy = std::max(maxy, y); } }
+    std::vector<int32_t> start, items; double inv_cell = 0; int64_t nx = 0, ny = 0;
     if (grid) {
         double cell = thr * (1.0 + 1e-9);
-        int64_t nx, ny;
         for (;;) { nx = (int64_t)std::floor((maxx - minx) / cell) + 1; ny = (int64_t)std::floor((maxy - miny) / cell) + 1;
             if (nx * ny <= std::max<int64_t>(4096, 8 * (int64_t)n_map)) break;      // a sparse map (cones along a 25 km line) gets coarser cells, not millions of empty ones
             cell *= 1.5; }
-        const double inv_cell = 1.0 / cell;
-        std::vector<int32_t> cell_of(n_map), start((size_t)(nx * ny) + 1, 0), items(n_map);
+        inv_cell = 1.0 / cell;
+        std::vector<int32_t> cell_of(n_map); start.assign((size_t)(nx * ny) + 1, 0); items.resize(n_map);
         for (int j = 0; j < n_map; ++j) {
             int64_t cx = (int64_t)std::floor((map_xy[2 * (size_t)j] - minx) * inv_cell), cy = (int64_t)std::floor((map_xy[2 * (size_t)j + 1] - miny) * inv_cell);
             cx = std::min(std::max<int64_t>(cx, 0), nx - 1); cy = std::min(std::max<int64_t>(cy, 0), ny - 1);
@@ -1034,16 +1097,108 @@ extern "C" int gs_associate_batch(gs_graph *g, int32_t n, const double *poses, i
         for (size_t c = 0; c + 1 < start.size(); ++c) start[c + 1] += start[c];
         { std::vector<int32_t> fill(start.begin(), start.end() - 1);
           for (int j = 0; j < n_map; ++j) items[(size_t)fill[cell_of[j]]++] = j; }          // ascending map index inside a cell
-        int32_t *cs = s.up(start.data(), start.size(), g->stream), *ci = s.up(items.data(), items.size(), g->stream);
-        if (!cs || !ci) return fail(GS_ERR_HIP, "hipMalloc failed");
-        launch_associate_grid(n, p, po, ob, g->cfg.lidar_to_cog, mx, mt, thr, type_tol, minx, miny, inv_cell, (int)nx, (int)ny, cs, ci, o, g->stream);
-        HIP_TRY(hipMemcpyAsync(out, o, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
-        HIP_TRY(hipStreamSynchronize(g->stream));        // the host vectors above must outlive the uploads
-        return GS_OK;
     }
-    launch_associate(n, p, po, ob, g->cfg.lidar_to_cog, n_map, mx, mt, thr, type_tol, o, g->stream);
+    if ((rc = arena_reserve(g, padded(3 * (size_t)npose, 8) + padded(n, 4) + padded(4 * (size_t)n, 8) + padded(2 * (size_t)n_map, 8) +
+                               padded(n_map, 4) + padded(n, 4) + padded(start.size(), 4) + padded(items.size(), 4))) != GS_OK) return rc;
+    Carver c{g}; double *p = c.get<double>(3 * (size_t)npose); int32_t *po = c.get<int32_t>(n);
+    double *ob = c.get<double>(4 * (size_t)n), *mx = c.get<double>(2 * (size_t)n_map);
+    int32_t *mt = c.get<int32_t>(n_map), *o = c.get<int32_t>(n), *cs = c.get<int32_t>(start.size()), *ci = c.get<int32_t>(items.size());
+    HIP_TRY(hipMemcpyAsync(p, poses, 3 * (size_t)npose * 8, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipMemcpyAsync(po, pose_of_obs, (size_t)n * 4, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipMemcpyAsync(ob, obs, 4 * (size_t)n * 8, hipMemcpyHostToDevice, g->stream));
+    if (n_map > 0) { HIP_TRY(hipMemcpyAsync(mx, map_xy, 2 * (size_t)n_map * 8, hipMemcpyHostToDevice, g->stream));
+                     HIP_TRY(hipMemcpyAsync(mt, map_type, (size_t)n_map * 4, hipMemcpyHostToDevice, g->stream)); }
+    if (grid) {
+        HIP_TRY(hipMemcpyAsync(cs, start.data(), start.size() * 4, hipMemcpyHostToDevice, g->stream));
+        HIP_TRY(hipMemcpyAsync(ci, items.data(), items.size() * 4, hipMemcpyHostToDevice, g->stream));
+        launch_associate_grid(n, p, po, ob, g->cfg.lidar_to_cog, mx, mt, thr, type_tol, minx, miny, inv_cell, (int)nx, (int)ny, cs, ci, o, g->stream);
+    } else launch_associate(n, p, po, ob, g->cfg.lidar_to_cog, n_map, mx, mt, thr, type_tol, o, g->stream);
     HIP_TRY(hipMemcpyAsync(out, o, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));        // (the host vectors above must outlive the uploads)
+    return GS_OK;
+}
+
+// ---- the per-keyframe path: resident map + one fused launch -------------------------------------------------------
+static int map_reserve(gs_graph *g, int want) {
+    if (want <= g->fe.map_cap) return GS_OK;
+    const int cap = std::max(want + want / 2, 1024);
+    double *xy = nullptr; int32_t *ty = nullptr;
+    HIP_TRY(hipMalloc((void **)&xy, (size_t)cap * 2 * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&ty, (size_t)cap * sizeof(int32_t)));
+    if (g->fe.map_n > 0) { HIP_TRY(hipMemcpyAsync(xy, g->fe.map_xy, (size_t)g->fe.map_n * 2 * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
+                           HIP_TRY(hipMemcpyAsync(ty, g->fe.map_type, (size_t)g->fe.map_n * sizeof(int32_t), hipMemcpyDeviceToDevice, g->stream)); }
     HIP_TRY(hipStreamSynchronize(g->stream));
+    if (g->fe.map_xy) hipFree(g->fe.map_xy);
+    if (g->fe.map_type) hipFree(g->fe.map_type);
+    g->fe.map_xy = xy; g->fe.map_type = ty; g->fe.map_cap = cap;
+    return GS_OK;
+}
+static int pin_map_reserve(gs_graph *g, size_t bytes) {
+    if (bytes <= g->fe.pin_map_bytes) return GS_OK;
+    HIP_TRY(hipStreamSynchronize(g->stream));                       // a previous staged copy may still be in flight
+    if (g->fe.pin_map) hipHostFree(g->fe.pin_map);
+    g->fe.pin_map = nullptr; g->fe.pin_map_bytes = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 2, 1 << 16);
+    HIP_TRY(hipHostMalloc((void **)&g->fe.pin_map, want, hipHostMallocDefault));
+    g->fe.pin_map_bytes = want;
+    return GS_OK;
+}
+extern "C" int gs_map_size(gs_graph *g) { return g ? g->fe.map_n : fail(GS_ERR_INVALID, "null graph"); }
+extern "C" int gs_map_clear(gs_graph *g) { if (!g) return fail(GS_ERR_INVALID, "null graph"); g->fe.map_n = 0; return GS_OK; }
+extern "C" int gs_map_append(gs_graph *g, int32_t n, const double *xy, const int32_t *type) {
+    if (!g || n < 0 || (n > 0 && (!xy || !type))) return fail(GS_ERR_INVALID, "bad argument");
+    int rc = ensure_device(g); if (rc != GS_OK) return rc;
+    if (n == 0) return GS_OK;
+    if ((rc = map_reserve(g, g->fe.map_n + n)) != GS_OK) return rc;
+    // staged through pinned memory so that the copy is asynchronous; the staging buffer is reused once the stream has passed
+    // it — every gs_frame_frontend call waits for the stream, and two appends without one in between wait here
+    const size_t bx = (size_t)n * 2 * sizeof(double), bt = (size_t)n * sizeof(int32_t);
+    if (g->fe.pin_map_busy) { HIP_TRY(hipStreamSynchronize(g->stream)); g->fe.pin_map_busy = false; }
+    if ((rc = pin_map_reserve(g, bx + bt)) != GS_OK) return rc;
+    std::memcpy(g->fe.pin_map, xy, bx); std::memcpy(g->fe.pin_map + bx, type, bt);
+    HIP_TRY(hipMemcpyAsync(g->fe.map_xy + 2 * (size_t)g->fe.map_n, g->fe.pin_map, bx, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipMemcpyAsync(g->fe.map_type + g->fe.map_n, g->fe.pin_map + bx, bt, hipMemcpyHostToDevice, g->stream));
+    g->fe.pin_map_busy = true;                                      // no wait here: the next frame's launch is ordered behind the copies
+    g->fe.map_n += n;
+    return GS_OK;
+}
+extern "C" int gs_map_set_xy(gs_graph *g, int32_t first, int32_t n, const double *xy) {
+    if (!g || first < 0 || n < 0 || (n > 0 && !xy)) return fail(GS_ERR_INVALID, "bad argument");
+    if (first + n > g->fe.map_n) return fail(GS_ERR_INVALID, "beyond the end of the map");
+    int rc = ensure_device(g); if (rc != GS_OK) return rc;
+    if (n == 0) return GS_OK;
+    HIP_TRY(hipMemcpyAsync(g->fe.map_xy + 2 * (size_t)first, xy, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));                       // pageable source: the caller's buffer is free on return
+    g->fe.pin_map_busy = false;
+    return GS_OK;
+}
+extern "C" int gs_frame_frontend(gs_graph *g, const double pose[3], const double *obs, int32_t k, double thr, double type_tol,
+                                 int32_t signed_type, double *out_zxy, double *out_gxy, int32_t *out_idx) {
+    if (!g || !pose || k < 0 || (k > 0 && (!obs || !out_zxy || !out_gxy || !out_idx))) return fail(GS_ERR_INVALID, "bad argument");
+    int rc = ensure_device(g); if (rc != GS_OK) return rc;
+    if (k == 0) return GS_OK;
+    if (k > g->fe.cap_obs) {                                        // grow-only: staging and device buffers for k observations
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        if (g->fe.pin_in) hipHostFree(g->fe.pin_in);
+        if (g->fe.pin_out) hipHostFree(g->fe.pin_out);
+        if (g->fe.dev_in) hipFree(g->fe.dev_in);
+        if (g->fe.dev_out) hipFree(g->fe.dev_out);
+        g->fe.pin_in = nullptr; g->fe.pin_out = nullptr; g->fe.dev_in = nullptr; g->fe.dev_out = nullptr; g->fe.cap_obs = 0;
+        const int cap = std::max(64, k + k / 2);
+        const size_t bin = (3 + 4 * (size_t)cap) * sizeof(double), bout = (size_t)cap * (4 * sizeof(double) + sizeof(int32_t));
+        HIP_TRY(hipHostMalloc((void **)&g->fe.pin_in, bin, hipHostMallocDefault)); HIP_TRY(hipHostMalloc((void **)&g->fe.pin_out, bout, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&g->fe.dev_in, bin)); HIP_TRY(hipMalloc((void **)&g->fe.dev_out, bout));
+        g->fe.cap_obs = cap;
+    }
+    const size_t bin = (3 + 4 * (size_t)k) * sizeof(double), bz = (size_t)k * 2 * sizeof(double), bi = (size_t)k * sizeof(int32_t);
+    std::memcpy(g->fe.pin_in, pose, 3 * sizeof(double)); std::memcpy(g->fe.pin_in + 3, obs, 4 * (size_t)k * sizeof(double));
+    double *dz = (double *)g->fe.dev_out, *dg = dz + 2 * (size_t)k; int32_t *di = (int32_t *)(dg + 2 * (size_t)k);
+    HIP_TRY(hipMemcpyAsync(g->fe.dev_in, g->fe.pin_in, bin, hipMemcpyHostToDevice, g->stream));
+    launch_frame_frontend(k, g->fe.dev_in, g->cfg.lidar_to_cog, g->fe.map_n, g->fe.map_xy, g->fe.map_type, thr, type_tol, signed_type, dz, dg, di, g->stream);
+    HIP_TRY(hipMemcpyAsync(g->fe.pin_out, g->fe.dev_out, 2 * bz + bi, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    g->fe.pin_map_busy = false;
+    std::memcpy(out_zxy, g->fe.pin_out, bz); std::memcpy(out_gxy, g->fe.pin_out + bz, bz); std::memcpy(out_idx, g->fe.pin_out + 2 * bz, bi);
     return GS_OK;
 }
 

@@ -105,6 +105,10 @@ void launch_associate_grid(int n, const double *poses, const int32_t *pose_of_ob
 // structure phase on the device: expand the block assembly records into scalar / landmark records (k_build_sc3)
 struct Sc3Args { int64_t off[8]; int64_t L; int32_t N, M, Epp, fused; };
 void launch_build_sc3(const int32_t *bf, const int32_t *asm3, int32_t *sc3, int32_t *lm3, int n_fronts, const Sc3Args &A, hipStream_t st);
+void launch_build_ell(int64_t L, const int32_t *ell_ins, const int32_t *raw_l, const double *raw_z, const double *raw_info,
+                      const int32_t *pl_rank, int rank, int32_t *ell_l, double *ell_z, double *ell_w, hipStream_t st);
+void launch_frame_frontend(int k, const double *in, double lidar, int n_map, const double *map_xy, const int32_t *map_type,
+                           double thr, double type_tol, int signed_type, double *out_z, double *out_g, int32_t *out_idx, hipStream_t st);
 int  factor_lds_limit_f();      // largest front dimension that fits the LDS variant
 
 }  // namespace gs

@@ -34,6 +34,15 @@ struct gs_graph {
     int rank = 0, world = 1;
     double *exchange = nullptr; bool exchange_external = false;   // caller-provided exchange buffer (e.g. a torch tensor)
     bool force_gather = false;              // cfg.linearize_gather
+    // front end (A0 / A1): nothing is allocated or freed per call
+    struct FrontEnd {
+        char *arena = nullptr; size_t arena_bytes = 0;          // grow-only device scratch of the batch calls
+        double *pin_in = nullptr; char *pin_out = nullptr;      // per-frame path: pinned staging, device in / out, capacity in observations
+        double *dev_in = nullptr; char *dev_out = nullptr; int cap_obs = 0;
+        double *map_xy = nullptr; int32_t *map_type = nullptr;  // the resident association map (mirror of Slam::m_map), grow-only
+        int map_n = 0, map_cap = 0;
+        char *pin_map = nullptr; size_t pin_map_bytes = 0; bool pin_map_busy = false;   // pinned staging of map appends (busy: a copy out of it may be in flight)
+    } fe;
     int default_factor_variant = 0;         // see upload_graph
 };
 

@@ -134,6 +134,39 @@ __global__ void __launch_bounds__(256) k_associate_grid(int n, const double *__r
     out[i] = found == 0x7fffffff ? -1 : found;
 }
 
+// One keyframe's front end in ONE launch (A0 + A1 fused): workgroup i takes observation i of the frame — polar -> CoG-frame
+// XY (the edge measurement), -> global XY (the association query) — and its 256 threads scan the resident map for the
+// LOWEST index j with a matching type and distance < thr (= the reference's first match in insertion order, reference
+// src/slam.cpp:570-607; signed_type = the localizer's test without fabs, :360).  in = {pose x, y, theta, obs[4 * k]}.
+__global__ void __launch_bounds__(256) k_frame_frontend(int k, const double *__restrict__ in, double lidar, int n_map,
+        const double *__restrict__ map_xy, const int32_t *__restrict__ map_type, double thr, double type_tol, int signed_type,
+        double *__restrict__ out_z, double *__restrict__ out_g, int32_t *__restrict__ out_idx) {
+    __shared__ int red[4];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const double *obs = in + 3 + 4 * i;
+    double zx, zy; polar_to_xy(obs[0], obs[1], obs[2], lidar, zx, zy);
+    const double c = cos(in[2]), s = sin(in[2]);
+    const double gx = (zx * c - zy * s) + in[0], gy = (zx * s + zy * c) + in[1];
+    const double ty = obs[3]; const int tyi = (int)ty;
+    int found = 0x7fffffff;
+    for (int j = tid; j < n_map; j += 256) {
+        const bool type_ok = signed_type ? ((double)(map_type[j] - tyi) < type_tol) : (fabs((double)map_type[j] - ty) < type_tol);
+        if (type_ok) { const double dx = map_xy[2 * j] - gx, dy = map_xy[2 * j + 1] - gy;
+            if (sqrt(dx * dx + dy * dy) < thr) { found = j; break; } }     // ascending j per thread: its first hit is its lowest
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) found = min(found, __shfl_down(found, off, WAVE));
+    if ((tid & 63) == 0) red[tid >> 6] = found;
+    __syncthreads();
+    if (tid == 0) { found = min(min(red[0], red[1]), min(red[2], red[3]));
+        out_idx[i] = found == 0x7fffffff ? -1 : found;
+        out_z[2 * i] = zx; out_z[2 * i + 1] = zy; out_g[2 * i] = gx; out_g[2 * i + 1] = gy; }
+}
+void launch_frame_frontend(int k, const double *in, double lidar, int n_map, const double *map_xy, const int32_t *map_type,
+                           double thr, double type_tol, int signed_type, double *out_z, double *out_g, int32_t *out_idx, hipStream_t st) {
+    if (k > 0) hipLaunchKernelGGL(k_frame_frontend, dim3(k), dim3(256), 0, st, k, in, lidar, n_map, map_xy, map_type, thr, type_tol, signed_type, out_z, out_g, out_idx);
+}
+
 // ------------------------------------------------------------------ A5-A7
 // EdgeSE2PointXY with the pose's cos/sin already known: error, Jacobian rows A0/A1 (2x3); B = R(theta)^T
 __device__ __forceinline__ void edge_pl(double px, double py, double c, double s, double lx, double ly, double zx, double zy,
@@ -1821,6 +1854,26 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
 #endif
     if (TREE) f3_publish(d.done_b + fr.s, d.epoch, lane);
     F3_TS(38);
+}
+
+// ---- structure phase on the device: the ELL streams of the observation edges, permuted out of the insertion-order
+// arrays (which travel to HBM, unprocessed, while the host still builds the plan).  ell_ins[e] = insertion index of the
+// edge at ELL position e (-1: empty slot); pl_rank (pose-window shards): edges another rank evaluates stay empty here.
+__global__ void __launch_bounds__(256) k_build_ell(int64_t L, const int32_t *__restrict__ ell_ins, const int32_t *__restrict__ raw_l,
+        const double *__restrict__ raw_z, const double *__restrict__ raw_info, const int32_t *__restrict__ pl_rank, int rank,
+        int32_t *__restrict__ ell_l, double *__restrict__ ell_z, double *__restrict__ ell_w) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= L) return;
+    int k = ell_ins[e];
+    if (k >= 0 && pl_rank && pl_rank[k] != rank) k = -1;
+    int l = -1; double zx = 0, zy = 0, w0 = 0, w1 = 0, w2 = 0;
+    if (k >= 0) { l = raw_l[k]; zx = raw_z[2 * (int64_t)k]; zy = raw_z[2 * (int64_t)k + 1];
+        w0 = raw_info[3 * (int64_t)k]; w1 = raw_info[3 * (int64_t)k + 1]; w2 = raw_info[3 * (int64_t)k + 2]; }
+    ell_l[e] = l; ell_z[e] = zx; ell_z[L + e] = zy; ell_w[e] = w0; ell_w[L + e] = w1; ell_w[2 * L + e] = w2;
+}
+void launch_build_ell(int64_t L, const int32_t *ell_ins, const int32_t *raw_l, const double *raw_z, const double *raw_info,
+                      const int32_t *pl_rank, int rank, int32_t *ell_l, double *ell_z, double *ell_w, hipStream_t st) {
+    if (L > 0) hipLaunchKernelGGL(k_build_ell, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, L, ell_ins, raw_l, raw_z, raw_info, pl_rank, rank, ell_l, ell_z, ell_w);
 }
 
 // ---- structure phase on the device: the scalar assembly records (sc3) and the fused landmark records (lm3) of every

@@ -68,6 +68,8 @@ struct Builder {
     // pose, pose order for a landmark).
     void build_adjacency(const Plan &P) {
         const int N = g.n_poses(); const int T = P.ell_T; const int64_t SN = (int64_t)T * N;
+        int tsh = 0; while ((1 << tsh) < T) ++tsh;                   // T is 1, 2, 4 or 8
+        auto pose_of_ell = [&](int64_t e) { while (e >= SN) e -= SN; return (int)(e >> tsh); };      // slot plane = at most R - 1 subtractions
         inc_start.assign(nv + 1, 0);
         parallel_chunks(nv, 4096, [&](int64_t b0, int64_t e0, int) {
             for (int v = (int)b0; v < (int)e0; ++v) { int n = 0;
@@ -76,7 +78,7 @@ struct Builder {
                         n += fp_of_pose[(code & 1) ? g.pp_i[k] : g.pp_j[k]] >= 0; }
                     for (int s = P.pl_start[p]; s < P.pl_start[p + 1]; ++s) n += fl_of_lm[g.pl_l[P.pl_order[s]]] >= 0;
                 } else { const int l = lm_of_fl[v - nfp];
-                    for (int q = P.lm_start[l]; q < P.lm_start[l + 1]; ++q) n += fp_of_pose[(int)((P.lm_edges[q] % SN) / T)] >= 0; }
+                    for (int q = P.lm_start[l]; q < P.lm_start[l + 1]; ++q) n += fp_of_pose[pose_of_ell(P.lm_edges[q])] >= 0; }
                 inc_start[v + 1] = n; } });
         for (int v = 0; v < nv; ++v) inc_start[v + 1] += inc_start[v];
         inc.resize(inc_start[nv]);
@@ -92,7 +94,7 @@ struct Builder {
                     for (int s = P.pl_start[p]; s < P.pl_start[p + 1]; ++s) { const int k = P.pl_order[s], fl = fl_of_lm[g.pl_l[k]];
                         if (fl >= 0) *o++ = {nfp + fl, P.ell_of_ins[k], 2}; }
                 } else { const int lf = v - nfp, l = lm_of_fl[lf]; int32_t *co = &cone_obs[cone_obs_start[lf]];
-                    for (int q = P.lm_start[l]; q < P.lm_start[l + 1]; ++q) { const int e = P.lm_edges[q]; const int fp = fp_of_pose[(int)((e % SN) / T)];
+                    for (int q = P.lm_start[l]; q < P.lm_start[l + 1]; ++q) { const int e = P.lm_edges[q]; const int fp = fp_of_pose[pose_of_ell(e)];
                         if (fp >= 0) { *o++ = {fp, e, 3}; *co++ = fp; } }
                     std::sort(&cone_obs[cone_obs_start[lf]], co); }      // landmark observer lists (free-pose positions, ascending)
             } });
@@ -342,6 +344,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     GS_PT(2);
     // ---- elimination order by nested dissection ----
     B.build_adjacency(plan);
+    GS_PT(21);
     B.assigned.assign(B.nfp, 0);
     { std::vector<int32_t> all(B.nfl); for (int l = 0; l < B.nfl; ++l) all[l] = l; B.nd(0, B.nfp, all, B.sn, 0); }
     const int S = (int)B.sn.size();

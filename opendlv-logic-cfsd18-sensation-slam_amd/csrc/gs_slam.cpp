@@ -103,22 +103,53 @@ static int optimize_and_update_map(gs_slam *s) {
     ++s->optimise_calls;
     if (rc < 0) return rc;
     for (auto &c : s->map) { double xy[2]; if ((rc = gs_get_landmark(s->g, c.id, xy)) != GS_OK) return rc; c.x = xy[0]; c.y = xy[1]; }
-    return GS_OK;
+    // the association map in HBM follows m_map: it holds every cone up to the ones added by earlier frames
+    const int nres = gs_map_size(s->g);
+    std::vector<double> xy(2 * (size_t)nres);
+    for (int j = 0; j < nres; ++j) { xy[2 * j] = s->map[j].x; xy[2 * j + 1] = s->map[j].y; }
+    return gs_map_set_xy(s->g, 0, nres, xy.data());
 }
 
 static double cone_distance(const MapCone &c, double x, double y) {     // distanceBetweenCones, :708-711
     return std::sqrt((c.x - x) * (c.x - x) + (c.y - y) * (c.y - y));
 }
 
-// the frame's A0 results: CoG-frame XY of every observation (edge measurement) and its global XY (association query)
-struct FrameXY { std::vector<double> zxy, gxy; };
+// appends the cones m_map gained since the last call to the association map in HBM
+static int sync_resident_map(gs_slam *s) {
+    const int have = gs_map_size(s->g), want = (int)s->map.size();
+    if (have < 0) return have;
+    if (want <= have) return GS_OK;
+    std::vector<double> xy(2 * (size_t)(want - have)); std::vector<int32_t> ty(want - have);
+    for (int j = have; j < want; ++j) { xy[2 * (size_t)(j - have)] = s->map[j].x; xy[2 * (size_t)(j - have) + 1] = s->map[j].y; ty[j - have] = s->map[j].type; }
+    return gs_map_append(s->g, want - have, xy.data(), ty.data());
+}
+
+// One keyframe's front end: CoG-frame XY of every observation (the edge measurement), its global XY (the association
+// query) and its first match in the map as it stood at the start of the frame — ONE fused launch against the map that
+// stays resident in HBM (gs_frame_frontend), one wait.  Under reference_quirks one more "observation" rides along: the
+// pose itself, which the reference's localizer passes where (azimuth, zenith, distance) is expected.
+struct FrameXY { std::vector<double> zxy, gxy; std::vector<int32_t> idx; double quirk_z[2] = {0, 0}; };
+static int frame_frontend(gs_slam *s, const double pose[3], const double *cones, int k, bool localizer_test, FrameXY &fx) {
+    const bool quirks = s->cfg.reference_quirks != 0;
+    const int kk = k + (quirks ? 1 : 0);
+    std::vector<double> obs(4 * (size_t)kk);
+    std::memcpy(obs.data(), cones, 4 * (size_t)k * sizeof(double));
+    if (quirks) { obs[4 * (size_t)k] = pose[0]; obs[4 * (size_t)k + 1] = pose[1]; obs[4 * (size_t)k + 2] = pose[2]; obs[4 * (size_t)k + 3] = 0; }
+    fx.zxy.resize(2 * (size_t)kk); fx.gxy.resize(2 * (size_t)kk); fx.idx.resize(kk);
+    // the localizer's type test has no fabs in the reference (src/slam.cpp:360): kept only under reference_quirks
+    int rc = gs_frame_frontend(s->g, pose, obs.data(), kk, s->cfg.same_cone_threshold, 1e-4, localizer_test && quirks ? 1 : 0,
+                               fx.zxy.data(), fx.gxy.data(), fx.idx.data());
+    if (rc != GS_OK) return rc;
+    if (quirks) { fx.quirk_z[0] = fx.zxy[2 * (size_t)k]; fx.quirk_z[1] = fx.zxy[2 * (size_t)k + 1]; }
+    return GS_OK;
+}
 
 // addConesToMap, reference src/slam.cpp:552-635
 static int add_cones_to_map(gs_slam *s, const double pose[3], const double *cones, int k, const FrameXY &fx) {
     int rc;
     const std::vector<double> &zxy = fx.zxy, &gxy = fx.gxy;
-    std::vector<int32_t> pose_of(k, 0), idx(k, -1);
     const bool quirks = s->cfg.reference_quirks != 0;
+    const int m0 = gs_map_size(s->g);                                // the map the association kernel saw (= m_map at the start of the frame)
     int first = 0;
     if (s->map.empty()) {                                            // :554-567
         MapCone c{gxy[0], gxy[1], (int)cones[3], 0};
@@ -126,19 +157,13 @@ static int add_cones_to_map(gs_slam *s, const double pose[3], const double *cone
         if ((rc = add_cone_to_graph(s, c, &zxy[0])) != GS_OK) return rc;
         if (!quirks) first = 1;                     // the reference re-matches i = 0 and adds the edge twice
     }
-    // A1 against the map as it stands at the start of the frame, on the device
-    const int m0 = (int)s->map.size();
-    { std::vector<double> mxy(2 * (size_t)m0); std::vector<int32_t> mty(m0);
-      for (int j = 0; j < m0; ++j) { mxy[2 * j] = s->map[j].x; mxy[2 * j + 1] = s->map[j].y; mty[j] = s->map[j].type; }
-      if ((rc = gs_associate_batch(s->g, k, pose, 1, pose_of.data(), cones, m0, mxy.data(), mty.data(),
-                                   s->cfg.same_cone_threshold, 1e-4, idx.data())) != GS_OK) return rc; }
     double min_distance = 100;
     bool optimise_pending = false;
     for (int i = first; i < k; ++i) {                                // :570-634
         const double d2car = cones[4 * i + 2], type_i = cones[4 * i + 3];
         bool found = false; int j = -1;
         if (!s->loop_closing) {                                      // the while loop's guard, :575
-            if (idx[i] >= 0) { found = true; j = idx[i]; }
+            if (fx.idx[i] >= 0) { found = true; j = fx.idx[i]; }     // A1 on the device: first match among the cones of earlier frames
             else for (int t = m0; t < (int)s->map.size(); ++t)       // cones appended earlier in this frame
                 if (std::fabs(s->map[t].type - type_i) < 1e-4 && cone_distance(s->map[t], gxy[2 * i], gxy[2 * i + 1]) < s->cfg.same_cone_threshold) { found = true; j = t; break; }
         }
@@ -156,38 +181,31 @@ static int add_cones_to_map(gs_slam *s, const double pose[3], const double *cone
             if ((rc = add_cone_to_graph(s, c, &zxy[2 * i])) != GS_OK) return rc;
         }
         if (s->loop_closing) {                                       // :625-633
-            if (quirks) { if ((rc = optimize_and_update_map(s)) != GS_OK) return rc; s->loop_closing_complete = true; }   // §8-B.2: once per remaining observation
+            if (quirks) { if ((rc = sync_resident_map(s)) != GS_OK) return rc;
+                          if ((rc = optimize_and_update_map(s)) != GS_OK) return rc; s->loop_closing_complete = true; }   // §8-B.2: once per remaining observation
             else optimise_pending = true;
         }
     }
+    if ((rc = sync_resident_map(s)) != GS_OK) return rc;             // this frame's new cones join the map in HBM (one asynchronous copy)
     if (optimise_pending) { if ((rc = optimize_and_update_map(s)) != GS_OK) return rc; s->loop_closing_complete = true; }
     return GS_OK;
 }
 
 // localizer, reference src/slam.cpp:340-414: re-associate against the frozen map, one more edge per re-observed cone,
 // the send pose is the raw estimate of the newest pose vertex (optimizeGraph is commented out there, :403)
-static int localizer(gs_slam *s, const double pose[3], const double *cones, int k, const FrameXY &fx) {
+static int localizer(gs_slam *s, const double *cones, int k, const FrameXY &fx) {
     int rc;
-    const std::vector<double> &zxy = fx.zxy, &gxy = fx.gxy;
     const bool quirks = s->cfg.reference_quirks != 0;
     uint32_t current = s->current_cone_index; double min_distance = 100; int reobserved = 0;
     for (int i = 0; i < k; ++i) {
-        const double d2car = cones[4 * i + 2]; const int type_i = (int)cones[4 * i + 3];          // static_cast<int>, :357
-        for (size_t j = 0; j < s->map.size(); ++j) {
-            // the reference omits fabs on the (integer) type difference (:360); kept only under reference_quirks
-            const double dt = (double)(s->map[j].type - type_i);
-            const bool type_ok = quirks ? (dt < 1e-4) : (std::fabs(dt) < 1e-4);
-            if (cone_distance(s->map[j], gxy[2 * i], gxy[2 * i + 1]) < s->cfg.same_cone_threshold && type_ok) {
-                ++reobserved;
-                double z[2] = {zxy[2 * i], zxy[2 * i + 1]};
-                if (quirks) {   // §8-B.4: the reference passes the POSE where (az, zen, dist) is expected (:373)
-                    if ((rc = gs_polar_to_xy_batch(s->g, 1, &pose[0], &pose[1], &pose[2], z)) != GS_OK) return rc;
-                }
-                if ((rc = add_cone_measurement(s, s->map[j].id, z)) != GS_OK) return rc;
-                if (d2car < min_distance) { current = (uint32_t)j; min_distance = d2car; }
-                break;
-            }
-        }
+        const double d2car = cones[4 * i + 2];
+        const int j = fx.idx[i];                                     // A1 on the device: the while loop of :355-382 against the whole map
+        if (j < 0) continue;
+        ++reobserved;
+        // §8-B.4: the reference passes the POSE where (az, zen, dist) is expected (:373)
+        const double *z = quirks ? fx.quirk_z : &fx.zxy[2 * (size_t)i];
+        if ((rc = add_cone_measurement(s, s->map[j].id, z)) != GS_OK) return rc;
+        if (d2car < min_distance) { current = (uint32_t)j; min_distance = d2car; }
     }
     if (reobserved > 0) s->current_cone_index = current;            // :387 (uninitialised in the reference when nothing matched)
     // updatePoseFromGraph (:416-422)
@@ -218,17 +236,19 @@ extern "C" int gs_slam_perform(gs_slam *s, const double odometry[3], const doubl
     s->pose_id++;
     if (k == 0) return GS_OK;          // initializeCollection never passes an empty frame (:245)
 
-    // ---- A0 for the whole frame on the device
-    FrameXY fx; fx.zxy.resize(2 * (size_t)k); fx.gxy.resize(2 * (size_t)k);
-    { std::vector<double> az(k), zen(k), dist(k); std::vector<int32_t> pose_of(k, 0);
-      for (int i = 0; i < k; ++i) { az[i] = cones[4 * i]; zen[i] = cones[4 * i + 1]; dist[i] = cones[4 * i + 2]; }
-      if ((rc = gs_polar_to_xy_batch(s->g, k, az.data(), zen.data(), dist.data(), fx.zxy.data())) != GS_OK) return rc;
-      if ((rc = gs_cone_to_global_batch(s->g, k, pose, 1, pose_of.data(), cones, fx.gxy.data())) != GS_OK) return rc; }
-
     // two independent ifs in the reference (:329-334): the frame that completes the loop closure ALSO runs the localizer,
-    // against the map updateMap has just rewritten
-    if (!s->loop_closing_complete) { if ((rc = add_cones_to_map(s, pose, cones, k, fx)) != GS_OK) return rc; }
-    if (s->loop_closing_complete && k > 1) { if ((rc = localizer(s, pose, cones, k, fx)) != GS_OK) return rc; }
+    // against the map updateMap has just rewritten (a second front-end launch, in that one frame only)
+    FrameXY fx;
+    if (!s->loop_closing_complete) {
+        if ((rc = frame_frontend(s, pose, cones, k, false, fx)) != GS_OK) return rc;
+        if ((rc = add_cones_to_map(s, pose, cones, k, fx)) != GS_OK) return rc;
+        if (s->loop_closing_complete && k > 1) {
+            if ((rc = frame_frontend(s, pose, cones, k, true, fx)) != GS_OK) return rc;
+            if ((rc = localizer(s, cones, k, fx)) != GS_OK) return rc; }
+    } else if (k > 1) {
+        if ((rc = frame_frontend(s, pose, cones, k, true, fx)) != GS_OK) return rc;
+        if ((rc = localizer(s, cones, k, fx)) != GS_OK) return rc;
+    }
     return GS_OK;
 }
 

@@ -203,6 +203,42 @@ def test_single_iteration_random_graph(pkg, po):
         G.close()
 
 
+# ---------------------------------------------------------------- A0 + A1 fused: one keyframe against the resident map
+def test_frame_frontend_against_the_resident_map_matches_oracle(G, frontend, bench_graphs):
+    """gs_frame_frontend: the per-keyframe path (one launch, map resident in HBM, appended and rewritten in place) against
+    the oracle's A0 and insertion-order scan, for maps below and above a workgroup's stride, with decoys of the wrong
+    type, first-match-wins, the localizer's signed type test (reference src/slam.cpp:360) and the azimuth-0 NaN quirk."""
+    t, g = bench_graphs(10000, 2000)
+    rng = np.random.default_rng(3)
+    map_xy = g["lm_est"].copy(); map_ty = g["lm_type"].astype(np.int32).copy()
+    G.map_clear(); assert G.map_size() == 0
+    G.map_append(map_xy[:100], map_ty[:100]); G.map_append(map_xy[100:], map_ty[100:])       # grown in two steps
+    assert G.map_size() == len(map_xy)
+    for k in (17, 400, 3000):
+        pose = t["odom_poses"][k]; obs = np.asarray(t["obs"][k], dtype=np.float64).copy()
+        obs = np.vstack([obs, obs[:2] * [1, 1, 1, 0] + [0, 0, 0, 7]])                  # two observations of a type no cone has
+        z, gx, idx = G.frame_frontend(pose, obs, 1.2)
+        zo = frontend.polar_to_xy(obs[:, 0], obs[:, 1], obs[:, 2]); go = frontend.cone_to_global(pose[None], np.zeros(len(obs), dtype=np.int32), obs)
+        io = frontend.associate(pose[None], np.zeros(len(obs), dtype=np.int32), obs, map_xy, map_ty, 1.2)
+        assert np.abs(z - zo).max() < 1e-12 * max(1.0, np.abs(zo).max()) and np.abs(gx - go).max() < 1e-12 * np.abs(go).max()
+        assert np.array_equal(idx, io) and (idx[:-2] >= 0).all() and (idx[-2:] == -1).all()
+        # signed type test: (type_j - (int)type_i) < tol also accepts cones of a LOWER type code
+        _, _, isg = G.frame_frontend(pose, obs, 1.2, signed_type=1)
+        d = np.hypot(map_xy[None, :, 0] - go[:, None, 0], map_xy[None, :, 1] - go[:, None, 1])
+        ok = (d < 1.2) & ((map_ty[None, :] - obs[:, 3].astype(np.int64)[:, None]) < 1e-4)
+        want = np.where(ok.any(1), ok.argmax(1), -1)
+        assert np.array_equal(isg, want)
+    # first match wins over the nearest; rewriting positions in place (updateMap) is seen by the next frame
+    pose = np.array([1.0, 2.0, 0.3]); obs = np.array([[5.0, 0.0, 8.0, 1.0]])
+    go = frontend.cone_to_global(pose[None], np.zeros(1, dtype=np.int32), obs)[0]
+    G.map_clear(); G.map_append([go + [0.9, 0.0], go + [0.1, 0.0], go + [5.0, 0.0]], [1, 1, 1])
+    assert G.frame_frontend(pose, obs, 1.2)[2][0] == 0
+    G.map_set_xy(0, [go + [3.0, 0.0]]); assert G.frame_frontend(pose, obs, 1.2)[2][0] == 1
+    zn, gn, inn = G.frame_frontend(pose, np.array([[0.0, 0.0, 8.0, 1.0]]), 1.2)          # azimuth 0: NaN (SURVEY 8-B.3), no match
+    assert np.isnan(zn).all() and inn[0] == -1
+    G.map_clear()
+
+
 # ---------------------------------------------------------------- A10: the reference's optimize(10)
 @pytest.mark.parametrize("N,M", [(50, 30), (1000, 200), (10000, 2000), (100000, 10000)])
 def test_ten_iterations_match_oracle(pkg, po, bench_graphs, N, M):
