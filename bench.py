@@ -52,7 +52,7 @@ def cpu_baseline(pkg, g, iters):
     wall = time.perf_counter() - t0
     analyze_ms = float(solver.timings()[0]) if solver is not None else 0.0
     per_iter_s = (wall - analyze_ms * 1e-3) / max(done, 1)      # symbolic analysis is iteration-0 work, like the GPU plan
-    return og, dict(value=1.0 / per_iter_s, unit="GN iterations/s", cores=1, kind=kind,
+    return og, dict(wall_ms_end_to_end=wall * 1e3, ms_symbolic=analyze_ms, value=1.0 / per_iter_s, unit="GN iterations/s", cores=1, kind=kind,
                     sample="%d GN iterations of the same %d-pose / %d-cone graph, single thread; g2o arithmetic restated "
                            "in C (oracle/), linear solve = %s; symbolic analysis (%.0f ms) excluded like the GPU plan build"
                            % (done, len(g["pose_est"]), len(g["lm_est"]),
@@ -60,6 +60,48 @@ def cpu_baseline(pkg, g, iters):
                               else "oracle's own up-looking LDLT (oracle/_ref absent)", analyze_ms),
                     ms_linearize=float(tm[0]) / max(done, 1), ms_solve=float(tm[2] - analyze_ms) / max(done, 1),
                     host_cpus=os.cpu_count())
+
+
+def frame_latency(pkg, np):
+    """Per-keyframe latency of the real-time path (reference loop: src/slam.cpp:570-607, budgets of 20 ms gathering / 500 ms
+    keyframe period in usecase/docker-compose.yml:16): A0 + A1 of ONE frame of K = 16 cones against a resident map of 200
+    and of 10k cones (gs_frame_frontend: one launch, one wait), next to the CPU oracle's A0 + insertion-order scan of the
+    same frame, and whole gs_slam_perform frames (graph insertion included) on the 1k-pose / 200-cone track."""
+    from oracle import pyoracle as po
+    fe = po.OracleFrontend()
+    out = {"cones_per_frame": 16}
+    for name, key in (("cfg2", "map_200"), ("cfg4", "map_10k")):
+        N, M = pkg.track.CONFIGS[name]
+        t = pkg.track.generate(N, M); g = pkg.track.bench_graph(t, fe)
+        mxy, mty = g["lm_est"], g["lm_type"].astype(np.int32)
+        F = pkg.Graph(); F.map_append(mxy, mty)
+        frames = [(t["odom_poses"][k], np.vstack([t["obs"][k], t["obs"][k + 1]])) for k in range(10, N - 2, max(1, N // 200))][:200]
+        F.frame_frontend(*frames[0], 1.2)
+        t0 = time.perf_counter()
+        for pose, obs in frames:
+            F.frame_frontend(pose, obs, 1.2)
+        out[key + "_gpu_us"] = (time.perf_counter() - t0) / len(frames) * 1e6
+        zero = np.zeros(16, dtype=np.int32)
+        t0 = time.perf_counter()
+        for pose, obs in frames:
+            fe.polar_to_xy(obs[:, 0], obs[:, 1], obs[:, 2]); fe.cone_to_global(pose[None], zero, obs); fe.associate(pose[None], zero, obs, mxy, mty, 1.2)
+        out[key + "_cpu_oracle_us"] = (time.perf_counter() - t0) / len(frames) * 1e6
+        F.close()
+    N, M = pkg.track.CONFIGS["cfg2"]
+    t = pkg.track.generate(N, M)
+    S = pkg.Slam(same_cone_threshold=1.2, cone_mapping_threshold=67.0)
+    tm_map, tm_loc = [], []
+    for k in list(range(N)) + list(range(60)):
+        closed = S.loop_closed
+        t0 = time.perf_counter(); S.perform_slam(t["odom_poses"][k], t["obs"][k]); dt = time.perf_counter() - t0
+        if closed: tm_loc.append(dt)
+        elif not S.loop_closed: tm_map.append(dt)
+        else: out["slam_loop_closing_frame_ms"] = dt * 1e3           # optimizeGraph (structure + 10 iterations) + updateMap + localizer
+    out["slam_perform_mapping_frame_us"] = float(np.median(tm_map)) * 1e6 if tm_map else None
+    out["slam_perform_localizer_frame_us"] = float(np.median(tm_loc)) * 1e6 if tm_loc else None
+    out["slam_track"] = "1000 poses / 200 cones, 8 cones per frame, %d mapping frames, %d localizer frames" % (len(tm_map), len(tm_loc))
+    S.close()
+    return out
 
 
 def main():
@@ -223,6 +265,17 @@ def main():
         out["landmark_rmse_vs_oracle_rel"] = float(np.sqrt(((Lm - og.landmarks()) ** 2).sum(1).mean()) / rms)
         out["heading_max_abs_diff_vs_oracle"] = float(np.abs(P[:, 2] - og.poses()[:, 2]).max())
         out["parity_iterations"] = int(done)
+        # what one call of the reference's optimizeGraph costs END TO END after the graph has changed: structure phase
+        # (initializeOptimization + analyzePattern there; plan + upload here) + 10 Gauss-Newton iterations + read-back
+        G3 = pkg.Graph(device=local); G3.load_bench_graph(g)
+        t0 = time.perf_counter(); G3.optimize(10); e2e_gpu = (time.perf_counter() - t0) * 1e3
+        st3 = G3.stats(); G3.close()
+        og2, cb2 = cpu_baseline(pkg, g, 10)
+        out["optimize10_end_to_end_ms"] = dict(gpu=e2e_gpu, gpu_structure_ms=st3.ms_structure, cpu=cb2["wall_ms_end_to_end"],
+                                               cpu_symbolic_ms=cb2["ms_symbolic"], ratio=cb2["wall_ms_end_to_end"] / e2e_gpu,
+                                               note="fresh handle, graph already inserted; wall clock of gs_optimize(10) "
+                                                    "including plan build, upload and estimate read-back vs the CPU path's "
+                                                    "buildStructure + analyzePattern + 10 iterations")
         # ... and the handle that was TIMED ran exactly that arithmetic: the same number of iterations through
         # gs_optimize on the second handle must reproduce its estimates bit for bit (every sum has a fixed order)
         more = args.warmup + args.steps - int(done)
@@ -236,6 +289,8 @@ def main():
         G2.close()
     else:
         out["cpu_baseline"] = None
+    if rank == 0 and world == 1 and not dist_mode and not args.no_cpu and args.workload == "cfg4":
+        out["frame_latency"] = frame_latency(pkg, np)
     if rank == 0:
         print(json.dumps(out))
     G.close()
