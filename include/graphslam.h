@@ -323,6 +323,8 @@ int  gs_slam_collect_direction(gs_slam *s, uint32_t object_id, double azimuth_de
 int  gs_slam_collect_distance(gs_slam *s, uint32_t object_id, double distance);
 int  gs_slam_collect_type(gs_slam *s, uint32_t object_id, uint32_t type);
 int  gs_slam_collect_flush(gs_slam *s, const double pose_xytheta[3], int32_t *k_out, double *cones_out_4xk);
+/* the first half of gs_slam_collect_flush alone: extract the leftmost lastObjectId + 1 columns and reset the collector */
+int  gs_slam_collect_extract(gs_slam *s, int32_t *k_out, double *cones_out_4xk);
 int  gs_slam_encode_cones(gs_slam *s, int32_t cones_per_packet, float *azimuth_deg, float *distance, int32_t *type);
 /* ---- odometry intake and pose output (row f-4), host side -------------------------
  * gs_wgs84_to_cartesian / gs_wgs84_from_cartesian <- wgs84::toCartesian / fromCartesian (src/WGS84toCartesian.hpp:39-113,
@@ -347,6 +349,39 @@ int  gs_slam_next_yaw_rate(gs_slam *s, double angular_velocity_z);
 int  gs_slam_set_sample_times(gs_slam *s, int64_t yaw_received_us, int64_t last_cone_us);
 int  gs_slam_get_odometry(gs_slam *s, double out_xy_heading_yawrate[4]);
 int  gs_slam_encode_pose(gs_slam *s, float out_lon_lat_heading[3]);
+
+/* ---- the microservice shell (row f-3), transport-independent ---------------------------------------------------------
+ * Mirrors main() of the reference (src/opendlv-logic-cfsd18-sensation-slam.cpp:49-119) around the Slam mirror: the same
+ * command-line keys and the "at least 10 arguments" rule (:52), the seven data triggers behind their senderStamp filters
+ * (:71-108), the gathering window and the keyframe gate (src/slam.cpp:221-257, 286-295), and the messages the localizer
+ * publishes (sendPose + sendCones, :404-410, 656-695).  Messages cross this boundary decoded; csrc/gs_shell_cluon.cpp binds
+ * it to cluon's OD4Session (Envelope decode / od4.send).  Type ids are the message set's: 19 GeodeticWgs84Reading
+ * {v0 latitude, v1 longitude}, 1051 GeodeticHeadingReading {v0 northHeading}, 1116 Geolocation {v0 latitude, v1 longitude,
+ * v2 heading}, 1031 AngularVelocityReading {v0 angularVelocityZ}, 1133 ObjectDirection {object_id, v0 azimuth, v1 zenith},
+ * 1134 ObjectDistance {object_id, v0 distance}, 1131 ObjectType {object_id, v0 type}. */
+typedef struct gs_shell gs_shell;
+typedef struct gs_shell_msg {
+    int32_t  data_type;
+    uint32_t sender_stamp;
+    int64_t  sample_time_us;
+    uint32_t object_id;
+    uint32_t reserved;
+    double   v[3];
+} gs_shell_msg;
+/* argv as main() receives it; fewer than 10 arguments or a missing key -> GS_ERR_INVALID with the usage text in
+ * gs_last_error (the reference prints it and returns 1).  device as in gs_config (-2: host-only, for tests of the dispatch). */
+int  gs_shell_create(int32_t argc, const char *const *argv, int32_t device, gs_shell **out);
+int  gs_shell_destroy(gs_shell *sh);
+/* one incoming message; now_us = the caller's clock (starts the gathering window of a frame).  1 taken, 0 ignored. */
+int  gs_shell_on_message(gs_shell *sh, const gs_shell_msg *m, int64_t now_us);
+/* runs the frame whose gathering window (--gatheringTimeMs) has passed: extract, keyframe gate (--timeBetweenKeyframes, ms),
+ * performSLAM, outputs.  1 performSLAM ran, 0 nothing due / not a keyframe. */
+int  gs_shell_poll(gs_shell *sh, int64_t now_us);
+int  gs_shell_pending_output(gs_shell *sh);
+int  gs_shell_take_output(gs_shell *sh, int32_t capacity, gs_shell_msg *out);
+int  gs_shell_counters(gs_shell *sh, int64_t out_run_gated[2]);
+int  gs_shell_cid(gs_shell *sh);
+gs_slam *gs_shell_slam(gs_shell *sh);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,11 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class ShellMsg(C.Structure):
+    _fields_ = [("data_type", C.c_int32), ("sender_stamp", C.c_uint32), ("sample_time_us", C.c_int64),
+                ("object_id", C.c_uint32), ("reserved", C.c_uint32), ("v", C.c_double * 3)]
+
+
 class PlanInfo(C.Structure):
     _fields_ = [("n_scalar", C.c_int32), ("n_fronts", C.c_int32), ("n_levels", C.c_int32),
                 ("max_front", C.c_int32), ("l_doubles", C.c_int64), ("u_doubles", C.c_int64),
@@ -148,6 +153,16 @@ def lib():
     L.gs_dist_write_exchange.argtypes = [vp, _dp]
     u8 = C.POINTER(C.c_uint8)
     L.gs_dist_known.argtypes = [vp, u8, u8, u8, u8]
+    L.gs_slam_collect_extract.argtypes = [vp, C.POINTER(C.c_int32), _dp]
+    L.gs_shell_create.argtypes = [C.c_int32, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(vp)]
+    L.gs_shell_destroy.argtypes = [vp]
+    L.gs_shell_on_message.argtypes = [vp, C.POINTER(ShellMsg), C.c_int64]
+    L.gs_shell_poll.argtypes = [vp, C.c_int64]
+    L.gs_shell_pending_output.argtypes = [vp]
+    L.gs_shell_take_output.argtypes = [vp, C.c_int32, C.POINTER(ShellMsg)]
+    L.gs_shell_counters.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.gs_shell_cid.argtypes = [vp]
+    L.gs_shell_slam.argtypes = [vp]; L.gs_shell_slam.restype = vp
     L.gs_slam_perform.argtypes = [vp, _dp, _dp, C.c_int32]
     L.gs_slam_get_map.argtypes = [vp, C.c_int32, _dp, _ip]
     L.gs_slam_get_send_pose.argtypes = [vp, _dp]
@@ -468,15 +483,19 @@ class Graph:
 class Slam:
     """Mirror of the graph side of class Slam (reference src/slam.cpp:298-338 performSLAM and what it calls)."""
 
-    def __init__(self, cfg=None, **kw):
+    def __init__(self, cfg=None, _handle=None, **kw):
         self.L = lib()
-        if cfg is None:
-            cfg = default_config(**kw)
-        h = C.c_void_p()
-        rc = self.L.gs_slam_create(C.byref(cfg), C.byref(h))
-        if rc < 0:
-            raise GsError(rc, (self.L.gs_last_error() or b"").decode())
-        self.h = h
+        self._owned = _handle is None
+        if _handle is not None:
+            self.h = C.c_void_p(_handle)
+        else:
+            if cfg is None:
+                cfg = default_config(**kw)
+            h = C.c_void_p()
+            rc = self.L.gs_slam_create(C.byref(cfg), C.byref(h))
+            if rc < 0:
+                raise GsError(rc, (self.L.gs_last_error() or b"").decode())
+            self.h = h
         self.graph = Graph(_handle=self.L.gs_slam_graph(self.h))
 
     def _check(self, rc):
@@ -485,7 +504,7 @@ class Slam:
         return rc
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and self._owned:
             self.L.gs_slam_destroy(self.h)
         self.h = None
 
@@ -563,3 +582,57 @@ def wgs84_from_cartesian(ref_latlon, xy):
     L = lib(); o = np.zeros(2); r = _f64(ref_latlon); p = _f64(xy)
     if L.gs_wgs84_from_cartesian(_d(r), _d(p), _d(o)) != 0: raise GsError("gs_wgs84_from_cartesian failed")
     return o
+
+
+
+class Shell:
+    """The microservice shell (reference src/opendlv-logic-cfsd18-sensation-slam.cpp:49-119), decoded-message boundary."""
+    WGS84, ANGULAR_VELOCITY, HEADING, GEOLOCATION, OBJECT_TYPE, OBJECT_DIRECTION, OBJECT_DISTANCE = 19, 1031, 1051, 1116, 1131, 1133, 1134
+
+    def __init__(self, argv, device=-1):
+        self.L = lib()
+        arr = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
+        h = C.c_void_p()
+        rc = self.L.gs_shell_create(len(argv), arr, int(device), C.byref(h))
+        if rc < 0:
+            raise GsError(rc, (self.L.gs_last_error() or b"").decode())
+        self.h = h
+        self.slam = Slam(_handle=self.L.gs_shell_slam(self.h))
+
+    def _check(self, rc):
+        if rc < 0:
+            raise GsError(rc, (self.L.gs_last_error() or b"").decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gs_shell_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def on_message(self, data_type, sender_stamp, sample_time_us, now_us, object_id=0, v=(0.0, 0.0, 0.0)):
+        m = ShellMsg(); m.data_type = int(data_type); m.sender_stamp = int(sender_stamp); m.sample_time_us = int(sample_time_us)
+        m.object_id = int(object_id)
+        for i, x in enumerate(v):
+            m.v[i] = float(x)
+        return self._check(self.L.gs_shell_on_message(self.h, C.byref(m), int(now_us)))
+
+    def poll(self, now_us):
+        return self._check(self.L.gs_shell_poll(self.h, int(now_us)))
+
+    def take_output(self):
+        n = self._check(self.L.gs_shell_pending_output(self.h))
+        buf = (ShellMsg * max(n, 1))()
+        n = self._check(self.L.gs_shell_take_output(self.h, n, buf))
+        return [(m.data_type, m.sender_stamp, m.sample_time_us, m.object_id, (m.v[0], m.v[1], m.v[2])) for m in buf[:n]]
+
+    def counters(self):
+        a = (C.c_int64 * 2)(); self._check(self.L.gs_shell_counters(self.h, a)); return int(a[0]), int(a[1])
+
+    @property
+    def cid(self): return self._check(self.L.gs_shell_cid(self.h))

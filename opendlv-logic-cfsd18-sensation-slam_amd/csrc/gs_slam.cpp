@@ -273,14 +273,21 @@ extern "C" int gs_slam_collect_distance(gs_slam *s, uint32_t object_id, double d
 extern "C" int gs_slam_collect_type(gs_slam *s, uint32_t object_id, uint32_t type) { const double v = (double)type; return collect(s, object_id, 3, &v, 1); }
 // Slam::initializeCollection (reference src/slam.cpp:221-257) after its wait and without the keyframe gate (both are
 // transport timing, out of scope): take the leftmost m_lastObjectId + 1 columns, reset the collector, run performSLAM.
-extern "C" int gs_slam_collect_flush(gs_slam *s, const double pose_xytheta[3], int32_t *k_out, double *cones_out_4xk) {
-    if (!s || !pose_xytheta) return fail(GS_ERR_INVALID, "null argument");
+extern "C" int gs_slam_collect_extract(gs_slam *s, int32_t *k_out, double *cones_out_4xk) {
+    if (!s || !k_out || !cones_out_4xk) return fail(GS_ERR_INVALID, "null argument");
     const int k = (int)s->last_object_id + 1;
-    std::vector<double> extracted(s->collector.begin(), s->collector.begin() + 4 * (size_t)k);
+    std::memcpy(cones_out_4xk, s->collector.data(), 4 * (size_t)k * sizeof(double));       // extractedCones = leftCols(m_lastObjectId + 1), :241
     s->new_frame = true; s->last_object_id = 0;
     std::fill(s->collector.begin(), s->collector.end(), 0.0);
+    *k_out = k;
+    return GS_OK;
+}
+extern "C" int gs_slam_collect_flush(gs_slam *s, const double pose_xytheta[3], int32_t *k_out, double *cones_out_4xk) {
+    if (!s || !pose_xytheta) return fail(GS_ERR_INVALID, "null argument");
+    int32_t k = 0; std::vector<double> extracted(4 * 1000);
+    int rc = gs_slam_collect_extract(s, &k, extracted.data()); if (rc != GS_OK) return rc;
     if (k_out) *k_out = k;
-    if (cones_out_4xk) std::memcpy(cones_out_4xk, extracted.data(), extracted.size() * sizeof(double));
+    if (cones_out_4xk) std::memcpy(cones_out_4xk, extracted.data(), 4 * (size_t)k * sizeof(double));
     return gs_slam_perform(s, pose_xytheta, extracted.data(), k);      // extractedCones.cols() > 0 always holds (:245)
 }
 // Slam::sendCones + Cone::getDirection / getDistance (reference src/slam.cpp:656-677, src/cone.cpp:34-53): the
