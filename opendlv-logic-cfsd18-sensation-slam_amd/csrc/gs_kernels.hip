@@ -1428,10 +1428,13 @@ __device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[10], double 
 // with device-scope (sc1, write-through) stores, drains them (s_waitcnt), then sets done[front] = epoch; the parent
 // polls that flag and gathers with device-scope loads (the XCDs' L2s are not coherent with each other inside a kernel).
 // The poll is bounded: on expiry the front carries on, reports through d.fail, and the grid still drains.
+#ifndef F3_POLL_SLEEP
+#define F3_POLL_SLEEP 4
+#endif
 __device__ __forceinline__ bool f3_wait_flag(const int32_t *flag, int epoch) {
     for (int it = 0; it < (1 << 18); ++it) {
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); return true; }
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(F3_POLL_SLEEP);
     }
     return false;
 }
