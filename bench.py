@@ -207,18 +207,26 @@ def main():
     lin_ms = G.time_linearize(50)                  # this rank's window when sharded
     alg_bytes = G.linearize_bytes() // world       # E_pp*152 + E_pl*96 + N*120 + M*64  (SURVEY §8d), per window
     achieved = alg_bytes / (lin_ms * 1e-3) / 1e9
-    # HBM traffic per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, collected with rocprofv3 in
-    # separate passes by scripts/pmc_calib.sh and committed under profiles/): it cannot be collected from inside
-    # this process, so the committed measurement of the same kernel on the same workload is reported.
-    traffic = None
+    # HBM traffic per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE): rocprofv3 collects them in separate
+    # passes around the process (scripts/pmc_iter.sh), so this run cannot measure them itself.  The committed measurement
+    # of the same kernel on the same workload is reported — and only while the kernel source still hashes to what the
+    # counters were taken on (scripts/make_pmc_json.py); otherwise null.
+    traffic, traffic_src = None, None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_linearize_pmc.json")))
-        if args.workload == "cfg4":
-            traffic = pm["traffic_bytes_per_launch"]
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        from make_pmc_json import kernel_hash
+        for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            if fn.endswith("_linearize_pmc.json"):
+                pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                w = pm.get("workloads", {}).get(args.workload)
+                if w and pm.get("kernel_source_sha256") == kernel_hash() and world == 1:
+                    traffic = w["traffic_bytes_per_launch"]
+                    traffic_src = "committed_measurement profiles/%s (kernel source sha256 %s...)" % (fn, pm["kernel_source_sha256"][:12])
+                break
     except Exception:
         traffic = None
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                    traffic=traffic, kernel="k_linearize_ell: edge linearisation + assembly (A5-A7)", ms_per_launch=lin_ms,
+                    traffic=traffic, traffic_source=traffic_src, kernel="k_linearize_ell: edge linearisation + assembly (A5-A7)", ms_per_launch=lin_ms,
                     algorithmic_bytes=alg_bytes, note="back-to-back launches of this rank's window (N > 1: no per-phase events inside the sharded step)")
     out = dict(metric="GraphSLAM Gauss-Newton iters/sec at N poses x M cones; pose RMSE vs ref",
                value=value, unit="GN iterations/s (100k-pose windows)", n_gpus=world, steps=args.steps, warmup=args.warmup,

@@ -34,13 +34,22 @@ static int usable_devices() {
     return n;
 }
 
+// Device memory of a plan comes out of a few large chunks (8 MB, then doubling): the ~70 arrays of one structure phase
+// cost 7 hipMalloc calls instead of 70 (each is 50-100 us of the structure phase), and dev_free_all returns them together.
 template <class T> static int dev_alloc(gs_graph *g, T **ptr, size_t count) {
     *ptr = nullptr;
-    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-    void *p = nullptr;
-    HIP_TRY(hipMalloc(&p, bytes));
-    g->allocs.push_back(p);
-    *ptr = (T *)p;
+    const size_t bytes = (std::max<size_t>(count, 1) * sizeof(T) + 255) & ~(size_t)255;
+    if (g->pool_off + bytes > g->pool_size) {
+        size_t want = std::max<size_t>(g->pool_next, (size_t)8 << 20);
+        while (want < bytes) want <<= 1;
+        void *p = nullptr;
+        HIP_TRY(hipMalloc(&p, want));
+        g->allocs.push_back(p);
+        g->pool_base = (char *)p; g->pool_size = want; g->pool_off = 0;
+        g->pool_next = std::min<size_t>(want << 1, (size_t)1 << 30);
+    }
+    *ptr = (T *)(g->pool_base + g->pool_off);
+    g->pool_off += bytes;
     return GS_OK;
 }
 template <class T> static int dev_upload(gs_graph *g, T **ptr, const std::vector<T> &v) {
@@ -52,6 +61,7 @@ template <class T> static int dev_upload(gs_graph *g, T **ptr, const std::vector
 static void dev_free_all(gs_graph *g) {
     for (void *p : g->allocs) hipFree(p);
     g->allocs.clear();
+    g->pool_base = nullptr; g->pool_size = g->pool_off = 0; g->pool_next = 0;
     g->d = DevGraph();
     g->dev_valid = false;
 }
@@ -503,7 +513,8 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
           AL(done_f, P.fronts.size()); ZERO(done_f, P.fronts.size()); AL(done_b, P.fronts.size()); ZERO(done_b, P.fronts.size());
           d.epoch = 0; d.tree = 1;                                    // whole-tree launches for this rank's own subtrees (GS_TREE=0: one launch per level)
           if (const char *e = std::getenv("GS_TREE")) d.tree = std::atoi(e) != 0 ? 1 : 0;
-          for (size_t q = 0; q < lf.size(); ++q) { const int sidx = lf[q]; const Front &F = P.fronts[sidx]; int32_t *r = &fd[F3W * q];
+          parallel_chunks((int64_t)lf.size(), 1024, [&](int64_t qb, int64_t qe, int) {
+          for (size_t q = (size_t)qb; q < (size_t)qe; ++q) { const int sidx = lf[q]; const Front &F = P.fronts[sidx]; int32_t *r = &fd[F3W * q];
               r[0] = sidx; r[1] = F.npiv; r[2] = F.nbnd; r[3] = F.asm_off; r[4] = F.asm_cnt - F.asm_dup; r[5] = F.asm_dup;
               r[6] = F.child_cnt; r[7] = F.child_off; r[8] = (int32_t)(F.L_off & 0xffffffffLL); r[9] = (int32_t)(F.L_off >> 32);
               r[10] = F.piv0; r[11] = (int32_t)F.bnd_off;
@@ -513,7 +524,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
               r[24] = u3_off[sidx]; r[25] = u3_size[sidx]; r[31] = F.level;
               r[30] = (F.parent >= 0 && P.fronts[F.parent].owner == F.owner) ? F.parent : -1;   // whole-tree backward solve: wait for a parent of the SAME launch only (own in own, shared in shared; a subtree root's shared parent ran earlier)
               const int64_t xo = (P.world > 1 && (size_t)sidx < P.x_off.size()) ? P.x_off[sidx] : 0;
-              r[18] = (int32_t)(xo & 0xffffffffLL); r[19] = (int32_t)(xo >> 32); }
+              r[18] = (int32_t)(xo & 0xffffffffLL); r[19] = (int32_t)(xo >> 32); } });
           std::vector<int32_t> recs(P.asm_recs.size() * 4);
           const bool fused = P.lin_ell_ok && d.n_wtiles > 0;
           { bool too_many = false;
@@ -533,11 +544,13 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
           auto pack = [](int i, bool col_ok) -> int32_t {
               const int ro8 = ((i * (i + 1)) >> 1) * 8, co8 = col_ok ? i * 8 : -30000;
               return (int32_t)((uint32_t)(ro8 & 0xffff) | ((uint32_t)(co8 & 0xffff) << 16)); };
-          { std::fill(pinv.begin(), pinv.end(), pinv_none);
-            for (size_t c = 0; c < P.fronts.size(); ++c) { const Front &C = P.fronts[c]; if (C.parent < 0) continue;
-                const Front &Pa = P.fronts[C.parent]; int32_t *row = &pinv[64 * c];
+          parallel_chunks((int64_t)P.fronts.size(), 1024, [&](int64_t cb, int64_t ce, int) {
+            for (size_t c = (size_t)cb; c < (size_t)ce; ++c) { const Front &C = P.fronts[c]; int32_t *row = &pinv[64 * c];
+                std::fill(row, row + 64, pinv_none);
+                if (C.parent < 0) continue;
+                const Front &Pa = P.fronts[C.parent];
                 for (int i = 0; i < C.nbnd; ++i) row[P.child_map[C.map_off + i]] = pack(i, true);
-                row[Pa.npiv + Pa.nbnd] = pack(C.nbnd, false); } }
+                row[Pa.npiv + Pa.nbnd] = pack(C.nbnd, false); } });
           UP(pinv, pinv);
           GS_UT("f3 desc+asm3+pinv");
           // scalar assembly records {offset in H_arena, offset in the staging image}, padded per front to a multiple of
@@ -592,18 +605,19 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
               if (xtab.size() >= ((size_t)1 << 30)) return fail(GS_ERR_INVALID, "children table too large"); }
           xtab.resize(xtab.size() + 72, 0);
           UP(f3_x, xtab);
-          for (size_t q = 0; q < lf.size(); ++q) { int32_t *r = &fd[F3W * q];
+          parallel_chunks((int64_t)lf.size(), 1024, [&](int64_t qb, int64_t qe, int) {
+          for (size_t q = (size_t)qb; q < (size_t)qe; ++q) { int32_t *r = &fd[F3W * q];
               for (int k = 0; k < 2; ++k) { const int c = r[12 + k];
                   for (int R = 0; R < 64; ++R) r[32 + 64 * k + R] = c >= 0 ? pinv[64 * (size_t)c + R] : pinv_none; }
               // the front's own store table: row of the front -> its place in the front's packed update matrix
               const int np = r[1], nb = r[2];
-              for (int R = 0; R < 64; ++R) r[160 + R] = (R >= np && R <= np + nb) ? pack(R - np, R < np + nb) : pinv_none; }
+              for (int R = 0; R < 64; ++R) r[160 + R] = (R >= np && R <= np + nb) ? pack(R - np, R < np + nb) : pinv_none; } });
           UP(f3_desc, fd);
       } }
     GS_UT("f3 x+desc upload");
     AL(dbg_ts, 64); ZERO(dbg_ts, 64);
     AL(done_ts, 2 * P.fronts.size() + 2); ZERO(done_ts, 2 * P.fronts.size() + 2);
-    AL(Lbuf, P.l_doubles); AL(Ubuf, P.u_doubles); AL(xe, P.n_scalar); AL(dpose, (size_t)N * 3); AL(dlm, (size_t)M * 2); AL(fail, 4);
+    AL(Lbuf, P.l_doubles); AL(Ubuf, (d.factor_variant == 0 || d.factor_variant == 1) ? P.u_doubles : 1); AL(xe, P.n_scalar);      // variants 2 and 3 keep their update matrices in Uimg AL(dpose, (size_t)N * 3); AL(dlm, (size_t)M * 2); AL(fail, 4);
     HIP_TRY(hipMemsetAsync(d.fail, 0, 4 * sizeof(int32_t), g->stream));
     HIP_TRY(hipMemsetAsync(d.chi2, 0, 80 * sizeof(double), g->stream));
     HIP_TRY(hipMemsetAsync(d.dpose, 0, std::max<size_t>((size_t)N * 3, 1) * sizeof(double), g->stream));

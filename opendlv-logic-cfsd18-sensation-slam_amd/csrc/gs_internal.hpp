@@ -21,7 +21,8 @@ struct gs_graph {
     gs::Plan plan;
     uint64_t plan_version = ~0ull;          // h.structure_version the plan was built for
     gs::DevGraph d;
-    std::vector<void *> allocs;             // every device allocation of this handle
+    std::vector<void *> allocs;             // every device allocation of this handle (chunks the plan's arrays are carved from)
+    char *pool_base = nullptr; size_t pool_size = 0, pool_off = 0, pool_next = 0;
     bool dev_valid = false;                 // device mirrors the host graph + plan
     bool dev_estimates_newer = false;       // estimates in HBM are ahead of the host copy
     uint64_t dev_estimate_version = 0;

@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <thread>
 
 namespace gs {
@@ -45,7 +46,7 @@ struct Builder {
     std::vector<int32_t> pose_of_fp, lm_of_fl;
     // vertex-level adjacency with edge references (both endpoints free)
     struct Inc { int32_t other; int32_t epos; int32_t kind; };   // kind: 0 pp (this is i), 1 pp (this is j), 2 pl (this is pose), 3 pl (this is lm)
-    std::vector<int32_t> inc_start; std::vector<Inc> inc;
+    std::vector<int32_t> inc_start; std::unique_ptr<Inc[]> inc_store; Inc *inc = nullptr;   // (not a vector: 21 MB at 100k poses that need no zero fill)
     // ND helpers
     std::vector<int32_t> cone_obs_start, cone_obs;   // per free landmark: sorted free-pose positions
     std::vector<uint8_t> assigned;
@@ -81,7 +82,7 @@ struct Builder {
                     for (int q = P.lm_start[l]; q < P.lm_start[l + 1]; ++q) n += fp_of_pose[pose_of_ell(P.lm_edges[q])] >= 0; }
                 inc_start[v + 1] = n; } });
         for (int v = 0; v < nv; ++v) inc_start[v + 1] += inc_start[v];
-        inc.resize(inc_start[nv]);
+        inc_store.reset(new Inc[(size_t)inc_start[nv] + 1]); inc = inc_store.get();
         cone_obs_start.assign(nfl + 1, 0);
         for (int l = 0; l < nfl; ++l) cone_obs_start[l + 1] = cone_obs_start[l] + (inc_start[nfp + l + 1] - inc_start[nfp + l]);
         cone_obs.resize(cone_obs_start[nfl]);
