@@ -617,7 +617,8 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
     GS_UT("f3 x+desc upload");
     AL(dbg_ts, 64); ZERO(dbg_ts, 64);
     AL(done_ts, 2 * P.fronts.size() + 2); ZERO(done_ts, 2 * P.fronts.size() + 2);
-    AL(Lbuf, P.l_doubles); AL(Ubuf, (d.factor_variant == 0 || d.factor_variant == 1) ? P.u_doubles : 1); AL(xe, P.n_scalar);      // variants 2 and 3 keep their update matrices in Uimg AL(dpose, (size_t)N * 3); AL(dlm, (size_t)M * 2); AL(fail, 4);
+    AL(Lbuf, P.l_doubles); AL(Ubuf, (d.factor_variant == 0 || d.factor_variant == 1) ? P.u_doubles : 1);      // variants 2 and 3 keep their update matrices in Uimg
+    AL(xe, P.n_scalar); AL(dpose, (size_t)N * 3); AL(dlm, (size_t)M * 2); AL(fail, 4);
     HIP_TRY(hipMemsetAsync(d.fail, 0, 4 * sizeof(int32_t), g->stream));
     HIP_TRY(hipMemsetAsync(d.chi2, 0, 80 * sizeof(double), g->stream));
     HIP_TRY(hipMemsetAsync(d.dpose, 0, std::max<size_t>((size_t)N * 3, 1) * sizeof(double), g->stream));
