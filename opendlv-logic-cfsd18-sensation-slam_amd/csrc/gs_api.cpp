@@ -407,6 +407,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
 #define GS_UT(name) do { if (ut_on) { auto n_ = std::chrono::steady_clock::now(); std::fprintf(stderr, "upload %-18s %.2f ms\n", (name), std::chrono::duration<double, std::milli>(n_ - ut_prev).count()); ut_prev = n_; } } while (0)
     const int N = h.n_poses(), M = h.n_lms(), Epp = h.n_pp(), Epl = h.n_pl();
     d.N = N; d.M = M; d.Epp = Epp; d.Epl = Epl; d.n_scalar = P.n_scalar;
+    g->leaf_n = -1;
     int rc;
 #define UP(dst, vec) if ((rc = dev_upload(g, &d.dst, vec)) != GS_OK) return rc
     // estimates, fixed flags, odometry edges and the insertion-order observation arrays are in HBM already (RawUpload)
@@ -639,35 +640,6 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
     };
     level_params(P.level_start_owned, P.level_fronts_owned, g->own);
     level_params(P.level_start_shared, P.level_fronts_shared, g->shared);
-    // leaf instance of the factor kernel: level 0 of this rank's own fronts, if those really have no children (always
-    // true for an elimination tree's level 0).  Its fronts RECOMPUTE the observation blocks A^T Omega B from the edge data
-    // instead of reading them back from HBM, so the linearisation pass does not store them for the poses those fronts
-    // eliminate (pose_in_leaf; DevGraph::lin_skip_leaf is raised per iteration in enqueue_local).
-    g->leaf_n = 0; g->leaf_slot = 256;
-    if (d.factor_variant == 3 && nlev > 0) {
-        int n_leaf = g->own.start[1], slot = 256;
-        for (int q = 0; q < n_leaf; ++q) { const Front &F = P.fronts[P.level_fronts_owned[q]];
-            if (F.child_cnt != 0) { n_leaf = 0; break; }
-            slot = std::max(slot, (((F.npiv + F.nbnd + 1) | 1) * F.npiv + 1) & ~1); }
-        if (const char *e = std::getenv("GS_LEAF_KERNEL")) if (std::atoi(e) == 0) n_leaf = 0;
-        g->leaf_n = n_leaf; g->leaf_slot = slot;
-        bool fuse = n_leaf > 0 && d.n_wtiles > 0;
-        if (const char *e = std::getenv("GS_LEAF_FUSE_HPL")) fuse = fuse && std::atoi(e) != 0;      // A/B: 0 = leaves read H_pl from HBM
-        if (fuse) {
-            std::vector<uint8_t> leaf_scalar((size_t)P.n_scalar + 1, 0), in_leaf((size_t)N, 0);
-            for (int q = 0; q < n_leaf; ++q) { const Front &F = P.fronts[P.level_fronts_owned[q]];
-                std::fill(leaf_scalar.begin() + F.piv0, leaf_scalar.begin() + F.piv0 + F.npiv, (uint8_t)1); }
-            for (int p = 0; p < N; ++p) in_leaf[p] = P.pose_gidx[p] >= 0 && leaf_scalar[P.pose_gidx[p]];
-            UP(pose_in_leaf, in_leaf);
-            // {pose, landmark} of every observation-block record (the leaf fronts' block records carry the ELL index only)
-            std::vector<int32_t> pl((size_t)P.asm_recs.size() * 2, -1);
-            parallel_chunks((int64_t)P.asm_recs.size(), 1 << 14, [&](int64_t b, int64_t e1, int) {
-                for (size_t t = (size_t)b; t < (size_t)e1; ++t) { const int k = P.asm_recs[t].kind;
-                    if (k == ASM_PL || k == ASM_PL_T) { const int ins = P.ell_ins[(size_t)P.asm_recs[t].src];
-                        pl[2 * t] = h.pl_p[ins]; pl[2 * t + 1] = h.pl_l[ins]; } } });
-            UP(asm3_pl, pl);
-        }
-    }
     if (max_blocks_oversize > 0) {      // fronts beyond the LDS limit use a global workspace, one slice per block
         max_blocks_oversize = std::max<int64_t>(max_blocks_oversize, (int64_t)P.level_fronts_shared.size());
         AL(front_ws, d.front_ws_stride * max_blocks_oversize);
@@ -752,6 +724,14 @@ static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int
     const int nlev = (int)ls.start.size() - 1;
     if (g->d.factor_variant == 3 && g->d.tree && mode == 0 && base == 0 && nlev > 0) {     // every own level in one launch
         ++g->d.epoch;
+        // leaf instance: level 0 only if its fronts really have no children (always true for an elimination tree's level 0)
+        if (g->leaf_n < 0) {                                          // once per plan
+            int n_leaf = ls.start[1], slot = 256;
+            for (int q = 0; q < n_leaf; ++q) { const Front &F = g->plan.fronts[g->plan.level_fronts_owned[q]];
+                if (F.child_cnt != 0) { n_leaf = 0; break; }
+                slot = std::max(slot, (((F.npiv + F.nbnd + 1) | 1) * F.npiv + 1) & ~1); }
+            if (const char *e = std::getenv("GS_LEAF_KERNEL")) if (std::atoi(e) == 0) n_leaf = 0;
+            g->leaf_n = n_leaf; g->leaf_slot = slot; }
         launch_factor_tree(g->d, g->leaf_n, g->leaf_slot, ls.start[nlev], g->stream); return; }
     if (g->d.factor_variant == 3 && g->d.tree && mode == 2 && nlev > 0 && ls.start[nlev] > 0) {     // the shared top of a sharded graph, one flagged launch
         launch_factor_tree_top(g->d, base, ls.start[nlev], g->stream); return; }
@@ -784,9 +764,7 @@ static void enqueue_backsolve_levels(gs_graph *g, const gs_graph::LevelSet &ls, 
 // pose-window shards, first half: linearise this shard's edges, factorise its own subtrees, write its contribution
 // to every shared front into the exchange buffer (the caller all-reduces that buffer: RCCL sum, fp64)
 static void enqueue_local(gs_graph *g, bool timed) {
-    ++g->d.iter;
-    // the leaf fronts recompute their observation blocks only when the leaf instance really runs (whole-tree launches)
-    g->d.lin_skip_leaf = (g->d.factor_variant == 3 && g->d.tree && g->leaf_n > 0 && g->d.pose_in_leaf != nullptr) ? 1 : 0;                                                     // kernels see the iteration they belong to (fault injection, gs_debug_fail_at_iteration)
+    ++g->d.iter;                                                     // kernels see the iteration they belong to (fault injection, gs_debug_fail_at_iteration)
     if (timed) hipEventRecord(g->ev[0], g->stream);
     launch_linearize(g->d, g->stream);
     if (timed) hipEventRecord(g->ev[1], g->stream);
@@ -918,9 +896,8 @@ extern "C" int gs_chi2(gs_graph *g, double *out) {
 extern "C" int gs_linearize(gs_graph *g) {
     if (!g) return fail(GS_ERR_INVALID, "null graph");
     int rc = ensure_ready(g); if (rc != GS_OK) return rc;
-    { DevGraph full = g->d; full.lin_skip_leaf = 0;           // stand-alone pass (export, parity): every H_pl block goes to HBM
-      launch_linearize(full, g->stream); }
-    launch_linearize_finalize(g->d, g->stream);              // materialise H_ll, b_l, chi2 for export
+    launch_linearize(g->d, g->stream);
+    launch_linearize_finalize(g->d, g->stream);              // stand-alone pass: materialise H_ll, b_l, chi2 for export
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("linearize: ") + hipGetErrorString(e));
     return GS_OK;
@@ -928,7 +905,6 @@ extern "C" int gs_linearize(gs_graph *g) {
 extern "C" int gs_time_linearize(gs_graph *g, int32_t reps, double *out_ms) {
     if (!g || !out_ms || reps <= 0) return fail(GS_ERR_INVALID, "bad argument");
     int rc = ensure_ready(g); if (rc != GS_OK) return rc;
-    g->d.lin_skip_leaf = (g->d.factor_variant == 3 && g->d.tree && g->leaf_n > 0 && g->d.pose_in_leaf != nullptr) ? 1 : 0;   // as inside an iteration
     launch_linearize(g->d, g->stream);                       // warm
     hipEventRecord(g->ev[0], g->stream);
     for (int r = 0; r < reps; ++r) launch_linearize(g->d, g->stream);

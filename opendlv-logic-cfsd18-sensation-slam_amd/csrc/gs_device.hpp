@@ -30,8 +30,6 @@ struct DevGraph {
     double *pose_est = nullptr, *lm_est = nullptr;             // [N*3], [M*2]
     double *pose_cs = nullptr;                                  // [N*2] cos, sin of every pose's theta (kept by k_pose_trig / k_update)
     uint8_t *pose_fixed = nullptr, *lm_fixed = nullptr;
-    uint8_t *pose_in_leaf = nullptr; int32_t lin_skip_leaf = 0; // poses eliminated by leaf-instance fronts: those fronts recompute H_pl, the linearisation pass does not store it (lin_skip_leaf)
-    int32_t *asm3_pl = nullptr;                                 // [record][2] {pose, landmark} of the observation-block records (leaf instance)
     int32_t *pose_gidx = nullptr, *lm_gidx = nullptr;          // first scalar in elimination order, -1 fixed
     // observation edges, ELL
     int32_t ell_T = 1, ell_R = 1; int64_t ell_len = 0;

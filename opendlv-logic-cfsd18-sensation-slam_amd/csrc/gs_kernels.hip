@@ -486,10 +486,8 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
                 e.w00[j] = LD_S(d.ell_w, o); e.w01[j] = LD_S(d.ell_w + L, o); e.w11[j] = LD_S(d.ell_w + 2 * L, o); } }
     };
     double px = 0, py = 0; bool fp = true; int q0 = 0, q1 = 0;       // theta itself is not needed: its cos/sin are cached per pose
-    bool keep_hpl = true;                                          // false: a leaf-instance front recomputes this pose's H_pl blocks (lin_skip_leaf)
     if (live) { px = d.pose_est[3 * p]; py = d.pose_est[3 * p + 1]; fp = d.pose_fixed[p];
-                q0 = d.ppadj_start[p]; q1 = d.ppadj_start[p + 1];
-                if (d.lin_skip_leaf) keep_hpl = d.pose_in_leaf[p] == 0; }
+                q0 = d.ppadj_start[p]; q1 = d.ppadj_start[p + 1]; }
     const int4 wd = reinterpret_cast<const int4 *>(d.wt_desc)[wt];        // {first group, #groups, first position, #positions}
     double sn = 0.0, cs = 1.0;                                     // cos/sin of theta are kept per pose (k_update): no sincos here
     if (live) { const double2 t2 = reinterpret_cast<const double2 *>(d.pose_cs)[p]; cs = t2.x; sn = t2.y; }
@@ -522,9 +520,8 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
                 quad_pl(px, py, cs, sn, lx[j], ly[j], e.zx[j], e.zy[j], e.w00[j], e.w01[j], e.w11[j], q);
                 if (!(fp && fl[j])) chi += q.chi;
                 const bool both = !fp && !fl[j];
-                if (keep_hpl) {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) ST_S(d.Hpl + k * L, o, both ? q.W6[k] : 0.0); }
+                for (int k = 0; k < 6; ++k) ST_S(d.Hpl + k * L, o, both ? q.W6[k] : 0.0);
 #pragma unroll
                 for (int k = 0; k < 6; ++k) H[k] += q.Hp[k];
 #pragma unroll
@@ -1244,23 +1241,6 @@ __device__ __forceinline__ void asm3_load(const DevGraph &d, int kind_cnt, int s
             for (int k = 0; k < 6; ++k) v[k] = d.Hpl[k * S + src]; } break;
     }
 }
-// the same for a leaf-instance front when the linearisation pass does not store H_pl (lin_skip_leaf): an observation block
-// A^T Omega B is recomputed from the edge's measurement / information and the two estimates — the bytes of the edge record
-// instead of the bytes of the block, no round trip through HBM.  pl = {pose, landmark} of the record (asm3_pl).
-__device__ __forceinline__ void asm3_load_leaf(const DevGraph &d, int kind_cnt, int src, int2 pl, double (&v)[9]) {
-    const int kind = kind_cnt & 0xff;
-    if (!d.lin_skip_leaf || kind < 4) { asm3_load(d, kind_cnt, src, v); return; }
-    const int64_t L = d.ell_len;
-    const double zx = d.ell_z[src], zy = d.ell_z[L + src], w00 = d.ell_w[src], w01 = d.ell_w[L + src], w11 = d.ell_w[2 * L + src];
-    const double px = d.pose_est[3 * pl.x], py = d.pose_est[3 * pl.x + 1];
-    const double2 cs = reinterpret_cast<const double2 *>(d.pose_cs)[pl.x];
-    const double2 lm = reinterpret_cast<const double2 *>(d.lm_est)[pl.y];
-    PlQuad q;
-    quad_pl(px, py, cs.x, cs.y, lm.x, lm.y, zx, zy, w00, w01, w11, q);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) v[k] = q.W6[k];
-    v[6] = v[7] = v[8] = 0.0;
-}
 // staging of a front's original entries before they go to the accumulators.  StageT<false>: the 64 x 64 tile image
 // (20 KB).  StageT<true>: only the pivot columns, column-major (f+1) x npiv with an odd leading dimension (~9 KB) —
 // leaves have nothing else to stage, and the smaller footprint is what lets three workgroups share a CU.
@@ -1512,12 +1492,11 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
     // (16 bytes for the 5-9 scalars of one H block) is a quarter of the scalar records' bytes
     constexpr bool BLK = LEAF && F3_LEAF_BLOCKS;
     const int nsc = (top || BLK) ? 0 : fr.sc_cnt, nlm = (top || BLK) ? 0 : fr.lm_cnt;
-    int4 brec[2]; int2 bpl[2];
+    int4 brec[2];
     if (BLK) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) { const int t = lane + 64 * u;
-            brec[u] = (t < fr.asm_uniq) ? reinterpret_cast<const int4 *>(d.asm3)[fr.asm_off + t] : make_int4(-1, 0, 0, 0);
-            bpl[u] = (d.lin_skip_leaf && t < fr.asm_uniq) ? reinterpret_cast<const int2 *>(d.asm3_pl)[fr.asm_off + t] : make_int2(0, 0); } }
+            brec[u] = (t < fr.asm_uniq) ? reinterpret_cast<const int4 *>(d.asm3)[fr.asm_off + t] : make_int4(-1, 0, 0, 0); } }
     const int2 *sc3 = reinterpret_cast<const int2 *>(d.sc3) + fr.sc_off;
     int2 sc[8];
 #pragma unroll
@@ -1548,13 +1527,12 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
         if (BLK) {
             double bv[2][9];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) if (brec[u].x >= 0) asm3_load_leaf(d, brec[u].x, brec[u].y, bpl[u], bv[u]);
+            for (int u = 0; u < 2; ++u) if (brec[u].x >= 0) asm3_load(d, brec[u].x, brec[u].y, bv[u]);
 #pragma unroll
             for (int u = 0; u < 2; ++u) if (brec[u].x >= 0) asm3_put<false>(P, brec[u].x, brec[u].z, brec[u].w, bv[u]);
             for (int t = lane + 128; t < fr.asm_uniq; t += 64) {
                 const int4 r = reinterpret_cast<const int4 *>(d.asm3)[fr.asm_off + t];
-                const int2 rp = d.lin_skip_leaf ? reinterpret_cast<const int2 *>(d.asm3_pl)[fr.asm_off + t] : make_int2(0, 0);
-                double w[9]; asm3_load_leaf(d, r.x, r.y, rp, w); asm3_put<false>(P, r.x, r.z, r.w, w); }
+                double w[9]; asm3_load(d, r.x, r.y, w); asm3_put<false>(P, r.x, r.z, r.w, w); }
         }
         double val[8];
 #pragma unroll
@@ -1586,10 +1564,7 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
         if (fr.asm_dup > 0) {                                        // parallel edges: added one by one, in record order
             if (lane == 0) for (int t = fr.asm_uniq; t < fr.asm_uniq + fr.asm_dup; ++t) {
                 const int4 r = reinterpret_cast<const int4 *>(d.asm3)[fr.asm_off + t];
-                double w[9];
-                if (LEAF && d.lin_skip_leaf) asm3_load_leaf(d, r.x, r.y, reinterpret_cast<const int2 *>(d.asm3_pl)[fr.asm_off + t], w);
-                else asm3_load(d, r.x, r.y, w);
-                asm3_put<true>(P, r.x, r.z, r.w, w); }
+                double w[9]; asm3_load(d, r.x, r.y, w); asm3_put<true>(P, r.x, r.z, r.w, w); }
         }
     }
     wave_lds_sync();
