@@ -500,7 +500,6 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
           std::vector<int32_t> lf = P.level_fronts_owned;
           lf.insert(lf.end(), P.level_fronts_shared.begin(), P.level_fronts_shared.end());
           constexpr int F3W = 224;                           // 32 descriptor ints + the row tables of the first two children + the front's own store table
-          std::vector<int32_t> fd(lf.size() * F3W, 0);
           // update matrices, packed: row r' (0 .. nbnd, the last = rhs) of the boundary block holds columns 0 .. min(r', nbnd - 1)
           // at r'(r'+1)/2; then one double that stays zero (clamped gathers land on it) and one that collects clamped stores
           std::vector<int32_t> u3_off(P.fronts.size()), u3_size(P.fronts.size());
@@ -513,106 +512,45 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
           AL(done_f, P.fronts.size()); ZERO(done_f, P.fronts.size()); AL(done_b, P.fronts.size()); ZERO(done_b, P.fronts.size());
           d.epoch = 0; d.tree = 1;                                    // whole-tree launches for this rank's own subtrees (GS_TREE=0: one launch per level)
           if (const char *e = std::getenv("GS_TREE")) d.tree = std::atoi(e) != 0 ? 1 : 0;
-          parallel_chunks((int64_t)lf.size(), 1024, [&](int64_t qb, int64_t qe, int) {
-          for (size_t q = (size_t)qb; q < (size_t)qe; ++q) { const int sidx = lf[q]; const Front &F = P.fronts[sidx]; int32_t *r = &fd[F3W * q];
-              r[0] = sidx; r[1] = F.npiv; r[2] = F.nbnd; r[3] = F.asm_off; r[4] = F.asm_cnt - F.asm_dup; r[5] = F.asm_dup;
-              r[6] = F.child_cnt; r[7] = F.child_off; r[8] = (int32_t)(F.L_off & 0xffffffffLL); r[9] = (int32_t)(F.L_off >> 32);
-              r[10] = F.piv0; r[11] = (int32_t)F.bnd_off;
-              for (int k = 0; k < 2; ++k) { r[12 + k] = -1; r[16 + k] = 0;
-                  if (k < F.child_cnt) { const int c = P.children[F.child_off + k]; const Front &C = P.fronts[c];
-                      r[12 + k] = c; r[16 + k] = C.owner; r[26 + k] = u3_off[c]; r[28 + k] = u3_size[c]; } }
-              r[24] = u3_off[sidx]; r[25] = u3_size[sidx]; r[31] = F.level;
-              r[30] = (F.parent >= 0 && P.fronts[F.parent].owner == F.owner) ? F.parent : -1;   // whole-tree backward solve: wait for a parent of the SAME launch only (own in own, shared in shared; a subtree root's shared parent ran earlier)
-              const int64_t xo = (P.world > 1 && (size_t)sidx < P.x_off.size()) ? P.x_off[sidx] : 0;
-              r[18] = (int32_t)(xo & 0xffffffffLL); r[19] = (int32_t)(xo >> 32); } });
-          std::vector<int32_t> recs(P.asm_recs.size() * 4);
+          // ---- everything below is expanded ON THE DEVICE from the compact plan arrays
           const bool fused = P.lin_ell_ok && d.n_wtiles > 0;
-          { bool too_many = false;
-            parallel_chunks((int64_t)P.asm_recs.size(), 1 << 14, [&](int64_t b, int64_t e1, int) {
-              for (size_t t = (size_t)b; t < (size_t)e1; ++t) { int kind = P.asm_recs[t].kind, src = P.asm_recs[t].src;
-                  if (kind == 1 && fused) { const int q0 = P.lm_grp_start[src], q1 = P.lm_grp_start[src + 1];
-                      if (q1 - q0 >= (1 << 22)) too_many = true;
-                      kind = 1 | ((q1 - q0) << 8); src = q0; }
-                  recs[4 * t] = kind; recs[4 * t + 1] = src; recs[4 * t + 2] = P.asm_recs[t].r0; recs[4 * t + 3] = P.asm_recs[t].c0; } });
-            if (too_many) return fail(GS_ERR_INVALID, "landmark seen from too many wave tiles"); }
-          UP(asm3, recs);
-          // per front: where each row R of its PARENT finds this front's row in its tile image, as byte offsets split
-          // into a row part (low 16 bits) and a column part (high 16 bits); -30000 = no such row (sum goes negative)
-          std::vector<int32_t> pinv(P.fronts.size() * 64);
-          const int32_t pinv_none = (int32_t)((uint32_t)((-30000) & 0xffff) | ((uint32_t)(-30000) << 16));
-          // pack(i, col_ok): boundary row i of a front inside its packed update matrix: row part i(i+1)/2, column part i (bytes)
-          auto pack = [](int i, bool col_ok) -> int32_t {
-              const int ro8 = ((i * (i + 1)) >> 1) * 8, co8 = col_ok ? i * 8 : -30000;
-              return (int32_t)((uint32_t)(ro8 & 0xffff) | ((uint32_t)(co8 & 0xffff) << 16)); };
-          parallel_chunks((int64_t)P.fronts.size(), 1024, [&](int64_t cb, int64_t ce, int) {
-            for (size_t c = (size_t)cb; c < (size_t)ce; ++c) { const Front &C = P.fronts[c]; int32_t *row = &pinv[64 * c];
-                std::fill(row, row + 64, pinv_none);
-                if (C.parent < 0) continue;
-                const Front &Pa = P.fronts[C.parent];
-                for (int i = 0; i < C.nbnd; ++i) row[P.child_map[C.map_off + i]] = pack(i, true);
-                row[Pa.npiv + Pa.nbnd] = pack(C.nbnd, false); } });
-          UP(pinv, pinv);
-          GS_UT("f3 desc+asm3+pinv");
+          // block assembly records: the plan's, as they are (AsmRec = 4 ints); landmark-diagonal records of the fused
+          // linearisation get their partial-slot range patched in by a kernel
+          static_assert(sizeof(AsmRec) == 16, "AsmRec is uploaded as 4 int32");
+          if ((rc = dev_alloc(g, &d.asm3, P.asm_recs.size() * 4)) != GS_OK) return rc;
+          if (!P.asm_recs.empty()) HIP_TRY(hipMemcpyAsync(d.asm3, P.asm_recs.data(), P.asm_recs.size() * sizeof(AsmRec), hipMemcpyHostToDevice, g->stream));
+          if (fused) { for (int l = 0; l < M; ++l) if (P.lm_grp_start[l + 1] - P.lm_grp_start[l] >= (1 << 22)) return fail(GS_ERR_INVALID, "landmark seen from too many wave tiles");
+              launch_patch_asm3((int64_t)P.asm_recs.size(), d.asm3, d.lm_grp_start, g->stream); }
+          GS_UT("asm3");
           // scalar assembly records {offset in H_arena, offset in the staging image}, padded per front to a multiple of
-          // 64 with (0 -> image offset 1, a don't-care upper-triangle slot); fused landmark diagonals go to lm3
-          // (expanded ON THE DEVICE from the block records: the host only counts them per front)
+          // 64 with (0 -> image offset 1, a don't-care upper-triangle slot); fused landmark diagonals go to lm3.
+          // The host only counts them per front.
           { const size_t S = P.fronts.size();
-            std::vector<int32_t> sc_off(S), sc_cnt(S), lm_off(S), lm_cnt(S), bf(6 * S);
+            std::vector<int32_t> bf(8 * S, 0);
             parallel_chunks((int64_t)S, 2048, [&](int64_t b, int64_t e, int) {
                 for (int64_t sidx = b; sidx < e; ++sidx) { const Front &F = P.fronts[sidx]; int ns = 0, nl = 0;
                     for (int t = F.asm_off; t < F.asm_off + F.asm_cnt - F.asm_dup; ++t) { const int k = P.asm_recs[t].kind;
                         if (k == 0) ns += 9; else if (k == 1) { if (fused) ++nl; else ns += 5; } else if (k <= 3) ns += 9; else ns += 6; }
-                    sc_cnt[sidx] = (ns + 63) & ~63; lm_cnt[sidx] = nl; } });
+                    bf[8 * sidx + 4] = (ns + 63) & ~63; bf[8 * sidx + 6] = nl; } });
             int64_t so = 0, lo = 0;
-            for (size_t sidx = 0; sidx < S; ++sidx) { const Front &F = P.fronts[sidx];
+            for (size_t sidx = 0; sidx < S; ++sidx) { const Front &F = P.fronts[sidx]; int32_t *r = &bf[8 * sidx];
                 if (so >= ((int64_t)1 << 31) - 64) return fail(GS_ERR_INVALID, "too many assembly scalars");
-                sc_off[sidx] = (int32_t)so; lm_off[sidx] = (int32_t)lo; so += sc_cnt[sidx]; lo += lm_cnt[sidx];
-                int32_t *r = &bf[6 * sidx]; r[0] = F.asm_off; r[1] = F.asm_cnt - F.asm_dup; r[2] = F.npiv + F.nbnd; r[3] = sc_off[sidx]; r[4] = sc_cnt[sidx]; r[5] = lm_off[sidx]; }
-            for (size_t q = 0; q < lf.size(); ++q) { int32_t *r = &fd[F3W * q]; const int sidx = lf[q];
-                r[20] = sc_off[sidx]; r[21] = sc_cnt[sidx]; r[22] = lm_off[sidx]; r[23] = lm_cnt[sidx]; }
+                r[0] = F.asm_off; r[1] = F.asm_cnt - F.asm_dup; r[2] = F.npiv + F.nbnd; r[3] = (int32_t)so; r[5] = (int32_t)lo; so += r[4]; lo += r[6]; }
             AL(sc3, 2 * (size_t)so + 2); AL(lm3, 4 * (size_t)lo + 4);
             int32_t *bf_dev = nullptr; if ((rc = dev_upload(g, &bf_dev, bf)) != GS_OK) return rc;
             Sc3Args A; for (int k = 0; k < 8; ++k) A.off[k] = arena_off[k];
             A.L = P.ell_len; A.N = N; A.M = M; A.Epp = Epp; A.fused = fused ? 1 : 0;
             launch_build_sc3(bf_dev, d.asm3, d.sc3, d.lm3, (int)S, A, g->stream);
-            GS_UT("sc3 build"); }
-          GS_UT("sc3 upload");
-          // children table of every front: [row table 64 | front, u offset, u size, owner, place in the LDS image, batch, 0 0] per child.
-          // Batches (children whose update matrices are staged in the parent's LDS image together, factor kernel
-          // F3_LDS_GATHER): greedily up to 4 consecutive children, <= 2560 doubles (the image) in all, each <= 895 doubles.
-          std::vector<int32_t> xtab;
-          for (size_t q = 0; q < lf.size(); ++q) { int32_t *r = &fd[F3W * q]; const Front &F = P.fronts[lf[q]];
-              r[14] = (int32_t)xtab.size();
-              // batch shapes (28 staging doubles per lane either way): 0 = up to four children of <= 447 doubles each,
-              // 1 = up to two of <= 895; a child beyond that is gathered from HBM (batch -1)
-              const size_t x0 = xtab.size();
-              for (int k = 0; k < F.child_cnt; ++k) { const int c = P.children[F.child_off + k];
-                  xtab.insert(xtab.end(), pinv.begin() + 64 * (size_t)c, pinv.begin() + 64 * (size_t)c + 64);
-                  const int32_t hdr[8] = {c, u3_off[c], u3_size[c], P.fronts[c].owner, 0, -1, 0, 0};
-                  xtab.insert(xtab.end(), hdr, hdr + 8); }
-              { int batch = 0, k = 0; const int nc = F.child_cnt;
-                auto usz = [&](int kk) { return u3_size[P.children[F.child_off + kk]]; };
-                auto H = [&](int kk) { return &xtab[x0 + 72 * (size_t)kk + 64]; };
-                while (k < nc) {
-                    if (usz(k) + 1 > 14 * 64 - 1) { ++k; continue; }                       // stays batch -1
-                    const int shape = usz(k) + 1 <= 7 * 64 - 1 ? 0 : 1, cap = shape == 0 ? 4 : 2, lim = shape == 0 ? 7 * 64 - 1 : 14 * 64 - 1;
-                    int n = 0, tot = 0;
-                    while (k < nc && n < cap && usz(k) + 1 <= lim && (shape == 1 || usz(k) + 1 <= 7 * 64 - 1)) {
-                        const int need = (usz(k) + 2) & ~1;
-                        if (tot + need > 2560) break;
-                        int32_t *h = H(k); h[4] = tot; h[5] = batch; h[6] = shape; tot += need; ++n; ++k; }
-                    ++batch; } }
-              if (xtab.size() >= ((size_t)1 << 30)) return fail(GS_ERR_INVALID, "children table too large"); }
-          xtab.resize(xtab.size() + 72, 0);
-          UP(f3_x, xtab);
-          parallel_chunks((int64_t)lf.size(), 1024, [&](int64_t qb, int64_t qe, int) {
-          for (size_t q = (size_t)qb; q < (size_t)qe; ++q) { int32_t *r = &fd[F3W * q];
-              for (int k = 0; k < 2; ++k) { const int c = r[12 + k];
-                  for (int R = 0; R < 64; ++R) r[32 + 64 * k + R] = c >= 0 ? pinv[64 * (size_t)c + R] : pinv_none; }
-              // the front's own store table: row of the front -> its place in the front's packed update matrix
-              const int np = r[1], nb = r[2];
-              for (int R = 0; R < 64; ++R) r[160 + R] = (R >= np && R <= np + nb) ? pack(R - np, R < np + nb) : pinv_none; } });
-          UP(f3_desc, fd);
+            GS_UT("sc3 build");
+            // descriptors + children tables: one wave per level position (k_build_f3)
+            std::vector<int32_t> xrow(lf.size() + 1, 0);
+            for (size_t q = 0; q < lf.size(); ++q) { xrow[q + 1] = xrow[q] + 72 * P.fronts[lf[q]].child_cnt;
+                if (xrow[q + 1] >= (1 << 30)) return fail(GS_ERR_INVALID, "children table too large"); }
+            int32_t *xrow_dev = nullptr; if ((rc = dev_upload(g, &xrow_dev, xrow)) != GS_OK) return rc;
+            AL(f3_desc, lf.size() * (size_t)F3W); AL(f3_x, (size_t)xrow[lf.size()] + 72);
+            launch_build_f3((int)lf.size(), d.level_fronts, d.fronts, d.children, d.child_map, d.u3_off, d.u3_size, bf_dev, xrow_dev,
+                            P.world > 1 ? d.x_off : nullptr, d.f3_desc, d.f3_x, g->stream);
+            GS_UT("f3 tables"); }
       } }
     GS_UT("f3 x+desc upload");
     AL(dbg_ts, 64); ZERO(dbg_ts, 64);

@@ -109,6 +109,10 @@ void launch_build_ell(int64_t L, const int32_t *ell_ins, const int32_t *raw_l, c
                       const int32_t *pl_rank, int rank, int32_t *ell_l, double *ell_z, double *ell_w, hipStream_t st);
 void launch_frame_frontend(int k, const double *in, double lidar, int n_map, const double *map_xy, const int32_t *map_type,
                            double thr, double type_tol, int signed_type, double *out_z, double *out_g, int32_t *out_idx, hipStream_t st);
+void launch_build_f3(int nq, const int32_t *lf, const DevFront *fronts, const int32_t *children, const int32_t *child_map,
+                     const int32_t *u3_off, const int32_t *u3_size, const int32_t *bf, const int32_t *xrow_off, const int64_t *x_off,
+                     int32_t *f3_desc, int32_t *f3_x, hipStream_t st);
+void launch_patch_asm3(int64_t n, int32_t *asm3, const int32_t *lm_grp_start, hipStream_t st);
 int  factor_lds_limit_f();      // largest front dimension that fits the LDS variant
 
 }  // namespace gs

@@ -1879,6 +1879,104 @@ void launch_build_ell(int64_t L, const int32_t *ell_ins, const int32_t *raw_l, c
     if (L > 0) hipLaunchKernelGGL(k_build_ell, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, L, ell_ins, raw_l, raw_z, raw_info, pl_rank, rank, ell_l, ell_z, ell_w);
 }
 
+// ---- structure phase on the device: the per-level-position descriptors (f3_desc: 32 ints + the first two children's
+// row tables + the front's own store table) and the children tables (f3_x) of the variant-3 kernels, built from the
+// compact plan arrays that are in HBM anyway (fronts, children, child maps).  One wave per level position.  On the host
+// these tables were 35 MB built on threads and copied over PCIe: 9 ms of the structure phase at 100k poses.
+// pack(i, col_ok): boundary row i of a front inside its packed update matrix, as byte offsets {row part i(i+1)/2 * 8 (low 16
+// bits), column part i * 8 (high 16 bits)}; -30000 = none (the sum goes negative and the gather clamps to the zero slot).
+__device__ __forceinline__ int32_t f3_pack(int i, bool col_ok) {
+    const int ro8 = ((i * (i + 1)) >> 1) * 8, co8 = col_ok ? i * 8 : -30000;
+    return (int32_t)((uint32_t)(ro8 & 0xffff) | ((uint32_t)(co8 & 0xffff) << 16));
+}
+__global__ void __launch_bounds__(256) k_build_f3(int nq, const int32_t *__restrict__ lf, const DevFront *__restrict__ fronts,
+        const int32_t *__restrict__ children, const int32_t *__restrict__ child_map, const int32_t *__restrict__ u3_off,
+        const int32_t *__restrict__ u3_size, const int32_t *__restrict__ bf /*[front][8]*/, const int32_t *__restrict__ xrow_off,
+        const int64_t *__restrict__ x_off /* nullable */, int32_t *__restrict__ f3_desc, int32_t *__restrict__ f3_x) {
+    __shared__ int32_t s_row[4][64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + wave;
+    if (q >= nq) return;
+    const int32_t none = (int32_t)((uint32_t)((-30000) & 0xffff) | ((uint32_t)(-30000) << 16));
+    const int s = lf[q];
+    const DevFront F = fronts[s];
+    const int f = F.npiv + F.nbnd;
+    int32_t *r = f3_desc + (int64_t)q * F3_STRIDE;
+    // ---- the 32 descriptor ints: lane i computes entry i
+    { int c0 = -1, c1 = -1;
+      if (F.child_cnt > 0) c0 = children[F.child_off];
+      if (F.child_cnt > 1) c1 = children[F.child_off + 1];
+      const int64_t xo = x_off ? x_off[s] : 0;
+      int v = 0;
+      switch (lane) {
+          case 0: v = s; break;            case 1: v = F.npiv; break;       case 2: v = F.nbnd; break;      case 3: v = F.asm_off; break;
+          case 4: v = F.asm_cnt - F.asm_dup; break;                         case 5: v = F.asm_dup; break;   case 6: v = F.child_cnt; break;
+          case 7: v = F.child_off; break;  case 8: v = (int32_t)(F.L_off & 0xffffffffLL); break;           case 9: v = (int32_t)(F.L_off >> 32); break;
+          case 10: v = F.piv0; break;      case 11: v = (int32_t)F.bnd_off; break;
+          case 12: v = c0; break;          case 13: v = c1; break;          case 14: v = xrow_off[q]; break;
+          case 16: v = c0 >= 0 ? fronts[c0].owner : 0; break;               case 17: v = c1 >= 0 ? fronts[c1].owner : 0; break;
+          case 18: v = (int32_t)(xo & 0xffffffffLL); break;                 case 19: v = (int32_t)(xo >> 32); break;
+          case 20: v = bf[8 * s + 3]; break; case 21: v = bf[8 * s + 4]; break; case 22: v = bf[8 * s + 5]; break; case 23: v = bf[8 * s + 6]; break;
+          case 24: v = u3_off[s]; break;   case 25: v = u3_size[s]; break;
+          case 26: v = c0 >= 0 ? u3_off[c0] : 0; break;   case 27: v = c1 >= 0 ? u3_off[c1] : 0; break;
+          case 28: v = c0 >= 0 ? u3_size[c0] : 0; break;  case 29: v = c1 >= 0 ? u3_size[c1] : 0; break;
+          // whole-tree backward solve: wait for a parent of the SAME launch only (own in own, shared in shared)
+          case 30: v = (F.parent >= 0 && fronts[F.parent].owner == F.owner) ? F.parent : -1; break;
+          case 31: v = F.level; break;
+          default: v = 0; break;
+      }
+      if (lane < F3_INTS) r[lane] = v; }
+    // ---- the front's own store table: row of the front -> its place in the front's packed update matrix
+    r[160 + lane] = (lane >= F.npiv && lane <= f) ? f3_pack(lane - F.npiv, lane < f) : none;
+    if (F.child_cnt < 1) r[32 + lane] = none;
+    if (F.child_cnt < 2) r[96 + lane] = none;
+    // ---- children: row table (row R of THIS front -> the child's boundary row that lands on it) + header
+    int32_t *xt = f3_x + xrow_off[q];
+    for (int k = 0; k < F.child_cnt; ++k) {
+        const int c = children[F.child_off + k];
+        const int nbc = fronts[c].nbnd; const int64_t mo = fronts[c].map_off;
+        s_row[wave][lane] = none;
+        wave_lds_sync();
+        if (lane < nbc) s_row[wave][child_map[mo + lane]] = f3_pack(lane, true);
+        if (lane == 0) s_row[wave][f] = f3_pack(nbc, false);
+        wave_lds_sync();
+        const int32_t v = s_row[wave][lane];
+        xt[k * F3X + lane] = v;
+        if (k < 2) r[32 + 64 * k + lane] = v;
+        if (lane < 8) xt[k * F3X + 64 + lane] = lane == 0 ? c : (lane == 1 ? u3_off[c] : (lane == 2 ? u3_size[c] : (lane == 3 ? fronts[c].owner : (lane == 5 ? -1 : 0))));
+        wave_lds_sync();
+    }
+    // ---- batches for the LDS-staged gather (tuning build F3_LDS_GATHER): greedily up to 4 consecutive children of <= 447
+    // doubles or 2 of <= 895, <= 2560 doubles in all; header fields 4 (place in the image), 5 (batch), 6 (shape)
+    if (lane == 0) { int batch = 0, k = 0; const int nc = F.child_cnt;
+        while (k < nc) { const int usz = u3_size[children[F.child_off + k]];
+            if (usz + 1 > 14 * 64 - 1) { ++k; continue; }
+            const int shape = usz + 1 <= 7 * 64 - 1 ? 0 : 1, cap = shape == 0 ? 4 : 2, lim = shape == 0 ? 7 * 64 - 1 : 14 * 64 - 1;
+            int n = 0, tot = 0;
+            while (k < nc && n < cap) { const int u2 = u3_size[children[F.child_off + k]];
+                if (u2 + 1 > lim) break;
+                const int need = (u2 + 2) & ~1;
+                if (tot + need > 2560) break;
+                int32_t *h = xt + k * F3X + 64; h[4] = tot; h[5] = batch; h[6] = shape; tot += need; ++n; ++k; }
+            if (n == 0) ++k;
+            ++batch; } }
+}
+void launch_build_f3(int nq, const int32_t *lf, const DevFront *fronts, const int32_t *children, const int32_t *child_map,
+                     const int32_t *u3_off, const int32_t *u3_size, const int32_t *bf, const int32_t *xrow_off, const int64_t *x_off,
+                     int32_t *f3_desc, int32_t *f3_x, hipStream_t st) {
+    if (nq > 0) hipLaunchKernelGGL(k_build_f3, dim3((nq + 3) / 4), dim3(256), 0, st, nq, lf, fronts, children, child_map, u3_off, u3_size, bf, xrow_off, x_off, f3_desc, f3_x);
+}
+// landmark-diagonal block records of the fused linearisation: {kind 1, landmark} -> {1 | #partial slots << 8, first slot}
+__global__ void __launch_bounds__(256) k_patch_asm3(int64_t n, int32_t *__restrict__ asm3, const int32_t *__restrict__ lm_grp_start) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    if (asm3[4 * t] == 1) { const int l = asm3[4 * t + 1]; const int q0 = lm_grp_start[l], q1 = lm_grp_start[l + 1];
+        asm3[4 * t] = 1 | ((q1 - q0) << 8); asm3[4 * t + 1] = q0; }
+}
+void launch_patch_asm3(int64_t n, int32_t *asm3, const int32_t *lm_grp_start, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_patch_asm3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, asm3, lm_grp_start);
+}
+
 // ---- structure phase on the device: the scalar assembly records (sc3) and the fused landmark records (lm3) of every
 // front, expanded from the block records (asm3) that are in HBM already.  One wave per front; a lane takes a block
 // record, a wave prefix sum places its 5 / 6 / 9 scalars.  (On the host this expansion was 33 of the 110 ms of the
@@ -1888,7 +1986,7 @@ __global__ void __launch_bounds__(256) k_build_sc3(const int32_t *__restrict__ b
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int s = blockIdx.x * 4 + wave;
     if (s >= n_fronts) return;
-    const int asm_off = bf[6 * s], n_uniq = bf[6 * s + 1], f = bf[6 * s + 2], sc_off = bf[6 * s + 3], sc_cnt = bf[6 * s + 4], lm_off = bf[6 * s + 5];
+    const int asm_off = bf[8 * s], n_uniq = bf[8 * s + 1], f = bf[8 * s + 2], sc_off = bf[8 * s + 3], sc_cnt = bf[8 * s + 4], lm_off = bf[8 * s + 5];
     int sbase = sc_off, lbase = lm_off;
     auto img = [](int r, int c) { const int I = r >> 4, J = c >> 4; return (((I * (I + 1)) >> 1) + J) * 256 + (r & 15) * 16 + (c & 15); };
     for (int t0 = 0; t0 < n_uniq; t0 += 64) {
