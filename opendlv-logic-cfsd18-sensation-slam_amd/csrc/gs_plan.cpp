@@ -361,13 +361,20 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
 
     GS_PT(3);
     // ---- symbolic factorisation over supernodes ----
+    // boundary of a supernode = the later-eliminated vertices its own vertices touch (independent per supernode: host
+    // threads) + what its children's boundaries carry beyond it (one sequential bottom-up sweep, elimination order)
     std::vector<std::vector<int32_t>> bndv(S), kids(S);
     std::vector<int32_t> parent(S, -1), stamp(B.nv, -1);
+    parallel_chunks(S, 512, [&](int64_t b0, int64_t e0, int) {
+        std::vector<int32_t> st(B.nv, -1);
+        for (int s = (int)b0; s < (int)e0; ++s) { auto &bd = bndv[s];
+            for (int v : B.sn[s]) for (int q = B.inc_start[v]; q < B.inc_start[v + 1]; ++q) { const int w = B.inc[q].other;
+                if (sn_of[w] > s && st[w] != s) { st[w] = s; bd.push_back(w); } } } });
     for (int s = 0; s < S; ++s) {
         auto &bd = bndv[s];
-        for (int v : B.sn[s]) for (int q = B.inc_start[v]; q < B.inc_start[v + 1]; ++q) { int w = B.inc[q].other;
-            if (sn_of[w] > s && stamp[w] != s) { stamp[w] = s; bd.push_back(w); } }
-        for (int c : kids[s]) for (int w : bndv[c]) if (sn_of[w] != s && stamp[w] != s) { stamp[w] = s; bd.push_back(w); }
+        if (!kids[s].empty()) {
+            for (int w : bd) stamp[w] = s;
+            for (int c : kids[s]) for (int w : bndv[c]) if (sn_of[w] != s && stamp[w] != s) { stamp[w] = s; bd.push_back(w); } }
         std::sort(bd.begin(), bd.end(), [&](int x, int y) { return vpos[x] < vpos[y]; });
         if (!bd.empty()) { parent[s] = sn_of[bd[0]]; kids[parent[s]].push_back(s); }
     }
