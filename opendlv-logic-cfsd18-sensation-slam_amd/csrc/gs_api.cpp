@@ -52,7 +52,7 @@ template <class T> static int dev_alloc(gs_graph *g, T **ptr, size_t count) {
     g->pool_off += bytes;
     return GS_OK;
 }
-template <class T> static int dev_upload(gs_graph *g, T **ptr, const std::vector<T> &v) {
+template <class T, class A> static int dev_upload(gs_graph *g, T **ptr, const std::vector<T, A> &v) {
     int rc = dev_alloc(g, ptr, v.size());
     if (rc != GS_OK) return rc;
     if (!v.empty()) HIP_TRY(hipMemcpyAsync(*ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, g->stream));

@@ -8,11 +8,24 @@
 // nested-dissection multifrontal plan instead of AMD + simplicial column counts.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <unordered_map>
 #include <vector>
 
 namespace gs {
+
+// std::vector whose resize() leaves new elements uninitialised (arrays that are fully overwritten right after, in
+// parallel: zero-filling 20 MB first is 2-3 ms of the structure phase and serial page faults)
+template <class T> struct DefaultInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInitAlloc<U>; };
+    using std::allocator<T>::allocator;
+    template <class U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using uvec = std::vector<T, DefaultInitAlloc<T>>;
 
 struct HostGraph {
     // vertices, insertion order
@@ -84,8 +97,8 @@ struct Plan {
     std::vector<int32_t> grp_slot;                        // group -> partial-sum slot, slots ordered by (landmark, wave tile)
     // fronts in elimination (post)order
     std::vector<Front> fronts;
-    std::vector<int32_t> bnd_rows, child_map, children;
-    std::vector<AsmRec> asm_recs;
+    uvec<int32_t> bnd_rows, child_map; std::vector<int32_t> children;
+    uvec<AsmRec> asm_recs;
     // levels: fronts of level l are level_fronts[level_start[l] .. level_start[l+1])
     std::vector<int32_t> level_start, level_fronts;
     int32_t max_front = 0;

@@ -541,7 +541,7 @@ void export_plan(const Plan &p, std::vector<int32_t> &out) {
                        (int32_t)p.pp_order.size(), (int32_t)p.asm_recs.size(), (int32_t)p.bnd_rows.size(),
                        (int32_t)p.child_map.size(), (int32_t)p.children.size(), (int32_t)p.ell_len, p.ell_T, p.ell_R};
     out.insert(out.end(), hdr, hdr + 16);
-    auto app = [&](const std::vector<int32_t> &v) { out.insert(out.end(), v.begin(), v.end()); };
+    auto app = [&](const auto &v) { out.insert(out.end(), v.begin(), v.end()); };
     app(p.pose_gidx); app(p.lm_gidx); app(p.pl_order); app(p.pp_order); app(p.ell_ins);
     for (const auto &F : p.fronts) {
         int32_t r[13] = {F.npiv, F.nbnd, F.piv0, F.parent, F.level, F.owner, (int32_t)F.bnd_off, (int32_t)F.map_off,
