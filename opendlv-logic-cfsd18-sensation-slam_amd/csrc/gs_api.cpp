@@ -664,13 +664,14 @@ static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int
         ++g->d.epoch;
         // leaf instance: level 0 only if its fronts really have no children (always true for an elimination tree's level 0)
         if (g->leaf_n < 0) {                                          // once per plan
-            int n_leaf = ls.start[1], slot = 256;
+            int n_leaf = ls.start[1], slot = 256; g->leaf_max_f = 0;
             for (int q = 0; q < n_leaf; ++q) { const Front &F = g->plan.fronts[g->plan.level_fronts_owned[q]];
+                g->leaf_max_f = std::max(g->leaf_max_f, F.npiv + F.nbnd);
                 if (F.child_cnt != 0) { n_leaf = 0; break; }
                 slot = std::max(slot, (((F.npiv + F.nbnd + 1) | 1) * F.npiv + 1) & ~1); }
             if (const char *e = std::getenv("GS_LEAF_KERNEL")) if (std::atoi(e) == 0) n_leaf = 0;
             g->leaf_n = n_leaf; g->leaf_slot = slot; }
-        launch_factor_tree(g->d, g->leaf_n, g->leaf_slot, ls.start[nlev], g->stream); return; }
+        launch_factor_tree(g->d, g->leaf_n, g->leaf_slot, g->leaf_max_f, ls.start[nlev], g->stream); return; }
     if (g->d.factor_variant == 3 && g->d.tree && mode == 2 && nlev > 0 && ls.start[nlev] > 0) {     // the shared top of a sharded graph, one flagged launch
         launch_factor_tree_top(g->d, base, ls.start[nlev], g->stream); return; }
     for (int l = 0; l < nlev; ++l)

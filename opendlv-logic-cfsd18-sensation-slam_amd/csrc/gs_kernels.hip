@@ -1355,9 +1355,10 @@ __device__ __forceinline__ double rcp_f64(double x) {             // reciprocal 
     return r;
 }
 
-template <int B>      // panel B: pivots 4B .. 4B+3 (tile column J0 = B / 4), LDL^T
-__device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[10], double *Pn, double *L, int npiv, int f, int lane) {
+template <int B, int NT = 4>      // panel B: pivots 4B .. 4B+3 (tile column J0 = B / 4), LDL^T; NT = tile rows of the front (3: fronts of <= 47 scalars)
+__device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[NT * (NT + 1) / 2], double *Pn, double *L, int npiv, int f, int lane) {
     constexpr int k0 = 4 * B, J0 = B / 4, jc = (B % 4) * 4;
+    static_assert(J0 < NT, "panel beyond the front's tile rows");
     if (k0 >= npiv) return false;                                   // uniform
     const int lc = lane & 15, lr = lane >> 4;
     // The wide levels of the tree are bound by instruction issue, so this function is written for few instructions:
@@ -1367,7 +1368,7 @@ __device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[10], double 
     // 1. the panel's four columns (rows of tiles J0..3) to LDS, row-major 64 x 4 (tile rows beyond f hold zeros)
     if (lc >= jc && lc < jc + 4) {
 #pragma unroll
-        for (int I = J0; I < 4; ++I)
+        for (int I = J0; I < NT; ++I)
 #pragma unroll
             for (int q = 0; q < 4; ++q) Pn[(16 * I + lr + 4 * q) * 4 + (lc - jc)] = acc[mf_tile(I, J0)][q];
     }
@@ -1409,11 +1410,11 @@ __device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[10], double 
     wave_lds_sync();
     // 3. trailing update on the matrix cores: T(I,J) -= A_I B_J^T, A = l (scaled), B = l * d (the unscaled column)
     const double dk = lr == 0 ? dd[0] : (lr == 1 ? dd[1] : (lr == 2 ? dd[2] : dd[3]));      // k = lane >> 4
-    double a[4];
+    double a[NT];
 #pragma unroll
-    for (int I = J0; I < 4; ++I) a[I] = Pn[(16 * I + lc) * 4 + lr];  // A[i = lane & 15][k = lane >> 4] = l[16 I + i][k]
+    for (int I = J0; I < NT; ++I) a[I] = Pn[(16 * I + lc) * 4 + lr];  // A[i = lane & 15][k = lane >> 4] = l[16 I + i][k]
 #pragma unroll
-    for (int I = J0; I < 4; ++I) if (16 * I <= f) {
+    for (int I = J0; I < NT; ++I) if (16 * I <= f) {
 #pragma unroll
         for (int J = J0; J <= I; ++J)
             acc[mf_tile(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[I], a[J] * dk, acc[mf_tile(I, J)], 0, 0, 0); }
@@ -1447,8 +1448,12 @@ __device__ __forceinline__ void f3_publish(int32_t *flag, int epoch, int lane) {
 // LEAF: fronts without children (level 0 of a rank's own subtrees, mode OWN only): no gather registers, pivot-column
 // staging => 3 waves per SIMD and 3 workgroups per CU instead of 2 (halving the resident waves was measured to cost
 // the leaf level x1.67: it is bound by resident waves x front latency, not yet by bandwidth)
-template <bool TREE, bool LEAF>
-__global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int level_off, int count, int mode, int leaf_slot) {
+// NT = tile rows held in the accumulators: 4 (fronts up to 63 scalars) or, leaf instance only, 3 (every leaf <= 47 scalars:
+// 6 tiles instead of 10 — a third fewer accumulator registers and spill traffic, five waves per SIMD instead of four)
+template <bool TREE, bool LEAF, int NT = 4>
+__global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(DevGraph d, int level_off, int count, int mode, int leaf_slot) {
+    static_assert(LEAF || NT == 4, "only the leaf instance has a three-tile-row form");
+    constexpr int NTILE = NT * (NT + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int fi = blockIdx.x * 4 + wave;
@@ -1585,9 +1590,9 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
     }
 #endif
     // ---- accumulators = originals + child 0 + child 1 (+ further children, rare)
-    v4d acc[10];
+    v4d acc[NTILE];
 #pragma unroll
-    for (int I = 0; I < 4; ++I)
+    for (int I = 0; I < NT; ++I)
 #pragma unroll
         for (int J = 0; J <= I; ++J) { const int t = mf_tile(I, J);
 #pragma unroll
@@ -1596,12 +1601,12 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
                     acc[t][q] = (J <= Jmax && col < npiv && row <= f) ? P.F[min(col, npiv - 1) * P.ld + min(row, f)] : 0.0; }
                 else acc[t][q] = (J <= Jmax) ? P.F[t * 256 + q * 64 + lane] : 0.0; } }
 #if !F3_LDS_GATHER
-    if (use[0]) {
+    if constexpr (!LEAF) if (use[0]) {
 #pragma unroll
         for (int t = 0; t < 10; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[t][q] += u0[t][q]; }
-    if (use[1]) {
+    if constexpr (!LEAF) if (use[1]) {
 #pragma unroll
         for (int t = 0; t < 10; ++t)
 #pragma unroll
@@ -1610,7 +1615,7 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
     // child's gather registers (acc + two gather sets is all the register file holds at two waves per SIMD); a child's
     // row table and {front, offset, size, owner} header come from one table per front (f3_x) and are fetched while the
     // previous child's gather is in flight — one round trip per extra child, no descriptor / pinv / offset lookups
-    if (!LEAF && fr.nchild > 2) {
+    if constexpr (!LEAF) if (fr.nchild > 2) {
         const int ne = fr.nchild - 2;
         const int32_t *xt = d.f3_x + fr.x_tab + 2 * F3X;                  // the table lists every child; the first two were handled above
         const bool plain = !TREE || (fr.level == 1 && leaf_slot != 0);     // children complete and visible: no flags, cached loads
@@ -1633,7 +1638,7 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
         }
     }
 #else
-    if (!LEAF && fr.nchild > 0) {
+    if constexpr (!LEAF) if (fr.nchild > 0) {
         const bool plain = !TREE || (fr.level == 1 && leaf_slot != 0);     // children complete and visible: no flags, cached loads
         const int nch = fr.nchild;
         // header field of child ci (uniform): the first eight from the prefetched lane-vector, later ones straight from the table
@@ -1710,7 +1715,7 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
     }
 #endif
     wave_lds_sync();
-    if (!LEAF && mode == FRONT_CONTRIB) {                            // this rank's share of a shared front -> exchange slot
+    if constexpr (!LEAF) if (mode == FRONT_CONTRIB) {                            // this rank's share of a shared front -> exchange slot
 #pragma unroll
         for (int t = 0; t < 10; ++t)
 #pragma unroll
@@ -1726,14 +1731,15 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
     double *Pn = P.F;
     double *L = d.Lbuf + fr.L_off;
     bool go = true, bad = false;
-    go = go && f3_panel_step<0>(bad, acc, Pn, L, npiv, f, lane);   go = go && f3_panel_step<1>(bad, acc, Pn, L, npiv, f, lane);
-    go = go && f3_panel_step<2>(bad, acc, Pn, L, npiv, f, lane);   go = go && f3_panel_step<3>(bad, acc, Pn, L, npiv, f, lane);
-    go = go && f3_panel_step<4>(bad, acc, Pn, L, npiv, f, lane);   go = go && f3_panel_step<5>(bad, acc, Pn, L, npiv, f, lane);
-    go = go && f3_panel_step<6>(bad, acc, Pn, L, npiv, f, lane);   go = go && f3_panel_step<7>(bad, acc, Pn, L, npiv, f, lane);
-    go = go && f3_panel_step<8>(bad, acc, Pn, L, npiv, f, lane);   go = go && f3_panel_step<9>(bad, acc, Pn, L, npiv, f, lane);
-    go = go && f3_panel_step<10>(bad, acc, Pn, L, npiv, f, lane);  go = go && f3_panel_step<11>(bad, acc, Pn, L, npiv, f, lane);
-    go = go && f3_panel_step<12>(bad, acc, Pn, L, npiv, f, lane);  go = go && f3_panel_step<13>(bad, acc, Pn, L, npiv, f, lane);
-    go = go && f3_panel_step<14>(bad, acc, Pn, L, npiv, f, lane);  go = go && f3_panel_step<15>(bad, acc, Pn, L, npiv, f, lane);
+    go = go && f3_panel_step<0, NT>(bad, acc, Pn, L, npiv, f, lane);   go = go && f3_panel_step<1, NT>(bad, acc, Pn, L, npiv, f, lane);
+    go = go && f3_panel_step<2, NT>(bad, acc, Pn, L, npiv, f, lane);   go = go && f3_panel_step<3, NT>(bad, acc, Pn, L, npiv, f, lane);
+    go = go && f3_panel_step<4, NT>(bad, acc, Pn, L, npiv, f, lane);   go = go && f3_panel_step<5, NT>(bad, acc, Pn, L, npiv, f, lane);
+    go = go && f3_panel_step<6, NT>(bad, acc, Pn, L, npiv, f, lane);   go = go && f3_panel_step<7, NT>(bad, acc, Pn, L, npiv, f, lane);
+    go = go && f3_panel_step<8, NT>(bad, acc, Pn, L, npiv, f, lane);   go = go && f3_panel_step<9, NT>(bad, acc, Pn, L, npiv, f, lane);
+    go = go && f3_panel_step<10, NT>(bad, acc, Pn, L, npiv, f, lane);  go = go && f3_panel_step<11, NT>(bad, acc, Pn, L, npiv, f, lane);
+    if constexpr (NT == 4) {
+    go = go && f3_panel_step<12, NT>(bad, acc, Pn, L, npiv, f, lane);  go = go && f3_panel_step<13, NT>(bad, acc, Pn, L, npiv, f, lane);
+    go = go && f3_panel_step<14, NT>(bad, acc, Pn, L, npiv, f, lane);  go = go && f3_panel_step<15, NT>(bad, acc, Pn, L, npiv, f, lane); }
     if (d.inject_iter != 0 && d.iter == d.inject_iter && level_off + fi == 0 && lane == 0) atomicMax(d.fail, d.inject_code);   // gs_debug_fail_at_iteration (fault injection for tests)
     if (bad && lane == 0) atomicMax(d.fail, 1);
     F3_TS(7);
@@ -1743,11 +1749,11 @@ __global__ void __launch_bounds__(256, LEAF ? 3 : 2) k_factor3(DevGraph d, int l
     {
         double *U = d.Uimg + fr.u_off;
         const uint32_t dump = (uint32_t)(fr.u_size + 1) * 8u;
-        int co[4];
+        int co[NT];
 #pragma unroll
-        for (int J = 0; J < 4; ++J) co[J] = __shfl(sv, 16 * J + lc, WAVE) >> 16;
+        for (int J = 0; J < NT; ++J) co[J] = __shfl(sv, 16 * J + lc, WAVE) >> 16;
 #pragma unroll
-        for (int I = 0; I < 4; ++I) {
+        for (int I = 0; I < NT; ++I) {
             if (16 * I + 15 < npiv || 16 * I > f) continue;         // uniform
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -2026,13 +2032,17 @@ void launch_build_sc3(const int32_t *bf, const int32_t *asm3, int32_t *sc3, int3
 }
 
 // whole-tree launches of variant 3 (own fronts of a single-GPU graph): every level in one kernel each
-void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int count, hipStream_t st) {
+void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int leaf_max_f, int count, hipStream_t st) {
     if (count <= 0) return;
     static bool attr_set_t = false;
     if (!attr_set_t) { (void)hipFuncSetAttribute((const void *)k_factor3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_factor3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_t = true; }
-    // level 0 (no children) through the high-occupancy leaf instance, everything above in one launch whose fronts wait on flags
-    if (n_leaf > 0) hipLaunchKernelGGL((k_factor3<true, true>), dim3((n_leaf + 3) / 4), dim3(256), (size_t)leaf_slot * 4 * sizeof(double), st, d, 0, n_leaf, FRONT_OWN, leaf_slot);
+        (void)hipFuncSetAttribute((const void *)k_factor3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_factor3<true, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_t = true; }
+    // level 0 (no children) through the high-occupancy leaf instance (three tile rows when every leaf has <= 47 scalars),
+    // everything above in one launch whose fronts wait on flags
+    static int nt3 = -1; if (nt3 < 0) { nt3 = 1; if (const char *e = getenv("GS_LEAF_NT3")) nt3 = atoi(e) != 0; }
+    if (n_leaf > 0 && leaf_max_f <= 47 && nt3) hipLaunchKernelGGL((k_factor3<true, true, 3>), dim3((n_leaf + 3) / 4), dim3(256), (size_t)leaf_slot * 4 * sizeof(double), st, d, 0, n_leaf, FRONT_OWN, leaf_slot);
+    else if (n_leaf > 0) hipLaunchKernelGGL((k_factor3<true, true>), dim3((n_leaf + 3) / 4), dim3(256), (size_t)leaf_slot * 4 * sizeof(double), st, d, 0, n_leaf, FRONT_OWN, leaf_slot);
     if (count > n_leaf) hipLaunchKernelGGL((k_factor3<true, false>), dim3((count - n_leaf + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, n_leaf, count - n_leaf, FRONT_OWN, n_leaf > 0 ? 1 : 0);   // last argument: a leaf launch preceded
 }
 // the shared top of a sharded graph (mode TOP: fronts start from the all-reduced exchange slots and gather their shared
