@@ -1343,6 +1343,12 @@ __device__ __forceinline__ void f3_gather_child_lds(const double *base, int usiz
 #define F3_LDS_GATHER 0
 #endif
 
+#ifndef F3_EXP_SKIP_EXTRAS
+#define F3_EXP_SKIP_EXTRAS 0
+#endif
+#ifndef F3_EXP_PLAIN
+#define F3_EXP_PLAIN 0
+#endif
 #ifndef F3_RCP_NEWTON
 #define F3_RCP_NEWTON 2
 #endif
@@ -1439,6 +1445,15 @@ __device__ __forceinline__ bool f3_wait_flag(const int32_t *flag, int epoch) {
     }
     return false;
 }
+// "Not written yet": a signalling-NaN bit pattern (both 32-bit halves equal, so hipMemsetD32 fills it).  Arithmetic
+// never produces a signalling NaN, so no computed value can be mistaken for it.  The whole-tree backward solve hands
+// a parent's solution to its children through the data itself: every factor front resets its own rows of xe to this
+// pattern, the parent stores its values (write-through, no wait for the acknowledgement, no flag) and a child polls the
+// rows it needs until none of them holds the pattern — one memory round trip per level less than store / wait / flag.
+#define F3_UNSET_BITS 0x7FF4A5A57FF4A5A5ull
+#define F3_UNSET_WORD 0x7FF4A5A5u
+__device__ __forceinline__ bool f3_is_unset(double v) { return (unsigned long long)__double_as_longlong(v) == F3_UNSET_BITS; }
+__device__ __forceinline__ double f3_unset() { return __longlong_as_double((long long)F3_UNSET_BITS); }
 __device__ __forceinline__ void f3_publish(int32_t *flag, int epoch, int lane) {
     __builtin_amdgcn_s_waitcnt(0);                                  // this wave's write-through stores have been acknowledged
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1467,6 +1482,7 @@ __global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(D
     const int sv = d.f3_desc[(int64_t)(level_off + fi) * F3_STRIDE + F3_INTS + 128 + lane];     // own store table
     const F3 fr = f3_load(d.f3_desc, level_off + fi, lane);
     const int npiv = fr.npiv, f = npiv + fr.nbnd;
+    if (lane < npiv) d.xe[fr.piv0 + lane] = f3_unset();             // this front's solution rows: not written yet (the whole-tree backward solve polls them)
     StageT<LEAF> P{smem + (int64_t)wave * (LEAF ? leaf_slot : MF_IMG), f, (f + 1) | 1};
     const int lc = lane & 15, lr = lane >> 4;
     F3_TS(1);
@@ -1583,11 +1599,15 @@ __global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(D
             if (use[1]) f3_gather_child<false>(d.Uimg + fr.c_uoff[1], fr.c_usize[1], pv[1], lane, u1);
         } else {
             bool okw = true;                                         // child 0's gather is issued while child 1 may still be working
-            if (use[0]) { okw = f3_wait_flag(d.done_f + fr.c_id[0], d.epoch) && okw; f3_gather_child<true>(d.Uimg + fr.c_uoff[0], fr.c_usize[0], pv[0], lane, u0); }
-            if (use[1]) { okw = f3_wait_flag(d.done_f + fr.c_id[1], d.epoch) && okw; f3_gather_child<true>(d.Uimg + fr.c_uoff[1], fr.c_usize[1], pv[1], lane, u1); }
+            if (use[0]) { okw = f3_wait_flag(d.done_f + fr.c_id[0], d.epoch) && okw; f3_gather_child<!F3_EXP_PLAIN>(d.Uimg + fr.c_uoff[0], fr.c_usize[0], pv[0], lane, u0); }
+            if (use[1]) { okw = f3_wait_flag(d.done_f + fr.c_id[1], d.epoch) && okw; f3_gather_child<!F3_EXP_PLAIN>(d.Uimg + fr.c_uoff[1], fr.c_usize[1], pv[1], lane, u1); }
             if (!okw && lane == 0) atomicMax(d.fail, 2);
         }
     }
+#endif
+    F3_TS(9);
+#ifdef F3_EXP_L1_DELAY
+    if (TREE && fr.level == 1) for (int i = 0; i < F3_EXP_L1_DELAY; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
     // ---- accumulators = originals + child 0 + child 1 (+ further children, rare)
     v4d acc[NTILE];
@@ -1611,11 +1631,12 @@ __global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(D
         for (int t = 0; t < 10; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[t][q] += u1[t][q]; }
+    F3_TS(10);
     // third and later children (the multi-way splits above the leaves have up to 8), one at a time through the first
     // child's gather registers (acc + two gather sets is all the register file holds at two waves per SIMD); a child's
     // row table and {front, offset, size, owner} header come from one table per front (f3_x) and are fetched while the
     // previous child's gather is in flight — one round trip per extra child, no descriptor / pinv / offset lookups
-    if constexpr (!LEAF) if (fr.nchild > 2) {
+    if constexpr (!LEAF) if (fr.nchild > 2 && !F3_EXP_SKIP_EXTRAS) {
         const int ne = fr.nchild - 2;
         const int32_t *xt = d.f3_x + fr.x_tab + 2 * F3X;                  // the table lists every child; the first two were handled above
         const bool plain = !TREE || (fr.level == 1 && leaf_slot != 0);     // children complete and visible: no flags, cached loads
@@ -1820,8 +1841,16 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
 #pragma unroll
         for (int cc = 1; cc < 32; ++cc) lcol[cc] = S[min(min(lane, cc - 1), npiv - 1) * lds + min(cc, f)];
         w = S[me * lds + f];
-        if (fr.parent >= 0 && !f3_wait_flag(d.done_b + fr.parent, d.epoch) && lane == 0) atomicMax(d.fail, 2);
-        const double xb = (row >= 0) ? ld_off_coh(d.xe, (uint32_t)row * 8u) : 0.0;        // 0 beyond the boundary: those terms vanish
+        double xb = 0.0;                                             // 0 beyond the boundary: those terms vanish
+        if (nbnd > 0) {                                              // the boundary rows belong to the ancestors: poll the values themselves
+            bool got = false;
+            for (int it = 0; it < (1 << 18); ++it) {
+                if (row >= 0) xb = ld_off_coh(d.xe, (uint32_t)row * 8u);
+                if (!__any(row >= 0 && f3_is_unset(xb))) { got = true; break; }
+                __builtin_amdgcn_s_sleep(F3_POLL_SLEEP);
+            }
+            if (!got) { if (lane == 0) atomicMax(d.fail, 2); if (f3_is_unset(xb)) xb = 0.0; }     // bounded: report, carry on, drain
+        }
         F3_TS(35);
 #pragma unroll
         for (int r0 = 0; r0 < 64; r0 += 16) if (r0 < nbnd) {         // uniform
@@ -1861,7 +1890,6 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
 #if F3_DONE_TS
     if (lane == 0) d.done_ts[d.n_fronts + fr.s] = wall_clock64();
 #endif
-    if (TREE) f3_publish(d.done_b + fr.s, d.epoch, lane);
     F3_TS(38);
 }
 

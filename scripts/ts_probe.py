@@ -11,7 +11,7 @@ if len(sys.argv) > 2:                                            # probe the fir
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
     from plan_exec import Plan
     H = pkg.Graph(device=-2); H.load_bench_graph(g); H.plan_build_host(); P = Plan(H.plan_export()); H.close()
-    os.environ["GS_DBG"] = str(16 | (int(P.level_start[int(sys.argv[2])]) << 8))
+    os.environ["GS_DBG"] = str(16 | ((int(P.level_start[int(sys.argv[2])]) + (int(sys.argv[3]) if len(sys.argv) > 3 else 0)) << 8))   # argv[3]: position inside the level
 G.initialize_optimization()
 for _ in range(4):
     G.iterate()
@@ -19,6 +19,8 @@ G.synchronize()
 ts = G.debug_timestamps()
 f = ts[0:9]; b = ts[32:39]
 print("factor  phases (us):", [round((int(f[i + 1]) - int(f[i])) / 100.0, 2) for i in range(8)], "total", (int(f[8]) - int(f[0])) / 100.0)
+if ts[9] and ts[10]:
+    print("   inside phase 5 (us): children 0/1 gathered %.2f | accumulators built + summed %.2f | further children %.2f" % ((int(ts[9]) - int(f[5])) / 100.0, (int(ts[10]) - int(ts[9])) / 100.0, (int(f[6]) - int(ts[10])) / 100.0))
 print("   0 desc | 1 issue rec+pinv | 2 wait | 3 zero LDS | 4 gather issue+wait | 5 originals | 6 acc sum | 7 panels | 8 U out")
 print("backsolve phases (us):", [round((int(b[i + 1]) - int(b[i])) / 100.0, 2) for i in range(6)], "total", (int(b[6]) - int(b[0])) / 100.0)
 print("   32 desc | 33 L->LDS | 34 xe gather | 35 boundary mat-vec | 36 substitution | 37 store")
