@@ -1325,34 +1325,61 @@ __device__ __forceinline__ void f3_gather_child(const double *Uc, int usize, int
     f3_gather_child_at<COH>(Uc, usize, g, u);
 }
 
-// The same gather with the child's packed update matrix already staged in LDS (base = its first double, the zero double
-// behind it included): the by-destination reads are LDS reads (~64 cycles) instead of 40 scattered global loads.
-__device__ __forceinline__ void f3_gather_child_lds(const double *base, int usize, int pv, int lane, double (&u)[10][4]) {
-    const int lc = lane & 15, lr = lane >> 4;
-    int co[4];
-#pragma unroll
-    for (int J = 0; J < 4; ++J) co[J] = __shfl(pv, 16 * J + lc, WAVE) >> 16;
-#pragma unroll
-    for (int I = 0; I < 4; ++I)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ro = (int)(short)(__shfl(pv, 16 * I + lr + 4 * q, WAVE) & 0xffff);
-#pragma unroll
-            for (int J = 0; J <= I; ++J) { const uint32_t o = min((uint32_t)(ro + co[J]), (uint32_t)usize * 8u);
-                u[mf_tile(I, J)][q] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + o); }
-        }
+// ---- by source (round 2, non-leaf fronts).  Measured on MI355X: a wave's SCATTERED 8-byte global access costs ~60
+// cycles of address processing per instruction — the 80 by-destination loads of two children are 2 us of every level's
+// chain, the 40 by-destination stores of the update matrix 1 us — while a CONTIGUOUS one (lane i at byte 8 i) costs a
+// few.  A packed update matrix is 7-14 doubles per lane when read or written in storage order, so the non-leaf fronts
+// move it that way and do the permutation in LDS: a child's element idx = 64 k + lane is boundary entry (r', c') of the
+// child (a function of idx alone: each lane keeps its 14 (r', c') pairs for the whole kernel), the child's table maps r'
+// and c' to their place in the parent's tile image {row part (low 16 bits), column part (high 16 bits)}, and the lane adds
+// its element there (read, add, write; children in list order: the sum order originals + child 0 + child 1 + ... is the
+// by-destination one's).  The places depend on the plan only: a front that waits for its children computes them before
+// the wait.  Going out, the accumulators pass through the image and every lane reads its elements' places back.
+static constexpr int F3_KREG = 14;                                   // elements per lane kept in registers: update matrices up to 896 doubles (boundary <= 40)
+__device__ __forceinline__ int f3_rc_of(int idx) {                   // packed index -> r' | c' << 8 (row r' holds columns 0 .. r' at r'(r'+1)/2)
+    int r = (int)((__fsqrt_rn(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+    if (((r * (r + 1)) >> 1) > idx) --r;
+    if ((((r + 1) * (r + 2)) >> 1) <= idx) ++r;
+    return r | ((idx - ((r * (r + 1)) >> 1)) << 8);
 }
-// F3_LDS_GATHER = 1 (tuning build; default 0): children's update matrices are fetched with coalesced loads (8 bytes per
-// lane, every cache line used once and fully), staged in the front's LDS image — free once the original entries have
-// moved to the accumulators — and gathered by destination from there; up to four children per batch have their loads in
-// flight together (the batches and each child's place in the image are laid out on the host, children-table header
-// fields 4-6).  Measured at cfg4 on MI355X, same box: factor phase 0.326 ms against 0.194 ms for the default — the
-// staging registers on top of the 80 accumulator registers spill 35 VGPRs to scratch at two waves per SIMD, and the
-// reloads sit in every front's dependent chain.  0: gather by destination straight from HBM / L2 (two children at a
-// time in registers, further ones one by one).
-#ifndef F3_LDS_GATHER
-#define F3_LDS_GATHER 0
-#endif
+__device__ __forceinline__ int f3_img_rowpart(int R) { const int I = R >> 4; return (((I * (I + 1)) >> 1) << 8) + ((R & 15) << 4); }
+__device__ __forceinline__ int f3_img_colpart(int C) { return ((C >> 4) << 8) + (C & 15); }
+// places in the parent's image of a child's elements: tab = the child's table (lane r' holds {row part, column part} of row r').
+// Everything below is branch-free per lane (a lane beyond the matrix loads the zero double behind it and adds it to image
+// element 1 — row 0, column 1: upper triangle of a diagonal tile, don't-care everywhere) so that the loads, the LDS reads
+// and the LDS writes of a group each go out back to back: one latency per group, not one per element.  Elements
+// [K0, K1) of every lane; the callers take 0-8 always and 8-14 for matrices of more than 512 doubles.
+template <int K0, int K1>
+__device__ __forceinline__ void f3_child_places(int tab, const int (&rc)[F3_KREG], int usize, int lane, int (&dst)[F3_KREG]) {
+#pragma unroll
+    for (int k = K0; k < K1; ++k) {
+        const int p = (__shfl(tab, rc[k] & 0xff, WAVE) & 0xffff) + (int)((uint32_t)__shfl(tab, rc[k] >> 8, WAVE) >> 16);
+        dst[k] = (64 * k + lane < usize) ? p : 1;
+        asm volatile("" : "+v"(dst[k])); }                         // computed HERE (before the caller's wait), not sunk behind it
+}
+template <int K0, int K1>
+__device__ __forceinline__ void f3_child_loads(const double *Uc, int usize, int lane, double (&st)[F3_KREG]) {
+#pragma unroll
+    for (int k = K0; k < K1; ++k) st[k] = ld_off_coh(Uc, (uint32_t)min(64 * k + lane, usize) * 8u);
+}
+template <int K0, int K1>
+__device__ __forceinline__ void f3_child_scatter(double *img, const int (&dst)[F3_KREG], const double (&st)[F3_KREG]) {
+    double o[F3_KREG];                                               // a child's places are distinct: all reads, then all writes
+#pragma unroll
+    for (int k = K0; k < K1; ++k) o[k] = img[dst[k]];
+#pragma unroll
+    for (int k = K0; k < K1; ++k) img[dst[k]] = o[k] + st[k];
+}
+// elements 896 .. of a large update matrix (boundary > 40 rows), one row of 64 at a time
+__device__ __forceinline__ void f3_child_tail(double *img, const double *Uc, int usize, int tab, int lane) {
+    for (int base = 64 * F3_KREG; base < usize; base += 64) {
+        const int idx = base + lane, rc = f3_rc_of(min(idx, usize - 1));
+        const int p = (__shfl(tab, rc & 0xff, WAVE) & 0xffff) + (int)((uint32_t)__shfl(tab, rc >> 8, WAVE) >> 16);
+        const int dst = idx < usize ? p : 1;
+        const double v = ld_off_coh(Uc, (uint32_t)min(idx, usize) * 8u);
+        img[dst] += v;
+    }
+}
 
 #ifndef F3_RCP_NEWTON
 #define F3_RCP_NEWTON 2
@@ -1465,6 +1492,27 @@ __device__ __forceinline__ void f3_publish(int32_t *flag, int epoch, int lane) {
     if (lane == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// two children of a front into its LDS image, by source.  flag != nullptr: a child of the SAME launch — its flag is awaited
+// (the places are computed first: nothing but the loads and the read-add-writes is behind the wait).  The loads are
+// device-scope either way: in storage order every line is fetched once, so there is nothing a cached load would save.
+__device__ __forceinline__ bool f3_gather_pair(double *img, const int (&rc)[F3_KREG], int lane, int epoch,
+        bool onA, const double *UA, int uszA, int tabA, const int32_t *flagA, bool onB, const double *UB, int uszB, int tabB, const int32_t *flagB) {
+    int dA[F3_KREG], dB[F3_KREG]; double sA[F3_KREG], sB[F3_KREG];
+    const bool bigA = uszA > 512, bigB = uszB > 512;                 // uniform
+    if (onA) { f3_child_places<0, 8>(tabA, rc, uszA, lane, dA); if (bigA) f3_child_places<8, F3_KREG>(tabA, rc, uszA, lane, dA); }
+    if (onB) { f3_child_places<0, 8>(tabB, rc, uszB, lane, dB); if (bigB) f3_child_places<8, F3_KREG>(tabB, rc, uszB, lane, dB); }
+    bool ok = true;                                                  // child A's loads are issued while child B may still be working
+    if (onA) { if (flagA) ok = f3_wait_flag(flagA, epoch) && ok;
+        f3_child_loads<0, 8>(UA, uszA, lane, sA); if (bigA) f3_child_loads<8, F3_KREG>(UA, uszA, lane, sA); }
+    if (onB) { if (flagB) ok = f3_wait_flag(flagB, epoch) && ok;
+        f3_child_loads<0, 8>(UB, uszB, lane, sB); if (bigB) f3_child_loads<8, F3_KREG>(UB, uszB, lane, sB); }
+    if (onA) { f3_child_scatter<0, 8>(img, dA, sA); if (bigA) f3_child_scatter<8, F3_KREG>(img, dA, sA);
+        if (uszA > 64 * F3_KREG) f3_child_tail(img, UA, uszA, tabA, lane); }
+    if (onB) { f3_child_scatter<0, 8>(img, dB, sB); if (bigB) f3_child_scatter<8, F3_KREG>(img, dB, sB);
+        if (uszB > 64 * F3_KREG) f3_child_tail(img, UB, uszB, tabB, lane); }
+    return ok;
+}
+
 // LEAF: fronts without children (level 0 of a rank's own subtrees, mode OWN only): no gather registers, pivot-column
 // staging => 3 waves per SIMD and 3 workgroups per CU instead of 2 (halving the resident waves was measured to cost
 // the leaf level x1.67: it is bound by resident waves x front latency, not yet by bandwidth)
@@ -1492,24 +1540,16 @@ __global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(D
     const int lc = lane & 15, lr = lane >> 4;
     F3_TS(1);
     const bool top = mode == FRONT_TOP;
-    // ---- round trip 2a: the children's update matrices, gathered by destination (in flight until the accumulators are built)
     bool use[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k)
         use[k] = !LEAF && fr.c_id[k] >= 0 && !(mode == FRONT_CONTRIB && fr.c_owner[k] != d.rank) && !(top && fr.c_owner[k] >= 0);   // uniform
-#if !F3_LDS_GATHER
-    double u0[10][4], u1[10][4];
-    if (!TREE) {
-        if (use[0]) f3_gather_child<false>(d.Uimg + fr.c_uoff[0], fr.c_usize[0], pv[0], lane, u0);
-        if (use[1]) f3_gather_child<false>(d.Uimg + fr.c_uoff[1], fr.c_usize[1], pv[1], lane, u1);
-    }
-#else
-    // headers {front, offset, size, owner, LDS base, batch} of the first eight children: lane 8 c + field
-    const int32_t *xt = d.f3_x + fr.x_tab;
-    int hx = 0;
-    if (!LEAF && (lane >> 3) < fr.nchild) hx = xt[(lane >> 3) * F3X + 64 + (lane & 7)];
-    (void)use; (void)pv;
-#endif
+    int rc[F3_KREG], own[F3_KREG];                                   // (r', c') of this lane's elements of any packed update matrix; their places in THIS front's image
+    if constexpr (!LEAF) {
+#pragma unroll
+        for (int k = 0; k < F3_KREG; ++k) { rc[k] = f3_rc_of(64 * k + lane);
+            own[k] = min(f3_img_rowpart(npiv + (rc[k] & 0xff)) + f3_img_colpart(npiv + (rc[k] >> 8)), MF_IMG - 1);
+            asm volatile("" : "+v"(own[k])); } }                    // computed HERE (before the wait), not rematerialised behind the panels
     // ---- round trip 2b: scalar assembly records (eight per lane up front), landmark records
 #ifndef F3_LEAF_BLOCKS
 #define F3_LEAF_BLOCKS 1
@@ -1538,7 +1578,7 @@ __global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(D
 #pragma unroll
         for (int I = 0; I < 4; ++I)
 #pragma unroll
-            for (int J = 0; J <= I; ++J) if (J <= Jmax) {
+            for (int J = 0; J <= I; ++J) {                             // every tile: the children add into the boundary block as well
 #pragma unroll
                 for (int q = 0; q < 4; ++q) P.F[mf_tile(I, J) * 256 + q * 64 + lane] = 0.0; }
     }
@@ -1595,8 +1635,36 @@ __global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(D
     }
     wave_lds_sync();
     F3_TS(5);
-    // ---- accumulators = originals + child 0 + child 1 (+ further children, rare).  The originals move out of LDS BEFORE the
-    // wait for the children: only the sums remain behind the gather (0.9 -> 0.2 us of every level's chain)
+    // ---- the children's update matrices, by source, into the image: originals + child 0 + child 1 + ... (list order), two
+    // at a time.  The first two children's tables came with the descriptor; further ones (the multi-way splits above the
+    // leaves have up to 8 children) come from the front's children table (f3_x: row table + {front, offset, size, owner} per
+    // child), the next pair's while this pair is in flight.
+    if constexpr (!LEAF) if (fr.nchild > 0) {
+        const bool plain = !TREE || (fr.level == 1 && leaf_slot != 0);     // children of an EARLIER launch: complete and visible — no flags to wait for
+        const int32_t *xt = d.f3_x + fr.x_tab;
+        int tA = pv[0], tB = pv[1];
+        int a_id = fr.c_id[0], a_uoff = fr.c_uoff[0], a_usz = fr.c_usize[0], a_own = fr.c_owner[0];
+        int b_id = fr.c_id[1], b_uoff = fr.c_uoff[1], b_usz = fr.c_usize[1], b_own = fr.c_owner[1];
+        bool okw = true;
+        for (int e = 0; e < fr.nchild; e += 2) {
+            const bool onA = !(mode == FRONT_CONTRIB && a_own != d.rank) && !(top && a_own >= 0);
+            const bool onB = e + 1 < fr.nchild && !(mode == FRONT_CONTRIB && b_own != d.rank) && !(top && b_own >= 0);
+            int nA = 0, nhA = 0, nB = 0, nhB = 0;
+            const bool more = e + 2 < fr.nchild;
+            if (more) { const int na = e + 2, nb = min(e + 3, fr.nchild - 1);
+                nA = xt[na * F3X + lane]; nhA = xt[na * F3X + 64 + (lane & 7)]; nB = xt[nb * F3X + lane]; nhB = xt[nb * F3X + 64 + (lane & 7)]; }
+            okw = f3_gather_pair(P.F, rc, lane, d.epoch, onA, d.Uimg + a_uoff, a_usz, tA, plain ? nullptr : d.done_f + a_id,
+                                 onB, d.Uimg + b_uoff, b_usz, tB, plain ? nullptr : d.done_f + b_id) && okw;
+            if (e == 0) F3_TS(9);
+            if (more) { tA = nA; tB = nB;
+                a_id = __builtin_amdgcn_readlane(nhA, 0); a_uoff = __builtin_amdgcn_readlane(nhA, 1); a_usz = __builtin_amdgcn_readlane(nhA, 2); a_own = __builtin_amdgcn_readlane(nhA, 3);
+                b_id = __builtin_amdgcn_readlane(nhB, 0); b_uoff = __builtin_amdgcn_readlane(nhB, 1); b_usz = __builtin_amdgcn_readlane(nhB, 2); b_own = __builtin_amdgcn_readlane(nhB, 3); }
+        }
+        if (!okw && lane == 0) atomicMax(d.fail, 2);
+        wave_lds_sync();
+    }
+    F3_TS(10);
+    // ---- accumulators <- the image
     v4d acc[NTILE];
 #pragma unroll
     for (int I = 0; I < NT; ++I)
@@ -1606,141 +1674,7 @@ __global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(D
             for (int q = 0; q < 4; ++q) {
                 if (LEAF) { const int row = 16 * I + lr + 4 * q, col = 16 * J + lc;       // pivot-column panel: (row, col) at col * ld + row
                     acc[t][q] = (J <= Jmax && col < npiv && row <= f) ? P.F[min(col, npiv - 1) * P.ld + min(row, f)] : 0.0; }
-                else acc[t][q] = (J <= Jmax) ? P.F[t * 256 + q * 64 + lane] : 0.0; } }
-#if !F3_LDS_GATHER
-    if (TREE) {                                                      // everything above ran while the children were still working
-        if (fr.level == 1 && leaf_slot != 0) {
-            // children = leaves of the PREVIOUS launch: complete and visible — no flags, and ordinary (cached) loads: the
-            // gather touches every line from several instructions, device-scope loads would refetch it each time
-            if (use[0]) f3_gather_child<false>(d.Uimg + fr.c_uoff[0], fr.c_usize[0], pv[0], lane, u0);
-            if (use[1]) f3_gather_child<false>(d.Uimg + fr.c_uoff[1], fr.c_usize[1], pv[1], lane, u1);
-        } else {
-            bool okw = true;                                         // child 0's gather is issued while child 1 may still be working
-            F3Off g0, g1;                                            // the lane permutes of both row tables: before the wait
-            if (use[0]) f3_gather_offsets(pv[0], lane, g0);
-            if (use[1]) f3_gather_offsets(pv[1], lane, g1);
-            if (use[0]) { okw = f3_wait_flag(d.done_f + fr.c_id[0], d.epoch) && okw; f3_gather_child_at<true>(d.Uimg + fr.c_uoff[0], fr.c_usize[0], g0, u0); }
-            if (use[1]) { okw = f3_wait_flag(d.done_f + fr.c_id[1], d.epoch) && okw; f3_gather_child_at<true>(d.Uimg + fr.c_uoff[1], fr.c_usize[1], g1, u1); }
-            if (!okw && lane == 0) atomicMax(d.fail, 2);
-        }
-    }
-#endif
-    F3_TS(9);
-#if !F3_LDS_GATHER
-    if constexpr (!LEAF) if (use[0]) {
-#pragma unroll
-        for (int t = 0; t < 10; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[t][q] += u0[t][q]; }
-    if constexpr (!LEAF) if (use[1]) {
-#pragma unroll
-        for (int t = 0; t < 10; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[t][q] += u1[t][q]; }
-    F3_TS(10);
-    // third and later children (the multi-way splits above the leaves have up to 8), one at a time through the first
-    // child's gather registers (acc + two gather sets is all the register file holds at two waves per SIMD); a child's
-    // row table and {front, offset, size, owner} header come from one table per front (f3_x) and are fetched while the
-    // previous child's gather is in flight — one round trip per extra child, no descriptor / pinv / offset lookups
-    if constexpr (!LEAF) if (fr.nchild > 2) {
-        const int ne = fr.nchild - 2;
-        const int32_t *xt = d.f3_x + fr.x_tab + 2 * F3X;                  // the table lists every child; the first two were handled above
-        const bool plain = !TREE || (fr.level == 1 && leaf_slot != 0);     // children complete and visible: no flags, cached loads
-        int pa = xt[lane], ha = xt[64 + (lane & 7)];
-        for (int e = 0; e < ne; ++e) {
-            const int a_id = __builtin_amdgcn_readlane(ha, 0), a_uoff = __builtin_amdgcn_readlane(ha, 1), a_usz = __builtin_amdgcn_readlane(ha, 2), a_own = __builtin_amdgcn_readlane(ha, 3);
-            const bool ua = !(mode == FRONT_CONTRIB && a_own != d.rank) && !(top && a_own >= 0);
-            if (ua) {
-                if (plain) f3_gather_child<false>(d.Uimg + a_uoff, a_usz, pa, lane, u0);
-                else { if (!f3_wait_flag(d.done_f + a_id, d.epoch) && lane == 0) atomicMax(d.fail, 2);
-                       f3_gather_child<true>(d.Uimg + a_uoff, a_usz, pa, lane, u0); }
-            }
-            const int en = min(e + 1, ne - 1);                             // the next child's table (the last one re-reads its own)
-            pa = xt[en * F3X + lane]; ha = xt[en * F3X + 64 + (lane & 7)];
-            if (ua) {
-#pragma unroll
-                for (int t = 0; t < 10; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[t][q] += u0[t][q]; }
-        }
-    }
-#else
-    if constexpr (!LEAF) if (fr.nchild > 0) {
-        const bool plain = !TREE || (fr.level == 1 && leaf_slot != 0);     // children complete and visible: no flags, cached loads
-        const int nch = fr.nchild;
-        // header field of child ci (uniform): the first eight from the prefetched lane-vector, later ones straight from the table
-        auto hdr = [&](int ci, int field) -> int {
-            return ci < 8 ? __builtin_amdgcn_readlane(hx, 8 * ci + field) : __builtin_amdgcn_readfirstlane(xt[ci * F3X + 64 + field]); };
-        wave_lds_sync();                                                   // every lane has read the original entries out of the image
-        for (int b0 = 0; b0 < nch;) {
-            const int bid = hdr(b0, 5);
-            int cnt = 1;
-            if (bid >= 0) while (cnt < 4 && b0 + cnt < nch && hdr(b0 + cnt, 5) == bid) ++cnt;
-            int bp[4];                                                     // row tables of the batch: in flight while the flags are awaited
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bp[j] = (j < cnt) ? xt[(b0 + j) * F3X + lane] : 0;
-            if (bid < 0) {                                                 // too large to stage (boundary > 40 rows): by destination from HBM
-                const int id = hdr(b0, 0), uoff = hdr(b0, 1), usz = hdr(b0, 2), own = hdr(b0, 3);
-                if (!((mode == FRONT_CONTRIB && own != d.rank) || (top && own >= 0))) {
-                    double ug[10][4];
-                    if (plain) f3_gather_child<false>(d.Uimg + uoff, usz, bp[0], lane, ug);
-                    else { if (!f3_wait_flag(d.done_f + id, d.epoch) && lane == 0) atomicMax(d.fail, 2);
-                           f3_gather_child<true>(d.Uimg + uoff, usz, bp[0], lane, ug); }
-#pragma unroll
-                    for (int t = 0; t < 10; ++t)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[t][q] += ug[t][q];
-                }
-                b0 += 1; continue;
-            }
-            // Two batch shapes, both 28 staging doubles per lane: four small children (<= 447 doubles each: the leaves under a
-            // multi-way split) or two large ones (<= 895: the top of the tree).  Header field 6 says which.
-            auto stage = [&](auto NCc, auto Kc) {
-                constexpr int NC = decltype(NCc)::value, K = decltype(Kc)::value;
-                // phase 1: coalesced loads of every child of the batch (8 bytes per lane), all in flight together
-                double st[NC][K];
-                int c_usz[NC], c_base[NC]; bool c_on[NC];
-                bool okw = true;
-#pragma unroll
-                for (int j = 0; j < NC; ++j) { c_on[j] = false; c_usz[j] = 0; c_base[j] = 0;
-                    if (j < cnt) { const int ci = b0 + j;
-                        const int id = hdr(ci, 0), uoff = hdr(ci, 1), own = hdr(ci, 3);
-                        c_usz[j] = hdr(ci, 2); c_base[j] = hdr(ci, 4);
-                        c_on[j] = !((mode == FRONT_CONTRIB && own != d.rank) || (top && own >= 0));
-                        if (c_on[j]) {
-                            if (!plain) okw = f3_wait_flag(d.done_f + id, d.epoch) && okw;
-                            const double *Uc = d.Uimg + uoff;
-#pragma unroll
-                            for (int k = 0; k < K; ++k) { const int idx = 64 * k + lane;
-                                st[j][k] = 0.0;
-                                if (64 * k <= c_usz[j]) { const uint32_t o = (uint32_t)min(idx, c_usz[j]) * 8u;     // lanes beyond the zero double re-read it
-                                    st[j][k] = plain ? ld_off(Uc, o) : ld_off_coh(Uc, o); } }
-                        } } }
-                if (!okw && lane == 0) atomicMax(d.fail, 2);
-                // phase 2: into the image
-#pragma unroll
-                for (int j = 0; j < NC; ++j) if (c_on[j]) {
-#pragma unroll
-                    for (int k = 0; k < K; ++k) { const int idx = 64 * k + lane;
-                        if (64 * k <= c_usz[j] && idx <= c_usz[j]) P.F[c_base[j] + idx] = st[j][k]; } }
-                wave_lds_sync();
-                // phase 3: by destination out of LDS, children in list order (fixed summation order)
-#pragma unroll
-                for (int j = 0; j < NC; ++j) if (c_on[j]) {
-                    double ug[10][4];
-                    f3_gather_child_lds(P.F + c_base[j], c_usz[j], bp[j], lane, ug);
-#pragma unroll
-                    for (int t = 0; t < 10; ++t)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[t][q] += ug[t][q]; }
-            };
-            if (hdr(b0, 6) == 0) stage(std::integral_constant<int, 4>{}, std::integral_constant<int, 7>{});
-            else stage(std::integral_constant<int, 2>{}, std::integral_constant<int, 14>{});
-            wave_lds_sync();                                               // before the next batch (or the panels) overwrite the image
-            b0 += cnt;
-        }
-    }
-#endif
+                else acc[t][q] = P.F[t * 256 + q * 64 + lane]; } }
     wave_lds_sync();
     if constexpr (!LEAF) if (mode == FRONT_CONTRIB) {                            // this rank's share of a shared front -> exchange slot
 #pragma unroll
@@ -1773,7 +1707,33 @@ __global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(D
     // ---- Schur complement out, packed: element (row, col) -> rowpart(row) + colpart(col) from the front's own table; pivot
     // rows / columns make the sum negative and the upper-triangle lanes of the diagonal tiles are forced there: the
     // unsigned min sends all of those to the spare double behind the matrix
-    {
+    if constexpr (!LEAF) {
+        // non-leaf fronts: by source — the accumulators pass through the image, every lane reads its elements (boundary entry
+        // (r', c') = image (npiv + r', npiv + c')) and the stores are contiguous: 13 instead of 40 scattered ones
+        double *U = d.Uimg + fr.u_off;
+        const int usz = fr.u_size;
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) P.F[t * 256 + q * 64 + lane] = acc[t][q];
+        wave_lds_sync();
+        auto place = [&](int rcv) { return min(f3_img_rowpart(npiv + (rcv & 0xff)) + f3_img_colpart(npiv + (rcv >> 8)), MF_IMG - 1); };
+        auto out = [&](auto K0c, auto K1c) {                         // branch-free per lane: lanes beyond the matrix store to the spare double behind it
+            constexpr int K0 = decltype(K0c)::value, K1 = decltype(K1c)::value;
+            double v[F3_KREG];
+#pragma unroll
+            for (int k = K0; k < K1; ++k) v[k] = P.F[own[k]];
+#pragma unroll
+            for (int k = K0; k < K1; ++k) { const int idx = 64 * k + lane; const uint32_t o = (uint32_t)(idx < usz ? idx : usz + 1) * 8u;
+                if (TREE) st_off_wt(U, o, v[k]); else st_off(U, o, v[k]); } };
+        out(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+        if (usz > 512) out(std::integral_constant<int, 8>{}, std::integral_constant<int, F3_KREG>{});
+        for (int base = 64 * F3_KREG; base < usz; base += 64) {      // boundary > 40 rows
+            const int idx = base + lane;
+            const double v = P.F[place(f3_rc_of(min(idx, usz - 1)))];
+            const uint32_t o = (uint32_t)(idx < usz ? idx : usz + 1) * 8u;
+            if (TREE) st_off_wt(U, o, v); else st_off(U, o, v); }
+    } else {
         double *U = d.Uimg + fr.u_off;
         const uint32_t dump = (uint32_t)(fr.u_size + 1) * 8u;
         int co[NT], rov[NT][4];                                      // all lane permutes of the store table first: one LDS latency, not one per row
@@ -1937,7 +1897,6 @@ __global__ void __launch_bounds__(256) k_build_f3(int nq, const int32_t *__restr
         const int32_t *__restrict__ children, const int32_t *__restrict__ child_map, const int32_t *__restrict__ u3_off,
         const int32_t *__restrict__ u3_size, const int32_t *__restrict__ bf /*[front][8]*/, const int32_t *__restrict__ xrow_off,
         const int64_t *__restrict__ x_off /* nullable */, int32_t *__restrict__ f3_desc, int32_t *__restrict__ f3_x) {
-    __shared__ int32_t s_row[4][64];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + wave;
     if (q >= nq) return;
@@ -1970,40 +1929,23 @@ __global__ void __launch_bounds__(256) k_build_f3(int nq, const int32_t *__restr
           default: v = 0; break;
       }
       if (lane < F3_INTS) r[lane] = v; }
-    // ---- the front's own store table: row of the front -> its place in the front's packed update matrix
+    // ---- the front's own store table (leaf instance): row of the front -> its place in the front's packed update matrix
     r[160 + lane] = (lane >= F.npiv && lane <= f) ? f3_pack(lane - F.npiv, lane < f) : none;
-    if (F.child_cnt < 1) r[32 + lane] = none;
-    if (F.child_cnt < 2) r[96 + lane] = none;
-    // ---- children: row table (row R of THIS front -> the child's boundary row that lands on it) + header
+    if (F.child_cnt < 1) r[32 + lane] = 0;
+    if (F.child_cnt < 2) r[96 + lane] = 0;
+    // ---- children: row table + header {front, update-matrix offset, size, owner}
     int32_t *xt = f3_x + xrow_off[q];
     for (int k = 0; k < F.child_cnt; ++k) {
         const int c = children[F.child_off + k];
         const int nbc = fronts[c].nbnd; const int64_t mo = fronts[c].map_off;
-        s_row[wave][lane] = none;
-        wave_lds_sync();
-        if (lane < nbc) s_row[wave][child_map[mo + lane]] = f3_pack(lane, true);
-        if (lane == 0) s_row[wave][f] = f3_pack(nbc, false);
-        wave_lds_sync();
-        const int32_t v = s_row[wave][lane];
+        // by source: boundary row r' of the child (r' = nbc: its rhs row) -> the place of its parent row in the parent's tile image
+        int32_t v = 0;
+        if (lane <= nbc) { const int R = lane < nbc ? child_map[mo + lane] : f;
+            v = (int32_t)((uint32_t)f3_img_rowpart(R) | ((uint32_t)f3_img_colpart(R) << 16)); }
         xt[k * F3X + lane] = v;
         if (k < 2) r[32 + 64 * k + lane] = v;
-        if (lane < 8) xt[k * F3X + 64 + lane] = lane == 0 ? c : (lane == 1 ? u3_off[c] : (lane == 2 ? u3_size[c] : (lane == 3 ? fronts[c].owner : (lane == 5 ? -1 : 0))));
-        wave_lds_sync();
+        if (lane < 8) xt[k * F3X + 64 + lane] = lane == 0 ? c : (lane == 1 ? u3_off[c] : (lane == 2 ? u3_size[c] : (lane == 3 ? fronts[c].owner : 0)));
     }
-    // ---- batches for the LDS-staged gather (tuning build F3_LDS_GATHER): greedily up to 4 consecutive children of <= 447
-    // doubles or 2 of <= 895, <= 2560 doubles in all; header fields 4 (place in the image), 5 (batch), 6 (shape)
-    if (lane == 0) { int batch = 0, k = 0; const int nc = F.child_cnt;
-        while (k < nc) { const int usz = u3_size[children[F.child_off + k]];
-            if (usz + 1 > 14 * 64 - 1) { ++k; continue; }
-            const int shape = usz + 1 <= 7 * 64 - 1 ? 0 : 1, cap = shape == 0 ? 4 : 2, lim = shape == 0 ? 7 * 64 - 1 : 14 * 64 - 1;
-            int n = 0, tot = 0;
-            while (k < nc && n < cap) { const int u2 = u3_size[children[F.child_off + k]];
-                if (u2 + 1 > lim) break;
-                const int need = (u2 + 2) & ~1;
-                if (tot + need > 2560) break;
-                int32_t *h = xt + k * F3X + 64; h[4] = tot; h[5] = batch; h[6] = shape; tot += need; ++n; ++k; }
-            if (n == 0) ++k;
-            ++batch; } }
 }
 void launch_build_f3(int nq, const int32_t *lf, const DevFront *fronts, const int32_t *children, const int32_t *child_map,
                      const int32_t *u3_off, const int32_t *u3_size, const int32_t *bf, const int32_t *xrow_off, const int64_t *x_off,
