@@ -1159,19 +1159,19 @@ __global__ void __launch_bounds__(256, 2) k_factor_mfma(DevGraph d, int level_of
 // latency), so these kernels are built around the number of dependent memory round trips per front:
 //   1. one 96-byte descriptor per level position (front, its first two children, arena offsets): one coalesced load;
 //   2. assembly records + the children's inverse row maps;                     (one round trip)
-//   3. the original H values AND both children's update matrices, all in flight together: children are GATHERED by
-//      destination — accumulator element (R, C) of the parent reads element (pinv[R], pinv[C]) of the child's tile
-//      image — so there is no scatter through LDS, no read-modify-write chain, and the sum order is fixed
-//      (originals + child 0 + child 1 + ...).  (Measured alternatives: coalesced tile loads + ds_add_f64 scatter is
-//      3x slower — LDS f64 atomics retire ~270 cycles per wave instruction; register read-modify-write through LDS
-//      costs two more LDS round trips per child.)
+//   3. the original H values, then the children's update matrices: read in storage order (contiguous loads) and added
+//      into the front's LDS image by source, children in list order (sum order originals + child 0 + child 1 + ...); see
+//      "by source" below.  (Round 1 gathered by destination, 40 scattered loads per lane and child, to avoid the LDS
+//      read-modify-write; round 2 measured what a scattered wave access costs — ~60 cycles of address processing per
+//      instruction — and that a packed matrix is only 7-14 contiguous loads per lane.  LDS f64 atomics stay out:
+//      ~270 cycles per wave instruction.)
 //   4. LDL^T panels of 4 pivots on the fp64 matrix cores: T(I,J) -= (c/d) c^T, one reciprocal per pivot instead of a
 //      square root and a division; the rhs is row f of the front, so row f of the L panel is D^-1 L^-1 b and the
 //      backward solve has a unit diagonal (no division there either).
 // Record formats (built in gs_api.cpp upload_graph):
 //   f3_desc [level position][24] int32: 0 front, 1 npiv, 2 nbnd, 3 asm_off, 4 #unique records, 5 #duplicate records,
 //      6 #children, 7 child_off, 8-9 L_off, 10 piv0, 11 bnd_off, 12-13 child front (-1 none), 14 offset of the front's children table in f3_x (F3X ints per child: its 64-entry row
-//      table, then {front, update-matrix offset, size, owner, place in the LDS image, batch (-1: too large to stage)}), 15 unused,
+//      table, then {front, update-matrix offset, size, owner}), 15 unused,
 //      16-17 child owner, 18-19 exchange slot offset, 20 sc_off, 21 #scalar records (multiple of 64), 22 lm_off, 23 #landmark records
 //   sc3 [scalar][2]: {offset of the value in H_arena, offset in the staging image}: the original blocks flattened to
 //      scalars, so the assembly is branch-free (load record, load value, one LDS store)
@@ -1183,17 +1183,19 @@ __global__ void __launch_bounds__(256, 2) k_factor_mfma(DevGraph d, int level_of
 //      0 .. min(r', nbnd - 1) at r'(r'+1)/2 — half the bytes of 16 x 16 tile images, and a parent row's columns are
 //      contiguous (fewer cache lines per gather).  Behind each: one double that stays zero (clamped gathers read it)
 //      and one that swallows clamped stores.  offset(r', c') = rowpart(r') + colpart(c'), so both the child's store and
-//      the parent's gather address an element with one add:
-//   pinv [front][64] int32: for row R of the PARENT, the boundary row of THIS front that lands on it, as byte offsets
-//      {rowpart = r'(r'+1)/2 * 8 (low 16 bits), colpart = r' * 8 (high 16 bits)}; -30000 = none (the sum goes negative).
-//      The tables of a front's first two children and the front's own store table (row of the front -> {rowpart,
-//      colpart}) sit right behind its descriptor (f3_desc stride 224 ints): known after the FIRST round trip.
+//      the leaf instance's by-destination store addresses an element with one add:
+//   child table [64] int32 (behind the descriptor for the first two children, in f3_x for all): for boundary row r' of
+//      the CHILD (r' = its nbnd: the rhs row) the place of the parent row it lands on in the parent's tile image, as
+//      {row part (low 16 bits), column part (high 16 bits)}: image index of (R, C) = rowpart(R) + colpart(C).
+//      own store table [64] (leaf instance): row of the front -> {rowpart = r'(r'+1)/2 * 8, colpart = r' * 8} byte
+//      offsets in its packed update matrix, -30000 = none (the sum goes negative, the store is clamped to the spare
+//      double).  All three sit right behind the descriptor (f3_desc stride 224 ints): known after the FIRST round trip.
 struct F3 {
     int s, npiv, nbnd, asm_off, asm_uniq, asm_dup, nchild, child_off, piv0, bnd_off, c_id[2], x_tab, c_owner[2];
     int sc_off, sc_cnt, lm_off, lm_cnt, u_off, u_size, c_uoff[2], c_usize[2], parent, level;
     int64_t L_off, x_off;
 };
-static constexpr int F3_INTS = 32, F3_STRIDE = 224, F3X = 72;   // 32 descriptor ints, pinv of child 0, pinv of child 1, own store table (64 ints each)
+static constexpr int F3_INTS = 32, F3_STRIDE = 224, F3X = 72;   // 32 descriptor ints, table of child 0, table of child 1, own store table (64 ints each)
 __device__ __forceinline__ F3 f3_load(const int32_t *desc, int idx, int lane) {
     const int v = (lane < F3_INTS) ? desc[(int64_t)idx * F3_STRIDE + lane] : 0;
     auto g = [&](int i) { return __builtin_amdgcn_readlane(v, i); };
@@ -1288,43 +1290,10 @@ __device__ __forceinline__ void asm3_put(const St &P, int kind_cnt, int r0, int 
     }
 }
 
-// gather one child's update matrix by destination: pv = pinv[child][lane]; accumulator element (R, C) of the parent
-// reads byte offset rowpart(R) + colpart(C) of the child's tile image.  A missing row makes the sum negative, which
-// the unsigned min clamps to the zero double behind the packed matrix: three instructions per element, no branches.
-// (Upper-triangle elements of the diagonal tiles read some other, finite, element: they are don't-care everywhere.)
 // device-scope (sc1) load: fetched from the memory side, not from this XCD's L2 — data another XCD wrote during THIS kernel
 __device__ __forceinline__ double ld_off_coh(const double *base, uint32_t byte_off) {
     return __hip_atomic_load(reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// the row / column parts every lane needs of a child's row table (20 lane permutes): they depend on the plan only, so a
-// front that waits for its children computes them BEFORE the wait and keeps them out of the dependent chain
-struct F3Off { int ro[16], co[4]; };
-__device__ __forceinline__ void f3_gather_offsets(int pv, int lane, F3Off &g) {
-    const int lc = lane & 15, lr = lane >> 4;
-#pragma unroll
-    for (int J = 0; J < 4; ++J) g.co[J] = __shfl(pv, 16 * J + lc, WAVE) >> 16;
-#pragma unroll
-    for (int I = 0; I < 4; ++I)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) g.ro[4 * I + q] = (int)(short)(__shfl(pv, 16 * I + lr + 4 * q, WAVE) & 0xffff);
-}
-template <bool COH>
-__device__ __forceinline__ void f3_gather_child_at(const double *Uc, int usize, const F3Off &g, double (&u)[10][4]) {
-#pragma unroll
-    for (int I = 0; I < 4; ++I)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int J = 0; J <= I; ++J)
-            { const uint32_t o = min((uint32_t)(g.ro[4 * I + q] + g.co[J]), (uint32_t)usize * 8u);
-                u[mf_tile(I, J)][q] = COH ? ld_off_coh(Uc, o) : ld_off(Uc, o); }
-}
-template <bool COH>
-__device__ __forceinline__ void f3_gather_child(const double *Uc, int usize, int pv, int lane, double (&u)[10][4]) {
-    F3Off g; f3_gather_offsets(pv, lane, g);
-    f3_gather_child_at<COH>(Uc, usize, g, u);
-}
-
 // ---- by source (round 2, non-leaf fronts).  Measured on MI355X: a wave's SCATTERED 8-byte global access costs ~60
 // cycles of address processing per instruction — the 80 by-destination loads of two children are 2 us of every level's
 // chain, the 40 by-destination stores of the update matrix 1 us — while a CONTIGUOUS one (lane i at byte 8 i) costs a
