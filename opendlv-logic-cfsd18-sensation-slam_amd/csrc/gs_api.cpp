@@ -407,7 +407,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
 #define GS_UT(name) do { if (ut_on) { auto n_ = std::chrono::steady_clock::now(); std::fprintf(stderr, "upload %-18s %.2f ms\n", (name), std::chrono::duration<double, std::milli>(n_ - ut_prev).count()); ut_prev = n_; } } while (0)
     const int N = h.n_poses(), M = h.n_lms(), Epp = h.n_pp(), Epl = h.n_pl();
     d.N = N; d.M = M; d.Epp = Epp; d.Epl = Epl; d.n_scalar = P.n_scalar;
-    g->leaf_n = -1;
+    g->leaf_n = -1; g->block_n = -1;
     int rc;
 #define UP(dst, vec) if ((rc = dev_upload(g, &d.dst, vec)) != GS_OK) return rc
     // estimates, fixed flags, odometry edges and the insertion-order observation arrays are in HBM already (RawUpload)
@@ -671,7 +671,15 @@ static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int
                 slot = std::max(slot, (((F.npiv + F.nbnd + 1) | 1) * F.npiv + 1) & ~1); }
             if (const char *e = std::getenv("GS_LEAF_KERNEL")) if (std::atoi(e) == 0) n_leaf = 0;
             g->leaf_n = n_leaf; g->leaf_slot = slot; }
-        launch_factor_tree(g->d, g->leaf_n, g->leaf_slot, g->leaf_max_f, ls.start[nlev], g->stream); return; }
+        // the upper levels — few fronts, all of them in the dependent chain — get four waves per front: whole levels from the
+        // top down while a level has at most GS_BLOCK_FRONTS (512) fronts (those workgroups are all resident at once)
+        if (g->block_n < 0) { int thr = 512; if (const char *e = std::getenv("GS_BLOCK_FRONTS")) thr = std::atoi(e);
+            int nb = 0;
+            for (int l = nlev - 1; l >= 1; --l) { const int nl = ls.start[l + 1] - ls.start[l];
+                if (nl > thr || (l == 1 && g->leaf_n == 0)) break;
+                nb += nl; }
+            g->block_n = std::min(nb, ls.start[nlev] - std::max(g->leaf_n, 0)); }
+        launch_factor_tree(g->d, g->leaf_n, g->leaf_slot, g->leaf_max_f, ls.start[nlev], g->block_n, g->stream); return; }
     if (g->d.factor_variant == 3 && g->d.tree && mode == 2 && nlev > 0 && ls.start[nlev] > 0) {     // the shared top of a sharded graph, one flagged launch
         launch_factor_tree_top(g->d, base, ls.start[nlev], g->stream); return; }
     for (int l = 0; l < nlev; ++l)

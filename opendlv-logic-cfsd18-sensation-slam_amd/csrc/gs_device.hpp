@@ -87,7 +87,7 @@ void launch_linearize_finalize(const DevGraph &d, hipStream_t st);   // H_ll, b_
 void launch_chi2_only(const DevGraph &d, hipStream_t st);
 // mode: 0 own front, 1 contribution of this rank to a shared front (-> exchange), 2 shared front from the exchange
 void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f, int mode, hipStream_t st);
-void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int leaf_max_f, int count, hipStream_t st);   // variant 3: leaf level + every level above, two launches
+void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int leaf_max_f, int count, int n_block, hipStream_t st);   // variant 3: leaf level + every level above, two launches
 void launch_factor_tree_top(const DevGraph &d, int first, int count, hipStream_t st);           // shared top of a sharded graph (mode TOP)
 void launch_backsolve_tree(const DevGraph &d, int first, int count, int max_npiv, int max_f, hipStream_t st);
 void launch_backsolve_level(const DevGraph &d, int level_off, int count, int max_npiv, int max_nbnd, hipStream_t st);

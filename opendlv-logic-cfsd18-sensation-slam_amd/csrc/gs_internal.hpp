@@ -31,6 +31,7 @@ struct gs_graph {
     LevelSet own, shared;                   // this rank's fronts / the shared top (pose-window shards)
     int shared_base = 0;                    // offset of the shared list inside d.level_fronts
     int leaf_max_f = 0;                     // largest leaf front (<= 47: the three-tile-row leaf instance)
+    int block_n = -1;                       // trailing level positions of the whole-tree factor launch that get a workgroup each (-1: not decided yet)
     int leaf_n = -1, leaf_slot = 0;             // level-0 fronts handled by the leaf instance of the factor kernel, its LDS slot (doubles per wave)
     double ms_structure = 0;
     int rank = 0, world = 1;

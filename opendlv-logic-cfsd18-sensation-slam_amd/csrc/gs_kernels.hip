@@ -1362,28 +1362,9 @@ __device__ __forceinline__ double rcp_f64(double x) {             // reciprocal 
     return r;
 }
 
-template <int B, int NT = 4>      // panel B: pivots 4B .. 4B+3 (tile column J0 = B / 4), LDL^T; NT = tile rows of the front (3: fronts of <= 47 scalars)
-__device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[NT * (NT + 1) / 2], double *Pn, double *L, int npiv, int f, int lane) {
-    constexpr int k0 = 4 * B, J0 = B / 4, jc = (B % 4) * 4;
-    static_assert(J0 < NT, "panel beyond the front's tile rows");
-    if (k0 >= npiv) return false;                                   // uniform
-    const int lc = lane & 15, lr = lane >> 4;
-    // The wide levels of the tree are bound by instruction issue, so this function is written for few instructions:
-    // one exec-mask region for the spill and one for the L stores, no uniform branches inside them, the positivity
-    // test as one compare per pivot into a flag that is looked at once per front (no protective select: a front with a
-    // bad pivot produces garbage, the solve is reported as failed).
-    // 1. the panel's four columns (rows of tiles J0..3) to LDS, row-major 64 x 4 (tile rows beyond f hold zeros)
-    if (lc >= jc && lc < jc + 4) {
-#pragma unroll
-        for (int I = J0; I < NT; ++I)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Pn[(16 * I + lr + 4 * q) * 4 + (lc - jc)] = acc[mf_tile(I, J0)][q];
-    }
-    wave_lds_sync();
-    // 2. factorise the panel, lane r = row r:  l = c / d from the diagonal down (the diagonal itself becomes 1), 0 above
-    double p[4], dd[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) p[j] = Pn[lane * 4 + j];
+// the pivots of the panel k0 .. k0+3 on its four columns, one row per lane: p <- l (0 above the diagonal, 1 on it), dd <- the pivots (0
+// for a column that is not a pivot)
+__device__ __forceinline__ void f3_panel_pivots(int k0, bool &bad, double (&p)[4], double (&dd)[4], int npiv, int lane) {    // k0 (first pivot of the panel): uniform
     // one pivot of the panel.  If every column of this panel is a pivot (all panels of a front but possibly the last)
     // there are no uniform branches between the pivots and no merges of the p[] registers after them.
     auto pivot = [&](int j, bool is_pivot) {
@@ -1407,6 +1388,33 @@ __device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[NT * (NT + 1
 #pragma unroll
         for (int j = 0; j < 4; ++j) pivot(j, k0 + j < npiv);
     }
+}
+
+template <int B, int NT = 4>      // panel B: pivots 4B .. 4B+3 (tile column J0 = B / 4), LDL^T; NT = tile rows of the front (3: fronts of <= 47 scalars)
+__device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[NT * (NT + 1) / 2], double *Pn, double *L, int npiv, int f, int lane) {
+    constexpr int k0 = 4 * B, J0 = B / 4, jc = (B % 4) * 4;
+    static_assert(J0 < NT, "panel beyond the front's tile rows");
+    if (k0 >= npiv) return false;                                   // uniform
+    const int lc = lane & 15, lr = lane >> 4;
+    // The wide levels of the tree are bound by instruction issue, so this function is written for few instructions:
+    // one exec-mask region for the spill and one for the L stores, no uniform branches inside them, the positivity
+    // test as one compare per pivot into a flag that is looked at once per front (no protective select: a front with a
+    // bad pivot produces garbage, the solve is reported as failed).  (One instance per panel, sixteen in a row: a loop
+    // over the panels of a tile column was measured slower here — 0.186 against 0.176 ms — and faster in the four-wave
+    // form below, which runs every front on a CU whose instruction cache has not seen the code.)
+    // 1. the panel's four columns (rows of tiles J0..3) to LDS, row-major 64 x 4 (tile rows beyond f hold zeros)
+    if (lc >= jc && lc < jc + 4) {
+#pragma unroll
+        for (int I = J0; I < NT; ++I)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Pn[(16 * I + lr + 4 * q) * 4 + (lc - jc)] = acc[mf_tile(I, J0)][q];
+    }
+    wave_lds_sync();
+    // 2. factorise the panel, lane r = row r:  l = c / d from the diagonal down (the diagonal itself becomes 1), 0 above
+    double p[4], dd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = Pn[lane * 4 + j];
+    f3_panel_pivots(k0, bad, p, dd, npiv, lane);
     if (lane <= f) {                                                // the panel's columns of L (rows < col are 0, the diagonal is 1), one masked region
         double *Lc = L + (int64_t)k0 * (f + 1) + lane;
 #pragma unroll
@@ -1482,19 +1490,214 @@ __device__ __forceinline__ bool f3_gather_pair(double *img, const int (&rc)[F3_K
     return ok;
 }
 
+#ifndef F3_DONE_TS
+#define F3_DONE_TS 0
+#endif
+// ---- four waves per front: the upper levels of a whole-tree launch (round 2).  Up there the chain of dependent fronts is
+// the whole cost and the chip is nearly empty, so a front gets a workgroup: the ten accumulator tiles are spread over the
+// four waves (tile t belongs to wave t mod 4: three tiles at most, MI355X runs fp64 MFMA at the vector rate — one wave's ten
+// tiles are ~1000 of a panel's ~2200 cycles), the records, the children's elements and the update matrix over 256
+// threads.  Every wave factorises the panel itself (the same instructions on the same values, in lockstep on four SIMDs),
+// so a panel costs one workgroup barrier.  Element by element the arithmetic and its order are the wave-per-front
+// kernel's: the results are bit-identical.
+__device__ __forceinline__ int f3_tile_row(int t) { return t >= 6 ? 3 : (t >= 3 ? 2 : (t >= 1 ? 1 : 0)); }
+__device__ __forceinline__ bool f3_block_panel(int B, bool &bad, v4d (&acc)[3], double *Pn, double *Pw, double *L, int npiv, int f, int wave, int lane) {
+    const int k0 = 4 * B, J0 = B >> 2, jc = (B & 3) * 4;             // uniform
+    if (k0 >= npiv) return false;                                   // uniform over the workgroup
+    const int lc = lane & 15, lr = lane >> 4;
+    double *Pb = Pn + (B & 1) * 256;                                 // two buffers: the next panel's spill must not meet this panel's readers
+    // 1. the panel's four columns out of whichever waves own the tiles of tile column J0
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { const int t = 4 * s + wave, I = f3_tile_row(t), J = t - ((I * (I + 1)) >> 1);     // uniform per wave
+        if (t < 10 && J == J0 && lc >= jc && lc < jc + 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Pb[(16 * I + lr + 4 * q) * 4 + (lc - jc)] = acc[s][q]; } }
+    __syncthreads();
+    // 2. every wave factorises the panel (lane r = row r)
+    double p[4], dd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = Pb[lane * 4 + j];
+    f3_panel_pivots(k0, bad, p, dd, npiv, lane);
+    if (wave == 0 && lane <= f) {
+        double *Lc = L + (int64_t)k0 * (f + 1) + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (k0 + j < npiv) F3_ST_L(Lc + (int64_t)j * (f + 1), p[j]);
+    }
+    // 3. trailing update of the wave's own tiles; the operand layout comes through the wave's private buffer (no barrier)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Pw[lane * 4 + j] = p[j];
+    const double dk = lr == 0 ? dd[0] : (lr == 1 ? dd[1] : (lr == 2 ? dd[2] : dd[3]));
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { const int t = 4 * s + wave, I = f3_tile_row(t), J = t - ((I * (I + 1)) >> 1);
+        if (t < 10 && J >= J0) {
+            const double aI = Pw[(16 * I + lc) * 4 + lr], aJ = Pw[(16 * J + lc) * 4 + lr];
+            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI, aJ * dk, acc[s], 0, 0, 0); } }
+    wave_lds_sync();
+    return true;
+}
+// one child into the image by source, 256 threads: element 256 k + tid, k < 4 (matrices up to 1024 doubles), the rest in a loop
+__device__ __forceinline__ void f3_block_child(double *img, const double *Uc, int usz, int tab, const int (&rc)[4], int tid) {
+    int dst[4]; double st[4], o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int pl = (__shfl(tab, rc[k] & 0xff, WAVE) & 0xffff) + (int)((uint32_t)__shfl(tab, rc[k] >> 8, WAVE) >> 16);
+        dst[k] = (256 * k + tid < usz) ? pl : 1; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st[k] = ld_off_coh(Uc, (uint32_t)min(256 * k + tid, usz) * 8u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = img[dst[k]];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) img[dst[k]] = o[k] + st[k];
+    for (int base = 1024; base < usz; base += 256) {                // boundary > 43 rows
+        const int idx = base + tid, rcv = f3_rc_of(min(idx, usz - 1));
+        const int pl = (__shfl(tab, rcv & 0xff, WAVE) & 0xffff) + (int)((uint32_t)__shfl(tab, rcv >> 8, WAVE) >> 16);
+        const double v = ld_off_coh(Uc, (uint32_t)min(idx, usz) * 8u);
+        img[idx < usz ? pl : 1] += v; }
+}
+__device__ __forceinline__ void f3_block_front(const DevGraph &d, int pos, int leaf_slot, double *smem, bool ts_on) {
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+#define F3B_TS(i) do { if (ts_on) { __builtin_amdgcn_s_waitcnt(0); if (tid == 0) d.dbg_ts[i] = wall_clock64(); } } while (0)
+    F3B_TS(0);
+    const int tab0 = d.f3_desc[(int64_t)pos * F3_STRIDE + F3_INTS + lane], tab1 = d.f3_desc[(int64_t)pos * F3_STRIDE + F3_INTS + 64 + lane];
+    const F3 fr = f3_load(d.f3_desc, pos, lane);
+    const int npiv = fr.npiv, f = npiv + fr.nbnd;
+    if (wave == 0 && lane < npiv) d.xe[fr.piv0 + lane] = f3_unset();
+    double *img = smem, *Pn = smem + MF_IMG, *Pw = smem + MF_IMG + 512 + wave * 256;
+    StageT<false> P{img, f, (f + 1) | 1};
+    int rc[4], own[4];                                               // (r', c') of this thread's elements of any packed matrix; their places in THIS front's image
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { rc[k] = f3_rc_of(256 * k + tid);
+        own[k] = min(f3_img_rowpart(npiv + (rc[k] & 0xff)) + f3_img_colpart(npiv + (rc[k] >> 8)), MF_IMG - 1);
+        asm volatile("" : "+v"(own[k])); }
+    // ---- records (scalar records come in multiples of 64: a wave's 64 are all there or none)
+    const int nsc = fr.sc_cnt, nlm = fr.lm_cnt;
+    const int2 *sc3 = reinterpret_cast<const int2 *>(d.sc3) + fr.sc_off;
+    int2 sc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { sc[u] = make_int2(0, 1);
+        if (256 * u + 64 * wave < nsc) { const long long v = F3_LD_REC(reinterpret_cast<const long long *>(sc3 + 256 * u + tid)); sc[u] = make_int2((int)(v & 0xffffffffLL), (int)(v >> 32)); } }
+    int4 lmr = make_int4(0, 0, 0, 0);
+    if (tid < nlm) lmr = reinterpret_cast<const int4 *>(d.lm3)[fr.lm_off + tid];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) img[256 * k + tid] = 0.0;
+    __syncthreads();
+    // ---- the original values
+    {
+        double val[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) if (256 * u + 64 * wave < nsc) val[u] = F3_LD_VAL(d.H_arena, (uint32_t)sc[u].x * 8u);
+        double lv[5] = {0, 0, 0, 0, 0};
+        if (tid < nlm) { const int64_t G = d.n_groups;
+            for (int q0 = 0; q0 < lmr.x; q0 += 4) {                  // four slots' loads in flight, added in slot order
+                double t4[4][5];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int q = min(q0 + j, lmr.x - 1);
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) t4[j][k] = d.lm_part[k * G + lmr.y + q]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) lv[k] += (q0 + j < lmr.x) ? t4[j][k] : 0.0; } }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) if (256 * u + 64 * wave < nsc) img[sc[u].y] = val[u];
+        for (int base = 512; base + 64 * wave < nsc; base += 256) { const int2 r = sc3[base + tid]; img[r.y] = ld_off(d.H_arena, (uint32_t)r.x * 8u); }
+        if (tid < nlm) { const int r0 = lmr.z, c0 = lmr.w;
+            P.at(r0, c0) = lv[0]; P.at(r0 + 1, c0) = lv[1]; P.at(r0 + 1, c0 + 1) = lv[2]; P.at(f, c0) = lv[3]; P.at(f, c0 + 1) = lv[4]; }
+        for (int t = 256 + tid; t < nlm; t += 256) {
+            const int4 r = reinterpret_cast<const int4 *>(d.lm3)[fr.lm_off + t]; const int64_t G = d.n_groups; double a[5] = {0, 0, 0, 0, 0};
+            for (int q = 0; q < r.x; ++q)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) a[k] += d.lm_part[k * G + r.y + q];
+            P.at(r.z, r.w) = a[0]; P.at(r.z + 1, r.w) = a[1]; P.at(r.z + 1, r.w + 1) = a[2]; P.at(f, r.w) = a[3]; P.at(f, r.w + 1) = a[4]; }
+        __syncthreads();
+        if (fr.asm_dup > 0) {                                        // parallel edges: added one by one, in record order
+            if (tid == 0) for (int t = fr.asm_uniq; t < fr.asm_uniq + fr.asm_dup; ++t) {
+                const int4 r = reinterpret_cast<const int4 *>(d.asm3)[fr.asm_off + t];
+                double w[9]; asm3_load(d, r.x, r.y, w); asm3_put<true>(P, r.x, r.z, r.w, w); }
+            __syncthreads();
+        }
+    }
+    F3B_TS(5);
+    // ---- the children, by source, in list order; a barrier between two children (their places overlap)
+    if (fr.nchild > 0) {
+        const bool plain = fr.level == 1 && leaf_slot != 0;
+        const int32_t *xt = d.f3_x + fr.x_tab;
+        bool okw = true;
+        for (int e = 0; e < fr.nchild; ++e) {
+            int tab, c_id, c_uoff, c_usz;
+            if (e == 0) { tab = tab0; c_id = fr.c_id[0]; c_uoff = fr.c_uoff[0]; c_usz = fr.c_usize[0]; }
+            else if (e == 1) { tab = tab1; c_id = fr.c_id[1]; c_uoff = fr.c_uoff[1]; c_usz = fr.c_usize[1]; }
+            else { tab = xt[e * F3X + lane]; const int h = xt[e * F3X + 64 + (lane & 7)];
+                c_id = __builtin_amdgcn_readlane(h, 0); c_uoff = __builtin_amdgcn_readlane(h, 1); c_usz = __builtin_amdgcn_readlane(h, 2); }
+            if (!plain) okw = f3_wait_flag(d.done_f + c_id, d.epoch) && okw;
+            f3_block_child(img, d.Uimg + c_uoff, c_usz, tab, rc, tid);
+            __syncthreads();
+        }
+        if (!okw && tid == 0) atomicMax(d.fail, 2);
+    }
+    F3B_TS(10);
+    // ---- accumulators: wave w holds tiles w, w + 4, w + 8
+    v4d acc[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { const int t = 4 * s + wave;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[s][q] = t < 10 ? img[t * 256 + q * 64 + lane] : 0.0; }
+    F3B_TS(6);
+    double *L = d.Lbuf + fr.L_off;
+    bool go = true, bad = false;
+#pragma clang loop unroll(disable)
+    for (int B = 0; B < 16 && go; ++B) go = f3_block_panel(B, bad, acc, Pn, Pw, L, npiv, f, wave, lane);
+    if (bad && tid == 0) atomicMax(d.fail, 1);
+    F3B_TS(7);
+    // ---- Schur complement out through the image, contiguous stores
+    __syncthreads();                                                 // nobody reads the image any more (the accumulators were loaded long ago): kept for the panel buffers' sake
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { const int t = 4 * s + wave;
+        if (t < 10) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) img[t * 256 + q * 64 + lane] = acc[s][q]; } }
+    __syncthreads();
+    {
+        double *U = d.Uimg + fr.u_off; const int usz = fr.u_size;
+        double v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = img[own[k]];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int idx = 256 * k + tid; if (256 * k < usz) st_off_wt(U, (uint32_t)(idx < usz ? idx : usz + 1) * 8u, v[k]); }
+        for (int base = 1024; base < usz; base += 256) { const int idx = base + tid; const int rcv = f3_rc_of(min(idx, usz - 1));
+            const double w = img[min(f3_img_rowpart(npiv + (rcv & 0xff)) + f3_img_colpart(npiv + (rcv >> 8)), MF_IMG - 1)];
+            st_off_wt(U, (uint32_t)(idx < usz ? idx : usz + 1) * 8u, w); }
+    }
+#if F3_DONE_TS
+    if (tid == 0) d.done_ts[fr.s] = wall_clock64();
+#endif
+    __builtin_amdgcn_s_waitcnt(0);                                  // every wave's write-through stores have been acknowledged
+    __syncthreads();
+    if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __hip_atomic_store(d.done_f + fr.s, d.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    F3B_TS(8);
+#undef F3B_TS
+}
+
 // LEAF: fronts without children (level 0 of a rank's own subtrees, mode OWN only): no gather registers, pivot-column
 // staging => 3 waves per SIMD and 3 workgroups per CU instead of 2 (halving the resident waves was measured to cost
 // the leaf level x1.67: it is bound by resident waves x front latency, not yet by bandwidth)
 // NT = tile rows held in the accumulators: 4 (fronts up to 63 scalars) or, leaf instance only, 3 (every leaf <= 47 scalars:
 // 6 tiles instead of 10 — a third fewer accumulator registers and spill traffic, five waves per SIMD instead of four)
 template <bool TREE, bool LEAF, int NT = 4>
-__global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(DevGraph d, int level_off, int count, int mode, int leaf_slot) {
+__global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(DevGraph d, int level_off, int count, int mode, int leaf_slot, int n_wave_fronts) {
     static_assert(LEAF || NT == 4, "only the leaf instance has a three-tile-row form");
     constexpr int NTILE = NT * (NT + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // whole-tree launches: the first n_wave_fronts level positions one wave each (four per workgroup), the rest — the upper
+    // levels — one workgroup each
+    if constexpr (TREE && !LEAF) {
+        const int wave_blocks = (n_wave_fronts + 3) >> 2;
+        if ((int)blockIdx.x >= wave_blocks) { const int pos = level_off + n_wave_fronts + ((int)blockIdx.x - wave_blocks);
+            f3_block_front(d, pos, leaf_slot, smem, (d.dbg & 16) && pos == (d.dbg >> 8)); return; }
+    }
     const int fi = blockIdx.x * 4 + wave;
-    if (fi >= count) return;                                        // whole wave leaves; no block barrier below
+    if (fi >= (TREE && !LEAF ? n_wave_fronts : count)) return;      // whole wave leaves; no block barrier below
     const bool ts_on = ((d.dbg & 8) && count == (d.dbg >> 8) && fi == 0) || ((d.dbg & 16) && level_off + fi == (d.dbg >> 8));   // 16: probe the front at a level POSITION
 #define F3_TS(i) do { if (ts_on) { __builtin_amdgcn_s_waitcnt(0); if (lane == 0) d.dbg_ts[i] = wall_clock64(); } } while (0)
     F3_TS(0);
@@ -1729,9 +1932,6 @@ __global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(D
             }
         }
     }
-#ifndef F3_DONE_TS
-#define F3_DONE_TS 0
-#endif
 #if F3_DONE_TS
     if (lane == 0) d.done_ts[fr.s] = wall_clock64();
 #endif
@@ -1981,7 +2181,7 @@ void launch_build_sc3(const int32_t *bf, const int32_t *asm3, int32_t *sc3, int3
 }
 
 // whole-tree launches of variant 3 (own fronts of a single-GPU graph): every level in one kernel each
-void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int leaf_max_f, int count, hipStream_t st) {
+void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int leaf_max_f, int count, int n_block, hipStream_t st) {
     if (count <= 0) return;
     static bool attr_set_t = false;
     if (!attr_set_t) { (void)hipFuncSetAttribute((const void *)k_factor3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1990,9 +2190,11 @@ void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int leaf_m
     // level 0 (no children) through the high-occupancy leaf instance (three tile rows when every leaf has <= 47 scalars),
     // everything above in one launch whose fronts wait on flags
     static int nt3 = -1; if (nt3 < 0) { nt3 = 1; if (const char *e = getenv("GS_LEAF_NT3")) nt3 = atoi(e) != 0; }
-    if (n_leaf > 0 && leaf_max_f <= 47 && nt3) hipLaunchKernelGGL((k_factor3<true, true, 3>), dim3((n_leaf + 3) / 4), dim3(256), (size_t)leaf_slot * 4 * sizeof(double), st, d, 0, n_leaf, FRONT_OWN, leaf_slot);
-    else if (n_leaf > 0) hipLaunchKernelGGL((k_factor3<true, true>), dim3((n_leaf + 3) / 4), dim3(256), (size_t)leaf_slot * 4 * sizeof(double), st, d, 0, n_leaf, FRONT_OWN, leaf_slot);
-    if (count > n_leaf) hipLaunchKernelGGL((k_factor3<true, false>), dim3((count - n_leaf + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, n_leaf, count - n_leaf, FRONT_OWN, n_leaf > 0 ? 1 : 0);   // last argument: a leaf launch preceded
+    if (n_leaf > 0 && leaf_max_f <= 47 && nt3) hipLaunchKernelGGL((k_factor3<true, true, 3>), dim3((n_leaf + 3) / 4), dim3(256), (size_t)leaf_slot * 4 * sizeof(double), st, d, 0, n_leaf, FRONT_OWN, leaf_slot, 0);
+    else if (n_leaf > 0) hipLaunchKernelGGL((k_factor3<true, true>), dim3((n_leaf + 3) / 4), dim3(256), (size_t)leaf_slot * 4 * sizeof(double), st, d, 0, n_leaf, FRONT_OWN, leaf_slot, 0);
+    // the last n_block level positions (whole upper levels) get a workgroup each, the others a wave each
+    if (count > n_leaf) { const int nw = count - n_leaf - n_block;
+        hipLaunchKernelGGL((k_factor3<true, false>), dim3((nw + 3) / 4 + n_block), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, n_leaf, count - n_leaf, FRONT_OWN, n_leaf > 0 ? 1 : 0, nw); }   // leaf_slot argument: a leaf launch preceded
 }
 // the shared top of a sharded graph (mode TOP: fronts start from the all-reduced exchange slots and gather their shared
 // children only): one flagged launch as well
@@ -2000,7 +2202,7 @@ void launch_factor_tree_top(const DevGraph &d, int first, int count, hipStream_t
     if (count <= 0) return;
     static bool attr_set_tt = false;
     if (!attr_set_tt) { (void)hipFuncSetAttribute((const void *)k_factor3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_tt = true; }
-    hipLaunchKernelGGL((k_factor3<true, false>), dim3((count + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, first, count, FRONT_TOP, 0);
+    hipLaunchKernelGGL((k_factor3<true, false>), dim3((count + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, first, count, FRONT_TOP, 0, count);
 }
 void launch_backsolve_tree(const DevGraph &d, int first, int count, int max_npiv, int max_f, hipStream_t st) {
     if (count <= 0) return;                                          // positions [first, first + count), root first
@@ -2017,7 +2219,7 @@ void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f,
         if (!attr_set_3) { (void)hipFuncSetAttribute((const void *)k_factor3<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_3 = true; }
         static size_t lds3 = 0;                                      // GS_F3_LDS_KB: occupancy experiments (more LDS per block = fewer resident blocks)
         if (lds3 == 0) { lds3 = (size_t)MF_IMG * 4 * sizeof(double); if (const char *e = getenv("GS_F3_LDS_KB")) lds3 = std::max(lds3, (size_t)atoi(e) * 1024); }
-        hipLaunchKernelGGL((k_factor3<false, false>), dim3((count + 3) / 4), dim3(256), lds3, st, d, level_off, count, mode, 0);
+        hipLaunchKernelGGL((k_factor3<false, false>), dim3((count + 3) / 4), dim3(256), lds3, st, d, level_off, count, mode, 0, count);
         return;
     }
     if (max_f <= 63 && d.factor_variant == 2) {
