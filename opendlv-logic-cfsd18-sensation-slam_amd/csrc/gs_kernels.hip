@@ -1363,7 +1363,10 @@ __device__ __forceinline__ double rcp_f64(double x) {             // reciprocal 
 }
 
 // the pivots of the panel k0 .. k0+3 on its four columns, one row per lane: p <- l (0 above the diagonal, 1 on it), dd <- the pivots (0
-// for a column that is not a pivot)
+// for a column that is not a pivot).  (Measured alternative: every lane factorises the 4 x 4 diagonal block itself from LDS
+// broadcast reads and eliminates its own row against it — bit-identical, no lane broadcasts in the chain of four
+// reciprocals, 35 more VALU instructions per panel: the chain of the upper levels unchanged, the leaf level slower,
+// factor 0.179 against 0.170 ms.)
 __device__ __forceinline__ void f3_panel_pivots(int k0, bool &bad, double (&p)[4], double (&dd)[4], int npiv, int lane) {    // k0 (first pivot of the panel): uniform
     // one pivot of the panel.  If every column of this panel is a pivot (all panels of a front but possibly the last)
     // there are no uniform branches between the pivots and no merges of the p[] registers after them.
@@ -1535,15 +1538,20 @@ __device__ __forceinline__ bool f3_block_panel(int B, bool &bad, v4d (&acc)[3], 
     wave_lds_sync();
     return true;
 }
-// one child into the image by source, 256 threads: element 256 k + tid, k < 4 (matrices up to 1024 doubles), the rest in a loop
-__device__ __forceinline__ void f3_block_child(double *img, const double *Uc, int usz, int tab, const int (&rc)[4], int tid) {
-    int dst[4]; double st[4], o[4];
+// children into the image by source, 256 threads: element 256 k + tid, k < 4 (matrices up to 1024 doubles), the rest in a loop
+__device__ __forceinline__ void f3_block_places(int tab, const int (&rc)[4], int usz, int tid, int (&dst)[4]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int pl = (__shfl(tab, rc[k] & 0xff, WAVE) & 0xffff) + (int)((uint32_t)__shfl(tab, rc[k] >> 8, WAVE) >> 16);
-        dst[k] = (256 * k + tid < usz) ? pl : 1; }
+        dst[k] = (256 * k + tid < usz) ? pl : 1;
+        asm volatile("" : "+v"(dst[k])); }                           // computed HERE (before the caller's wait)
+}
+__device__ __forceinline__ void f3_block_loads(const double *Uc, int usz, int tid, double (&st)[4]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) st[k] = ld_off_coh(Uc, (uint32_t)min(256 * k + tid, usz) * 8u);
+}
+__device__ __forceinline__ void f3_block_scatter(double *img, const double *Uc, int usz, int tab, int tid, const int (&dst)[4], const double (&st)[4]) {
+    double o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = img[dst[k]];
 #pragma unroll
@@ -1618,20 +1626,31 @@ __device__ __forceinline__ void f3_block_front(const DevGraph &d, int pos, int l
         }
     }
     F3B_TS(5);
-    // ---- the children, by source, in list order; a barrier between two children (their places overlap)
+    // ---- the children, by source, in list order, two at a time: places before the waits, both children's loads in flight
+    // together, a barrier between two children's read-add-writes (their places overlap)
     if (fr.nchild > 0) {
         const bool plain = fr.level == 1 && leaf_slot != 0;
         const int32_t *xt = d.f3_x + fr.x_tab;
         bool okw = true;
-        for (int e = 0; e < fr.nchild; ++e) {
-            int tab, c_id, c_uoff, c_usz;
-            if (e == 0) { tab = tab0; c_id = fr.c_id[0]; c_uoff = fr.c_uoff[0]; c_usz = fr.c_usize[0]; }
-            else if (e == 1) { tab = tab1; c_id = fr.c_id[1]; c_uoff = fr.c_uoff[1]; c_usz = fr.c_usize[1]; }
-            else { tab = xt[e * F3X + lane]; const int h = xt[e * F3X + 64 + (lane & 7)];
-                c_id = __builtin_amdgcn_readlane(h, 0); c_uoff = __builtin_amdgcn_readlane(h, 1); c_usz = __builtin_amdgcn_readlane(h, 2); }
-            if (!plain) okw = f3_wait_flag(d.done_f + c_id, d.epoch) && okw;
-            f3_block_child(img, d.Uimg + c_uoff, c_usz, tab, rc, tid);
+        for (int e = 0; e < fr.nchild; e += 2) {
+            const bool hasB = e + 1 < fr.nchild;
+            int tA, a_id, a_uoff, a_usz, tB, b_id, b_uoff, b_usz;
+            if (e == 0) { tA = tab0; a_id = fr.c_id[0]; a_uoff = fr.c_uoff[0]; a_usz = fr.c_usize[0];
+                          tB = tab1; b_id = fr.c_id[1]; b_uoff = fr.c_uoff[1]; b_usz = fr.c_usize[1]; }
+            else { const int eb = hasB ? e + 1 : e;
+                tA = xt[e * F3X + lane]; const int hA = xt[e * F3X + 64 + (lane & 7)]; tB = xt[eb * F3X + lane]; const int hB = xt[eb * F3X + 64 + (lane & 7)];
+                a_id = __builtin_amdgcn_readlane(hA, 0); a_uoff = __builtin_amdgcn_readlane(hA, 1); a_usz = __builtin_amdgcn_readlane(hA, 2);
+                b_id = __builtin_amdgcn_readlane(hB, 0); b_uoff = __builtin_amdgcn_readlane(hB, 1); b_usz = __builtin_amdgcn_readlane(hB, 2); }
+            int dA[4], dB[4]; double sA[4], sB[4];
+            f3_block_places(tA, rc, a_usz, tid, dA);
+            if (hasB) f3_block_places(tB, rc, b_usz, tid, dB);
+            if (!plain) okw = f3_wait_flag(d.done_f + a_id, d.epoch) && okw;
+            f3_block_loads(d.Uimg + a_uoff, a_usz, tid, sA);
+            if (hasB) { if (!plain) okw = f3_wait_flag(d.done_f + b_id, d.epoch) && okw;
+                f3_block_loads(d.Uimg + b_uoff, b_usz, tid, sB); }
+            f3_block_scatter(img, d.Uimg + a_uoff, a_usz, tA, tid, dA, sA);
             __syncthreads();
+            if (hasB) { f3_block_scatter(img, d.Uimg + b_uoff, b_usz, tB, tid, dB, sB); __syncthreads(); }
         }
         if (!okw && tid == 0) atomicMax(d.fail, 2);
     }
