@@ -448,6 +448,31 @@ def test_irregular_graphs_one_step_matches_oracle(pkg, po, shape):
 
 
 # ---------------------------------------------------------------- f-1: the Slam host mirror (performSLAM graph side)
+@pytest.mark.parametrize("seed,shape", [(506, dict(n_poses=120, n_lms=18, obs_per_pose=3, extra_pp=6, dup_edges=1)),
+                                        (500, dict(n_poses=120, n_lms=18, obs_per_pose=2, extra_pp=6, dup_edges=1)),
+                                        (500, dict(n_poses=60, n_lms=18, obs_per_pose=3, extra_pp=6, dup_edges=1))])
+def test_fat_update_matrices_on_the_matrix_core_kernels(pkg, po, monkeypatch, seed, shape):
+    """Fronts of at most 63 scalars whose children hand up update matrices of 46-52 boundary rows (1100-1430 doubles) and
+    that have up to 7 children: beyond the 896 / 1024 elements a lane / thread of the wave-per-front / four-wave kernels
+    keeps in registers, so the tail loops of the by-source scatter and of the Schur complement store run.  One Gauss-Newton
+    step against the oracle in every launch mode, and the modes bit for bit against each other."""
+    g = random_graph(seed, **shape)
+    og = make_oracle_graph(po, g); og.build_system(); og.apply_update(og.solve_ldlt(0)); dp_o, dl_o = og.delta()
+    scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
+    outs = []
+    for env in ({}, {"GS_BLOCK_FRONTS": "0"}, {"GS_TREE": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        G = fresh(pkg, g); done, st = G.optimize(1); dp, dl = G.export_delta()
+        assert st.max_front <= 63 and done == 1 and st.numeric_failure == 0, (env, st.max_front)
+        assert np.abs(dp - dp_o).max() / scale < 1e-9 and np.abs(dl - dl_o).max() / scale < 1e-9, env
+        outs.append((dp.copy(), dl.copy())); G.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    for dp, dl in outs[1:]:
+        assert np.array_equal(dp, outs[0][0]) and np.array_equal(dl, outs[0][1])
+
+
 @pytest.mark.parametrize("quirks", [0, 1])
 def test_slam_mirror_frame_by_frame_matches_reference_logic(pkg, quirks):
     """csrc/gs_slam.cpp (C++ over the HIP C-ABI) against tests/ref_slam.py (the reference's performSLAM / addConesToMap /
