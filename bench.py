@@ -255,6 +255,30 @@ def main():
         # 27.4 — so nothing is subtracted)
         lin_in = phases.ms_linearize
         out["phases_ms"]["event_overhead"] = phases.ms_event_overhead
+        # ---- the solver (A8) against its own bytes: every L and update-matrix double is written once and read once, every
+        # block of H read once.  Dependent latency bounds it, not bandwidth; the entry says by how much, and how close the
+        # measured HBM traffic (committed PMC measurement, same rule as roofline.traffic) is to that minimum.
+        h_bytes = 8 * (9 * N + 9 * G.n_pp + 6 * G.n_pl + 5 * M)
+        sol_alg = 2 * plan.factor_bytes + h_bytes
+        sol_ms = phases.ms_factor + phases.ms_backsolve
+        sol_traffic, sol_src = None, None
+        try:
+            from make_pmc_json import solver_hash
+            for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+                if fn.endswith("_solver_pmc.json"):
+                    pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                    w = pm.get("workloads", {}).get(args.workload)
+                    if w and pm.get("solver_source_sha256") == solver_hash():
+                        sol_traffic = w["traffic_bytes_per_iteration"]
+                        sol_src = "committed_measurement profiles/%s (solver source sha256 %s...)" % (fn, pm["solver_source_sha256"][:12])
+                    break
+        except Exception:
+            sol_traffic = None
+        out["solver"] = dict(kernels="k_factor3 (leaf + tree launch) + k_backsolve3 (tree launch + leaf levels), A8", ms_per_iteration=sol_ms,
+                             algorithmic_bytes=sol_alg, achieved=sol_alg / (sol_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=sol_alg / (sol_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=sol_traffic, traffic_source=sol_src,
+                             bound="dependent latency of the elimination tree (levels in sequence), instruction issue in the leaf level; not HBM",
+                             note="algorithmic_bytes = 2 x (L + update matrices) + H blocks read once")
         inside = alg_bytes / (lin_in * 1e-3) / 1e9
         out["roofline"].update(achieved=inside, frac=inside / HBM_PEAK_GBS, ms_per_launch=lin_in,
                                achieved_back_to_back=achieved, ms_per_launch_back_to_back=lin_ms,
