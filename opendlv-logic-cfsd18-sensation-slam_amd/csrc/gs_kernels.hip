@@ -1966,9 +1966,9 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int fi = blockIdx.x * 4 + wave;
     if (fi >= count) return;
-    const bool ts_on = (d.dbg & 8) && count == (d.dbg >> 8) && fi == 0;
-    F3_TS(32);
     const int pos = TREE ? level_off + (count - 1 - fi) : level_off + fi;
+    const bool ts_on = ((d.dbg & 8) && count == (d.dbg >> 8) && fi == 0) || ((d.dbg & 16) && pos == (d.dbg >> 8));   // 16: probe the front at a level POSITION
+    F3_TS(32);
     const F3 fr = f3_load(d.f3_desc, pos, lane);
     const int npiv = fr.npiv, nbnd = fr.nbnd, f = npiv + nbnd, ldl = f + 1, lds = (f + 1) | 1;
     F3_TS(33);

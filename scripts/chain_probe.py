@@ -24,3 +24,8 @@ us = lambda v: (int(v) - last) / 100.0
 print("front %d (level %d, npiv %d, nbnd %d), children done at %s us (last = 0)" % (fr, lev, P.npiv[fr], P.nbnd[fr], [round(us(v), 2) for v in t_k]))
 print("   start %.2f | originals assembled %.2f | children gathered %.2f | accumulators %.2f | panels start %.2f | panels done %.2f | done stamp %.2f | stores drained (probe only) %.2f"
       % (us(ts[0]), us(ts[5]), us(ts[9]), us(ts[10]), us(ts[6]), us(ts[7]), us(done[fr]), us(ts[8])))
+b = G.debug_front_times()[1]; par = int(P.parent[fr])
+if par >= 0 and ts[32]:
+    ub = lambda v: (int(v) - int(b[par])) / 100.0
+    print("backward solve: parent's done stamp = 0 | start %.2f | L in LDS %.2f | columns in registers, boundary values seen %.2f | mat-vec %.2f | substitution %.2f | done stamp %.2f | store drained (probe only) %.2f"
+          % (ub(ts[32]), ub(ts[34]), ub(ts[35]), ub(ts[36]), ub(ts[37]), ub(b[fr]), ub(ts[38])))
