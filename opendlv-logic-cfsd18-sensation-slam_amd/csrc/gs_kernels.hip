@@ -2373,7 +2373,11 @@ __global__ void __launch_bounds__(256) k_update(DevGraph d) {
     // the failure flag is up (zero pivot, a whole-tree launch that gave up on a flag, or — pose-window shards — a
     // failure any rank reported with its contribution) no update is applied any more.  fail[1] counts applied updates.
     const bool peer_failed = d.xfail_off >= 0 && d.exchange[d.xfail_off] != 0.0;
-    const bool stop = d.fail[0] != 0 || peer_failed || d.fail[2] != 0;       // fail[2]: gs_optimize_until's stop rule fired in an earlier iteration
+    // fail[2]: the iteration in which gs_optimize_until's stop rule fired (0: not yet).  Only an EARLIER iteration's verdict
+    // gates this launch: the block that evaluates the rule below writes it while other blocks of the same launch may still
+    // be reading — with the iteration number in the flag they all see "not before this iteration" whatever the timing.
+    const int conv_it = d.fail[2];
+    const bool stop = d.fail[0] != 0 || peer_failed || (conv_it != 0 && conv_it < d.iter);
     if (t == 0) { if (stop) { if (peer_failed) atomicMax(d.fail, 3); } else atomicAdd(d.fail + 1, 1); }
     // pose-window shards: a rank only tracks the vertices of its own subtrees and of the shared top
     if (stop) { }
@@ -2406,7 +2410,7 @@ __global__ void __launch_bounds__(256) k_update(DevGraph d) {
         // is within conv_tol (relative) of the previous one, no later update is applied
         if (threadIdx.x == 0 && d.conv_tol >= 0.0 && !stop) {
             const double prev = d.chi2[70];
-            if (prev >= 0.0 && fabs(prev - tot) <= d.conv_tol * tot) d.fail[2] = 1;
+            if (prev >= 0.0 && fabs(prev - tot) <= d.conv_tol * tot) d.fail[2] = d.iter;
             d.chi2[70] = tot;
         }
     }
