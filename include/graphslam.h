@@ -62,7 +62,7 @@ typedef struct gs_config {
     int32_t leaf_poses;         /* nested-dissection leaf size in poses; 0 = default        */
     int32_t factor_variant;     /* front factorisation kernel: 0 = default (3 when every front has <= 63
                                    scalars, else 4); 3 = wave-per-front LDL^T on the fp64 matrix cores
-                                   (v_mfma_f64_16x16x4_f64), children gathered by destination;
+                                   (v_mfma_f64_16x16x4_f64), update matrices moved in storage order;
                                    2 = wave-per-front Cholesky on the matrix cores; 1 = wave-per-front
                                    VALU; 4 = block-per-front VALU, any front size.  1-3 need every front
                                    <= 63 scalars and fall back to 4 otherwise                      */

@@ -509,7 +509,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
                 if (tot >= ((int64_t)1 << 31)) return fail(GS_ERR_INVALID, "update-matrix arena beyond 32-bit offsets"); }
             AL(Uimg, (size_t)tot + 2); ZERO(Uimg, (size_t)tot + 2); }
           UP(u3_off, u3_off); UP(u3_size, u3_size);
-          AL(done_f, P.fronts.size()); ZERO(done_f, P.fronts.size()); AL(done_b, P.fronts.size()); ZERO(done_b, P.fronts.size());
+          AL(done_f, P.fronts.size()); ZERO(done_f, P.fronts.size());
           d.epoch = 0; d.tree = 1;                                    // whole-tree launches for this rank's own subtrees (GS_TREE=0: one launch per level)
           if (const char *e = std::getenv("GS_TREE")) d.tree = std::atoi(e) != 0 ? 1 : 0;
           // ---- everything below is expanded ON THE DEVICE from the compact plan arrays

@@ -71,7 +71,7 @@ struct DevGraph {
     // per-front inverse row maps into the parent (formats: gs_kernels.hip, "variant 3")
     int32_t *f3_x = nullptr;                                    // row tables + headers of the third and later children of a front (72 ints per child)
     int32_t *f3_desc = nullptr, *asm3 = nullptr, *pinv = nullptr, *sc3 = nullptr, *lm3 = nullptr, *u3_off = nullptr, *u3_size = nullptr;
-    int32_t *done_f = nullptr, *done_b = nullptr; int32_t epoch = 0, tree = 0;   // whole-tree launches: per-front completion flags (= epoch when done)
+    int32_t *done_f = nullptr; int32_t epoch = 0, tree = 0;     // whole-tree factor launches: per-front completion flags (= epoch when done); the backward solve polls xe itself
     double *H_arena = nullptr;                                  // Hpp_diag | b_pose | Hpp_off | Hpl | lm_part | Hll_diag | b_lm, one allocation
     // pose-window shards (world == 1: everything is "own", no exchange)
     int32_t rank = 0, wt_lo = 0, wt_hi = 0;                     // this shard sweeps wave tiles [wt_lo, wt_hi)

@@ -394,7 +394,7 @@ def test_leaf_size_does_not_change_the_answer(pkg, bench_graphs):
 def test_factor_kernel_variants_match_oracle(pkg, po, bench_graphs, variant):
     """4 = block-per-front VALU (any front size), 1 = wave-per-front VALU, 2 = wave-per-front Cholesky on the fp64 matrix
     cores (v_mfma_f64_16x16x4_f64, update matrices as 16x16 tile images), 3 = the default: latency-shaped matrix-core
-    kernels (LDL^T panels, children gathered by destination, flat descriptors).  Same plan, same answer."""
+    kernels (LDL^T panels, update matrices moved in storage order, flat descriptors).  Same plan, same answer."""
     for N, M in ((1000, 200), (10000, 2000)):
         _, g = bench_graphs(N, M)
         og = make_oracle_graph(po, g); og.optimize(4, ordering=1)
