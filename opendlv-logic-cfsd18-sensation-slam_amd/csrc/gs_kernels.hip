@@ -1997,7 +1997,8 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
 #pragma unroll
         for (int r = 0; r < 64; ++r) l21[r] = S[me * lds + npiv + min(r, nb1)];
 #pragma unroll
-        for (int cc = 1; cc < 32; ++cc) lcol[cc] = S[min(min(lane, cc - 1), npiv - 1) * lds + min(cc, f)];
+        for (int cc = 1; cc < 32; ++cc) { lcol[cc] = S[min(min(lane, cc - 1), npiv - 1) * lds + min(cc, f)];
+            lcol[cc] = lane < cc ? lcol[cc] : 0.0; }                  // the mask of the substitution step goes into the coefficient HERE, before the wait
         w = S[me * lds + f];
         double xb = 0.0;                                             // 0 beyond the boundary: those terms vanish
         if (nbnd > 0) {                                              // the boundary rows belong to the ancestors: poll the values themselves
@@ -2011,16 +2012,16 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
         }
         F3_TS(35);
 #pragma unroll
-        for (int r0 = 0; r0 < 64; r0 += 16) if (r0 < nbnd) {         // uniform
+        for (int r0 = 0; r0 < 64; r0 += 8) if (r0 < nbnd) {          // uniform; groups of 8: at most 7 terms beyond the boundary (their x is 0)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) w -= l21[r0 + j] * lane_bcast(xb, r0 + j); }
+            for (int j = 0; j < 8; ++j) w -= l21[r0 + j] * lane_bcast(xb, r0 + j); }
         F3_TS(36);
         for (int cc = npiv - 1; cc >= 32; --cc) {                    // fronts with more than 32 pivots: the upper steps from LDS
             const double lv = S[min(lane, cc - 1) * lds + cc]; const double xcc = lane_bcast(w, cc);
             if (lane < cc) w -= lv * xcc; }
 #pragma unroll
         for (int cc = 31; cc >= 1; --cc) if (cc < npiv) {            // uniform
-            const double xcc = lane_bcast(w, cc); if (lane < cc) w -= lcol[cc] * xcc; }
+            const double xcc = lane_bcast(w, cc); w -= lcol[cc] * xcc; }   // lanes >= cc: coefficient 0 (a select per step was half of the step's dependent chain)
     } else {
         const double xb = (row >= 0) ? d.xe[row] : 0.0;
         wave_lds_sync();
