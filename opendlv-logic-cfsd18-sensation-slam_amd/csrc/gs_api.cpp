@@ -664,19 +664,24 @@ static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int
         ++g->d.epoch;
         // leaf instance: level 0 only if its fronts really have no children (always true for an elimination tree's level 0)
         if (g->leaf_n < 0) {                                          // once per plan
-            int n_leaf = ls.start[1], slot = 256; g->leaf_max_f = 0;
+            int n_leaf = ls.start[1], F_leaf_all = 0, slot = 256; g->leaf_max_f = 0;
             for (int q = 0; q < n_leaf; ++q) { const Front &F = g->plan.fronts[g->plan.level_fronts_owned[q]];
                 g->leaf_max_f = std::max(g->leaf_max_f, F.npiv + F.nbnd);
                 if (F.child_cnt != 0) { n_leaf = 0; break; }
                 slot = std::max(slot, (((F.npiv + F.nbnd + 1) | 1) * F.npiv + 1) & ~1); }
-            if (const char *e = std::getenv("GS_LEAF_KERNEL")) if (std::atoi(e) == 0) n_leaf = 0;
+            F_leaf_all = n_leaf;                                        // GS_LEAF_KERNEL=2: leaf launches whatever their number
+            // few leaves (all resident at once anyway: <= GS_LEAF_MIN, default 2048): no separate leaf launches, the whole-tree
+            // launches take level 0 as well — two kernel boundaries less per iteration (cfg1-cfg3: 6-11 % of it)
+            { int lmin = 2048; if (const char *e = std::getenv("GS_LEAF_MIN")) lmin = std::atoi(e);
+              if (n_leaf <= lmin) n_leaf = 0; }
+            if (const char *e = std::getenv("GS_LEAF_KERNEL")) { if (std::atoi(e) == 0) n_leaf = 0; else if (std::atoi(e) == 2) n_leaf = F_leaf_all; }
             g->leaf_n = n_leaf; g->leaf_slot = slot; }
         // the upper levels — few fronts, all of them in the dependent chain — get four waves per front: whole levels from the
         // top down while a level has at most GS_BLOCK_FRONTS (512) fronts (those workgroups are all resident at once)
         if (g->block_n < 0) { int thr = 512; if (const char *e = std::getenv("GS_BLOCK_FRONTS")) thr = std::atoi(e);
             int nb = 0;
-            for (int l = nlev - 1; l >= 1; --l) { const int nl = ls.start[l + 1] - ls.start[l];
-                if (nl > thr || (l == 1 && g->leaf_n == 0)) break;
+            for (int l = nlev - 1; l >= (g->leaf_n > 0 ? 1 : 0); --l) { const int nl = ls.start[l + 1] - ls.start[l];
+                if (nl > thr) break;
                 nb += nl; }
             g->block_n = std::min(nb, ls.start[nlev] - std::max(g->leaf_n, 0)); }
         launch_factor_tree(g->d, g->leaf_n, g->leaf_slot, g->leaf_max_f, ls.start[nlev], g->block_n, g->stream); return; }

@@ -1666,6 +1666,7 @@ __device__ __forceinline__ void f3_block_front(const DevGraph &d, int pos, int l
     bool go = true, bad = false;
 #pragma clang loop unroll(disable)
     for (int B = 0; B < 16 && go; ++B) go = f3_block_panel(B, bad, acc, Pn, Pw, L, npiv, f, wave, lane);
+    if (d.inject_iter != 0 && d.iter == d.inject_iter && pos == 0 && tid == 0) atomicMax(d.fail, d.inject_code);   // gs_debug_fail_at_iteration (fault injection for tests)
     if (bad && tid == 0) atomicMax(d.fail, 1);
     F3B_TS(7);
     // ---- Schur complement out through the image, contiguous stores

@@ -411,11 +411,12 @@ def test_factor_kernel_variants_match_oracle(pkg, po, bench_graphs, variant):
 
 
 @pytest.mark.parametrize("env", [{"GS_TREE": "0"}, {"GS_LEAF_KERNEL": "0"}, {"GS_TREE": "0", "GS_FACTOR_VARIANT": "3"},
-                                 {"GS_BLOCK_FRONTS": "0"}, {"GS_BLOCK_FRONTS": "16"}])
+                                 {"GS_BLOCK_FRONTS": "0"}, {"GS_BLOCK_FRONTS": "16"}, {"GS_LEAF_KERNEL": "2"},
+                                 {"GS_LEAF_KERNEL": "2", "GS_BLOCK_FRONTS": "0"}])
 def test_solver_launch_modes_give_the_same_answer(pkg, po, bench_graphs, monkeypatch, env):
     """The default solver runs one flagged launch for all levels above the leaves plus leaf-instance launches; the
     same kernels also run one launch per level (GS_TREE=0, what the shared top of a sharded graph uses) and without
-    the leaf instances (GS_LEAF_KERNEL=0).  The upper levels of the whole-tree launch give a front four waves instead of
+    the leaf instances (GS_LEAF_KERNEL=0; the default below 2 049 leaves, 2 forces them).  The upper levels of the whole-tree launch give a front four waves instead of
     one (levels of at most GS_BLOCK_FRONTS fronts; at this size the default puts every level above the leaves there, 0
     none, 16 the top five).  Every mode must agree with the oracle and, bit for bit, with the default."""
     _, g = bench_graphs(10000, 2000)
