@@ -216,6 +216,11 @@ int gs_debug_front_times(gs_graph *g, int64_t *out, int64_t capacity);
 /* Fault injection (tests of the failure semantics; the reference has none): the k-th iteration enqueued after
  * this call reports `code` (1 = zero pivot, 2 = front-flag timeout) from its first front; k = 0 disarms. */
 int gs_debug_fail_at_iteration(gs_graph *g, int32_t k, int32_t code);
+/* The factor-kernel variant a plan with the given largest front and H-arena size (doubles) is given for a requested variant
+ * (gs_config.factor_variant; 0 = default): 3 = matrix-core LDL^T fronts with 32-bit byte offsets into the arena (fronts <= 63
+ * scalars, arena < 2^29 doubles), 4 = block-per-front kernel with 64-bit addressing (anything else).  Pure function; what
+ * gs_initialize_optimization applies.  No reference counterpart. */
+int gs_debug_select_factor_variant(int32_t requested, int32_t max_front, int64_t arena_doubles);
 
 int64_t gs_linearize_bytes(gs_graph *g);
 int  gs_export_system(gs_graph *g, double *Hpp_diag, double *Hll_diag, double *Hpp_off,
@@ -326,6 +331,11 @@ int  gs_slam_collect_flush(gs_slam *s, const double pose_xytheta[3], int32_t *k_
 /* the first half of gs_slam_collect_flush alone: extract the leftmost lastObjectId + 1 columns and reset the collector */
 int  gs_slam_collect_extract(gs_slam *s, int32_t *k_out, double *cones_out_4xk);
 int  gs_slam_encode_cones(gs_slam *s, int32_t cones_per_packet, float *azimuth_deg, float *distance, int32_t *type);
+/* gs_cone_encode <- Cone::getDirection / Cone::getDistance (src/cone.cpp:34-53) for ONE cone seen from `pose`: the float32
+ * azimuthAngle (degrees) and distance fields (zenithAngle is always 0).  reference_quirks != 0 keeps the reference's unit slip
+ * (heading * 1 / RAD2DEG, src/cone.cpp:37-39).  Stateless; gs_slam_encode_cones calls it per cone.  Pinned against the reference's
+ * own cone.cpp (oracle/_ref/libref_cone.so, tests/test_cone.py). */
+int  gs_cone_encode(const double cone_xy[2], const double pose_xytheta[3], int32_t reference_quirks, float *azimuth_deg, float *distance);
 /* ---- odometry intake and pose output (row f-4), host side -------------------------
  * gs_wgs84_to_cartesian / gs_wgs84_from_cartesian <- wgs84::toCartesian / fromCartesian (src/WGS84toCartesian.hpp:39-113,
  *      119-146): ellipsoidal polyconic projection about the reference point and its step-search inverse; arrays are

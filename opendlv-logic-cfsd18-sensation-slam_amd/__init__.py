@@ -7,7 +7,7 @@ The directory name contains hyphens, import it with
     importlib.import_module("opendlv-logic-cfsd18-sensation-slam_amd")
 """
 from . import binding, track  # noqa: F401
-from .binding import Config, Graph, GsError, Shell, Slam, Stats, default_config, device_count, wgs84_from_cartesian, wgs84_to_cartesian  # noqa: F401
+from .binding import Config, Graph, GsError, Shell, Slam, Stats, cone_encode, default_config, device_count, wgs84_from_cartesian, wgs84_to_cartesian  # noqa: F401
 
 
 def build(force=False):

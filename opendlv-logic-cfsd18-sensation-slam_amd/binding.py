@@ -133,6 +133,7 @@ def lib():
     L.gs_optimize.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
     L.gs_optimize_until.argtypes = [vp, C.c_int32, C.c_double, C.POINTER(Stats)]
     L.gs_debug_fail_at_iteration.argtypes = [vp, C.c_int32, C.c_int32]
+    L.gs_debug_select_factor_variant.argtypes = [C.c_int32, C.c_int32, C.c_int64]
     L.gs_chi2.argtypes = [vp, _dp]
     L.gs_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.gs_time_linearize.argtypes = [vp, C.c_int32, _dp]
@@ -171,6 +172,7 @@ def lib():
     L.gs_slam_collect_type.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.gs_slam_collect_flush.argtypes = [vp, _dp, C.POINTER(C.c_int32), _dp]
     L.gs_slam_encode_cones.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    L.gs_cone_encode.argtypes = [_dp, _dp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.gs_wgs84_to_cartesian.argtypes = [_dp, _dp, _dp]
     L.gs_wgs84_from_cartesian.argtypes = [_dp, _dp, _dp]
     L.gs_slam_set_gps_reference.argtypes = [vp, C.c_double, C.c_double]
@@ -507,6 +509,8 @@ class Slam:
         if getattr(self, "h", None) and self._owned:
             self.L.gs_slam_destroy(self.h)
         self.h = None
+        if getattr(self, "graph", None) is not None:
+            self.graph.h = None                    # borrowed from the slam handle: gone with it (a NULL handle is refused by the C-ABI)
 
     def __del__(self):
         try:
@@ -571,6 +575,14 @@ class Slam:
         return az, di, ty
 
 
+def cone_encode(cone_xy, pose, reference_quirks=0):
+    """Product implementation of Cone::getDirection / getDistance (reference src/cone.cpp:34-53): (azimuth deg, distance) as float32."""
+    L = lib(); az, di = C.c_float(), C.c_float(); c = _f64(cone_xy); p = _f64(pose)
+    rc = L.gs_cone_encode(_d(c), _d(p), int(reference_quirks), C.byref(az), C.byref(di))
+    if rc != 0: raise GsError(rc, (L.gs_last_error() or b"").decode())
+    return np.float32(az.value), np.float32(di.value)
+
+
 def wgs84_to_cartesian(ref_latlon, pos_latlon):
     """Product implementation of the reference's wgs84::toCartesian (host side, no device needed)."""
     L = lib(); o = np.zeros(2); r = _f64(ref_latlon); p = _f64(pos_latlon)
@@ -607,6 +619,8 @@ class Shell:
     def close(self):
         if getattr(self, "h", None):
             self.L.gs_shell_destroy(self.h)
+            self.slam.h = None                     # the shell owned it: the borrowed handles must not outlive it
+            self.slam.graph.h = None
         self.h = None
 
     def __del__(self):

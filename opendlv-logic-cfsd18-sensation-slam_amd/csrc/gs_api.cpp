@@ -369,6 +369,7 @@ static void se2_inverse_host(const double *a, double *out) {
 // and the observation edges as inserted (permuted into the ELL layout on the device afterwards).
 struct RawUpload {
     std::thread th; int rc = GS_OK; std::string err;
+    ~RawUpload() { if (th.joinable()) th.join(); }                  // an exception (bad_alloc in the plan build) must not meet a joinable thread: std::terminate
     int32_t *pl_l = nullptr; double *pl_z = nullptr, *pl_info = nullptr;
     std::vector<double> zinv;
 };
@@ -444,11 +445,12 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
         }
     } else if (P.world > 1) return fail(GS_ERR_INVALID, "pose-window shards need the fused linearisation layout (<= 32 observations per pose)");
     // block-sparse H and b live in ONE arena (the variant-3 front assembly addresses every scalar by its offset in it)
-    int64_t arena_off[8];
+    int64_t arena_off[8], arena_doubles = 0;
     { const int64_t sizes[7] = {(int64_t)N * 6, (int64_t)N * 3, (int64_t)Epp * 9, (int64_t)P.ell_len * 6, (int64_t)d.n_groups * 5, (int64_t)M * 3, (int64_t)M * 2};
       arena_off[0] = 0;
       for (int k = 0; k < 7; ++k) arena_off[k + 1] = arena_off[k] + ((sizes[k] + 1) & ~(int64_t)1);       // 16-byte aligned parts
       if (arena_off[7] >= ((int64_t)1 << 31)) return fail(GS_ERR_INVALID, "graph too large for 32-bit arena offsets");
+      arena_doubles = arena_off[7];
       AL(H_arena, (size_t)arena_off[7] + 2);
       // blocks of edges / tiles this rank never evaluates must read as zero
       ZERO(H_arena, (size_t)arena_off[7] + 2);
@@ -490,8 +492,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
     // Cholesky on the matrix cores (first version); 1 = wave-per-front VALU; 4 = block-per-front VALU (any front size).
     { int v = g->default_factor_variant;
       if (const char *e = std::getenv("GS_FACTOR_VARIANT")) v = std::atoi(e);
-      if (v <= 0 || v > 4) v = 3;                                     // 0 = default
-      if (v != 4 && P.max_front > 63) v = 4;                          // the wave-per-front kernels hold a front in 64 lanes
+      v = gs_debug_select_factor_variant(v, P.max_front, arena_doubles);
       if (v == 4) v = 0;                                              // device-side code for the block-per-front kernel
       d.factor_variant = v;
       if (const char *e = std::getenv("GS_DBG")) d.dbg = std::atoi(e);
@@ -591,6 +592,20 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
     g->dev_valid = true; g->dev_estimates_newer = false;
     g->dev_estimate_version = h.estimate_version;
     return GS_OK;
+}
+
+// The factor kernel a plan gets (gs_config.factor_variant, GS_FACTOR_VARIANT overrides): 0 = default = 3.
+//   3 = wave-per-front LDL^T on the fp64 matrix cores, latency-shaped; 2 = wave-per-front Cholesky on the matrix cores (first
+//   version); 1 = wave-per-front VALU; 4 = block-per-front VALU (any front size, 64-bit addressing throughout).
+// Variants 1-3 hold a front in 64 lanes; variant 3 additionally names every scalar of the linearised system by a 32-bit BYTE
+// offset into H_arena ((uint32_t)record * 8 in the front kernels): beyond 2^29 doubles (4 GiB) those would wrap and assemble the
+// wrong entries silently, so such a graph gets variant 4.
+extern "C" int gs_debug_select_factor_variant(int32_t requested, int32_t max_front, int64_t arena_doubles) {
+    int v = requested;
+    if (v <= 0 || v > 4) v = 3;
+    if (v != 4 && max_front > 63) v = 4;
+    if (v == 3 && arena_doubles >= ((int64_t)1 << 29)) v = 4;
+    return v;
 }
 
 static int build_plan_host(gs_graph *g) {

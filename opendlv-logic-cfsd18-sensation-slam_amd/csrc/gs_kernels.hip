@@ -15,11 +15,19 @@
 //
 // All fp64; every sum has a fixed order (no floating-point atomics) so results are bitwise reproducible.
 #include "gs_device.hpp"
+#include <mutex>
+#include <set>
 #include <type_traits>
+#include <utility>
 
 namespace gs {
 
 static constexpr int WAVE = 64;
+// GS_G2O_ORDER (default 1): the edge residuals in g2o's operation order (inverse, then compose) without fused
+// multiply-adds; 0 = differences first (fewer rounding errors, but not the reference's numbers) — A/B builds only
+#ifndef GS_G2O_ORDER
+#define GS_G2O_ORDER 1
+#endif
 
 // constants exactly as the reference declares them (src/slam.hpp:134-136; PI is a FLOAT literal)
 __device__ static constexpr double kDeg2Rad = 0.017453292522222;
@@ -29,6 +37,7 @@ __device__ static constexpr double kPi = 3.14159265358979323846;
 
 // g2o normalize_theta
 __device__ __forceinline__ double normalize_theta(double th) {
+#pragma clang fp contract(off)                                      // m * 2 pi is rounded before the subtraction, as on the CPU path
     if (th >= -kPi && th < kPi) return th;
     double m = floor(th / (2.0 * kPi));
     th = th - m * 2.0 * kPi;
@@ -172,29 +181,21 @@ void launch_frame_frontend(int k, const double *in, double lidar, int n_map, con
 __device__ __forceinline__ void edge_pl(double px, double py, double c, double s, double lx, double ly, double zx, double zy,
                                         double &ex, double &ey, double A0[3], double A1[3]) {
     double dx = lx - px, dy = ly - py;
+#if GS_G2O_ORDER
+    {   // g2o EdgeSE2PointXY::computeError: (x_p^-1 * l) - z with SE2::inverse() = (R^T (-t), -theta) and SE2 * point =
+        // R p + t, in g2o's operation order and without fused multiply-adds: at kilometre coordinates the two products
+        // cancel to the metre-sized residual and HOW they are rounded is 1e-12 m of it — the CPU path's rounding is the bar
+#pragma clang fp contract(off)
+        const double ix = -(c * px + s * py), iy = s * px - c * py;
+        ex = ((c * lx + s * ly) + ix) - zx;
+        ey = ((c * ly - s * lx) + iy) - zy;
+    }
+#else
     ex = (c * dx + s * dy) - zx;
     ey = (-s * dx + c * dy) - zy;
+#endif
     A0[0] = -c; A0[1] = -s; A0[2] = c * dy - s * dx;
     A1[0] = s;  A1[1] = -c; A1[2] = -s * dy - c * dx;
-}
-
-// EdgeSE2: e = vec(zinv * (xi^-1 * xj)), A = Z*Ji, B = Z*Jj (rows); zinv5 = (x, y, theta, cos, sin) of z^-1
-__device__ __forceinline__ void edge_pp(const double xi[3], const double xj[3], double ci, double si,
-                                        const double zinv5[5], double e[3], double A[3][3], double B[3][3]) {
-    double dx = xj[0] - xi[0], dy = xj[1] - xi[1];
-    double rx = ci * dx + si * dy, ry = -si * dx + ci * dy;           // rel = xi^-1 * xj
-    double rth = normalize_theta(normalize_theta(-xi[2]) + xj[2]);
-    double cz = zinv5[3], sz = zinv5[4];
-    e[0] = zinv5[0] + (cz * rx - sz * ry);
-    e[1] = zinv5[1] + (sz * rx + cz * ry);
-    e[2] = normalize_theta(zinv5[2] + rth);
-    double Ji[3][3] = {{-ci, -si, -si * dx + ci * dy}, {si, -ci, -ci * dx - si * dy}, {0.0, 0.0, -1.0}};
-    double Jj[3][3] = {{ci, si, 0.0}, {-si, ci, 0.0}, {0.0, 0.0, 1.0}};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        A[0][c] = cz * Ji[0][c] - sz * Ji[1][c]; A[1][c] = sz * Ji[0][c] + cz * Ji[1][c]; A[2][c] = Ji[2][c];
-        B[0][c] = cz * Jj[0][c] - sz * Jj[1][c]; B[1][c] = sz * Jj[0][c] + cz * Jj[1][c]; B[2][c] = Jj[2][c];
-    }
 }
 
 // One observation edge: everything constructQuadraticForm produces, packed symmetric.
@@ -239,7 +240,7 @@ template <bool WRITE_H>
 __device__ __forceinline__ double pp_incidence(const DevGraph &d, int k, int role, const double xi[3], const double xj[3],
                                                double ci, double si, const double zinv5[5], const double w[6],
                                                bool fi, bool fj, double H[6], double b[3]) {
-    // Structure of the EdgeSE2 Jacobians (edge_pp above): with M = rot(z^-1) * R_i^T = [[m0, m1], [-m1, m0]],
+    // Structure of the EdgeSE2 Jacobians (g2o EdgeSE2::linearizeOplus): with M = rot(z^-1) * R_i^T = [[m0, m1], [-m1, m0]],
     //   B = [[m0, m1, 0], [-m1, m0, 0], [0, 0, 1]],   A = [-B(:,0), -B(:,1), a2],  a2 = (a02, a12, -1),
     // so with G = B^T W B and wa2 = W a2 everything needed is G (6), wa2 (3) and three dot products:
     //   A^T W A = [[g00, g01, -t0], [., g11, -t1], [., ., t2]],  A^T W B = [[-g00, -g01, -g02], [-g01, -g11, -g12], [t0, t1, wa2_2]],
@@ -249,7 +250,20 @@ __device__ __forceinline__ double pp_incidence(const DevGraph &d, int k, int rol
     const double rx = ci * dx + si * dy, ry = -si * dx + ci * dy;     // rel = xi^-1 * xj
     const double rth = normalize_theta(normalize_theta(-xi[2]) + xj[2]);
     const double cz = zinv5[3], sz = zinv5[4];
+#if GS_G2O_ORDER
+    double e0, e1;
+    {   // g2o EdgeSE2::computeError: z^-1 * (x_i^-1 * x_j) as inverse-then-compose (SE2::inverse = (R^T (-t), -theta), SE2 * SE2 =
+        // (R_a t_b + t_a, theta_a + theta_b)), every product rounded on its own (no fused multiply-add): at the reference's
+        // initial point these residuals are zero in exact arithmetic and what is computed IS the rounding — follow the CPU path's
+#pragma clang fp contract(off)
+        const double ix = -(ci * xi[0] + si * xi[1]), iy = si * xi[0] - ci * xi[1];
+        const double qx = ix + (ci * xj[0] + si * xj[1]), qy = iy + (ci * xj[1] - si * xj[0]);
+        e0 = zinv5[0] + (cz * qx - sz * qy); e1 = zinv5[1] + (sz * qx + cz * qy);
+    }
+    const double e2 = normalize_theta(zinv5[2] + rth);
+#else
     const double e0 = zinv5[0] + (cz * rx - sz * ry), e1 = zinv5[1] + (sz * rx + cz * ry), e2 = normalize_theta(zinv5[2] + rth);
+#endif
     const double w00 = w[0], w01 = w[1], w02 = w[2], w11 = w[3], w12 = w[4], w22 = w[5];
     const double We0 = w00 * e0 + w01 * e1 + w02 * e2, We1 = w01 * e0 + w11 * e1 + w12 * e2, We2 = w02 * e0 + w12 * e1 + w22 * e2;
     if (role == 0 && !(fi && fj)) chi = e0 * We0 + e1 * We1 + e2 * We2;
@@ -779,6 +793,14 @@ __global__ void __launch_bounds__(256) k_factor_level(DevGraph d, int level_off,
 }
 
 static constexpr int LDS_LIMIT_BYTES = 160 * 1024;
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (function, DEVICE): a process that opens handles on two
+// devices must set it on each (a process-wide "done" flag would launch the 80 KB LDS kernels on the second device without it)
+static void allow_max_lds(const void *fn) {
+    static std::mutex mu; static std::set<std::pair<int, const void *>> done;
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.insert({dev, fn}).second) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES);
+}
 int factor_lds_limit_f() {
     int f = 1;
     while ((int64_t)(((f + 2) | 1)) * (f + 1) * 8 <= LDS_LIMIT_BYTES) ++f;
@@ -2204,10 +2226,7 @@ void launch_build_sc3(const int32_t *bf, const int32_t *asm3, int32_t *sc3, int3
 // whole-tree launches of variant 3 (own fronts of a single-GPU graph): every level in one kernel each
 void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int leaf_max_f, int count, int n_block, hipStream_t st) {
     if (count <= 0) return;
-    static bool attr_set_t = false;
-    if (!attr_set_t) { (void)hipFuncSetAttribute((const void *)k_factor3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_factor3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_factor3<true, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_t = true; }
+    allow_max_lds((const void *)k_factor3<true, false>); allow_max_lds((const void *)k_factor3<true, true>); allow_max_lds((const void *)k_factor3<true, true, 3>);
     // level 0 (no children) through the high-occupancy leaf instance (three tile rows when every leaf has <= 47 scalars),
     // everything above in one launch whose fronts wait on flags
     static int nt3 = -1; if (nt3 < 0) { nt3 = 1; if (const char *e = getenv("GS_LEAF_NT3")) nt3 = atoi(e) != 0; }
@@ -2221,45 +2240,39 @@ void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int leaf_m
 // children only): one flagged launch as well
 void launch_factor_tree_top(const DevGraph &d, int first, int count, hipStream_t st) {
     if (count <= 0) return;
-    static bool attr_set_tt = false;
-    if (!attr_set_tt) { (void)hipFuncSetAttribute((const void *)k_factor3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_tt = true; }
+    allow_max_lds((const void *)k_factor3<true, false>);
     hipLaunchKernelGGL((k_factor3<true, false>), dim3((count + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, first, count, FRONT_TOP, 0, count);
 }
 void launch_backsolve_tree(const DevGraph &d, int first, int count, int max_npiv, int max_f, hipStream_t st) {
     if (count <= 0) return;                                          // positions [first, first + count), root first
     const int slot = ((((max_f + 1) | 1) * max_npiv) + 1) & ~1;
-    static bool attr_set_bt = false;
-    if (!attr_set_bt) { (void)hipFuncSetAttribute((const void *)k_backsolve3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_bt = true; }
+    allow_max_lds((const void *)k_backsolve3<true>);
     hipLaunchKernelGGL(k_backsolve3<true>, dim3((count + 3) / 4), dim3(256), (size_t)slot * 4 * sizeof(double), st, d, first, count, slot);
 }
 
 void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f, int mode, hipStream_t st) {
     if (count <= 0) return;
     if (max_f <= 63 && d.factor_variant == 3) {
-        static bool attr_set_3 = false;
-        if (!attr_set_3) { (void)hipFuncSetAttribute((const void *)k_factor3<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_3 = true; }
+        allow_max_lds((const void *)k_factor3<false, false>);
         static size_t lds3 = 0;                                      // GS_F3_LDS_KB: occupancy experiments (more LDS per block = fewer resident blocks)
         if (lds3 == 0) { lds3 = (size_t)MF_IMG * 4 * sizeof(double); if (const char *e = getenv("GS_F3_LDS_KB")) lds3 = std::max(lds3, (size_t)atoi(e) * 1024); }
         hipLaunchKernelGGL((k_factor3<false, false>), dim3((count + 3) / 4), dim3(256), lds3, st, d, level_off, count, mode, 0, count);
         return;
     }
     if (max_f <= 63 && d.factor_variant == 2) {
-        static bool attr_set_m = false;
-        if (!attr_set_m) { (void)hipFuncSetAttribute((const void *)k_factor_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_m = true; }
+        allow_max_lds((const void *)k_factor_mfma);
         hipLaunchKernelGGL(k_factor_mfma, dim3((count + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double) + 8 * 64 * sizeof(int32_t), st, d, level_off, count, mode);
         return;
     }
     if (max_f <= 63 && d.factor_variant == 1) {   // VALU wave-per-front variant: measured SLOWER than the block kernel, kept for A/B only
         const int slot = ((max_f * (max_f + 1)) / 2 + max_f + 1) & ~1;                // doubles per wave, 16-B aligned
-        static bool attr_set_w = false;
-        if (!attr_set_w) { (void)hipFuncSetAttribute((const void *)k_factor_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_w = true; }
+        allow_max_lds((const void *)k_factor_wave);
         hipLaunchKernelGGL(k_factor_wave, dim3((count + 3) / 4), dim3(256), (size_t)slot * 4 * sizeof(double), st, d, level_off, count, mode, slot);
         return;
     }
     int64_t bytes = (int64_t)((max_f + 1) | 1) * max_f * 8;
     if (bytes <= LDS_LIMIT_BYTES) {
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_factor_level<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_BYTES); attr_set = true; }
+        allow_max_lds((const void *)k_factor_level<true>);
         hipLaunchKernelGGL(k_factor_level<true>, dim3(count), dim3(256), (size_t)bytes, st, d, level_off, mode);
     } else {
         hipLaunchKernelGGL(k_factor_level<false>, dim3(count), dim3(256), 0, st, d, level_off, mode);
@@ -2338,15 +2351,13 @@ void launch_backsolve_level(const DevGraph &d, int level_off, int count, int max
     if (count <= 0) return;
     if (d.factor_variant == 3) {                                     // LDL^T panels: unit-diagonal backward solve
         const int f = max_npiv + max_nbnd, slot = ((((f + 1) | 1) * max_npiv) + 1) & ~1;
-        static bool attr_set_b3 = false;
-        if (!attr_set_b3) { (void)hipFuncSetAttribute((const void *)k_backsolve3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_b3 = true; }
+        allow_max_lds((const void *)k_backsolve3<false>);
         hipLaunchKernelGGL(k_backsolve3<false>, dim3((count + 3) / 4), dim3(256), (size_t)slot * 4 * sizeof(double), st, d, level_off, count, slot);
         return;
     }
     if (max_npiv + max_nbnd <= 63) {
         const int f = max_npiv + max_nbnd, slot = ((((f + 1) | 1) * max_npiv) + 1) & ~1;
-        static bool attr_set_b = false;
-        if (!attr_set_b) { (void)hipFuncSetAttribute((const void *)k_backsolve_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_b = true; }
+        allow_max_lds((const void *)k_backsolve_wave);
         hipLaunchKernelGGL(k_backsolve_wave, dim3((count + 3) / 4), dim3(256), (size_t)slot * 4 * sizeof(double), st, d, level_off, count, slot);
         return;
     }

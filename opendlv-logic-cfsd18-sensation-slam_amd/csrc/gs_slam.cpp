@@ -294,20 +294,29 @@ extern "C" int gs_slam_collect_flush(gs_slam *s, const double pose_xytheta[3], i
 // conesPerPacket map cones starting at m_currentConeIndex, wrapping around the map, seen from m_sendPose; message
 // fields are float32.  Quirk 8-B.7 (the radian heading scaled by 1/RAD2DEG before it is subtracted from degrees) is
 // reproduced under cfg.reference_quirks, otherwise the heading is converted to degrees.
+// One cone as the three messages carry it: Cone::getDirection / Cone::getDistance (reference src/cone.cpp:34-53), float32
+// fields.  reference_quirks != 0: the reference's arithmetic as written — the radian heading scaled by 1 / RAD2DEG before
+// it is subtracted from degrees; 0: the heading converted to degrees.  Stateless (no handle, no device).
+extern "C" int gs_cone_encode(const double cone_xy[2], const double pose_xytheta[3], int32_t reference_quirks, float *azimuth_deg, float *distance) {
+    if (!cone_xy || !pose_xytheta || !azimuth_deg || !distance) return fail(GS_ERR_INVALID, "null argument");
+    const double RAD2DEG = 57.295779513082325;                       // reference src/cone.hpp:55, src/slam.hpp:135
+    const double x = cone_xy[0] - pose_xytheta[0], y = cone_xy[1] - pose_xytheta[1];
+    const double heading = reference_quirks ? pose_xytheta[2] * (1 / RAD2DEG) : pose_xytheta[2] * RAD2DEG;
+    *azimuth_deg = (float)(std::atan2(y, x) * RAD2DEG - heading);
+    *distance = (float)std::sqrt(x * x + y * y);
+    return GS_OK;
+}
 extern "C" int gs_slam_encode_cones(gs_slam *s, int32_t cones_per_packet, float *azimuth_deg, float *distance, int32_t *type) {
     if (!s || cones_per_packet < 0 || (cones_per_packet > 0 && (!azimuth_deg || !distance || !type))) return fail(GS_ERR_INVALID, "bad argument");
     if (cones_per_packet > 0 && s->map.empty()) return fail(GS_ERR_INVALID, "empty map");
-    const double RAD2DEG = 57.295779513082325;                       // reference src/slam.hpp:135
     const size_t n = s->map.size();
     for (int i = 0; i < cones_per_packet; ++i) {
         size_t index = s->current_cone_index + (size_t)i;
         if (index >= n) index -= n;                                  // the reference's single wrap (:666-667) ...
         if (index >= n) index %= n;                                  // ... made safe for conesPerPacket > map size (reference: out of bounds)
         const MapCone &c = s->map[index];
-        const double x = c.x - s->send_pose[0], y = c.y - s->send_pose[1];
-        const double heading = s->cfg.reference_quirks ? s->send_pose[2] * (1 / RAD2DEG) : s->send_pose[2] * RAD2DEG;
-        azimuth_deg[i] = (float)(std::atan2(y, x) * RAD2DEG - heading);
-        distance[i] = (float)std::sqrt(x * x + y * y);
+        const double xy[2] = {c.x, c.y};
+        gs_cone_encode(xy, s->send_pose, s->cfg.reference_quirks, &azimuth_deg[i], &distance[i]);
         type[i] = c.type;
     }
     return GS_OK;

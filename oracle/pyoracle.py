@@ -305,3 +305,28 @@ def ref_to_cartesian(ref_latlon, pos_latlon):
 def ref_from_cartesian(ref_latlon, xy):
     R = ref_wgs84(); o = np.zeros(2)
     R.ref_wgs84_from_cartesian(_d(np.ascontiguousarray(ref_latlon, dtype=np.float64)), _d(np.ascontiguousarray(xy, dtype=np.float64)), _d(o)); return o
+
+
+_ref_cone = None
+
+
+def ref_cone():
+    """The reference's own Cone class (src/cone.cpp), compiled into oracle/_ref/libref_cone.so (None if not built)."""
+    global _ref_cone
+    if _ref_cone is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_cone.so")
+        if not os.path.exists(path):
+            return None
+        R = C.CDLL(path)
+        dp, fp = C.POINTER(C.c_double), C.POINTER(C.c_float)
+        R.ref_cone_encode.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, dp, fp, fp, fp]
+        R.ref_cone_record.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, dp]
+        _ref_cone = R
+    return _ref_cone
+
+
+def ref_cone_encode(x, y, ctype, cid, pose):
+    """Cone(x, y, type, id).getDirection(pose), .getDistance(pose) of the reference: (azimuthAngle, zenithAngle, distance) as float32."""
+    R = ref_cone(); az, zen, di = C.c_float(), C.c_float(), C.c_float()
+    R.ref_cone_encode(float(x), float(y), int(ctype), int(cid), _d(np.ascontiguousarray(pose, dtype=np.float64)), C.byref(az), C.byref(zen), C.byref(di))
+    return np.float32(az.value), np.float32(zen.value), np.float32(di.value)

@@ -178,3 +178,116 @@ class RefSlam:
             self.current_cone_index = current
         self.send_pose = self.g.poses()[self.n_poses - 1].copy()          # updatePoseFromGraph, :404-408, :416-422
         self.localizer_calls += 1
+
+
+class RefShell:
+    """Test-only restatement of the reference's process shell over RefSlam: main()'s senderStamp filters and seven triggers
+    (reference src/opendlv-logic-cfsd18-sensation-slam.cpp:65-108), Slam::setUp's keys (src/slam.cpp:736-756), the message
+    intake nextSplitPose / nextPose / nextYawRate / nextCone (:67-219), the gathering wait + keyframe gate
+    (initializeCollection :221-257, isKeyframe :286-295; the detached busy-wait thread becomes poll(now)), and what the
+    localizer publishes (sendPose + sendCones, :404-410, 656-695).  Geodesy = the reference's own header
+    (oracle/_ref/libref_wgs84.so) and cone messages = the reference's own Cone class (oracle/_ref/libref_cone.so) when
+    built.  The checker for csrc/gs_shell.cpp + gs_shell_cluon.*: nothing here calls the product."""
+    WGS84, ANGULAR_VELOCITY, HEADING, GEOLOCATION, OBJECT_TYPE, OBJECT_DIRECTION, OBJECT_DISTANCE = 19, 1031, 1051, 1116, 1131, 1133, 1134
+    PI = float(np.float32(3.14159265))                                    # src/slam.hpp:136: a float literal
+
+    def __init__(self, argv, quirks=False):
+        a = {}
+        for s in argv[1:]:
+            if s.startswith("--"):
+                k, _, v = s[2:].partition("="); a[k] = v if v else "1"
+        self.gathering_ms = int(a["gatheringTimeMs"]); self.tbk = float(a["timeBetweenKeyframes"])       # setUp, :739-745
+        self.cones_per_packet = int(a["conesPerPacket"]); self.sender_stamp = int(a["id"])
+        self.gps_ref = (float(a["refLatitude"]), float(a["refLongitude"]))
+        self.detect, self.estimation = int(a["detectConeId"]), int(a["estimationId"])                    # main, :67-68
+        self.quirks = bool(quirks)
+        self.slam = RefSlam(same_cone_threshold=float(a["sameConeThreshold"]), cone_mapping_threshold=float(a["coneMappingThreshold"]), quirks=quirks)
+        self.odometry = np.zeros(3)                                       # m_odometryData
+        self.geolocation_us = 0; self.yaw_us = 0; self.last_cone_us = 0   # m_geolocationReceivedTime, m_yawReceivedTime, m_lastTimeStamp
+        self.frame_open = False; self.frame_opened_us = 0; self.keyframe_us = 0      # m_keyframeTimeStamp() = 0
+        self.out = []; self.frames_run = 0; self.frames_gated = 0
+
+    def _to_cartesian(self, lat, lon):
+        if po.ref_wgs84() is None:
+            raise RuntimeError("oracle/_ref/libref_wgs84.so not built")
+        return po.ref_to_cartesian(self.gps_ref, (lat, lon))
+
+    def on_message(self, data_type, sender_stamp, sample_us, now_us, object_id=0, v=(0.0, 0.0, 0.0)):
+        S = self.slam
+        if data_type in (self.WGS84, self.HEADING, self.GEOLOCATION, self.ANGULAR_VELOCITY):
+            if sender_stamp != self.estimation:                           # :71-100: envelope.senderStamp() == senderStamp
+                return 0
+            if data_type == self.WGS84:                                   # nextSplitPose, :156-176
+                self.odometry[:2] = self._to_cartesian(v[0], v[1])
+            elif data_type == self.HEADING:                               # :177-184
+                h = v[0] - self.PI
+                h = h - 2 * self.PI if h > self.PI else h
+                h = h + 2 * self.PI if h < -self.PI else h
+                self.odometry[2] = h
+            elif data_type == self.GEOLOCATION:                           # nextPose, :187-209
+                self.geolocation_us = int(sample_us)
+                xy = self._to_cartesian(v[0], v[1]); self.odometry[:] = (xy[0], xy[1], v[2])
+            else:                                                         # nextYawRate, :211-219
+                S.next_yaw_rate(v[0]); self.yaw_us = int(sample_us)
+            return 1
+        if data_type in (self.OBJECT_DIRECTION, self.OBJECT_DISTANCE, self.OBJECT_TYPE):
+            if sender_stamp != self.detect:
+                return 0
+            self.last_cone_us = int(sample_us)                            # m_lastTimeStamp = data.sampleTimeStamp(), :73,102,129
+            if data_type == self.OBJECT_DIRECTION: opened = S.collect_direction(int(object_id), v[0], v[1])
+            elif data_type == self.OBJECT_DISTANCE: opened = S.collect_distance(int(object_id), v[0])
+            else: opened = S.collect_type(int(object_id), int(v[0]))
+            if opened:                                                    # std::thread coneCollector(&Slam::initializeCollection, this), :94-95
+                self.frame_open = True; self.frame_opened_us = int(now_us)
+            return 1
+        return 0                                                          # no trigger registered for this type, :102-108
+
+    def poll(self, now_us):
+        """initializeCollection once its busy-wait has ended (elapsed > m_timeDiffMilliseconds * 1000, :227-233)."""
+        S = self.slam
+        if not self.frame_open or now_us - self.frame_opened_us <= self.gathering_ms * 1000:
+            return 0
+        self.frame_open = False
+        extracted = S.collector[:, :S.last_object_id + 1].T.copy()        # leftCols(m_lastObjectId + 1), :241
+        S.new_frame = True; S.last_object_id = 0; S.collector[:] = 0.0    # :242-244
+        if extracted.shape[0] == 0:                                       # :248
+            return 0
+        elapsed_ms = abs(float(now_us - self.keyframe_us)) / 1000         # isKeyframe, :286-295
+        if not elapsed_ms > self.tbk:
+            self.frames_gated += 1; return 0
+        self.keyframe_us = int(now_us)
+        S.set_sample_times(self.yaw_us, self.last_cone_us)
+        calls = S.localizer_calls
+        S.perform(self.odometry.copy(), extracted)                        # performSLAM, :298-338 (its own 200 m guard first)
+        self.frames_run += 1
+        if S.localizer_calls > calls:                                     # sendPose(); sendCones(); at the end of localizer, :409-410
+            self._send_pose(); self._send_cones()
+        return 1
+
+    def _send_pose(self):                                                 # :679-695
+        S = self.slam
+        gps = po.ref_from_cartesian(self.gps_ref, S.send_pose[:2])       # {latitude, longitude}
+        lon_field = np.float32(gps[0]) if self.quirks else np.float32(gps[1])       # poseMessage.longitude(sendGPS[0]): the reference's swap (§8-B.7)
+        lat_field = np.float32(gps[1]) if self.quirks else np.float32(gps[0])
+        self.out.append((self.GEOLOCATION, self.sender_stamp, self.geolocation_us, 0, (float(lat_field), float(lon_field), float(np.float32(S.send_pose[2])))))
+
+    def _send_cones(self):                                                # :656-677
+        S = self.slam; n = len(S.map)
+        for i in range(self.cones_per_packet):
+            idx = S.current_cone_index + i
+            idx = idx if idx < n else idx - n                             # the reference's single wrap, :666-667
+            c = S.map[idx % n]
+            if po.ref_cone() is not None and self.quirks:                 # the reference's own Cone::getDirection / getDistance
+                az, _, di = po.ref_cone_encode(c[0], c[1], c[2], c[3], S.send_pose)
+            else:
+                x, y = c[0] - S.send_pose[0], c[1] - S.send_pose[1]
+                heading = S.send_pose[2] * (1 / 57.295779513082325) if self.quirks else S.send_pose[2] * 57.295779513082325
+                az = np.float32(np.arctan2(y, x) * 57.295779513082325 - heading); di = np.float32(np.sqrt(x * x + y * y))
+            st = (self.sender_stamp, self.geolocation_us, i)
+            self.out.append((self.OBJECT_DIRECTION,) + st + ((float(az), 0.0, 0.0),))
+            self.out.append((self.OBJECT_DISTANCE,) + st + ((float(di), 0.0, 0.0),))
+            self.out.append((self.OBJECT_TYPE,) + st + ((float(c[2]), 0.0, 0.0),))
+
+    def take_output(self):
+        o, self.out = self.out, []
+        return o

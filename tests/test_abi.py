@@ -113,3 +113,17 @@ def test_product_package_never_touches_the_oracle():
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "pyoracle" not in txt and "liboracle" not in txt and "orc_" not in txt, os.path.join(dp, f)
                 assert "/root/reference" not in txt, os.path.join(dp, f)
+
+
+def test_arena_beyond_32_bit_byte_offsets_leaves_the_matrix_core_fronts(pkg):
+    """The variant-3 front kernels name every scalar of the linearised system by a 32-bit BYTE offset into H_arena
+    ((uint32_t)record * 8): a graph whose arena reaches 2^29 doubles (4 GiB, ~6 x config 5 — it fits the HBM) must not get
+    them, or the offsets wrap and the wrong entries are assembled silently.  gs_debug_select_factor_variant is the rule
+    gs_initialize_optimization applies."""
+    sel = pkg.binding.lib().gs_debug_select_factor_variant
+    assert sel(0, 57, 10_000_000) == 3                      # config 4: default = matrix-core fronts
+    assert sel(0, 57, (1 << 29) - 1) == 3
+    assert sel(0, 57, 1 << 29) == 4                         # the guard fires at 2^29 doubles, not at 2^31
+    assert sel(3, 57, (1 << 30)) == 4
+    assert sel(2, 57, (1 << 30)) == 2                       # 64-bit addressing in the other kernels
+    assert sel(1, 64, 1000) == 4 and sel(4, 30, 1000) == 4 and sel(7, 30, 1000) == 3
