@@ -14,6 +14,8 @@ contributions to the shared top of the assembly tree (window-boundary poses and 
 windows — the shared rows of Omega / xi) are summed by one RCCL all-reduce (fp64) per iteration, and every rank
 finishes the top redundantly.  Weak scaling: value = N x (iterations/s of the whole graph), i.e. 100k-pose-window
 iterations per second, the same unit as the N = 1 line.
+`--workload cfg5 --shard` (N > 1) instead shards THE NAMED WORKLOAD: `--gpus 8 --workload cfg5 --shard` is BASELINE config 5
+itself, 1M poses / 50k cones by pose window across 8 GPUs (strong scaling: value = iterations/s of that one graph).
 
 One JSON line on stdout from rank 0, with `roofline` (edge-linearisation kernel, HIP events in this process)
 and, at N = 1, `cpu_baseline` (the CPU oracle + the reference's vendored Eigen solver on this host).
@@ -31,35 +33,64 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(pkg, g, iters):
+def cpu_baseline(pkg, g, iters, budget_s=22.0):
     """The Eigen CPU path: oracle restatement of the g2o arithmetic + the reference's
     vendored Eigen 3.3.4 SimplicialLDLT/AMD (oracle/_ref) when present, else the oracle's own LDLT.
-    Single thread, -O3 -DNDEBUG, no -march.  Bounded sample: `iters` iterations of the SAME graph."""
+    Single thread, -O3 -DNDEBUG, no -march.  Bounded sample: `iters` iterations of the SAME graph, one warm-up run and
+    then the MEDIAN over up to 5 repeats (as many as fit ~budget_s of CPU work; every repeat starts from the same
+    initial estimates on a fresh graph with a fresh solver, i.e. includes its own symbolic analysis, which is
+    reported and excluded per repeat like the GPU plan build)."""
     from oracle import pyoracle as po
-    og = po.OracleGraph()
-    og.add_poses(g["pose_est"]); og.add_landmarks(g["lm_est"])
-    og.add_odometry_edges(g["pp_i"], g["pp_j"], g["pp_z"], g["pp_info"])
-    og.add_observation_edges(g["pl_p"], g["pl_l"], g["pl_z"], g["pl_info"])
-    for i in g["fixed_poses"]:
-        og.set_fixed_pose(int(i))
-    for l in g["fixed_landmarks"]:
-        og.set_fixed_landmark(int(l))
-    solver, kind = None, "port"
-    if po.ref_eigen() is not None:
-        solver = po.EigenSolver(0)
-    t0 = time.perf_counter()
-    done, chi, tm = og.optimize(iters, ordering=1, solver=solver)
-    wall = time.perf_counter() - t0
-    analyze_ms = float(solver.timings()[0]) if solver is not None else 0.0
-    per_iter_s = (wall - analyze_ms * 1e-3) / max(done, 1)      # symbolic analysis is iteration-0 work, like the GPU plan
-    return og, dict(wall_ms_end_to_end=wall * 1e3, ms_symbolic=analyze_ms, value=1.0 / per_iter_s, unit="GN iterations/s", cores=1, kind=kind,
-                    sample="%d GN iterations of the same %d-pose / %d-cone graph, single thread; g2o arithmetic restated "
-                           "in C (oracle/), linear solve = %s; symbolic analysis (%.0f ms) excluded like the GPU plan build"
-                           % (done, len(g["pose_est"]), len(g["lm_est"]),
-                              "reference's vendored Eigen 3.3.4 SimplicialLDLT+AMD (oracle/_ref)" if solver is not None
-                              else "oracle's own up-looking LDLT (oracle/_ref absent)", analyze_ms),
-                    ms_linearize=float(tm[0]) / max(done, 1), ms_solve=float(tm[2] - analyze_ms) / max(done, 1),
-                    host_cpus=os.cpu_count())
+    import numpy as np
+
+    def one_run():
+        og = po.OracleGraph()
+        og.add_poses(g["pose_est"]); og.add_landmarks(g["lm_est"])
+        og.add_odometry_edges(g["pp_i"], g["pp_j"], g["pp_z"], g["pp_info"])
+        og.add_observation_edges(g["pl_p"], g["pl_l"], g["pl_z"], g["pl_info"])
+        for i in g["fixed_poses"]:
+            og.set_fixed_pose(int(i))
+        for l in g["fixed_landmarks"]:
+            og.set_fixed_landmark(int(l))
+        solver = po.EigenSolver(0) if po.ref_eigen() is not None else None
+        t0 = time.perf_counter()
+        done, chi, tm = og.optimize(iters, ordering=1, solver=solver)
+        wall = time.perf_counter() - t0
+        analyze_ms = float(solver.timings()[0]) if solver is not None else 0.0
+        return og, dict(wall=wall, analyze_ms=analyze_ms, done=int(done), per_iter_s=(wall - analyze_ms * 1e-3) / max(done, 1),
+                        ms_linearize=float(tm[0]) / max(done, 1), ms_solve=float(tm[2] - analyze_ms) / max(done, 1)), solver is not None
+
+    og, warm, eig = one_run()                                    # warm-up (page faults, caches, clocks); also sizes the sample
+    reps = int(max(1, min(5, budget_s // max(warm["wall"], 1e-3))))
+    runs = []
+    for _ in range(reps):
+        og, r, eig = one_run(); runs.append(r)
+    med = lambda k: float(np.median([r[k] for r in runs]))
+    per_iter_s = med("per_iter_s")
+    return og, dict(wall_ms_end_to_end=med("wall") * 1e3, ms_symbolic=med("analyze_ms"), value=1.0 / per_iter_s, unit="GN iterations/s", cores=1, kind="port",
+                    repeats=reps, warmup_runs=1, value_min=1.0 / max(r["per_iter_s"] for r in runs), value_max=1.0 / min(r["per_iter_s"] for r in runs),
+                    sample="median of %d runs (after 1 warm-up run) of %d GN iterations of the same %d-pose / %d-cone graph, single thread; g2o "
+                           "arithmetic restated in C (oracle/), linear solve = %s; symbolic analysis (%.0f ms per run) excluded like the GPU plan build"
+                           % (reps, runs[0]["done"], len(g["pose_est"]), len(g["lm_est"]),
+                              "reference's vendored Eigen 3.3.4 SimplicialLDLT+AMD (oracle/_ref)" if eig
+                              else "oracle's own up-looking LDLT (oracle/_ref absent)", med("analyze_ms")),
+                    ms_linearize=med("ms_linearize"), ms_solve=med("ms_solve"), host_cpus=os.cpu_count())
+
+
+def linearize_roofline_of(pkg, name, device, reps=10):
+    """The roofline kernel (k_linearize_ell) at another configuration, inside full Gauss-Newton iterations (HIP events around
+    the phase, gs_time_iterations) and back to back: cfg3 is launch-bound, cfg4 is the headline size, cfg5 (1.05 GB per pass)
+    is where the kernel is bound by HBM bandwidth."""
+    N, M = pkg.track.CONFIGS[name]
+    t = pkg.track.generate(N, M)
+    fe = pkg.Graph(device=device); g = pkg.track.bench_graph(t, fe); fe.close()
+    G = pkg.Graph(device=device); G.load_bench_graph(g); G.initialize_optimization()
+    ph = G.time_iterations(reps); b2b = G.time_linearize(reps); B = G.linearize_bytes()
+    G.close()
+    inside = B / (ph.ms_linearize * 1e-3) / 1e9
+    return dict(algorithmic_bytes=B, ms_per_launch=ph.ms_linearize, achieved=inside, frac=inside / HBM_PEAK_GBS,
+                ms_per_launch_back_to_back=b2b, frac_back_to_back=B / (b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                iteration_ms=ph.ms_total, iterations_per_s=1e3 / ph.ms_total)
 
 
 def frame_latency(pkg, np):
@@ -112,6 +143,10 @@ def main():
     ap.add_argument("--workload", default="cfg4")
     ap.add_argument("--cpu-iters", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--shard", action="store_true",
+                    help="N > 1: shard the NAMED workload itself over the ranks (strong scaling; `--workload cfg5 --shard --gpus 8` is "
+                         "BASELINE config 5: 1M poses / 50k cones by pose window across 8 GPUs) instead of N x the workload")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip roofline_by_config (cfg3 / cfg5 beside the timed workload)")
     args = ap.parse_args()
 
     import torch                                   # first: its HIP runtime is the one the process uses
@@ -142,7 +177,8 @@ def main():
     pkg = importlib.import_module("opendlv-logic-cfsd18-sensation-slam_amd")
 
     Nw, Mw = pkg.track.CONFIGS[args.workload]     # one pose window = the single-GPU workload
-    N, M = Nw * world, Mw * world
+    strong = args.shard and world > 1
+    N, M = (Nw, Mw) if strong else (Nw * world, Mw * world)
     track = pkg.track.generate(N, M)
     fe = pkg.Graph(device=local)
     g = pkg.track.bench_graph(track, fe)           # A0 on the device
@@ -195,7 +231,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt * 1e3 / args.steps
-    value = world * args.steps / dt                # 100k-pose-window iterations per second over the whole job
+    # weak: pose-window iterations per second over the whole job; strong (--shard): iterations per second of the ONE sharded graph
+    value = (1 if strong else world) * args.steps / dt
     # the handle that was timed must have WORKED: a zero pivot or a solver launch that gave up on a front applies no
     # update and is reported here (GsError -> non-zero exit, no JSON line), on every rank
     G.sync_estimates()
@@ -229,11 +266,14 @@ def main():
                     traffic=traffic, traffic_source=traffic_src, kernel="k_linearize_ell: edge linearisation + assembly (A5-A7)", ms_per_launch=lin_ms,
                     algorithmic_bytes=alg_bytes, note="back-to-back launches of this rank's window (N > 1: no per-phase events inside the sharded step)")
     out = dict(metric="GraphSLAM Gauss-Newton iters/sec at N poses x M cones; pose RMSE vs ref",
-               value=value, unit="GN iterations/s (100k-pose windows)", n_gpus=world, steps=args.steps, warmup=args.warmup,
-               ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64",
+               value=value, unit="GN iterations/s (whole %d-pose graph)" % N if strong else "GN iterations/s (%dk-pose windows)" % (Nw // 1000),
+               n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=ms_per_step, higher_is_better=True, scaling="strong" if strong else "weak", vs_baseline=None, dtype="f64",
                data="synthetic",
-               config=dict(workload="%s x %d: %d poses / %d cones closed synthetic cone track, K=8 observations per pose, "
-                                    "gauge = first 2 poses + first 2 cones" % (args.workload, world, N, M),
+               config=dict(workload=("%s sharded over %d pose windows: %d poses / %d cones closed synthetic cone track, K=8 observations per pose, "
+                                     "gauge = first 2 poses + first 2 cones" % (args.workload, world, N, M)) if strong else
+                                    ("%s x %d: %d poses / %d cones closed synthetic cone track, K=8 observations per pose, "
+                                     "gauge = first 2 poses + first 2 cones" % (args.workload, world, N, M)),
                            n_poses=N, n_cones=M, n_odometry_edges=G.n_pp, n_observation_edges=G.n_pl,
                            unknowns=3 * plan.n_free_poses + 2 * plan.n_free_landmarks,
                            parallelism=("%d pose windows, one per GPU; RCCL all-reduce of %d doubles per iteration"
@@ -323,9 +363,20 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0 and world == 1 and not dist_mode and not args.no_cpu and args.workload == "cfg4":
         out["frame_latency"] = frame_latency(pkg, np)
+    if rank == 0 and world == 1 and not dist_mode and not args.no_extra_configs and args.workload == "cfg4":
+        # the roofline kernel where it is launch-bound (cfg3), at the headline size (cfg4 = the entry above) and where it is
+        # HBM-bound (cfg5, 1.05 GB per pass): same kernel, same measurement (HIP events inside full iterations)
+        rb = {"cfg4": dict(algorithmic_bytes=alg_bytes, ms_per_launch=out["roofline"]["ms_per_launch"], achieved=out["roofline"]["achieved"],
+                           frac=out["roofline"]["frac"], ms_per_launch_back_to_back=lin_ms, frac_back_to_back=achieved / HBM_PEAK_GBS,
+                           iteration_ms=ms_per_step, iterations_per_s=value)}
+        G.close(); G = None                                     # cfg5 wants the HBM to itself
+        for name in ("cfg3", "cfg5"):
+            rb[name] = linearize_roofline_of(pkg, name, local)
+        out["roofline_by_config"] = rb
     if rank == 0:
         print(json.dumps(out))
-    G.close()
+    if G is not None:
+        G.close()
     if dist_mode:
         dist.destroy_process_group()
 

@@ -103,6 +103,10 @@ typedef struct gs_stats {
     int64_t factor_bytes;       /* L + update-matrix storage, bytes                         */
     double  ms_event_overhead;  /* gs_time_iterations: an empty event-to-event interval on the
                                    stream, i.e. the share of every phase time that is measurement */
+    int32_t fell_back;          /* 1: the handle runs one launch per level (the slow path) because a whole-tree launch gave
+                                   up on a front's completion flag — in this call or an earlier one; 0: whole-tree launches */
+    int32_t first_failure;      /* the first failure code this call met (0 none): a flag timeout (2) that the per-level
+                                   fallback then repaired leaves numeric_failure 0 and first_failure 2 */
 } gs_stats;
 
 int  gs_version(void);                               /* major*100+minor */

@@ -295,7 +295,7 @@ static int surface_failure(gs_graph *g) {
     int32_t st[2]; int rc = read_failure(g, st); if (rc != GS_OK) return rc;
     if (st[0] == 0) return GS_OK;
     rc = reset_failure(g); if (rc != GS_OK) return rc;
-    if (st[0] == 2) { g->d.tree = 0;
+    if (st[0] == 2) { g->d.tree = 0; g->fell_back = true;
         return fail(GS_ERR_TIMEOUT, "whole-tree launch: a front's completion flag did not arrive in time; no update was applied from that "
                                     "iteration on (estimates = last good iterate); the handle now uses one launch per level"); }
     return fail(GS_ERR_NUMERIC, st[0] == 3 ? "another rank met a zero pivot: no update applied from that iteration on (estimates = last good iterate)"
@@ -511,7 +511,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
             AL(Uimg, (size_t)tot + 2); ZERO(Uimg, (size_t)tot + 2); }
           UP(u3_off, u3_off); UP(u3_size, u3_size);
           AL(done_f, P.fronts.size()); ZERO(done_f, P.fronts.size());
-          d.epoch = 0; d.tree = 1;                                    // whole-tree launches for this rank's own subtrees (GS_TREE=0: one launch per level)
+          d.epoch = 0; d.tree = 1; g->fell_back = false;              // whole-tree launches for this rank's own subtrees (GS_TREE=0: one launch per level)
           if (const char *e = std::getenv("GS_TREE")) d.tree = std::atoi(e) != 0 ? 1 : 0;
           // ---- everything below is expanded ON THE DEVICE from the compact plan arrays
           const bool fused = P.lin_ell_ok && d.n_wtiles > 0;
@@ -772,6 +772,7 @@ static void fill_plan_stats(gs_graph *g, gs_stats *s) {
     s->n_odometry_edges = g->h.n_pp(); s->n_observation_edges = g->h.n_pl();
     s->n_fronts = (int32_t)P.fronts.size(); s->n_levels = (int32_t)P.level_start.size() - 1; s->max_front = P.max_front;
     s->factor_flops = P.factor_flops; s->factor_bytes = (P.l_doubles + P.u_doubles) * 8; s->ms_structure = g->ms_structure;
+    s->fell_back = g->fell_back ? 1 : 0;
 }
 
 extern "C" int gs_get_stats(gs_graph *g, gs_stats *s) {
@@ -804,9 +805,13 @@ static int optimize_impl(gs_graph *g, int32_t iterations, double rel_tol, gs_sta
     // Stop rule (gs_optimize_until): k_update compares the chi2 of consecutive linearisation points on the device and
     // raises fail[2]; later updates are skipped like after a failure.  The host enqueues chunks of 4 iterations and
     // looks at the flags in between, so at most 3 enqueued iterations run as no-ops after convergence.
-    int applied = 0, enq = 0; int32_t ff[4] = {0, 0, 0, 0}; bool fell_back = false;
+    // Chunks: the FIRST iteration on its own, then groups of 8 (stop rule: 4).  A whole-tree launch whose flag hand-off fails
+    // (its pollers are bounded and leave at once when any front has reported a failure, so such a launch drains in one poll
+    // budget, ~30 ms) would otherwise have every remaining iteration queued up behind it, each paying the same again: with
+    // chunks a timeout costs one chunk before the per-level fallback takes over.  One host round trip per chunk.
+    int applied = 0, enq = 0, first_failure = 0; int32_t ff[4] = {0, 0, 0, 0}; bool fell_back = false;
     while (enq < iterations) {
-        const int upto = until ? std::min(iterations, enq + 4) : iterations;
+        const int upto = std::min(iterations, enq == 0 ? 1 : enq + (until ? 4 : 8));
         for (int it = enq; it < upto; ++it) {
             enqueue_iteration(g, false);
             if (it < nh) hipMemcpyAsync(g->d.chi2 + 1 + it, g->d.chi2, sizeof(double), hipMemcpyDeviceToDevice, g->stream);
@@ -815,8 +820,9 @@ static int optimize_impl(gs_graph *g, int32_t iterations, double rel_tol, gs_sta
         HIP_TRY(hipMemcpyAsync(ff, g->d.fail, sizeof(ff), hipMemcpyDeviceToHost, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
         applied = ff[1];
+        if (ff[0] != 0 && first_failure == 0) first_failure = ff[0];
         if (ff[0] == 2 && g->d.tree && !fell_back) {
-            g->d.tree = 0; fell_back = true; g->d.inject_iter = 0;
+            g->d.tree = 0; fell_back = true; g->fell_back = true; g->d.inject_iter = 0;
             HIP_TRY(hipMemsetAsync(g->d.fail, 0, sizeof(int32_t), g->stream));      // the code only: the update count goes on
             enq = applied; ff[0] = 0; continue; }
         if (ff[0] != 0 || ff[2] != 0) break;
@@ -837,7 +843,7 @@ static int optimize_impl(gs_graph *g, int32_t iterations, double rel_tol, gs_sta
     if (g->cfg.verbose) for (int it = 0; it < nshow; ++it)  // g2o prints the chi2 AFTER the update of iteration it
         std::fprintf(stderr, "iteration= %d\t chi2= %.6f\t edges= %d\t schur= 0\n", it, it + 1 < applied ? hist[2 + it] : hist[1 + nh], g->h.n_pp() + g->h.n_pl());
     if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->struct_size = (int32_t)sizeof(*stats);
-        fill_plan_stats(g, stats); stats->iterations = applied; stats->numeric_failure = ff[0];
+        fill_plan_stats(g, stats); stats->iterations = applied; stats->numeric_failure = ff[0]; stats->first_failure = first_failure;
         stats->chi2_initial = iterations > 0 ? hist[1] : hist[1 + nh]; stats->chi2_final = hist[1 + nh]; stats->ms_total = ms; }
     if (ff[0]) { rc = reset_failure(g); if (rc != GS_OK) return rc; }
     if (ff[0] == 2) { g_last_error = "a front's completion flag did not arrive in time, with one launch per level as well"; return 0; }

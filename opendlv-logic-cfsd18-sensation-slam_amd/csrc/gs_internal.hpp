@@ -47,6 +47,7 @@ struct gs_graph {
         char *pin_map = nullptr; size_t pin_map_bytes = 0; bool pin_map_busy = false;   // pinned staging of map appends (busy: a copy out of it may be in flight)
     } fe;
     int default_factor_variant = 0;         // see upload_graph
+    bool fell_back = false;                 // a whole-tree launch gave up on a flag: this handle uses one launch per level until the next plan
 };
 
 namespace gs {

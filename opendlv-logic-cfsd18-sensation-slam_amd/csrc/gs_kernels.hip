@@ -1472,9 +1472,13 @@ __device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[NT * (NT + 1
 #ifndef F3_POLL_SLEEP
 #define F3_POLL_SLEEP 4
 #endif
-__device__ __forceinline__ bool f3_wait_flag(const int32_t *flag, int epoch) {
+// `fail` = d.fail: every 64 polls the waiter also looks at the launch's failure code and LEAVES AT ONCE when any front has
+// reported one (returns true: nothing more to report; the iteration applies no update anyway) — so after the first expiry
+// of a poll budget (~30 ms) the rest of the grid drains immediately instead of every front spending its own budget.
+__device__ __forceinline__ bool f3_wait_flag(const int32_t *flag, int epoch, const int32_t *fail) {
     for (int it = 0; it < (1 << 18); ++it) {
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); return true; }
+        if ((it & 63) == 63 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
         __builtin_amdgcn_s_sleep(F3_POLL_SLEEP);
     }
     return false;
@@ -1497,16 +1501,16 @@ __device__ __forceinline__ void f3_publish(int32_t *flag, int epoch, int lane) {
 // two children of a front into its LDS image, by source.  flag != nullptr: a child of the SAME launch — its flag is awaited
 // (the places are computed first: nothing but the loads and the read-add-writes is behind the wait).  The loads are
 // device-scope either way: in storage order every line is fetched once, so there is nothing a cached load would save.
-__device__ __forceinline__ bool f3_gather_pair(double *img, const int (&rc)[F3_KREG], int lane, int epoch,
+__device__ __forceinline__ bool f3_gather_pair(double *img, const int (&rc)[F3_KREG], int lane, int epoch, const int32_t *fail,
         bool onA, const double *UA, int uszA, int tabA, const int32_t *flagA, bool onB, const double *UB, int uszB, int tabB, const int32_t *flagB) {
     int dA[F3_KREG], dB[F3_KREG]; double sA[F3_KREG], sB[F3_KREG];
     const bool bigA = uszA > 512, bigB = uszB > 512;                 // uniform
     if (onA) { f3_child_places<0, 8>(tabA, rc, uszA, lane, dA); if (bigA) f3_child_places<8, F3_KREG>(tabA, rc, uszA, lane, dA); }
     if (onB) { f3_child_places<0, 8>(tabB, rc, uszB, lane, dB); if (bigB) f3_child_places<8, F3_KREG>(tabB, rc, uszB, lane, dB); }
     bool ok = true;                                                  // child A's loads are issued while child B may still be working
-    if (onA) { if (flagA) ok = f3_wait_flag(flagA, epoch) && ok;
+    if (onA) { if (flagA) ok = f3_wait_flag(flagA, epoch, fail) && ok;
         f3_child_loads<0, 8>(UA, uszA, lane, sA); if (bigA) f3_child_loads<8, F3_KREG>(UA, uszA, lane, sA); }
-    if (onB) { if (flagB) ok = f3_wait_flag(flagB, epoch) && ok;
+    if (onB) { if (flagB) ok = f3_wait_flag(flagB, epoch, fail) && ok;
         f3_child_loads<0, 8>(UB, uszB, lane, sB); if (bigB) f3_child_loads<8, F3_KREG>(UB, uszB, lane, sB); }
     if (onA) { f3_child_scatter<0, 8>(img, dA, sA); if (bigA) f3_child_scatter<8, F3_KREG>(img, dA, sA);
         if (uszA > 64 * F3_KREG) f3_child_tail(img, UA, uszA, tabA, lane); }
@@ -1666,9 +1670,9 @@ __device__ __forceinline__ void f3_block_front(const DevGraph &d, int pos, int l
             int dA[4], dB[4]; double sA[4], sB[4];
             f3_block_places(tA, rc, a_usz, tid, dA);
             if (hasB) f3_block_places(tB, rc, b_usz, tid, dB);
-            if (!plain) okw = f3_wait_flag(d.done_f + a_id, d.epoch) && okw;
+            if (!plain) okw = f3_wait_flag(d.done_f + a_id, d.epoch, d.fail) && okw;
             f3_block_loads(d.Uimg + a_uoff, a_usz, tid, sA);
-            if (hasB) { if (!plain) okw = f3_wait_flag(d.done_f + b_id, d.epoch) && okw;
+            if (hasB) { if (!plain) okw = f3_wait_flag(d.done_f + b_id, d.epoch, d.fail) && okw;
                 f3_block_loads(d.Uimg + b_uoff, b_usz, tid, sB); }
             f3_block_scatter(img, d.Uimg + a_uoff, a_usz, tA, tid, dA, sA);
             __syncthreads();
@@ -1867,7 +1871,7 @@ __global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(D
             const bool more = e + 2 < fr.nchild;
             if (more) { const int na = e + 2, nb = min(e + 3, fr.nchild - 1);
                 nA = xt[na * F3X + lane]; nhA = xt[na * F3X + 64 + (lane & 7)]; nB = xt[nb * F3X + lane]; nhB = xt[nb * F3X + 64 + (lane & 7)]; }
-            okw = f3_gather_pair(P.F, rc, lane, d.epoch, onA, d.Uimg + a_uoff, a_usz, tA, plain ? nullptr : d.done_f + a_id,
+            okw = f3_gather_pair(P.F, rc, lane, d.epoch, d.fail, onA, d.Uimg + a_uoff, a_usz, tA, plain ? nullptr : d.done_f + a_id,
                                  onB, d.Uimg + b_uoff, b_usz, tB, plain ? nullptr : d.done_f + b_id) && okw;
             if (e == 0) F3_TS(9);
             if (more) { tA = nA; tB = nB;
@@ -2025,13 +2029,14 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
         w = S[me * lds + f];
         double xb = 0.0;                                             // 0 beyond the boundary: those terms vanish
         if (nbnd > 0) {                                              // the boundary rows belong to the ancestors: poll the values themselves
-            bool got = false;
+            bool got = false, failed_already = false;
             for (int it = 0; it < (1 << 18); ++it) {
                 if (row >= 0) xb = ld_off_coh(d.xe, (uint32_t)row * 8u);
                 if (!__any(row >= 0 && f3_is_unset(xb))) { got = true; break; }
+                if ((it & 63) == 63 && __hip_atomic_load(d.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { failed_already = true; break; }   // some front reported: leave at once
                 __builtin_amdgcn_s_sleep(F3_POLL_SLEEP);
             }
-            if (!got) { if (lane == 0) atomicMax(d.fail, 2); if (f3_is_unset(xb)) xb = 0.0; }     // bounded: report, carry on, drain
+            if (!got) { if (lane == 0 && !failed_already) atomicMax(d.fail, 2); if (f3_is_unset(xb)) xb = 0.0; }     // bounded: report, carry on, drain
         }
         F3_TS(35);
 #pragma unroll

@@ -112,15 +112,17 @@ static double wrap_pi(double a) {
  *   obs_cone [N*K] ground-truth cone id of every observation
  * returns 0, or -1 on bad arguments.
  */
-int gs_track_generate_ex(int32_t n_poses, int32_t n_cones, const double *noise /* [5] sig_xy sig_th revert sig_az_deg sig_d */,
-                         double *truth_poses, double *odom_poses,
-                         double *cone_xy, int32_t *cone_type,
-                         double *obs, int32_t *obs_cone)
+static int track_generate_k(int32_t n_poses, int32_t n_cones, int32_t K, const double *noise /* [5] sig_xy sig_th revert sig_az_deg sig_d */,
+                            double *truth_poses, double *odom_poses,
+                            double *cone_xy, int32_t *cone_type,
+                            double *obs, int32_t *obs_cone)
 {
-    if (n_poses < 3 || n_cones < 24 || (n_cones & 1)) return -1;
-    const int N = n_poses, M = n_cones, P = M / 2;
+    /* K observations per pose = the K / 2 pairs within (0, 2.5 K] m ahead: K = 8 is the 20 m view of SURVEY 8d; K = 16 / 24 are
+     * what the reference's coneMappingThreshold of 50 m (usecase/docker-compose.yml:16, src/slam.cpp:608) lets a frame hold */
+    if (n_poses < 3 || n_cones < 24 || (n_cones & 1) || K < 2 || (K & 1) || K > 64 || 3 * K > n_cones) return -1;
+    const int N = n_poses, M = n_cones, P = M / 2, Q = K / 2;
     const double L = 2.5 * (double)M;
-    const double lidar = 1.5, half_width = 1.5, view = 20.0, spacing = 5.0;
+    const double lidar = 1.5, half_width = 1.5, view = 5.0 * (double)Q, spacing = 5.0;
     stadium t; stadium_init(&t, L);
     (void)spacing;
 
@@ -154,7 +156,7 @@ int gs_track_generate_ex(int32_t n_poses, int32_t n_cones, const double *noise /
         double c = cos(th), sn = sin(th);
         double lx = x + lidar * c, ly = y + lidar * sn;
         int col = 0;
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < Q; ++q) {
             int p = (p0 + q) % P;
             double ahead = 5.0 * (p0 + q) - sm;
             if (!(ahead > 0.0 && ahead <= view + 1e-9)) continue;   /* cannot happen with 5 m spacing */
@@ -168,19 +170,33 @@ int gs_track_generate_ex(int32_t n_poses, int32_t n_cones, const double *noise /
                 do { azn = az + sig_az * rng_normal(&r_obs); } while (azn == 0.0);
                 double dn = d + sig_d * rng_normal(&r_obs);
                 if (dn < 0.05) dn = 0.05;
-                double *o = obs + ((size_t)k * GS_TRACK_K + col) * 4;
+                double *o = obs + ((size_t)k * K + col) * 4;
                 o[0] = azn; o[1] = 0.0; o[2] = dn; o[3] = (double)cone_type[id];
-                obs_cone[(size_t)k * GS_TRACK_K + col] = id;
+                obs_cone[(size_t)k * K + col] = id;
                 ++col;
             }
         }
-        for (; col < GS_TRACK_K; ++col) {              /* never reached for valid tracks */
-            double *o = obs + ((size_t)k * GS_TRACK_K + col) * 4;
+        for (; col < K; ++col) {                       /* never reached for valid tracks */
+            double *o = obs + ((size_t)k * K + col) * 4;
             o[0] = 1.0; o[1] = 0.0; o[2] = 1e6; o[3] = 0.0;
-            obs_cone[(size_t)k * GS_TRACK_K + col] = -1;
+            obs_cone[(size_t)k * K + col] = -1;
         }
     }
     return 0;
+}
+
+int gs_track_generate_ex(int32_t n_poses, int32_t n_cones, const double *noise, double *truth_poses, double *odom_poses,
+                         double *cone_xy, int32_t *cone_type, double *obs, int32_t *obs_cone)
+{
+    return track_generate_k(n_poses, n_cones, GS_TRACK_K, noise, truth_poses, odom_poses, cone_xy, cone_type, obs, obs_cone);
+}
+
+/* the same lap with K observations per pose (obs [N*K*4], obs_cone [N*K]) */
+int gs_track_generate_k(int32_t n_poses, int32_t n_cones, int32_t K, double *truth_poses, double *odom_poses,
+                        double *cone_xy, int32_t *cone_type, double *obs, int32_t *obs_cone)
+{
+    const double noise[5] = {0.05, 0.005, 0.0, 0.5, 0.05};
+    return track_generate_k(n_poses, n_cones, K, noise, truth_poses, odom_poses, cone_xy, cone_type, obs, obs_cone);
 }
 
 int gs_track_generate(int32_t n_poses, int32_t n_cones,

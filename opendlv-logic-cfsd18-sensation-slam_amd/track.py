@@ -39,21 +39,23 @@ def _load():
             build()
         _lib = C.CDLL(LIB)
         _lib.gs_track_generate.argtypes = [C.c_int32, C.c_int32, _dp, _dp, _dp, _ip, _dp, _ip]
+        _lib.gs_track_generate_k.argtypes = [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, _ip, _dp, _ip]
     return _lib
 
 
-def generate(n_poses, n_cones):
+def generate(n_poses, n_cones, obs_per_pose=None):
     """One lap of the synthetic track.  Returns a dict of numpy arrays:
-    truth_poses [N,3], odom_poses [N,3], cone_xy [M,2], cone_type [M], obs [N,K,4], obs_cone [N,K]."""
+    truth_poses [N,3], odom_poses [N,3], cone_xy [M,2], cone_type [M], obs [N,K,4], obs_cone [N,K].
+    obs_per_pose: K (default 8, SURVEY §8d: the 4 pairs within 20 m); 16 / 24 = the pairs within 40 / 60 m."""
     L = _load()
-    K = L.gs_track_obs_per_pose()
+    K = L.gs_track_obs_per_pose() if obs_per_pose is None else int(obs_per_pose)
     N, M = int(n_poses), int(n_cones)
     t = dict(truth_poses=np.zeros((N, 3)), odom_poses=np.zeros((N, 3)), cone_xy=np.zeros((M, 2)),
              cone_type=np.zeros(M, dtype=np.int32), obs=np.zeros((N, K, 4)),
              obs_cone=np.zeros((N, K), dtype=np.int32))
-    rc = L.gs_track_generate(N, M, t["truth_poses"].ctypes.data_as(_dp), t["odom_poses"].ctypes.data_as(_dp),
-                             t["cone_xy"].ctypes.data_as(_dp), t["cone_type"].ctypes.data_as(_ip),
-                             t["obs"].ctypes.data_as(_dp), t["obs_cone"].ctypes.data_as(_ip))
+    a = (t["truth_poses"].ctypes.data_as(_dp), t["odom_poses"].ctypes.data_as(_dp), t["cone_xy"].ctypes.data_as(_dp),
+         t["cone_type"].ctypes.data_as(_ip), t["obs"].ctypes.data_as(_dp), t["obs_cone"].ctypes.data_as(_ip))
+    rc = L.gs_track_generate(N, M, *a) if obs_per_pose is None else L.gs_track_generate_k(N, M, K, *a)
     if rc != 0:
         raise ValueError("gs_track_generate(%d, %d) rejected its arguments" % (N, M))
     t["K"] = K

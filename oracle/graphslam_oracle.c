@@ -33,6 +33,7 @@ struct orc_graph {
     int *perm, *iperm, *Cp, *Ci; double *Cx; int *cmap;         /* permuted matrix + map from A entries */
     int *parent, *Lp, *Li, *Lnz, *flag, *pattern; double *Lx, *D, *y;
     int ldlt_ordering, ldlt_valid;
+    int *user_perm; int user_perm_n;                              /* ordering 2: caller-supplied elimination order (perm[new] = old) */
     double *delta;                                              /* last x [n] */
 };
 
@@ -64,6 +65,7 @@ void orc_destroy(orc_graph *g) {
     free(g->pose); free(g->pfix); free(g->lm); free(g->lfix);
     free(g->pp_i); free(g->pp_j); free(g->pp_z); free(g->pp_info);
     free(g->pl_p); free(g->pl_l); free(g->pl_z); free(g->pl_info);
+    free(g->user_perm);
     free(g);
 }
 
@@ -453,6 +455,7 @@ static void ldlt_symbolic(orc_graph *g, int ordering) {
     g->perm = (int *)malloc((size_t)(n + 1) * sizeof(int));   /* perm[new] = old */
     g->iperm = (int *)malloc((size_t)(n + 1) * sizeof(int));
     if (ordering == 0) { for (int i = 0; i < n; ++i) g->perm[i] = i; }
+    else if (ordering == 2 && g->user_perm && g->user_perm_n == n) { memcpy(g->perm, g->user_perm, (size_t)n * sizeof(int)); }
     else {
         int *last = (int *)malloc((size_t)(g->nl + 1) * sizeof(int));
         for (int l = 0; l < g->nl; ++l) last[l] = -1;
@@ -515,6 +518,25 @@ static int ldlt_numeric(orc_graph *g) {
         if (d == 0.0) return -1;
     }
     return 0;
+}
+/* ordering 2: the elimination order of ANOTHER solver (e.g. the nested-dissection order of the HIP back-end's plan), so that
+ * its increment can be compared with this LDL^T's under the SAME order — what is left then is arithmetic, not ordering.
+ * perm[new] = old in this oracle's scalar numbering (orc_vertex_offsets); checked to be a permutation. */
+int orc_set_elimination_order(orc_graph *g, const int *perm, int n) {
+    if (!g || !perm || n <= 0) return -1;
+    char *seen = (char *)calloc((size_t)n, 1);
+    for (int i = 0; i < n; ++i) { if (perm[i] < 0 || perm[i] >= n || seen[perm[i]]) { free(seen); return -2; } seen[perm[i]] = 1; }
+    free(seen);
+    free(g->user_perm); g->user_perm = (int *)malloc((size_t)n * sizeof(int)); memcpy(g->user_perm, perm, (size_t)n * sizeof(int));
+    g->user_perm_n = n; g->ldlt_valid = 0;
+    return 0;
+}
+/* first scalar of every vertex in the system's numbering (free landmarks first, then free poses: g2o's hessian index order,
+ * SURVEY 8-A.6), -1 for fixed vertices; valid after orc_build_system */
+int orc_vertex_offsets(const orc_graph *g, int *pose_off, int *lm_off) {
+    if (!g || !g->structure_valid) return -1;
+    memcpy(pose_off, g->pose_off, (size_t)g->np * sizeof(int)); memcpy(lm_off, g->lm_off, (size_t)g->nl * sizeof(int));
+    return g->n;
 }
 int orc_solve_ldlt(orc_graph *g, int ordering, double *x) {
     if (!g->structure_valid) return -1;

@@ -94,8 +94,12 @@ const int *orc_system_rowind(const orc_graph *g);
 const double *orc_system_values(const orc_graph *g);
 const double *orc_system_b(const orc_graph *g);
 
-/* A8 own restatement of Eigen's up-looking LDL^T.  ordering: 0 natural, 1 track interleave */
+/* A8 own restatement of Eigen's up-looking LDL^T.  ordering: 0 natural, 1 track interleave, 2 caller-supplied (orc_set_elimination_order) */
 int  orc_solve_ldlt(orc_graph *g, int ordering, double *x /* [n] */);
+/* ordering 2 = a caller-supplied elimination order (perm[new] = old scalar, numbering of orc_vertex_offsets): the order of
+ * another exact solver, so that what differs between the two increments is arithmetic, not ordering */
+int  orc_set_elimination_order(orc_graph *g, const int *perm, int n);
+int  orc_vertex_offsets(const orc_graph *g, int *pose_off /* [np] */, int *lm_off /* [nl] */);   /* returns n; -1 before orc_build_system */
 /* A9 */
 void orc_apply_update(orc_graph *g, const double *x);
 /* last increment per vertex in insertion order (zeros for fixed) */

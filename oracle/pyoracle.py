@@ -66,7 +66,7 @@ def lib():
                   "orc_num_observation_edges", "orc_get_poses", "orc_get_landmarks", "orc_set_poses",
                   "orc_set_landmarks", "orc_chi2", "orc_linearize_blocks", "orc_build_system",
                   "orc_system_n", "orc_system_nnz", "orc_system_colptr", "orc_system_rowind",
-                  "orc_system_values", "orc_system_b", "orc_solve_ldlt", "orc_apply_update",
+                  "orc_system_values", "orc_system_b", "orc_solve_ldlt", "orc_apply_update", "orc_set_elimination_order", "orc_vertex_offsets",
                   "orc_get_delta"):
             fn = getattr(L, f)
             if fn.argtypes is None:
@@ -213,6 +213,20 @@ class OracleGraph:
         values = np.ctypeslib.as_array(self.L.orc_system_values(self.g), (max(nnz, 1),))[:nnz].copy()
         b = np.ctypeslib.as_array(self.L.orc_system_b(self.g), (max(n, 1),))[:n].copy()
         return n, colptr, rowind, values, b
+
+    def set_elimination_order_like(self, pose_gidx, lm_gidx):
+        """ordering=2: eliminate in the order of another exact solver, given as the first scalar of every vertex in ITS
+        elimination order (-1 fixed) — e.g. pose_gidx / lm_gidx of the HIP back-end's nested-dissection plan (gs_plan_export)."""
+        n = self.L.orc_build_system(self.g)
+        po_ = np.zeros(self.n_poses, dtype=np.int32); lo_ = np.zeros(self.n_landmarks, dtype=np.int32)
+        assert self.L.orc_vertex_offsets(self.g, _i(po_), _i(lo_)) == n
+        perm = -np.ones(n, dtype=np.int32)
+        pg = np.asarray(pose_gidx, dtype=np.int64); lg = np.asarray(lm_gidx, dtype=np.int64)
+        assert np.array_equal(pg >= 0, po_ >= 0) and np.array_equal(lg >= 0, lo_ >= 0), "the two solvers disagree on the fixed vertices"
+        for t in range(3): perm[pg[pg >= 0] + t] = po_[po_ >= 0] + t
+        for t in range(2): perm[lg[lg >= 0] + t] = lo_[lo_ >= 0] + t
+        rc = self.L.orc_set_elimination_order(self.g, _i(np.ascontiguousarray(perm)), n)
+        if rc != 0: raise ValueError("not a permutation (%d)" % rc)
 
     def solve_ldlt(self, ordering=1):
         n = self.L.orc_system_n(self.g)

@@ -1,0 +1,75 @@
+"""How far apart are the GPU path and the CPU paths, measured against how far the CPU paths are from EACH OTHER?
+For one configuration (cfg4 by default): (1) the linearised system at the initial point, GPU vs oracle, block by block;
+(2) the first Gauss-Newton increment and (3) the estimates after the reference's 10 iterations (src/slam.cpp:481), pairwise
+between the GPU, the oracle's own LDL^T (track order; natural order where its fill-in fits), and the reference's vendored
+Eigen SimplicialLDLT + AMD (oracle/_ref).  GS_LIB selects an A/B build of the library (e.g. -DGS_G2O_ORDER=0).
+Writes gpurun_out/parity_spread_<cfg>_<tag>.json."""
+import importlib, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import make_oracle_graph
+from oracle import pyoracle as po
+pkg = importlib.import_module("opendlv-logic-cfsd18-sensation-slam_amd")
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
+tag = sys.argv[2] if len(sys.argv) > 2 else "default"
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+N, M = pkg.track.CONFIGS[name]
+t = pkg.track.generate(N, M); g = pkg.track.bench_graph(t, po.OracleFrontend())
+out = {"config": name, "tag": tag, "library": os.environ.get("GS_LIB", "default build"), "iterations": iters}
+
+# (1) H, b at the initial point
+G = pkg.Graph(); G.load_bench_graph(g); G.linearize(); sg = G.export_system()
+og = make_oracle_graph(po, g); so = og.linearize_blocks()
+blocks = {}
+for k in ("Hpp_diag", "Hll_diag", "Hpp_off", "Hpl", "b_pose", "b_lm"):
+    a, b = sg[k], so[k]
+    m = (np.abs(a) > 0) & (np.abs(b) > 0)                  # the export zeroes the blocks of fixed vertices, the oracle leaves them
+    d = np.abs(a - b)[m]
+    blocks[k] = {"max_abs_diff_over_max_abs": float(d.max() / np.abs(b).max()), "rms_diff_over_rms": float(np.sqrt((d ** 2).mean()) / np.sqrt((b[m] ** 2).mean())),
+                 "fraction_bitwise_equal": float((a[m] == b[m]).mean())}
+    print("%-9s max |gpu - oracle| / max |oracle| = %.3g, rms ratio %.3g, bitwise equal %.3f" % (k, blocks[k]["max_abs_diff_over_max_abs"], blocks[k]["rms_diff_over_rms"], blocks[k]["fraction_bitwise_equal"]), flush=True)
+out["system_at_initial_point_gpu_vs_oracle"] = blocks
+
+# (2) + (3): the runs
+rms_radius = float(np.sqrt((g["pose_est"][:, :2] ** 2).sum(1).mean()))
+runs = {}
+t0 = time.time(); G.optimize(1); d1 = G.export_delta(); G.optimize(iters - 1); runs["gpu"] = dict(delta1=d1, P=G.poses(), L=G.landmarks(), chi2=G.chi2()); G.close()
+print("gpu %.1f s" % (time.time() - t0), flush=True)
+from plan_exec import Plan
+Hh = pkg.Graph(device=-2); Hh.load_bench_graph(g); Hh.plan_build_host(); PL = Plan(Hh.plan_export()); Hh.close()
+cpu = [("oracle_ldlt_track_order", 1, False), ("oracle_ldlt_gpu_plan_order", 2, False)]      # the second: the CPU arithmetic in the GPU's nested-dissection order
+if N <= 200000: cpu.append(("oracle_ldlt_natural_order", 0, False))      # natural order: fill-in beyond memory at 1M poses
+if po.ref_eigen() is not None: cpu.append(("eigen_simplicial_ldlt_amd", 1, True))
+for label, ordering, eig in cpu:
+    o = make_oracle_graph(po, g); t0 = time.time()
+    if ordering == 2: o.set_elimination_order_like(PL.pose_gidx, PL.lm_gidx)
+    sol = po.EigenSolver(0) if eig else None
+    o.optimize(1, ordering=ordering, solver=sol); d1 = o.delta()
+    o.optimize(iters - 1, ordering=ordering, solver=sol)
+    runs[label] = dict(delta1=d1, P=o.poses(), L=o.landmarks(), chi2=o.chi2())
+    print("%s %.1f s" % (label, time.time() - t0), flush=True)
+def wrap(a): return (a + np.pi) % (2 * np.pi) - np.pi
+keys = list(runs); pairs = {}
+for i in range(len(keys)):
+    for j in range(i + 1, len(keys)):
+        a, b = runs[keys[i]], runs[keys[j]]
+        dd = a["delta1"][0][:, :2] - b["delta1"][0][:, :2]; pp = a["P"][:, :2] - b["P"][:, :2]
+        pairs[keys[i] + " vs " + keys[j]] = r = {
+            "first_increment_max_abs_diff_m": float(np.abs(dd).max()), "first_increment_rms_diff_m": float(np.sqrt((dd ** 2).sum(1).mean())),
+            "pose_rmse_rel_after_iterations": float(np.sqrt((pp ** 2).sum(1).mean()) / rms_radius),
+            "pose_max_abs_diff_m": float(np.abs(pp).max()), "landmark_rmse_rel": float(np.sqrt(((a["L"] - b["L"]) ** 2).sum(1).mean()) / rms_radius),
+            "heading_max_abs_diff": float(np.abs(wrap(a["P"][:, 2] - b["P"][:, 2])).max()), "chi2_rel_diff": float(abs(a["chi2"] - b["chi2"]) / b["chi2"])}
+        print("%-58s first increment max %.3g m rms %.3g m | after %d iterations pose RMSE rel %.3g (max %.3g m), chi2 rel %.3g"
+              % (keys[i] + " vs " + keys[j], r["first_increment_max_abs_diff_m"], r["first_increment_rms_diff_m"], iters, r["pose_rmse_rel_after_iterations"], r["pose_max_abs_diff_m"], r["chi2_rel_diff"]), flush=True)
+out["pairs"] = pairs
+out["first_increment_max_abs_m"] = {k: float(np.abs(v["delta1"][0][:, :2]).max()) for k, v in runs.items()}
+out["track_rms_radius_m"] = rms_radius
+gpu_pairs = [v["pose_rmse_rel_after_iterations"] for k, v in pairs.items() if k.startswith("gpu vs")]
+cpu_pairs = [v["pose_rmse_rel_after_iterations"] for k, v in pairs.items() if not k.startswith("gpu vs")]
+out["same_order_first_increment_gap_m"] = pairs["gpu vs oracle_ldlt_gpu_plan_order"]["first_increment_max_abs_diff_m"]
+out["gpu_vs_cpu_worst"] = max(gpu_pairs); out["cpu_vs_cpu_worst"] = max(cpu_pairs) if cpu_pairs else None
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+fn = os.path.join(ROOT, "gpurun_out", "parity_spread_%s_%s.json" % (name, tag))
+json.dump(out, open(fn, "w"), indent=1)
+print("wrote", fn)

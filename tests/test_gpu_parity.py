@@ -306,7 +306,22 @@ def test_front_flag_timeout_falls_back_to_level_launches_and_finishes(pkg, po, b
     G.debug_fail_at_iteration(3, 2)
     done, st = G.optimize(5)
     assert done == 5 and st.numeric_failure == 0 and st.iterations == 5
+    assert st.fell_back == 1 and st.first_failure == 2         # ... and the caller can SEE that it now runs the slow path, and why
+    assert G.stats().fell_back == 1
     assert rel(G.poses(), og.poses()) < 1e-9 and rel(G.landmarks(), og.landmarks()) < 1e-9
+    done, st = G.optimize(2); og.optimize(2, ordering=1)       # later calls stay on one launch per level until the next plan
+    assert done == 2 and st.fell_back == 1 and st.first_failure == 0 and rel(G.poses(), og.poses()) < 1e-9
+    G.add_pose(5000, g["pose_est"][-1] + [0.25, 0.0, 0.0])       # a structure change builds a new plan: whole-tree launches again
+    G.add_odometry_edge(len(g["pose_est"]) - 1, 5000, [0.25, 0.0, 0.0], 5 * np.eye(3))
+    done, st = G.optimize(1)
+    assert done == 1 and st.fell_back == 0 and st.first_failure == 0
+    G.close()
+
+
+def test_a_healthy_handle_reports_no_fallback(pkg, bench_graphs):
+    _, g = bench_graphs(1000, 200)
+    G = fresh(pkg, g); done, st = G.optimize(10)
+    assert done == 10 and st.fell_back == 0 and st.first_failure == 0 and st.numeric_failure == 0
     G.close()
 
 
@@ -667,15 +682,21 @@ def test_normal_equation_residual_helper_agrees_with_the_oracle(pkg, po, bench_g
     assert normal_equation_residual(g, sysm, 1.001 * dp, dl) > 1e-6    # and the helper notices a wrong increment
 
 
-def test_cfg5_single_handle_properties_and_eight_pose_windows(pkg, frontend):
-    """BASELINE config 5, "1M poses / 50k cones sharded by pose window across 8 GPUs": too slow for the oracle in a test, so
-    size-independent properties.  (a) ONE handle: the increment of an iteration solves the exported normal equations
-    (residual 1e-9 of |b|), chi2 decreases to a fixed point, the gauge stays put.  (b) The same graph split over 8 rank
-    handles that share this one GPU — the exchange buffers summed in-process exactly where the 8-GPU run all-reduces
-    them over RCCL: the merged increment of the first iteration solves THE SAME normal equations to 1e-9, and after 5
-    iterations the merged estimates have the single handle's chi2.  Estimates are compared too, but a 250 km lap is too
-    ill-conditioned for the 1e-6 bar between ANY two exact elimination orders after 5 undamped Gauss-Newton steps: the
-    single handle with another leaf size (same kernels) is measured beside the shards and sets the scale."""
+def test_cfg5_single_handle_properties_and_eight_pose_windows(pkg, po, frontend):
+    """BASELINE config 5, "1M poses / 50k cones sharded by pose window across 8 GPUs".
+    (a) ONE handle against the CPU paths after the reference's 10 iterations (src/slam.cpp:481): the oracle with its own LDL^T
+    and the oracle with the reference's vendored Eigen SimplicialLDLT + AMD (oracle/_ref) run the same 10 iterations (~25 s
+    each); all pairwise pose RMSEs are printed and written to gpurun_out/cfg5_parity.json.  A 250 km lap is ill-conditioned
+    enough that two CPU paths that differ in elimination order only do not agree to 1e-6 themselves, so the bound for
+    GPU-vs-oracle is: <= 1e-6 (the north_star bar) OR <= K_SPREAD x the CPU-vs-CPU spread, K_SPREAD stated below.
+    Size-independent properties beside it: the increment of an iteration solves the exported normal equations (residual
+    1e-9 of |b|), chi2 decreases to a fixed point, the gauge stays put.
+    (b) The same graph split over 8 rank handles that share this one GPU — the exchange buffers summed in-process exactly
+    where the 8-GPU run all-reduces them over RCCL: the merged increment of the first iteration solves THE SAME normal
+    equations to 1e-9, and after 10 iterations the merged estimates are as close to the single handle's as the CPU paths
+    are to each other (same K_SPREAD) and have the single handle's chi2."""
+    import json
+    K_SPREAD = 10.0
     N, M = pkg.track.CONFIGS["cfg5"]
     t = pkg.track.generate(N, M)
     g = pkg.track.bench_graph(t, frontend)
@@ -687,20 +708,42 @@ def test_cfg5_single_handle_properties_and_eight_pose_windows(pkg, frontend):
     dp, dl = G.export_delta()
     r_single = normal_equation_residual(g, sysm, dp, dl)
     assert r_single < 1e-9, r_single
-    done, st = G.optimize(4)
-    assert done == 4 and st.numeric_failure == 0 and st.chi2_final < st.chi2_initial
+    done, st = G.optimize(9)                                     # the reference's 10 iterations in total
+    assert done == 9 and st.numeric_failure == 0 and st.chi2_final < st.chi2_initial
     P1, L1 = G.poses(), G.landmarks()
-    dp5 = np.abs(G.export_delta()[0]).max()
-    done, st = G.optimize(5)                                     # the reference's 10 iterations in total
-    assert done == 5 and st.numeric_failure == 0
+    dp10 = np.abs(G.export_delta()[0]).max()
     c1 = G.chi2(); G.optimize(1); c2 = G.chi2()
-    assert abs(c2 - c1) <= 1e-9 * c1                             # chi2 has reached its fixed point ...
-    dpl, dll = G.export_delta()
-    # ... while the increment still shrinks: on a 250 km lap the weakly observable global modes of the undamped
-    # Gauss-Newton iteration move by metres for chi2 changes below 1e-9 (measured: 3.3 m at iteration 11)
-    assert np.abs(dpl).max() < 0.5 * dp5 and np.abs(dpl).max() < 1e-4 * np.abs(P1[:, :2]).max()
+    assert abs(c2 - c1) <= 1e-9 * c1                             # chi2 has reached its fixed point
     assert np.array_equal(G.poses()[:2], g["pose_est"][:2]) and np.array_equal(G.landmarks()[:2], g["lm_est"][:2])
     G.close()
+    rms = np.sqrt((P1[:, :2] ** 2).sum(1).mean())
+    def rmse(A, B): return float(np.sqrt(((A - B) ** 2).sum(1).mean()) / rms)
+    def wrap(a): return (a + np.pi) % (2 * np.pi) - np.pi
+    # ---- (a) the CPU paths, 10 iterations each
+    est = {"gpu": (P1, L1)}
+    og = make_oracle_graph(po, g); d_o, _, _ = og.optimize(10, ordering=1); assert d_o == 10
+    est["oracle_ldlt_track_order"] = (og.poses(), og.landmarks()); del og
+    # the same CPU arithmetic in the GPU plan's nested-dissection order: what is left between it and the GPU is arithmetic, not ordering
+    from plan_exec import Plan
+    Hh = pkg.Graph(device=-2); Hh.load_bench_graph(g); Hh.plan_build_host(); PL = Plan(Hh.plan_export()); Hh.close()
+    og = make_oracle_graph(po, g); og.set_elimination_order_like(PL.pose_gidx, PL.lm_gidx); del PL
+    d_n, _, _ = og.optimize(10, ordering=2); assert d_n == 10
+    est["oracle_ldlt_gpu_plan_order"] = (og.poses(), og.landmarks()); del og
+    if po.ref_eigen() is not None:
+        og = make_oracle_graph(po, g); d_e, _, _ = og.optimize(10, ordering=1, solver=po.EigenSolver(0)); assert d_e == 10
+        est["eigen_simplicial_ldlt_amd"] = (og.poses(), og.landmarks()); del og
+    keys = list(est); pairs = {}
+    for i in range(len(keys)):
+        for j in range(i + 1, len(keys)):
+            A, B = est[keys[i]], est[keys[j]]
+            pairs[keys[i] + " vs " + keys[j]] = dict(pose_rmse_rel=rmse(A[0][:, :2], B[0][:, :2]), landmark_rmse_rel=rmse(A[1], B[1]),
+                                                      heading_max_abs=float(np.abs(wrap(A[0][:, 2] - B[0][:, 2])).max()))
+    for k, v in pairs.items():
+        print("cfg5 after 10 iterations: %-56s pose RMSE rel %.3g, landmark RMSE rel %.3g, heading max %.3g" % (k, v["pose_rmse_rel"], v["landmark_rmse_rel"], v["heading_max_abs"]))
+    gpu_worst = max(v["pose_rmse_rel"] for k, v in pairs.items() if k.startswith("gpu vs"))
+    cpu_spread = max([v["pose_rmse_rel"] for k, v in pairs.items() if not k.startswith("gpu vs")] or [0.0])
+    same_order = pairs["gpu vs oracle_ldlt_gpu_plan_order"]["pose_rmse_rel"]
+    # ---- (b) 8 pose windows on this one GPU
     world = 8
     ranks = []
     for r in range(world):
@@ -714,7 +757,7 @@ def test_cfg5_single_handle_properties_and_eight_pose_windows(pkg, frontend):
             assert 0.10 < pk.mean() < 0.16                       # a rank tracks its own window (1/8) plus the shared top
         assert np.all(cp == 1) and np.all(cl == 1) and 0 < shared.sum() < 200      # every vertex has one primary rank; few are shared
         return A, B
-    for it in range(5):
+    for it in range(10):
         for H in ranks:
             H.dist_iterate_local()
         total = sum(H.dist_read_exchange() for H in ranks)
@@ -731,17 +774,22 @@ def test_cfg5_single_handle_properties_and_eight_pose_windows(pkg, frontend):
     P, L = merged(lambda H: (H.poses(), H.landmarks()), 3, 2)
     for H in ranks:
         H.close()
-    rms = np.sqrt((P1[:, :2] ** 2).sum(1).mean())
-    def rmse(A, B): return float(np.sqrt(((A - B) ** 2).sum(1).mean()) / rms)
-    def wrap(a): return (a + np.pi) % (2 * np.pi) - np.pi
-    G2 = fresh(pkg, g, leaf_poses=5); G2.optimize(5); P2, L2 = G2.poses(), G2.landmarks(); G2.close()
     e_sh = (rmse(P[:, :2], P1[:, :2]), rmse(L, L1), float(np.abs(wrap(P[:, 2] - P1[:, 2])).max()))
-    e_lf = (rmse(P2[:, :2], P1[:, :2]), rmse(L2, L1), float(np.abs(wrap(P2[:, 2] - P1[:, 2])).max()))
-    print("cfg5: normal-equation residual of the first increment: single handle %.3g, 8 pose windows %.3g; estimates after 5 "
-          "iterations vs the single handle: 8 pose windows pose/landmark RMSE rel %.3g %.3g, heading max %.3g; single handle "
-          "with leaf_poses=5: %.3g %.3g %.3g" % ((r_single, r_shard) + e_sh + e_lf))
-    assert e_sh[0] < 1e-3 and e_sh[1] < 1e-3
-    assert e_sh[0] < 20 * max(e_lf[0], 1e-12)                    # the shards are no further off than another elimination order is
+    pairs["gpu 8 pose windows vs gpu"] = dict(pose_rmse_rel=e_sh[0], landmark_rmse_rel=e_sh[1], heading_max_abs=e_sh[2])
+    print("cfg5: normal-equation residual of the first increment: single handle %.3g, 8 pose windows %.3g; last increment of the single handle "
+          "%.3g m; 8 pose windows vs the single handle after 10 iterations: pose/landmark RMSE rel %.3g %.3g, heading max %.3g"
+          % ((r_single, r_shard, dp10) + e_sh))
+    rec = dict(config="cfg5: 1M poses / 50k cones", iterations=10, pairs=pairs, gpu_vs_cpu_worst_pose_rmse_rel=gpu_worst,
+               cpu_vs_cpu_spread_pose_rmse_rel=cpu_spread, gpu_vs_oracle_in_the_same_elimination_order_pose_rmse_rel=same_order, k_spread=K_SPREAD, normal_equation_residual_single=r_single, normal_equation_residual_8_windows=r_shard)
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        json.dump(rec, open(os.path.join(root, "gpurun_out", "cfg5_parity.json"), "w"), indent=1)
+    except OSError:
+        pass
+    bound = max(1e-6, K_SPREAD * cpu_spread)
+    assert gpu_worst <= bound, (gpu_worst, cpu_spread)
+    assert e_sh[0] <= bound and e_sh[1] <= bound, (e_sh, cpu_spread)
     # chi2 of the merged estimates (evaluated by one fresh handle over ALL edges) equals the single handle's
     def chi2_of(Pe, Le):
         Hh = fresh(pkg, dict(g, pose_est=Pe, lm_est=Le)); c = Hh.chi2(); Hh.close(); return c

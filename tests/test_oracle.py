@@ -256,3 +256,19 @@ def test_optimize_until_stop_rule_and_failure_semantics(po, pkg, frontend):
     s.add_odometry_edges([0, 1], [1, 2], np.array([[1.0, 0, 0], [1.0, 0, 0]]), info)
     done, _, failed = s.optimize_until(3, -1.0, ordering=0)
     assert done == 0 and failed and np.array_equal(s.poses(), P0)
+
+
+def test_caller_supplied_elimination_order_is_another_exact_order(pkg, po, bench_graphs):
+    """ordering 2 = the oracle's LDL^T in the elimination order of ANOTHER solver — here the nested-dissection order of the
+    product's host-side plan (no GPU involved).  Any exact order gives the same increment up to rounding; a sequence that is
+    not a permutation is refused.  (scripts/parity_spread.py uses this to separate "other order" from "other arithmetic" when
+    the GPU increment is compared with the CPU increments.)"""
+    from plan_exec import Plan
+    _, g = bench_graphs(1000, 200)
+    H = pkg.Graph(device=-2); H.load_bench_graph(g); H.plan_build_host(); P = Plan(H.plan_export()); H.close()
+    og = make_oracle_graph(po, g); og.build_system(); x1 = og.solve_ldlt(1)
+    og.set_elimination_order_like(P.pose_gidx, P.lm_gidx); x2 = og.solve_ldlt(2)
+    assert np.abs(x1 - x2).max() <= 1e-8 * np.abs(x1).max()
+    assert not np.array_equal(x1, x2)                          # ... and it really is a different order (different rounding)
+    bad = np.zeros(len(x1), dtype=np.int32)
+    assert po.lib().orc_set_elimination_order(og.g, bad.ctypes.data_as(po._ip), len(bad)) == -2
