@@ -60,12 +60,13 @@ typedef struct gs_config {
     int32_t verbose;            /* 1: print g2o-style "iteration= i chi2= ..." to stderr
                                    (reference: setVerbose(true), src/slam.cpp:63)          */
     int32_t leaf_poses;         /* nested-dissection leaf size in poses; 0 = default        */
-    int32_t factor_variant;     /* front factorisation kernel: 0 = default (3 when every front has <= 63
-                                   scalars, else 4); 3 = wave-per-front LDL^T on the fp64 matrix cores
-                                   (v_mfma_f64_16x16x4_f64), update matrices moved in storage order;
-                                   2 = wave-per-front Cholesky on the matrix cores; 1 = wave-per-front
-                                   VALU; 4 = block-per-front VALU, any front size.  1-3 need every front
-                                   <= 63 scalars and fall back to 4 otherwise                      */
+    int32_t factor_variant;     /* front factorisation kernel: 0 = default (3 when every front has <= 159
+                                   scalars, else 4); 3 = LDL^T on the fp64 matrix cores
+                                   (v_mfma_f64_16x16x4_f64), chosen PER FRONT: a wave for a front of <= 63
+                                   scalars, a workgroup for one of 64 .. 159; update matrices moved in
+                                   storage order; 2 = wave-per-front Cholesky on the matrix cores; 1 =
+                                   wave-per-front VALU (both: every front <= 63 scalars, else 4);
+                                   4 = block-per-front VALU, any front size                        */
     int32_t linearize_gather;   /* 1: force the general gather kernels instead of the fused tiled
                                    linearisation kernel (both are HIP; for tests and A/B timing)   */
     /* Slam-level constants, defaults are the reference's hard-coded values */
@@ -107,6 +108,9 @@ typedef struct gs_stats {
                                    up on a front's completion flag — in this call or an earlier one; 0: whole-tree launches */
     int32_t first_failure;      /* the first failure code this call met (0 none): a flag timeout (2) that the per-level
                                    fallback then repaired leaves numeric_failure 0 and first_failure 2 */
+    int32_t factor_variant;     /* the front kernels this plan runs on (gs_config.factor_variant after the per-plan rules): 3 = LDL^T on
+                                   the fp64 matrix cores (a wave per front up to 63 scalars, a workgroup per front up to 159), 4 = block VALU */
+    int32_t n_big_fronts;       /* fronts of more than 63 scalars (variant 3: the ones that get a workgroup) */
 } gs_stats;
 
 int  gs_version(void);                               /* major*100+minor */

@@ -493,7 +493,9 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
     { int v = g->default_factor_variant;
       if (const char *e = std::getenv("GS_FACTOR_VARIANT")) v = std::atoi(e);
       v = gs_debug_select_factor_variant(v, P.max_front, arena_doubles);
+      if (v == 3 && P.max_front > 63 && P.world > 1) v = 4;           // the workgroup-per-front form has no shard modes (contribution / shared top) yet
       if (v == 4) v = 0;                                              // device-side code for the block-per-front kernel
+      g->wg_f.clear(); g->wg_b.clear(); g->d_wg_f = g->d_wg_b = nullptr;
       d.factor_variant = v;
       if (const char *e = std::getenv("GS_DBG")) d.dbg = std::atoi(e);
       if (v == 2) { AL(Uimg, (size_t)P.fronts.size() * 2568); ZERO(Uimg, (size_t)P.fronts.size() * 2568); }   // 2560-double tile images
@@ -544,13 +546,14 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
             launch_build_sc3(bf_dev, d.asm3, d.sc3, d.lm3, (int)S, A, g->stream);
             GS_UT("sc3 build");
             // descriptors + children tables: one wave per level position (k_build_f3)
+            d.f3x_stride = P.max_front > 63 ? 168 : 72;                 // a child's row table: 64 entries, or 160 when the plan holds a big front
             std::vector<int32_t> xrow(lf.size() + 1, 0);
-            for (size_t q = 0; q < lf.size(); ++q) { xrow[q + 1] = xrow[q] + 72 * P.fronts[lf[q]].child_cnt;
+            for (size_t q = 0; q < lf.size(); ++q) { xrow[q + 1] = xrow[q] + d.f3x_stride * P.fronts[lf[q]].child_cnt;
                 if (xrow[q + 1] >= (1 << 30)) return fail(GS_ERR_INVALID, "children table too large"); }
             int32_t *xrow_dev = nullptr; if ((rc = dev_upload(g, &xrow_dev, xrow)) != GS_OK) return rc;
-            AL(f3_desc, lf.size() * (size_t)F3W); AL(f3_x, (size_t)xrow[lf.size()] + 72);
+            AL(f3_desc, lf.size() * (size_t)F3W); AL(f3_x, (size_t)xrow[lf.size()] + 168);
             launch_build_f3((int)lf.size(), d.level_fronts, d.fronts, d.children, d.child_map, d.u3_off, d.u3_size, bf_dev, xrow_dev,
-                            P.world > 1 ? d.x_off : nullptr, d.f3_desc, d.f3_x, g->stream);
+                            P.world > 1 ? d.x_off : nullptr, d.f3_desc, d.f3_x, d.f3x_stride, g->stream);
             GS_UT("f3 tables"); }
       } }
     GS_UT("f3 x+desc upload");
@@ -597,13 +600,15 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
 // The factor kernel a plan gets (gs_config.factor_variant, GS_FACTOR_VARIANT overrides): 0 = default = 3.
 //   3 = wave-per-front LDL^T on the fp64 matrix cores, latency-shaped; 2 = wave-per-front Cholesky on the matrix cores (first
 //   version); 1 = wave-per-front VALU; 4 = block-per-front VALU (any front size, 64-bit addressing throughout).
-// Variants 1-3 hold a front in 64 lanes; variant 3 additionally names every scalar of the linearised system by a 32-bit BYTE
+// Variants 1-2 hold a front in 64 lanes; variant 3 gives a front of up to 63 scalars a wave and one of 64 .. 159 a workgroup,
+// chosen per front; variant 3 additionally names every scalar of the linearised system by a 32-bit BYTE
 // offset into H_arena ((uint32_t)record * 8 in the front kernels): beyond 2^29 doubles (4 GiB) those would wrap and assemble the
 // wrong entries silently, so such a graph gets variant 4.
 extern "C" int gs_debug_select_factor_variant(int32_t requested, int32_t max_front, int64_t arena_doubles) {
     int v = requested;
     if (v <= 0 || v > 4) v = 3;
-    if (v != 4 && max_front > 63) v = 4;
+    if ((v == 1 || v == 2) && max_front > 63) v = 4;                // the first-generation wave-per-front kernels hold a front in 64 lanes
+    if (v == 3 && max_front > 159) v = 4;                           // variant 3: a wave up to 63 scalars, a workgroup up to 159 (ten tile rows)
     if (v == 3 && arena_doubles >= ((int64_t)1 << 29)) v = 4;
     return v;
 }
@@ -673,6 +678,57 @@ static int ensure_ready(gs_graph *g) {
 
 // ------------------------------------------------------------------ one Gauss-Newton iteration (A5-A9)
 // own fronts bottom-up (mode 0), shared top bottom-up from the all-reduced exchange buffer (mode 2)
+// ---- plans that hold a front of more than 63 scalars (single GPU): the workgroup tables of the table-driven launches, built on
+// first use.  Factor: level positions upwards from the end of the leaf launch — a big front a workgroup (NT = 7 or 10 tile
+// rows), a small front of the upper levels (the last block_n positions) four waves, other small fronts a wave each in groups of
+// up to four that do not straddle a level.  Backward solve: every position from the root downwards.
+static int build_big_tables(gs_graph *g, const gs_graph::LevelSet &ls) {
+    const Plan &P = g->plan; const int nlev = (int)ls.start.size() - 1, total = ls.start[nlev];
+    auto f_of = [&](int q) { const Front &F = P.fronts[P.level_fronts_owned[q]]; return F.npiv + F.nbnd; };
+    auto big_kind = [&](int f) { return f <= 111 ? 2 : 3; };
+    g->wg_f.clear(); g->wg_b.clear(); g->wg_f_level.assign(nlev + 1, 0); g->wg_b_level.assign(nlev + 1, 0);
+    g->small_max_npiv = 1; g->small_max_f = 1;
+    const int first = std::max(g->leaf_n, 0), first_block = total - std::max(g->block_n, 0);
+    for (int l = 0; l < nlev; ++l) {
+        g->wg_f_level[l] = (int)g->wg_f.size() / 2;
+        for (int q = std::max(ls.start[l], first); q < ls.start[l + 1]; ) {
+            const int f = f_of(q);
+            if (f > 63) { g->wg_f.push_back(q); g->wg_f.push_back(big_kind(f)); ++q; }
+            else if (q >= first_block) { g->wg_f.push_back(q); g->wg_f.push_back(1 | (1 << 8)); ++q; }
+            else { int cnt = 1; while (cnt < 4 && q + cnt < ls.start[l + 1] && q + cnt < first_block && f_of(q + cnt) <= 63) ++cnt;
+                g->wg_f.push_back(q); g->wg_f.push_back(0 | (cnt << 8)); q += cnt; } } }
+    g->wg_f_level[nlev] = (int)g->wg_f.size() / 2;
+    for (int l = nlev - 1; l >= 0; --l) {
+        g->wg_b_level[l + 1] = (int)g->wg_b.size() / 2;             // level l's entries: [wg_b_level[l + 1], wg_b_level[l])
+        for (int q = ls.start[l + 1] - 1; q >= ls.start[l]; ) {
+            const Front &F = P.fronts[P.level_fronts_owned[q]]; const int f = F.npiv + F.nbnd;
+            if (f > 63) { g->wg_b.push_back(q); g->wg_b.push_back(big_kind(f)); --q; }
+            else { int cnt = 0;
+                while (cnt < 4 && q - cnt >= ls.start[l] && f_of(q - cnt) <= 63) { const Front &S = P.fronts[P.level_fronts_owned[q - cnt]];
+                    g->small_max_npiv = std::max(g->small_max_npiv, (int)S.npiv); g->small_max_f = std::max(g->small_max_f, S.npiv + S.nbnd); ++cnt; }
+                g->wg_b.push_back(q); g->wg_b.push_back(0 | (cnt << 8)); q -= cnt; } } }
+    g->wg_b_level[0] = (int)g->wg_b.size() / 2;
+    int rc;
+    if ((rc = dev_alloc(g, (int32_t **)&g->d_wg_f, g->wg_f.size())) != GS_OK || (rc = dev_alloc(g, (int32_t **)&g->d_wg_b, g->wg_b.size())) != GS_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(g->d_wg_f, g->wg_f.data(), g->wg_f.size() * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));     // the host vectors live on the handle
+    HIP_TRY(hipMemcpyAsync(g->d_wg_b, g->wg_b.data(), g->wg_b.size() * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
+    return GS_OK;
+}
+static void enqueue_factor_big(gs_graph *g, const gs_graph::LevelSet &ls, bool tree) {
+    const int nlev = (int)ls.start.size() - 1;
+    if (!g->d_wg_f && build_big_tables(g, ls) != GS_OK) return;     // (an allocation failure surfaces as a launch error on the next call)
+    if (g->leaf_n > 0) launch_factor_tree(g->d, g->leaf_n, g->leaf_slot, g->leaf_max_f, g->leaf_n, 0, g->stream);       // the leaf instance alone
+    if (tree) launch_factor_tab(g->d, g->d_wg_f, g->wg_f_level[nlev], g->leaf_n > 0, g->plan.max_front, g->stream);
+    else for (int l = 0; l < nlev; ++l)                               // after a flag timeout: one launch per level (the flags of earlier launches are up)
+        launch_factor_tab(g->d, g->d_wg_f + g->wg_f_level[l], g->wg_f_level[l + 1] - g->wg_f_level[l], g->leaf_n > 0, g->plan.max_front, g->stream);
+}
+static void enqueue_backsolve_big(gs_graph *g, const gs_graph::LevelSet &ls, bool tree) {
+    const int nlev = (int)ls.start.size() - 1;
+    if (!g->d_wg_b) return;
+    if (tree) launch_backsolve_tab(g->d, g->d_wg_b, g->wg_b_level[0], g->small_max_npiv, g->small_max_f, g->plan.max_front, g->stream);
+    else for (int l = nlev - 1; l >= 0; --l)
+        launch_backsolve_tab(g->d, g->d_wg_b + g->wg_b_level[l + 1], g->wg_b_level[l] - g->wg_b_level[l + 1], g->small_max_npiv, g->small_max_f, g->plan.max_front, g->stream);
+}
 static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int base, int mode) {
     const int nlev = (int)ls.start.size() - 1;
     if (g->d.factor_variant == 3 && g->d.tree && mode == 0 && base == 0 && nlev > 0) {     // every own level in one launch
@@ -690,6 +746,7 @@ static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int
             { int lmin = 2048; if (const char *e = std::getenv("GS_LEAF_MIN")) lmin = std::atoi(e);
               if (n_leaf <= lmin) n_leaf = 0; }
             if (const char *e = std::getenv("GS_LEAF_KERNEL")) { if (std::atoi(e) == 0) n_leaf = 0; else if (std::atoi(e) == 2) n_leaf = F_leaf_all; }
+            if (g->leaf_max_f > 63) n_leaf = 0;                        // leaves beyond a wave: level 0 joins the table-driven launch
             g->leaf_n = n_leaf; g->leaf_slot = slot; }
         // the upper levels — few fronts, all of them in the dependent chain — get four waves per front: whole levels from the
         // top down while a level has at most GS_BLOCK_FRONTS (512) fronts (those workgroups are all resident at once)
@@ -699,7 +756,9 @@ static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int
                 if (nl > thr) break;
                 nb += nl; }
             g->block_n = std::min(nb, ls.start[nlev] - std::max(g->leaf_n, 0)); }
+        if (g->plan.max_front > 63) { enqueue_factor_big(g, ls, true); return; }
         launch_factor_tree(g->d, g->leaf_n, g->leaf_slot, g->leaf_max_f, ls.start[nlev], g->block_n, g->stream); return; }
+    if (g->d.factor_variant == 3 && !g->d.tree && mode == 0 && base == 0 && nlev > 0 && g->plan.max_front > 63) { ++g->d.epoch; enqueue_factor_big(g, ls, false); return; }
     if (g->d.factor_variant == 3 && g->d.tree && mode == 2 && nlev > 0 && ls.start[nlev] > 0) {     // the shared top of a sharded graph, one flagged launch
         launch_factor_tree_top(g->d, base, ls.start[nlev], g->stream); return; }
     for (int l = 0; l < nlev; ++l)
@@ -707,6 +766,7 @@ static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int
 }
 static void enqueue_backsolve_levels(gs_graph *g, const gs_graph::LevelSet &ls, int base) {
     const int nlev = (int)ls.start.size() - 1;
+    if (g->d.factor_variant == 3 && base == 0 && nlev > 0 && g->plan.max_front > 63) { enqueue_backsolve_big(g, ls, g->d.tree != 0); return; }
     if (g->d.factor_variant == 3 && g->d.tree && base == 0 && nlev > 0) {
         // levels >= 1 in one launch (fronts wait for their parent's flag), then the leaf level on its own: by then every
         // parent is done, so it needs no flags, and its LDS slot is sized for the leaves alone (more resident waves)
@@ -773,6 +833,9 @@ static void fill_plan_stats(gs_graph *g, gs_stats *s) {
     s->n_fronts = (int32_t)P.fronts.size(); s->n_levels = (int32_t)P.level_start.size() - 1; s->max_front = P.max_front;
     s->factor_flops = P.factor_flops; s->factor_bytes = (P.l_doubles + P.u_doubles) * 8; s->ms_structure = g->ms_structure;
     s->fell_back = g->fell_back ? 1 : 0;
+    s->factor_variant = g->dev_valid ? (g->d.factor_variant == 0 ? 4 : g->d.factor_variant) : 0;
+    s->n_big_fronts = 0;
+    for (const Front &F : P.fronts) s->n_big_fronts += (F.npiv + F.nbnd > 63);
 }
 
 extern "C" int gs_get_stats(gs_graph *g, gs_stats *s) {

@@ -69,7 +69,8 @@ struct DevGraph {
     double *Uimg = nullptr;                                     // variant 2: update matrices as 16x16 tile images; variant 3: packed lower triangles (u3_off, u3_size)
     // variant 3 (latency-shaped MFMA/LDL^T kernels): flat per-level descriptors, value-ready assembly records,
     // per-front inverse row maps into the parent (formats: gs_kernels.hip, "variant 3")
-    int32_t *f3_x = nullptr;                                    // row tables + headers of the third and later children of a front (72 ints per child)
+    int32_t *f3_x = nullptr;                                    // row tables + headers of the children of a front (f3x_stride ints per child)
+    int32_t f3x_stride = 72;                                    // 72 = a 64-entry table + 8 header ints; 168 = a 160-entry table (plans with a front of more than 63 scalars)
     int32_t *f3_desc = nullptr, *asm3 = nullptr, *pinv = nullptr, *sc3 = nullptr, *lm3 = nullptr, *u3_off = nullptr, *u3_size = nullptr;
     int32_t *done_f = nullptr; int32_t epoch = 0, tree = 0;     // whole-tree factor launches: per-front completion flags (= epoch when done); the backward solve polls xe itself
     double *H_arena = nullptr;                                  // Hpp_diag | b_pose | Hpp_off | Hpl | lm_part | Hll_diag | b_lm, one allocation
@@ -111,7 +112,10 @@ void launch_frame_frontend(int k, const double *in, double lidar, int n_map, con
                            double thr, double type_tol, int signed_type, double *out_z, double *out_g, int32_t *out_idx, hipStream_t st);
 void launch_build_f3(int nq, const int32_t *lf, const DevFront *fronts, const int32_t *children, const int32_t *child_map,
                      const int32_t *u3_off, const int32_t *u3_size, const int32_t *bf, const int32_t *xrow_off, const int64_t *x_off,
-                     int32_t *f3_desc, int32_t *f3_x, hipStream_t st);
+                     int32_t *f3_desc, int32_t *f3_x, int x_stride, hipStream_t st);
+// plans that hold a front of more than 63 scalars: table-driven whole-tree launches (workgroup -> {level position, kind | count << 8})
+void launch_factor_tab(const DevGraph &d, const int2 *wgt, int n_wg, int leaf_launch_preceded, int max_front, hipStream_t st);
+void launch_backsolve_tab(const DevGraph &d, const int2 *wgt, int n_wg, int max_npiv_small, int max_f_small, int max_front, hipStream_t st);
 void launch_patch_asm3(int64_t n, int32_t *asm3, const int32_t *lm_grp_start, hipStream_t st);
 int  factor_lds_limit_f();      // largest front dimension that fits the LDS variant
 

@@ -15,6 +15,7 @@
 //
 // All fp64; every sum has a fixed order (no floating-point atomics) so results are bitwise reproducible.
 #include "gs_device.hpp"
+#include <algorithm>
 #include <mutex>
 #include <set>
 #include <type_traits>
@@ -1217,7 +1218,7 @@ struct F3 {
     int sc_off, sc_cnt, lm_off, lm_cnt, u_off, u_size, c_uoff[2], c_usize[2], parent, level;
     int64_t L_off, x_off;
 };
-static constexpr int F3_INTS = 32, F3_STRIDE = 224, F3X = 72;   // 32 descriptor ints, table of child 0, table of child 1, own store table (64 ints each)
+static constexpr int F3_INTS = 32, F3_STRIDE = 224;   // 32 descriptor ints, table of child 0, table of child 1, own store table (64 ints each)
 __device__ __forceinline__ F3 f3_load(const int32_t *desc, int idx, int lane) {
     const int v = (lane < F3_INTS) ? desc[(int64_t)idx * F3_STRIDE + lane] : 0;
     auto g = [&](int i) { return __builtin_amdgcn_readlane(v, i); };
@@ -1664,7 +1665,8 @@ __device__ __forceinline__ void f3_block_front(const DevGraph &d, int pos, int l
             if (e == 0) { tA = tab0; a_id = fr.c_id[0]; a_uoff = fr.c_uoff[0]; a_usz = fr.c_usize[0];
                           tB = tab1; b_id = fr.c_id[1]; b_uoff = fr.c_uoff[1]; b_usz = fr.c_usize[1]; }
             else { const int eb = hasB ? e + 1 : e;
-                tA = xt[e * F3X + lane]; const int hA = xt[e * F3X + 64 + (lane & 7)]; tB = xt[eb * F3X + lane]; const int hB = xt[eb * F3X + 64 + (lane & 7)];
+                const int XS = d.f3x_stride, XH = XS - 8;            // per-child stride of f3_x (72, or 168 when the plan holds a big front), header behind the table
+                tA = xt[e * XS + lane]; const int hA = xt[e * XS + XH + (lane & 7)]; tB = xt[eb * XS + lane]; const int hB = xt[eb * XS + XH + (lane & 7)];
                 a_id = __builtin_amdgcn_readlane(hA, 0); a_uoff = __builtin_amdgcn_readlane(hA, 1); a_usz = __builtin_amdgcn_readlane(hA, 2);
                 b_id = __builtin_amdgcn_readlane(hB, 0); b_uoff = __builtin_amdgcn_readlane(hB, 1); b_usz = __builtin_amdgcn_readlane(hB, 2); }
             int dA[4], dB[4]; double sA[4], sB[4];
@@ -1729,29 +1731,19 @@ __device__ __forceinline__ void f3_block_front(const DevGraph &d, int pos, int l
 // the leaf level x1.67: it is bound by resident waves x front latency, not yet by bandwidth)
 // NT = tile rows held in the accumulators: 4 (fronts up to 63 scalars) or, leaf instance only, 3 (every leaf <= 47 scalars:
 // 6 tiles instead of 10 — a third fewer accumulator registers and spill traffic, five waves per SIMD instead of four)
-template <bool TREE, bool LEAF, int NT = 4>
-__global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(DevGraph d, int level_off, int count, int mode, int leaf_slot, int n_wave_fronts) {
+// one front on one wave (f <= 63): the body of the wave-per-front kernels.  pos = the front's level position (index of its
+// descriptor), smem = the workgroup's dynamic LDS (the wave takes slot `wave`), first = the launch's first position
+template <bool TREE, bool LEAF, int NT>
+__device__ __forceinline__ void f3_wave_front(const DevGraph &d, int pos, int mode, int leaf_slot, double *smem, int wave, int lane, bool ts_on, bool first) {
     static_assert(LEAF || NT == 4, "only the leaf instance has a three-tile-row form");
     constexpr int NTILE = NT * (NT + 1) / 2;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    // whole-tree launches: the first n_wave_fronts level positions one wave each (four per workgroup), the rest — the upper
-    // levels — one workgroup each
-    if constexpr (TREE && !LEAF) {
-        const int wave_blocks = (n_wave_fronts + 3) >> 2;
-        if ((int)blockIdx.x >= wave_blocks) { const int pos = level_off + n_wave_fronts + ((int)blockIdx.x - wave_blocks);
-            f3_block_front(d, pos, leaf_slot, smem, (d.dbg & 16) && pos == (d.dbg >> 8)); return; }
-    }
-    const int fi = blockIdx.x * 4 + wave;
-    if (fi >= (TREE && !LEAF ? n_wave_fronts : count)) return;      // whole wave leaves; no block barrier below
-    const bool ts_on = ((d.dbg & 8) && count == (d.dbg >> 8) && fi == 0) || ((d.dbg & 16) && level_off + fi == (d.dbg >> 8));   // 16: probe the front at a level POSITION
 #define F3_TS(i) do { if (ts_on) { __builtin_amdgcn_s_waitcnt(0); if (lane == 0) d.dbg_ts[i] = wall_clock64(); } } while (0)
     F3_TS(0);
     int pv[2];                                                       // the children's row tables ride behind the descriptor
-    pv[0] = d.f3_desc[(int64_t)(level_off + fi) * F3_STRIDE + F3_INTS + lane];
-    pv[1] = d.f3_desc[(int64_t)(level_off + fi) * F3_STRIDE + F3_INTS + 64 + lane];
-    const int sv = d.f3_desc[(int64_t)(level_off + fi) * F3_STRIDE + F3_INTS + 128 + lane];     // own store table
-    const F3 fr = f3_load(d.f3_desc, level_off + fi, lane);
+    pv[0] = d.f3_desc[(int64_t)pos * F3_STRIDE + F3_INTS + lane];
+    pv[1] = d.f3_desc[(int64_t)pos * F3_STRIDE + F3_INTS + 64 + lane];
+    const int sv = d.f3_desc[(int64_t)pos * F3_STRIDE + F3_INTS + 128 + lane];     // own store table
+    const F3 fr = f3_load(d.f3_desc, pos, lane);
     const int npiv = fr.npiv, f = npiv + fr.nbnd;
     if (lane < npiv) d.xe[fr.piv0 + lane] = f3_unset();             // this front's solution rows: not written yet (the whole-tree backward solve polls them)
     StageT<LEAF> P{smem + (int64_t)wave * (LEAF ? leaf_slot : MF_IMG), f, (f + 1) | 1};
@@ -1870,7 +1862,8 @@ __global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(D
             int nA = 0, nhA = 0, nB = 0, nhB = 0;
             const bool more = e + 2 < fr.nchild;
             if (more) { const int na = e + 2, nb = min(e + 3, fr.nchild - 1);
-                nA = xt[na * F3X + lane]; nhA = xt[na * F3X + 64 + (lane & 7)]; nB = xt[nb * F3X + lane]; nhB = xt[nb * F3X + 64 + (lane & 7)]; }
+                const int XS = d.f3x_stride, XH = XS - 8;
+                nA = xt[na * XS + lane]; nhA = xt[na * XS + XH + (lane & 7)]; nB = xt[nb * XS + lane]; nhB = xt[nb * XS + XH + (lane & 7)]; }
             okw = f3_gather_pair(P.F, rc, lane, d.epoch, d.fail, onA, d.Uimg + a_uoff, a_usz, tA, plain ? nullptr : d.done_f + a_id,
                                  onB, d.Uimg + b_uoff, b_usz, tB, plain ? nullptr : d.done_f + b_id) && okw;
             if (e == 0) F3_TS(9);
@@ -1902,7 +1895,7 @@ __global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(D
         wave_lds_sync();
         double *X = d.exchange + fr.x_off;
         for (int c = 0; c < f; ++c) if (lane <= f) X[c * (f + 1) + lane] = (lane >= c) ? P.at(lane, c) : 0.0;
-        if (fi == 0 && lane == 0) contrib_publish_fail(d);
+        if (first && lane == 0) contrib_publish_fail(d);
         return;
     }
     F3_TS(6);
@@ -1919,7 +1912,7 @@ __global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(D
     if constexpr (NT == 4) {
     go = go && f3_panel_step<12, NT>(bad, acc, Pn, L, npiv, f, lane);  go = go && f3_panel_step<13, NT>(bad, acc, Pn, L, npiv, f, lane);
     go = go && f3_panel_step<14, NT>(bad, acc, Pn, L, npiv, f, lane);  go = go && f3_panel_step<15, NT>(bad, acc, Pn, L, npiv, f, lane); }
-    if (d.inject_iter != 0 && d.iter == d.inject_iter && level_off + fi == 0 && lane == 0) atomicMax(d.fail, d.inject_code);   // gs_debug_fail_at_iteration (fault injection for tests)
+    if (d.inject_iter != 0 && d.iter == d.inject_iter && pos == 0 && lane == 0) atomicMax(d.fail, d.inject_code);   // gs_debug_fail_at_iteration (fault injection for tests)
     if (bad && lane == 0) atomicMax(d.fail, 1);
     F3_TS(7);
     // ---- Schur complement out, packed: element (row, col) -> rowpart(row) + colpart(col) from the front's own table; pivot
@@ -1986,15 +1979,26 @@ __global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(D
     F3_TS(8);
 }
 
-// backward solve of variant 3's LDL^T panels (unit diagonal): x_piv = L11^-T (y - L21^T x_bnd), one wave per front
-template <bool TREE>      // TREE: one launch, root first (wave w takes level position count - 1 - w), a front waits for its parent's flag
-__global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, int count, int slot_doubles) {
+template <bool TREE, bool LEAF, int NT = 4>
+__global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(DevGraph d, int level_off, int count, int mode, int leaf_slot, int n_wave_fronts) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // whole-tree launches: the first n_wave_fronts level positions one wave each (four per workgroup), the rest — the upper
+    // levels — one workgroup each
+    if constexpr (TREE && !LEAF) {
+        const int wave_blocks = (n_wave_fronts + 3) >> 2;
+        if ((int)blockIdx.x >= wave_blocks) { const int pos = level_off + n_wave_fronts + ((int)blockIdx.x - wave_blocks);
+            f3_block_front(d, pos, leaf_slot, smem, (d.dbg & 16) && pos == (d.dbg >> 8)); return; }
+    }
     const int fi = blockIdx.x * 4 + wave;
-    if (fi >= count) return;
-    const int pos = TREE ? level_off + (count - 1 - fi) : level_off + fi;
-    const bool ts_on = ((d.dbg & 8) && count == (d.dbg >> 8) && fi == 0) || ((d.dbg & 16) && pos == (d.dbg >> 8));   // 16: probe the front at a level POSITION
+    if (fi >= (TREE && !LEAF ? n_wave_fronts : count)) return;      // whole wave leaves; no block barrier below
+    const bool ts_on = ((d.dbg & 8) && count == (d.dbg >> 8) && fi == 0) || ((d.dbg & 16) && level_off + fi == (d.dbg >> 8));   // 16: probe the front at a level POSITION
+    f3_wave_front<TREE, LEAF, NT>(d, level_off + fi, mode, leaf_slot, smem, wave, lane, ts_on, fi == 0);
+}
+
+// backward solve of variant 3's LDL^T panels (unit diagonal): x_piv = L11^-T (y - L21^T x_bnd), one wave per front
+template <bool TREE>      // TREE: the front polls its boundary rows of the solution until its ancestors have written them
+__device__ __forceinline__ void bs3_wave_front(const DevGraph &d, int pos, double *smem, int slot_doubles, int wave, int lane, bool ts_on) {
     F3_TS(32);
     const F3 fr = f3_load(d.f3_desc, pos, lane);
     const int npiv = fr.npiv, nbnd = fr.nbnd, f = npiv + nbnd, ldl = f + 1, lds = (f + 1) | 1;
@@ -2079,6 +2083,302 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
 #endif
     F3_TS(38);
 }
+template <bool TREE>      // TREE: one launch, root first (wave w takes level position count - 1 - w), a front waits for its parent's flag
+__global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, int count, int slot_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int fi = blockIdx.x * 4 + wave;
+    if (fi >= count) return;
+    const int pos = TREE ? level_off + (count - 1 - fi) : level_off + fi;
+    const bool ts_on = ((d.dbg & 8) && count == (d.dbg >> 8) && fi == 0) || ((d.dbg & 16) && pos == (d.dbg >> 8));   // 16: probe the front at a level POSITION
+    bs3_wave_front<TREE>(d, pos, smem, slot_doubles, wave, lane, ts_on);
+}
+
+// ------------------------------------------------------------------ fronts of 64 .. 159 scalars (round 3)
+// A frame of the reference holds every cone within coneMappingThreshold (50 m in usecase/docker-compose.yml:16, reference
+// src/slam.cpp:608): 16-24 cones in view instead of the synthetic track's 8, separators of one pose + those cones and fronts of
+// 100-150 scalars.  Such a front gets a WORKGROUP and the same LDL^T on the fp64 matrix cores as the small ones: NT tile rows
+// (7: f <= 111, 10: f <= 159), the NT (NT + 1) / 2 lower 16 x 16 tiles spread over the four waves' accumulators (tile t on wave
+// t mod 4), panels of 4 pivots factorised redundantly by every wave (a lane owns rows lane, lane + 64, lane + 128), children
+// added by source through the LDS image, the update matrix out in storage order, the same flags.  The choice is PER FRONT
+// (a table maps workgroups to level positions: k_factor3_tab / k_backsolve3_tab), a small front of the same tree still runs on a
+// wave.  Record formats are the small fronts' (packed update matrices, scalar records, tile-image offsets: all generic in the
+// number of tile rows); a child's row table has BIG_TAB entries in f3_x when the plan holds a big front (d.f3x_stride).
+static constexpr int BIG_TAB = 160;
+enum { WG_WAVES = 0, WG_BLOCK4 = 1, WG_BIG7 = 2, WG_BIG10 = 3 };
+__device__ __forceinline__ int f3_tile_row_any(int t) {
+    int I = (int)((__fsqrt_rn(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    if (((I * (I + 1)) >> 1) > t) --I;
+    if ((((I + 1) * (I + 2)) >> 1) <= t) ++I;
+    return I;
+}
+template <int NT> struct BigDims {
+    static constexpr int NTILE = NT * (NT + 1) / 2, TPW = (NTILE + 3) / 4, ROWS = 16 * NT, IMG = NTILE * 256, NR = (ROWS + 63) / 64;
+    static constexpr int PANEL = ROWS * 4;                            // one panel buffer (ROWS x 4)
+    static constexpr int LDS_DOUBLES = IMG + 2 * PANEL + 4 * PANEL + BIG_TAB / 2;      // image, two spill buffers, a private buffer per wave, one child table
+};
+template <int NT>
+__device__ __forceinline__ bool f3_big_panel(int B, bool &bad, v4d (&acc)[BigDims<NT>::TPW], double *Pn, double *Pw, double *L, int npiv, int f, int wave, int lane) {
+    using D = BigDims<NT>;
+    const int k0 = 4 * B, J0 = B >> 2, jc = (B & 3) * 4;             // uniform
+    if (k0 >= npiv) return false;
+    const int lc = lane & 15, lr = lane >> 4;
+    double *Pb = Pn + (B & 1) * D::PANEL;
+    // 1. the panel's four columns out of whichever waves own the tiles of tile column J0
+#pragma unroll
+    for (int s = 0; s < D::TPW; ++s) { const int t = 4 * s + wave; const int I = f3_tile_row_any(min(t, D::NTILE - 1)), J = t - ((I * (I + 1)) >> 1);   // uniform per wave
+        if (t < D::NTILE && J == J0 && lc >= jc && lc < jc + 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Pb[(16 * I + lr + 4 * q) * 4 + (lc - jc)] = acc[s][q]; } }
+    __syncthreads();
+    // 2. every wave factorises the panel; a lane owns rows lane + 64 m
+    double p[D::NR][4], dd[4];
+#pragma unroll
+    for (int m = 0; m < D::NR; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[m][j] = (lane + 64 * m < D::ROWS) ? Pb[(lane + 64 * m) * 4 + j] : 0.0;
+    const int mk = k0 >> 6, lk = k0 & 63;                           // the panel's pivot rows live in row register mk, lanes lk .. lk + 3 (uniform)
+    auto pick = [&](int j) { double v = p[0][j];
+#pragma unroll
+        for (int m = 1; m < D::NR; ++m) v = (mk == m) ? p[m][j] : v;
+        return v; };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        dd[j] = 0.0;
+        if (k0 + j < npiv) {                                        // uniform
+            const int col = k0 + j;
+            const double cj = pick(j);                              // column j of the panel at the rows of register mk
+            const double piv = lane_bcast(cj, lk + j);
+            bad = bad || !(fabs(piv) > 0.0);                        // LDL^T: a ZERO pivot fails (Eigen SimplicialCholesky_impl.h:172-176), NaN is reported too
+            const double inv = rcp_f64(piv);
+            double c2[4];
+#pragma unroll
+            for (int j2 = j + 1; j2 < 4; ++j2) c2[j2] = lane_bcast(cj, lk + j2);      // the unscaled column at the later pivot rows
+#pragma unroll
+            for (int m = 0; m < D::NR; ++m) {
+                const double lj = (lane + 64 * m >= col) ? p[m][j] * inv : 0.0;      // row col itself becomes d / d = 1: a dead row in every later use
+#pragma unroll
+                for (int j2 = j + 1; j2 < 4; ++j2) p[m][j2] -= lj * c2[j2];
+                p[m][j] = lj; }
+            dd[j] = piv;
+        } else {
+#pragma unroll
+            for (int m = 0; m < D::NR; ++m) p[m][j] = 0.0; }
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int m = 0; m < D::NR; ++m) if (lane + 64 * m <= f) {
+            double *Lc = L + (int64_t)k0 * (f + 1) + lane + 64 * m;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (k0 + j < npiv) F3_ST_L(Lc + (int64_t)j * (f + 1), p[m][j]); }
+    }
+    // 3. trailing update of the wave's own tiles; operands through the wave's private buffer
+#pragma unroll
+    for (int m = 0; m < D::NR; ++m) if (lane + 64 * m < D::ROWS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Pw[(lane + 64 * m) * 4 + j] = p[m][j]; }
+    const double dk = lr == 0 ? dd[0] : (lr == 1 ? dd[1] : (lr == 2 ? dd[2] : dd[3]));
+#pragma unroll
+    for (int s = 0; s < D::TPW; ++s) { const int t = 4 * s + wave; const int I = f3_tile_row_any(min(t, D::NTILE - 1)), J = t - ((I * (I + 1)) >> 1);
+        if (t < D::NTILE && J >= J0 && 16 * I <= f) {
+            const double aI = Pw[(16 * I + lc) * 4 + lr], aJ = Pw[(16 * J + lc) * 4 + lr];
+            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI, aJ * dk, acc[s], 0, 0, 0); } }
+    wave_lds_sync();
+    return true;
+}
+template <int NT>
+__device__ __forceinline__ void f3_big_front(const DevGraph &d, int pos, double *smem) {
+    using D = BigDims<NT>;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const F3 fr = f3_load(d.f3_desc, pos, lane);
+    const int npiv = fr.npiv, f = npiv + fr.nbnd;
+    for (int r = tid; r < npiv; r += 256) d.xe[fr.piv0 + r] = f3_unset();        // this front's solution rows: not written yet
+    double *img = smem, *Pn = smem + D::IMG, *Pw = Pn + 2 * D::PANEL + wave * D::PANEL;
+    int32_t *tab = reinterpret_cast<int32_t *>(Pn + 6 * D::PANEL);
+    StageT<false> P{img, f, (f + 1) | 1};
+    for (int k = tid; k < D::IMG; k += 256) img[k] = 0.0;
+    __syncthreads();
+    // ---- the original values: scalar records {offset in H_arena, offset in the image} (padded to multiples of 64), landmark
+    // diagonal blocks of the fused linearisation as sums of their partial slots, parallel edges one by one
+    { const int nsc = fr.sc_cnt, nlm = fr.lm_cnt;
+      const int2 *sc3 = reinterpret_cast<const int2 *>(d.sc3) + fr.sc_off;
+      for (int base = 0; base < nsc; base += 1024) {                 // four records per thread in flight
+          int2 r4[4]; double v4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int i = base + 256 * u + tid; r4[u] = i < nsc ? sc3[i] : make_int2(0, 1); }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v4[u] = ld_off(d.H_arena, (uint32_t)r4[u].x * 8u);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if (base + 256 * u + tid < nsc) img[r4[u].y] = v4[u]; }
+      for (int t = tid; t < nlm; t += 256) {
+          const int4 r = reinterpret_cast<const int4 *>(d.lm3)[fr.lm_off + t]; const int64_t G = d.n_groups; double a[5] = {0, 0, 0, 0, 0};
+          for (int q = 0; q < r.x; ++q)
+#pragma unroll
+              for (int k = 0; k < 5; ++k) a[k] += d.lm_part[k * G + r.y + q];
+          P.at(r.z, r.w) = a[0]; P.at(r.z + 1, r.w) = a[1]; P.at(r.z + 1, r.w + 1) = a[2]; P.at(f, r.w) = a[3]; P.at(f, r.w + 1) = a[4]; }
+      __syncthreads();
+      if (fr.asm_dup > 0) {
+          if (tid == 0) for (int t = fr.asm_uniq; t < fr.asm_uniq + fr.asm_dup; ++t) {
+              const int4 r = reinterpret_cast<const int4 *>(d.asm3)[fr.asm_off + t];
+              double w[9]; asm3_load(d, r.x, r.y, w); asm3_put<true>(P, r.x, r.z, r.w, w); }
+          __syncthreads(); } }
+    // ---- the children, by source, in list order: table to LDS, the child's flag, its packed update matrix in storage order
+    bool okw = true;
+    for (int e = 0; e < fr.nchild; ++e) {
+        const int32_t *xt = d.f3_x + fr.x_tab + (int64_t)e * d.f3x_stride;
+        const int hv = xt[BIG_TAB + (lane & 7)];
+        const int c_id = __builtin_amdgcn_readlane(hv, 0), c_uoff = __builtin_amdgcn_readlane(hv, 1), c_usz = __builtin_amdgcn_readlane(hv, 2);
+        if (tid < BIG_TAB) tab[tid] = xt[tid];
+        okw = f3_wait_flag(d.done_f + c_id, d.epoch, d.fail) && okw;       // a child of an earlier launch has its flag set already
+        __syncthreads();
+        const double *Uc = d.Uimg + c_uoff;
+        for (int base = 0; base < c_usz; base += 1024) {
+            double v4[4]; int pl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int idx = base + 256 * u + tid; v4[u] = ld_off_coh(Uc, (uint32_t)min(idx, c_usz) * 8u);      // beyond the matrix: the zero double behind it
+                const int rc = f3_rc_of(min(idx, c_usz - 1));
+                pl[u] = idx < c_usz ? (tab[rc & 0xff] & 0xffff) + (int)((uint32_t)tab[rc >> 8] >> 16) : 1; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (base + 256 * u + tid < c_usz) img[pl[u]] += v4[u];      // a child's places are distinct
+        }
+        __syncthreads();
+    }
+    if (!okw && tid == 0) atomicMax(d.fail, 2);
+    // ---- accumulators: wave w holds tiles w, w + 4, ...
+    v4d acc[D::TPW];
+#pragma unroll
+    for (int s = 0; s < D::TPW; ++s) { const int t = 4 * s + wave;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[s][q] = t < D::NTILE ? img[t * 256 + q * 64 + lane] : 0.0; }
+    double *L = d.Lbuf + fr.L_off;
+    bool go = true, bad = false;
+#pragma clang loop unroll(disable)
+    for (int B = 0; B < 4 * NT && go; ++B) go = f3_big_panel<NT>(B, bad, acc, Pn, Pw, L, npiv, f, wave, lane);
+    if (d.inject_iter != 0 && d.iter == d.inject_iter && pos == 0 && tid == 0) atomicMax(d.fail, d.inject_code);   // gs_debug_fail_at_iteration
+    if (bad && tid == 0) atomicMax(d.fail, 1);
+    // ---- Schur complement out through the image, contiguous write-through stores
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < D::TPW; ++s) { const int t = 4 * s + wave;
+        if (t < D::NTILE) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) img[t * 256 + q * 64 + lane] = acc[s][q]; } }
+    __syncthreads();
+    { double *U = d.Uimg + fr.u_off; const int usz = fr.u_size;
+      for (int idx = tid; idx < usz; idx += 256) { const int rc = f3_rc_of(idx);
+          st_off_wt(U, (uint32_t)idx * 8u, img[f3_img_rowpart(npiv + (rc & 0xff)) + f3_img_colpart(npiv + (rc >> 8))]); } }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __hip_atomic_store(d.done_f + fr.s, d.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}
+// LDS of the backward solve of a big front: boundary values, right-hand side, L21 (column-major as stored) and L11 strictly
+// lower, packed by ROWS (row r holds its r columns at r (r - 1) / 2): f^2 / 2 doubles at most
+__host__ __device__ constexpr int bs3_big_lds_doubles(int f) { return 2 * BIG_TAB + (f * f) / 2 + f + 64; }
+template <bool TREE>
+__device__ __forceinline__ void bs3_big_front(const DevGraph &d, int pos, double *smem) {
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const F3 fr = f3_load(d.f3_desc, pos, lane);
+    const int npiv = fr.npiv, nbnd = fr.nbnd, f = npiv + nbnd, ldl = f + 1;
+    double *xb = smem, *w = smem + BIG_TAB, *S21 = smem + 2 * BIG_TAB, *S11 = S21 + npiv * nbnd;
+    const double *L = d.Lbuf + fr.L_off;
+    // ---- everything that does not depend on the ancestors first: the panel into LDS.  Column c's rows c + 1 .. f are contiguous:
+    // a lane takes rows c + 1 + lane + 64 m; four columns per wave in flight
+    for (int c0 = 4 * wave; c0 < npiv; c0 += 16) {
+        double v[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) { const int c = min(c0 + j, npiv - 1), r = c + 1 + lane + 64 * m; v[j][m] = F3_LD_L(&L[(int64_t)c * ldl + min(r, f)]); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) { const int c = c0 + j, r = c + 1 + lane + 64 * m;
+                if (c < npiv && r <= f) { if (r < npiv) S11[((r * (r - 1)) >> 1) + c] = v[j][m]; else if (r < f) S21[c * nbnd + (r - npiv)] = v[j][m]; else w[c] = v[j][m]; } }
+    }
+    // ---- the boundary rows belong to the ancestors: poll the values themselves (whole-tree launch), or read them
+    bool got = true, failed_already = false;
+    if (TREE) {
+        for (int r0 = 0; r0 < nbnd; r0 += 256) { const int r = r0 + tid; const int row = r < nbnd ? d.bnd_rows[fr.bnd_off + r] : -1;
+            double x = 0.0; bool mine = false;
+            for (int it = 0; it < (1 << 18); ++it) {
+                if (row >= 0) x = ld_off_coh(d.xe, (uint32_t)row * 8u);
+                mine = row >= 0 && f3_is_unset(x);
+                if (!__any(mine)) break;
+                if ((it & 63) == 63 && __hip_atomic_load(d.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { failed_already = true; break; }
+                __builtin_amdgcn_s_sleep(F3_POLL_SLEEP); }
+            if (mine) { got = false; x = 0.0; }
+            if (r < nbnd) xb[r] = x; }
+        if (__any(!got) && !failed_already && lane == 0) atomicMax(d.fail, 2);       // bounded: report, carry on, drain
+    } else {
+        for (int r = tid; r < nbnd; r += 256) xb[r] = d.xe[d.bnd_rows[fr.bnd_off + r]];
+    }
+    __syncthreads();
+    // ---- w_c = y_c - sum_r L21[r][c] x_bnd[r]: a wave per column, lanes over the boundary rows (fixed order: lane strides, then the shuffle tree)
+    for (int c = wave; c < npiv; c += 4) {
+        double a = 0.0;
+        for (int r = lane; r < nbnd; r += 64) a += S21[c * nbnd + r] * xb[r];
+        a = wave_sum(a);
+        if (lane == 0) w[c] -= a; }
+    __syncthreads();
+    // ---- L11^T x = w, unit diagonal, column oriented on wave 0: lane j keeps w_j, w_{j + 64}, w_{j + 128}
+    if (wave == 0) {
+        double wr[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) wr[m] = (lane + 64 * m < npiv) ? w[lane + 64 * m] : 0.0;
+        for (int cc = npiv - 1; cc >= 1; --cc) {
+            const int mc = cc >> 6;                                  // uniform
+            const double src = mc == 0 ? wr[0] : (mc == 1 ? wr[1] : wr[2]);
+            const double xcc = lane_bcast(src, cc & 63);
+            const double *row = S11 + ((cc * (cc - 1)) >> 1);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) { const int j = lane + 64 * m; if (64 * m < cc) { const double lv = j < cc ? row[j] : 0.0; wr[m] -= lv * xcc; } }
+        }
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { const int j = lane + 64 * m;
+            if (j < npiv) { if (TREE) st_off_wt(d.xe, (uint32_t)(fr.piv0 + j) * 8u, wr[m]); else d.xe[fr.piv0 + j] = wr[m]; } }
+    }
+}
+// Table-driven launches (plans that hold a big front): workgroup b takes wgt[b] = {first level position, kind | count << 8} — up to
+// four small fronts a wave each, a small front on four waves, or a big front.  Factor: the table follows the level positions
+// (children in earlier workgroups); backward solve: the reverse (ancestors in earlier workgroups).
+__global__ void __launch_bounds__(256, 2) k_factor3_tab(DevGraph d, const int2 *__restrict__ wgt, int leaf_launch_preceded) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int2 e = wgt[blockIdx.x];
+    const int pos = __builtin_amdgcn_readfirstlane(e.x), kind = __builtin_amdgcn_readfirstlane(e.y) & 0xff, cnt = __builtin_amdgcn_readfirstlane(e.y) >> 8;
+    if (kind == WG_WAVES) { if (wave < cnt) f3_wave_front<true, false, 4>(d, pos + wave, FRONT_OWN, leaf_launch_preceded, smem, wave, lane, false, false); }
+    else if (kind == WG_BLOCK4) f3_block_front(d, pos, leaf_launch_preceded, smem, false);
+    else if (kind == WG_BIG7) f3_big_front<7>(d, pos, smem);
+    else f3_big_front<10>(d, pos, smem);
+}
+__global__ void __launch_bounds__(256, 2) k_backsolve3_tab(DevGraph d, const int2 *__restrict__ wgt, int slot_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int2 e = wgt[blockIdx.x];
+    const int pos = __builtin_amdgcn_readfirstlane(e.x), kind = __builtin_amdgcn_readfirstlane(e.y) & 0xff, cnt = __builtin_amdgcn_readfirstlane(e.y) >> 8;
+    const bool ts_on = false;
+    if (kind == WG_WAVES || kind == WG_BLOCK4) { if (wave < cnt) bs3_wave_front<true>(d, pos - wave, smem, slot_doubles, wave, lane, ts_on); }     // root first: positions downwards
+    else bs3_big_front<true>(d, pos, smem);
+}
+size_t factor_tab_lds_bytes(int max_front) {
+    size_t b = (size_t)MF_IMG * 4 * sizeof(double);
+    if (max_front > 63) b = std::max(b, (size_t)BigDims<7>::LDS_DOUBLES * sizeof(double));
+    if (max_front > 111) b = std::max(b, (size_t)BigDims<10>::LDS_DOUBLES * sizeof(double));
+    return b;
+}
+void launch_factor_tab(const DevGraph &d, const int2 *wgt, int n_wg, int leaf_launch_preceded, int max_front, hipStream_t st) {
+    if (n_wg <= 0) return;
+    allow_max_lds((const void *)k_factor3_tab);
+    hipLaunchKernelGGL(k_factor3_tab, dim3(n_wg), dim3(256), factor_tab_lds_bytes(max_front), st, d, wgt, leaf_launch_preceded);
+}
+void launch_backsolve_tab(const DevGraph &d, const int2 *wgt, int n_wg, int max_npiv_small, int max_f_small, int max_front, hipStream_t st) {
+    if (n_wg <= 0) return;
+    const int slot = ((((max_f_small + 1) | 1) * std::max(max_npiv_small, 1)) + 1) & ~1;
+    size_t b = (size_t)slot * 4 * sizeof(double);
+    if (max_front > 63) b = std::max(b, (size_t)bs3_big_lds_doubles(max_front) * sizeof(double));
+    allow_max_lds((const void *)k_backsolve3_tab);
+    hipLaunchKernelGGL(k_backsolve3_tab, dim3(n_wg), dim3(256), b, st, d, wgt, slot);
+}
 
 // ---- structure phase on the device: the ELL streams of the observation edges, permuted out of the insertion-order
 // arrays (which travel to HBM, unprocessed, while the host still builds the plan).  ell_ins[e] = insertion index of the
@@ -2113,7 +2413,7 @@ __device__ __forceinline__ int32_t f3_pack(int i, bool col_ok) {
 __global__ void __launch_bounds__(256) k_build_f3(int nq, const int32_t *__restrict__ lf, const DevFront *__restrict__ fronts,
         const int32_t *__restrict__ children, const int32_t *__restrict__ child_map, const int32_t *__restrict__ u3_off,
         const int32_t *__restrict__ u3_size, const int32_t *__restrict__ bf /*[front][8]*/, const int32_t *__restrict__ xrow_off,
-        const int64_t *__restrict__ x_off /* nullable */, int32_t *__restrict__ f3_desc, int32_t *__restrict__ f3_x) {
+        const int64_t *__restrict__ x_off /* nullable */, int32_t *__restrict__ f3_desc, int32_t *__restrict__ f3_x, int x_stride) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + wave;
     if (q >= nq) return;
@@ -2150,24 +2450,26 @@ __global__ void __launch_bounds__(256) k_build_f3(int nq, const int32_t *__restr
     r[160 + lane] = (lane >= F.npiv && lane <= f) ? f3_pack(lane - F.npiv, lane < f) : none;
     if (F.child_cnt < 1) r[32 + lane] = 0;
     if (F.child_cnt < 2) r[96 + lane] = 0;
-    // ---- children: row table + header {front, update-matrix offset, size, owner}
+    // ---- children: row table + header {front, update-matrix offset, size, owner}; x_stride ints per child (72: a 64-entry table;
+    // 168: a 160-entry one, plans that hold a front of more than 63 scalars), the header in its last 8 ints
     int32_t *xt = f3_x + xrow_off[q];
     for (int k = 0; k < F.child_cnt; ++k) {
         const int c = children[F.child_off + k];
         const int nbc = fronts[c].nbnd; const int64_t mo = fronts[c].map_off;
         // by source: boundary row r' of the child (r' = nbc: its rhs row) -> the place of its parent row in the parent's tile image
-        int32_t v = 0;
-        if (lane <= nbc) { const int R = lane < nbc ? child_map[mo + lane] : f;
-            v = (int32_t)((uint32_t)f3_img_rowpart(R) | ((uint32_t)f3_img_colpart(R) << 16)); }
-        xt[k * F3X + lane] = v;
-        if (k < 2) r[32 + 64 * k + lane] = v;
-        if (lane < 8) xt[k * F3X + 64 + lane] = lane == 0 ? c : (lane == 1 ? u3_off[c] : (lane == 2 ? u3_size[c] : (lane == 3 ? fronts[c].owner : 0)));
+        for (int r0 = 0; r0 < x_stride - 8; r0 += 64) { const int rp = r0 + lane;
+            int32_t v = 0;
+            if (rp <= nbc) { const int R = rp < nbc ? child_map[mo + rp] : f;
+                v = (int32_t)((uint32_t)f3_img_rowpart(R) | ((uint32_t)f3_img_colpart(R) << 16)); }
+            if (rp < x_stride - 8) xt[k * x_stride + rp] = v;
+            if (k < 2 && r0 == 0) r[32 + 64 * k + lane] = v; }
+        if (lane < 8) xt[k * x_stride + (x_stride - 8) + lane] = lane == 0 ? c : (lane == 1 ? u3_off[c] : (lane == 2 ? u3_size[c] : (lane == 3 ? fronts[c].owner : 0)));
     }
 }
 void launch_build_f3(int nq, const int32_t *lf, const DevFront *fronts, const int32_t *children, const int32_t *child_map,
                      const int32_t *u3_off, const int32_t *u3_size, const int32_t *bf, const int32_t *xrow_off, const int64_t *x_off,
-                     int32_t *f3_desc, int32_t *f3_x, hipStream_t st) {
-    if (nq > 0) hipLaunchKernelGGL(k_build_f3, dim3((nq + 3) / 4), dim3(256), 0, st, nq, lf, fronts, children, child_map, u3_off, u3_size, bf, xrow_off, x_off, f3_desc, f3_x);
+                     int32_t *f3_desc, int32_t *f3_x, int x_stride, hipStream_t st) {
+    if (nq > 0) hipLaunchKernelGGL(k_build_f3, dim3((nq + 3) / 4), dim3(256), 0, st, nq, lf, fronts, children, child_map, u3_off, u3_size, bf, xrow_off, x_off, f3_desc, f3_x, x_stride);
 }
 // landmark-diagonal block records of the fused linearisation: {kind 1, landmark} -> {1 | #partial slots << 8, first slot}
 __global__ void __launch_bounds__(256) k_patch_asm3(int64_t n, int32_t *__restrict__ asm3, const int32_t *__restrict__ lm_grp_start) {

@@ -127,3 +127,5 @@ def test_arena_beyond_32_bit_byte_offsets_leaves_the_matrix_core_fronts(pkg):
     assert sel(3, 57, (1 << 30)) == 4
     assert sel(2, 57, (1 << 30)) == 2                       # 64-bit addressing in the other kernels
     assert sel(1, 64, 1000) == 4 and sel(4, 30, 1000) == 4 and sel(7, 30, 1000) == 3
+    # fronts beyond a wave: variant 3 gives them a workgroup up to 159 scalars (ten tile rows), chosen per front; beyond that variant 4
+    assert sel(0, 64, 1000) == 3 and sel(0, 153, 1000) == 3 and sel(0, 159, 1000) == 3 and sel(0, 160, 1000) == 4 and sel(2, 100, 1000) == 4
