@@ -373,6 +373,21 @@ def main():
         for name in ("cfg3", "cfg5"):
             rb[name] = linearize_roofline_of(pkg, name, local)
         out["roofline_by_config"] = rb
+        # tracks with 16 / 24 cones in view (what the reference's coneMappingThreshold of 50 m lets a frame hold, src/slam.cpp:608)
+        # at the headline size: separators of 35 / 51 scalars, fronts up to 105 / 153 — a workgroup per front, chosen per front
+        wv = {}
+        for K in (16, 24):
+            Nk, Mk = pkg.track.CONFIGS["cfg4"]
+            tk = pkg.track.generate(Nk, Mk, K)
+            fe = pkg.Graph(device=local); gk = pkg.track.bench_graph(tk, fe); fe.close()
+            Gk = pkg.Graph(device=local); Gk.load_bench_graph(gk); Gk.initialize_optimization(); stk = Gk.stats()
+            ph = Gk.time_iterations(10)
+            wv["K%d" % K] = dict(observations_per_pose=K, n_observation_edges=int(len(gk["pl_p"])), fronts=stk.n_fronts, big_fronts=stk.n_big_fronts, levels=stk.n_levels,
+                                 max_front=stk.max_front, factor_variant=stk.factor_variant, iteration_ms=ph.ms_total, iterations_per_s=1e3 / ph.ms_total,
+                                 phases_ms=dict(linearize=ph.ms_linearize, factor=ph.ms_factor, backsolve=ph.ms_backsolve, update=ph.ms_update),
+                                 per_edge_rate_vs_K8=(1e3 / ph.ms_total * len(gk["pl_p"])) / (value * out["config"]["n_observation_edges"]), structure_ms=stk.ms_structure)
+            Gk.close()
+        out["wide_view_tracks"] = wv
     if rank == 0:
         print(json.dumps(out))
     if G is not None:

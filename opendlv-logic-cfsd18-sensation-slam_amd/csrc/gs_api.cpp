@@ -618,6 +618,7 @@ static int build_plan_host(gs_graph *g) {
     if (const char *e = std::getenv("GS_LEAF_POSES")) o.leaf_poses = std::atoi(e);       // tuning override
     if (const char *e = std::getenv("GS_CLUSTER_WAYS")) o.cluster_ways = std::atoi(e);   // tuning override: 2 = binary dissection down to the leaves
     if (const char *e = std::getenv("GS_ELL_LANES")) o.ell_lanes = std::atoi(e);       // tuning knob: lanes per pose of the ELL layout
+    if (const char *e = std::getenv("GS_BIG_CLUSTER")) o.big_cluster_front = std::atoi(e);   // tuning override: 0 = clusters only where they fit a wave
     std::string err;
     if (!build_plan(g->h, o, g->plan, err)) { g->plan_version = ~0ull; return fail(GS_ERR_EMPTY, "plan: " + err); }
     g->plan_version = g->h.structure_version;
@@ -685,49 +686,54 @@ static int ensure_ready(gs_graph *g) {
 static int build_big_tables(gs_graph *g, const gs_graph::LevelSet &ls) {
     const Plan &P = g->plan; const int nlev = (int)ls.start.size() - 1, total = ls.start[nlev];
     auto f_of = [&](int q) { const Front &F = P.fronts[P.level_fronts_owned[q]]; return F.npiv + F.nbnd; };
-    auto big_kind = [&](int f) { return f <= 111 ? 2 : 3; };
-    g->wg_f.clear(); g->wg_b.clear(); g->wg_f_level.assign(nlev + 1, 0); g->wg_b_level.assign(nlev + 1, 0);
+    auto big_kind = [&](int f) { return f <= 79 ? 4 : (f <= 111 ? 2 : 3); };        // 5, 7 or 10 tile rows
+    g->wg_f.clear(); g->wg_b.clear(); g->seg_f.clear(); g->seg_b.clear();
     g->small_max_npiv = 1; g->small_max_f = 1;
+    for (const Front &F : P.fronts) if (F.npiv + F.nbnd <= 63) { g->small_max_npiv = std::max(g->small_max_npiv, (int)F.npiv); g->small_max_f = std::max(g->small_max_f, F.npiv + F.nbnd); }
+    auto push = [&](std::vector<int32_t> &tab, std::vector<gs_graph::WgSeg> &segs, int pos, int kind_cnt, int level, size_t lds) {
+        const int e = (int)tab.size() / 2; tab.push_back(pos); tab.push_back(kind_cnt);
+        if (!segs.empty() && segs.back().level == level && segs.back().lds == lds) ++segs.back().count; else segs.push_back({e, 1, level, lds}); };
     const int first = std::max(g->leaf_n, 0), first_block = total - std::max(g->block_n, 0);
-    for (int l = 0; l < nlev; ++l) {
-        g->wg_f_level[l] = (int)g->wg_f.size() / 2;
+    for (int l = 0; l < nlev; ++l)
         for (int q = std::max(ls.start[l], first); q < ls.start[l + 1]; ) {
             const int f = f_of(q);
-            if (f > 63) { g->wg_f.push_back(q); g->wg_f.push_back(big_kind(f)); ++q; }
-            else if (q >= first_block) { g->wg_f.push_back(q); g->wg_f.push_back(1 | (1 << 8)); ++q; }
+            if (f > 63) { const int k = big_kind(f); push(g->wg_f, g->seg_f, q, k, l, factor_tab_lds_bytes(k)); ++q; }
+            else if (q >= first_block) { push(g->wg_f, g->seg_f, q, 1 | (1 << 8), l, factor_tab_lds_bytes(1)); ++q; }
             else { int cnt = 1; while (cnt < 4 && q + cnt < ls.start[l + 1] && q + cnt < first_block && f_of(q + cnt) <= 63) ++cnt;
-                g->wg_f.push_back(q); g->wg_f.push_back(0 | (cnt << 8)); q += cnt; } } }
-    g->wg_f_level[nlev] = (int)g->wg_f.size() / 2;
-    for (int l = nlev - 1; l >= 0; --l) {
-        g->wg_b_level[l + 1] = (int)g->wg_b.size() / 2;             // level l's entries: [wg_b_level[l + 1], wg_b_level[l])
+                push(g->wg_f, g->seg_f, q, 0 | (cnt << 8), l, factor_tab_lds_bytes(0)); q += cnt; } }
+    for (int l = nlev - 1; l >= 0; --l)
         for (int q = ls.start[l + 1] - 1; q >= ls.start[l]; ) {
-            const Front &F = P.fronts[P.level_fronts_owned[q]]; const int f = F.npiv + F.nbnd;
-            if (f > 63) { g->wg_b.push_back(q); g->wg_b.push_back(big_kind(f)); --q; }
-            else { int cnt = 0;
-                while (cnt < 4 && q - cnt >= ls.start[l] && f_of(q - cnt) <= 63) { const Front &S = P.fronts[P.level_fronts_owned[q - cnt]];
-                    g->small_max_npiv = std::max(g->small_max_npiv, (int)S.npiv); g->small_max_f = std::max(g->small_max_f, S.npiv + S.nbnd); ++cnt; }
-                g->wg_b.push_back(q); g->wg_b.push_back(0 | (cnt << 8)); q -= cnt; } } }
-    g->wg_b_level[0] = (int)g->wg_b.size() / 2;
+            const int f = f_of(q);
+            if (f > 63) { // LDS by the size class of the front (the largest front of the class), so that runs of one class share a launch
+                const int k = big_kind(f), fc = k == 4 ? 79 : (k == 2 ? 111 : 159);
+                push(g->wg_b, g->seg_b, q, k, l, backsolve_tab_lds_bytes(k, fc, 0)); --q; }
+            else { int cnt = 1; while (cnt < 4 && q - cnt >= ls.start[l] && f_of(q - cnt) <= 63) ++cnt;
+                push(g->wg_b, g->seg_b, q, 0 | (cnt << 8), l, backsolve_tab_lds_bytes(0, g->small_max_f, g->small_max_npiv)); q -= cnt; } }
     int rc;
     if ((rc = dev_alloc(g, (int32_t **)&g->d_wg_f, g->wg_f.size())) != GS_OK || (rc = dev_alloc(g, (int32_t **)&g->d_wg_b, g->wg_b.size())) != GS_OK) return rc;
     HIP_TRY(hipMemcpyAsync(g->d_wg_f, g->wg_f.data(), g->wg_f.size() * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));     // the host vectors live on the handle
     HIP_TRY(hipMemcpyAsync(g->d_wg_b, g->wg_b.data(), g->wg_b.size() * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
     return GS_OK;
 }
+// launches = maximal runs of table entries with the same LDS need (whole-tree mode: across levels; after a flag timeout: never
+// across a level, so that no workgroup waits for one of its own launch)
+template <class Launch> static void for_each_run(const std::vector<gs_graph::WgSeg> &segs, bool across_levels, Launch &&fn) {
+    for (size_t i = 0; i < segs.size(); ) {
+        size_t j = i + 1; int n = segs[i].count;
+        while (j < segs.size() && segs[j].lds == segs[i].lds && (across_levels || segs[j].level == segs[i].level)) { n += segs[j].count; ++j; }
+        fn(segs[i].first, n, segs[i].lds);
+        i = j; }
+}
 static void enqueue_factor_big(gs_graph *g, const gs_graph::LevelSet &ls, bool tree) {
-    const int nlev = (int)ls.start.size() - 1;
     if (!g->d_wg_f && build_big_tables(g, ls) != GS_OK) return;     // (an allocation failure surfaces as a launch error on the next call)
     if (g->leaf_n > 0) launch_factor_tree(g->d, g->leaf_n, g->leaf_slot, g->leaf_max_f, g->leaf_n, 0, g->stream);       // the leaf instance alone
-    if (tree) launch_factor_tab(g->d, g->d_wg_f, g->wg_f_level[nlev], g->leaf_n > 0, g->plan.max_front, g->stream);
-    else for (int l = 0; l < nlev; ++l)                               // after a flag timeout: one launch per level (the flags of earlier launches are up)
-        launch_factor_tab(g->d, g->d_wg_f + g->wg_f_level[l], g->wg_f_level[l + 1] - g->wg_f_level[l], g->leaf_n > 0, g->plan.max_front, g->stream);
+    // "no flags to wait for at level 1" holds only if EVERY leaf went through the leaf launch (big leaves share the table launch with their parents)
+    const int leaf_pre = (g->leaf_n > 0 && g->leaf_n == ls.start[1]) ? 1 : 0;
+    for_each_run(g->seg_f, tree, [&](int first, int n, size_t lds) { launch_factor_tab(g->d, g->d_wg_f + first, n, leaf_pre, lds, g->stream); });
 }
-static void enqueue_backsolve_big(gs_graph *g, const gs_graph::LevelSet &ls, bool tree) {
-    const int nlev = (int)ls.start.size() - 1;
+static void enqueue_backsolve_big(gs_graph *g, const gs_graph::LevelSet &, bool tree) {
     if (!g->d_wg_b) return;
-    if (tree) launch_backsolve_tab(g->d, g->d_wg_b, g->wg_b_level[0], g->small_max_npiv, g->small_max_f, g->plan.max_front, g->stream);
-    else for (int l = nlev - 1; l >= 0; --l)
-        launch_backsolve_tab(g->d, g->d_wg_b + g->wg_b_level[l + 1], g->wg_b_level[l] - g->wg_b_level[l + 1], g->small_max_npiv, g->small_max_f, g->plan.max_front, g->stream);
+    for_each_run(g->seg_b, tree, [&](int first, int n, size_t lds) { launch_backsolve_tab(g->d, g->d_wg_b + first, n, g->small_max_npiv, g->small_max_f, lds, g->stream); });
 }
 static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int base, int mode) {
     const int nlev = (int)ls.start.size() - 1;
@@ -736,6 +742,8 @@ static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int
         // leaf instance: level 0 only if its fronts really have no children (always true for an elimination tree's level 0)
         if (g->leaf_n < 0) {                                          // once per plan
             int n_leaf = ls.start[1], F_leaf_all = 0, slot = 256; g->leaf_max_f = 0;
+            // leaves beyond a wave (the fronts of a level are sorted by size class: the small ones first) go to the table-driven launch
+            for (int q = 0; q < n_leaf; ++q) { const Front &F = g->plan.fronts[g->plan.level_fronts_owned[q]]; if (F.npiv + F.nbnd > 63) { n_leaf = q; break; } }
             for (int q = 0; q < n_leaf; ++q) { const Front &F = g->plan.fronts[g->plan.level_fronts_owned[q]];
                 g->leaf_max_f = std::max(g->leaf_max_f, F.npiv + F.nbnd);
                 if (F.child_cnt != 0) { n_leaf = 0; break; }
@@ -746,7 +754,6 @@ static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int
             { int lmin = 2048; if (const char *e = std::getenv("GS_LEAF_MIN")) lmin = std::atoi(e);
               if (n_leaf <= lmin) n_leaf = 0; }
             if (const char *e = std::getenv("GS_LEAF_KERNEL")) { if (std::atoi(e) == 0) n_leaf = 0; else if (std::atoi(e) == 2) n_leaf = F_leaf_all; }
-            if (g->leaf_max_f > 63) n_leaf = 0;                        // leaves beyond a wave: level 0 joins the table-driven launch
             g->leaf_n = n_leaf; g->leaf_slot = slot; }
         // the upper levels — few fronts, all of them in the dependent chain — get four waves per front: whole levels from the
         // top down while a level has at most GS_BLOCK_FRONTS (512) fronts (those workgroups are all resident at once)

@@ -116,7 +116,8 @@ struct Plan {
 };
 
 struct PlanOptions { int leaf_poses = 8; int world = 1; int rank = 0; int ell_lanes = 0;
-                     int cluster_ways = 0; };      // fan-out of the multi-way split above the leaves (0 = default 8, <= 2 = binary all the way down)
+                     int cluster_ways = 0;         // fan-out of the multi-way split above the leaves (0 = default 8, <= 2 = binary all the way down)
+                     int big_cluster_front = 111; };   // second-pass bound of a cluster front when 63 scalars cannot be met (<= 63: off)
 
 constexpr int LIN_R = 4;               // observation slots per lane handled by the fused linearisation kernel
 

@@ -49,7 +49,9 @@ struct gs_graph {
     int default_factor_variant = 0;         // see upload_graph
     // plans that hold a front of more than 63 scalars: table-driven whole-tree launches (workgroup -> {level position, kind | count << 8}),
     // built once per plan; *_level[l] = first table entry of level l (one launch per level after a fallback)
-    std::vector<int32_t> wg_f, wg_b; std::vector<int> wg_f_level, wg_b_level;
+    struct WgSeg { int first, count, level; size_t lds; };           // a run of table entries of one level with the same LDS need
+    std::vector<WgSeg> seg_f, seg_b;
+    std::vector<int32_t> wg_f, wg_b;
     int2 *d_wg_f = nullptr, *d_wg_b = nullptr; int small_max_npiv = 0, small_max_f = 0;
     bool fell_back = false;                 // a whole-tree launch gave up on a flag: this handle uses one launch per level until the next plan
 };

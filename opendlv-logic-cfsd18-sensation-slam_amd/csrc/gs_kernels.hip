@@ -2105,12 +2105,9 @@ __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, i
 // wave.  Record formats are the small fronts' (packed update matrices, scalar records, tile-image offsets: all generic in the
 // number of tile rows); a child's row table has BIG_TAB entries in f3_x when the plan holds a big front (d.f3x_stride).
 static constexpr int BIG_TAB = 160;
-enum { WG_WAVES = 0, WG_BLOCK4 = 1, WG_BIG7 = 2, WG_BIG10 = 3 };
-__device__ __forceinline__ int f3_tile_row_any(int t) {
-    int I = (int)((__fsqrt_rn(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-    if (((I * (I + 1)) >> 1) > t) --I;
-    if ((((I + 1) * (I + 2)) >> 1) <= t) ++I;
-    return I;
+enum { WG_WAVES = 0, WG_BLOCK4 = 1, WG_BIG7 = 2, WG_BIG10 = 3, WG_BIG5 = 4 };
+__device__ __forceinline__ int f3_tile_row_any(int t) {            // row I of tile t = I (I + 1) / 2 + J, t < 55; integer compares only (t is wave-uniform: scalar code)
+    return (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10) + (t >= 15) + (t >= 21) + (t >= 28) + (t >= 36) + (t >= 45);
 }
 template <int NT> struct BigDims {
     static constexpr int NTILE = NT * (NT + 1) / 2, TPW = (NTILE + 3) / 4, ROWS = 16 * NT, IMG = NTILE * 256, NR = (ROWS + 63) / 64;
@@ -2126,40 +2123,41 @@ __device__ __forceinline__ bool f3_big_panel(int B, bool &bad, v4d (&acc)[BigDim
     double *Pb = Pn + (B & 1) * D::PANEL;
     // 1. the panel's four columns out of whichever waves own the tiles of tile column J0
 #pragma unroll
-    for (int s = 0; s < D::TPW; ++s) { const int t = 4 * s + wave; const int I = f3_tile_row_any(min(t, D::NTILE - 1)), J = t - ((I * (I + 1)) >> 1);   // uniform per wave
+    for (int s = 0; s < D::TPW; ++s) { const int t = 4 * s + wave, I = f3_tile_row_any(t), J = t - ((I * (I + 1)) >> 1);   // uniform per wave
         if (t < D::NTILE && J == J0 && lc >= jc && lc < jc + 4) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) Pb[(16 * I + lr + 4 * q) * 4 + (lc - jc)] = acc[s][q]; } }
     __syncthreads();
-    // 2. every wave factorises the panel; a lane owns rows lane + 64 m
-    double p[D::NR][4], dd[4];
+    // 2. every wave factorises the panel; a lane owns rows lane + 64 m.  What the rows need from each other are the entries of the
+    // panel's 4 x 4 diagonal block: every lane reads it (LDS broadcast) and eliminates it alongside its own rows — the same
+    // operations on the same values as a lane-to-lane broadcast of the pivot rows, without a register picked by a runtime index
+    double p[D::NR][4], dd[4], Bd[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) Bd[r][c] = Pb[(k0 + r) * 4 + c];
 #pragma unroll
     for (int m = 0; m < D::NR; ++m)
 #pragma unroll
         for (int j = 0; j < 4; ++j) p[m][j] = (lane + 64 * m < D::ROWS) ? Pb[(lane + 64 * m) * 4 + j] : 0.0;
-    const int mk = k0 >> 6, lk = k0 & 63;                           // the panel's pivot rows live in row register mk, lanes lk .. lk + 3 (uniform)
-    auto pick = [&](int j) { double v = p[0][j];
-#pragma unroll
-        for (int m = 1; m < D::NR; ++m) v = (mk == m) ? p[m][j] : v;
-        return v; };
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         dd[j] = 0.0;
         if (k0 + j < npiv) {                                        // uniform
             const int col = k0 + j;
-            const double cj = pick(j);                              // column j of the panel at the rows of register mk
-            const double piv = lane_bcast(cj, lk + j);
+            const double piv = Bd[j][j];
             bad = bad || !(fabs(piv) > 0.0);                        // LDL^T: a ZERO pivot fails (Eigen SimplicialCholesky_impl.h:172-176), NaN is reported too
             const double inv = rcp_f64(piv);
-            double c2[4];
-#pragma unroll
-            for (int j2 = j + 1; j2 < 4; ++j2) c2[j2] = lane_bcast(cj, lk + j2);      // the unscaled column at the later pivot rows
 #pragma unroll
             for (int m = 0; m < D::NR; ++m) {
                 const double lj = (lane + 64 * m >= col) ? p[m][j] * inv : 0.0;      // row col itself becomes d / d = 1: a dead row in every later use
 #pragma unroll
-                for (int j2 = j + 1; j2 < 4; ++j2) p[m][j2] -= lj * c2[j2];
+                for (int j2 = j + 1; j2 < 4; ++j2) p[m][j2] -= lj * Bd[j2][j];       // the unscaled column at the later pivot rows
                 p[m][j] = lj; }
+#pragma unroll
+            for (int j2 = j + 1; j2 < 4; ++j2) { const double lb = Bd[j2][j] * inv;    // the block's own rows, the same way
+#pragma unroll
+                for (int j3 = j + 1; j3 <= j2; ++j3) Bd[j2][j3] -= lb * Bd[j3][j]; }
             dd[j] = piv;
         } else {
 #pragma unroll
@@ -2178,8 +2176,10 @@ __device__ __forceinline__ bool f3_big_panel(int B, bool &bad, v4d (&acc)[BigDim
 #pragma unroll
         for (int j = 0; j < 4; ++j) Pw[(lane + 64 * m) * 4 + j] = p[m][j]; }
     const double dk = lr == 0 ? dd[0] : (lr == 1 ? dd[1] : (lr == 2 ? dd[2] : dd[3]));
+    // (static tile coordinates — every wave walking all NT (NT + 1) / 2 tiles with a uniform test each, operands preloaded per tile
+    // row — were measured SLOWER: 548 against 596 it/s on the 24-cones-in-view track; the code is three times the size)
 #pragma unroll
-    for (int s = 0; s < D::TPW; ++s) { const int t = 4 * s + wave; const int I = f3_tile_row_any(min(t, D::NTILE - 1)), J = t - ((I * (I + 1)) >> 1);
+    for (int s = 0; s < D::TPW; ++s) { const int t = 4 * s + wave, I = f3_tile_row_any(t), J = t - ((I * (I + 1)) >> 1);
         if (t < D::NTILE && J >= J0 && 16 * I <= f) {
             const double aI = Pw[(16 * I + lc) * 4 + lr], aJ = Pw[(16 * J + lc) * 4 + lr];
             acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aI, aJ * dk, acc[s], 0, 0, 0); } }
@@ -2210,11 +2210,19 @@ __device__ __forceinline__ void f3_big_front(const DevGraph &d, int pos, double 
           for (int u = 0; u < 4; ++u) v4[u] = ld_off(d.H_arena, (uint32_t)r4[u].x * 8u);
 #pragma unroll
           for (int u = 0; u < 4; ++u) if (base + 256 * u + tid < nsc) img[r4[u].y] = v4[u]; }
+      // (with 24 cones in view a landmark is seen from ~30 wave tiles: eight slots' loads in flight, added in slot order)
       for (int t = tid; t < nlm; t += 256) {
           const int4 r = reinterpret_cast<const int4 *>(d.lm3)[fr.lm_off + t]; const int64_t G = d.n_groups; double a[5] = {0, 0, 0, 0, 0};
-          for (int q = 0; q < r.x; ++q)
+          for (int q0 = 0; q0 < r.x; q0 += 8) {
+              double t8[8][5];
 #pragma unroll
-              for (int k = 0; k < 5; ++k) a[k] += d.lm_part[k * G + r.y + q];
+              for (int j = 0; j < 8; ++j) { const int q = min(q0 + j, r.x - 1);
+#pragma unroll
+                  for (int k = 0; k < 5; ++k) t8[j][k] = d.lm_part[k * G + r.y + q]; }
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+#pragma unroll
+                  for (int k = 0; k < 5; ++k) a[k] += (q0 + j < r.x) ? t8[j][k] : 0.0; }
           P.at(r.z, r.w) = a[0]; P.at(r.z + 1, r.w) = a[1]; P.at(r.z + 1, r.w + 1) = a[2]; P.at(f, r.w) = a[3]; P.at(f, r.w + 1) = a[4]; }
       __syncthreads();
       if (fr.asm_dup > 0) {
@@ -2232,14 +2240,13 @@ __device__ __forceinline__ void f3_big_front(const DevGraph &d, int pos, double 
         okw = f3_wait_flag(d.done_f + c_id, d.epoch, d.fail) && okw;       // a child of an earlier launch has its flag set already
         __syncthreads();
         const double *Uc = d.Uimg + c_uoff;
-        for (int base = 0; base < c_usz; base += 1024) {
-            double v4[4]; int pl[4];
+        for (int base = 0; base < c_usz; base += 4096) {             // sixteen loads per thread in flight
+            double v16[16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int idx = base + 256 * u + tid; v4[u] = ld_off_coh(Uc, (uint32_t)min(idx, c_usz) * 8u);      // beyond the matrix: the zero double behind it
-                const int rc = f3_rc_of(min(idx, c_usz - 1));
-                pl[u] = idx < c_usz ? (tab[rc & 0xff] & 0xffff) + (int)((uint32_t)tab[rc >> 8] >> 16) : 1; }
+            for (int u = 0; u < 16; ++u) { const int idx = base + 256 * u + tid; v16[u] = ld_off_coh(Uc, (uint32_t)min(idx, c_usz) * 8u); }      // beyond the matrix: the zero double behind it
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (base + 256 * u + tid < c_usz) img[pl[u]] += v4[u];      // a child's places are distinct
+            for (int u = 0; u < 16; ++u) { const int idx = base + 256 * u + tid;
+                if (idx < c_usz) { const int rc = f3_rc_of(idx); img[(tab[rc & 0xff] & 0xffff) + (int)((uint32_t)tab[rc >> 8] >> 16)] += v16[u]; } }      // a child's places are distinct
         }
         __syncthreads();
     }
@@ -2247,9 +2254,9 @@ __device__ __forceinline__ void f3_big_front(const DevGraph &d, int pos, double 
     // ---- accumulators: wave w holds tiles w, w + 4, ...
     v4d acc[D::TPW];
 #pragma unroll
-    for (int s = 0; s < D::TPW; ++s) { const int t = 4 * s + wave;
+    for (int s = 0; s < D::TPW; ++s)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[s][q] = t < D::NTILE ? img[t * 256 + q * 64 + lane] : 0.0; }
+        for (int q = 0; q < 4; ++q) acc[s][q] = 4 * s + wave < D::NTILE ? img[(4 * s + wave) * 256 + q * 64 + lane] : 0.0;
     double *L = d.Lbuf + fr.L_off;
     bool go = true, bad = false;
 #pragma clang loop unroll(disable)
@@ -2267,6 +2274,9 @@ __device__ __forceinline__ void f3_big_front(const DevGraph &d, int pos, double 
     { double *U = d.Uimg + fr.u_off; const int usz = fr.u_size;
       for (int idx = tid; idx < usz; idx += 256) { const int rc = f3_rc_of(idx);
           st_off_wt(U, (uint32_t)idx * 8u, img[f3_img_rowpart(npiv + (rc & 0xff)) + f3_img_colpart(npiv + (rc >> 8))]); } }
+#if F3_DONE_TS
+    if (tid == 0) d.done_ts[fr.s] = wall_clock64();
+#endif
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __hip_atomic_store(d.done_f + fr.s, d.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -2336,6 +2346,9 @@ __device__ __forceinline__ void bs3_big_front(const DevGraph &d, int pos, double
 #pragma unroll
         for (int m = 0; m < 3; ++m) { const int j = lane + 64 * m;
             if (j < npiv) { if (TREE) st_off_wt(d.xe, (uint32_t)(fr.piv0 + j) * 8u, wr[m]); else d.xe[fr.piv0 + j] = wr[m]; } }
+#if F3_DONE_TS
+        if (lane == 0) d.done_ts[d.n_fronts + fr.s] = wall_clock64();
+#endif
     }
 }
 // Table-driven launches (plans that hold a big front): workgroup b takes wgt[b] = {first level position, kind | count << 8} — up to
@@ -2348,6 +2361,7 @@ __global__ void __launch_bounds__(256, 2) k_factor3_tab(DevGraph d, const int2 *
     const int pos = __builtin_amdgcn_readfirstlane(e.x), kind = __builtin_amdgcn_readfirstlane(e.y) & 0xff, cnt = __builtin_amdgcn_readfirstlane(e.y) >> 8;
     if (kind == WG_WAVES) { if (wave < cnt) f3_wave_front<true, false, 4>(d, pos + wave, FRONT_OWN, leaf_launch_preceded, smem, wave, lane, false, false); }
     else if (kind == WG_BLOCK4) f3_block_front(d, pos, leaf_launch_preceded, smem, false);
+    else if (kind == WG_BIG5) f3_big_front<5>(d, pos, smem);
     else if (kind == WG_BIG7) f3_big_front<7>(d, pos, smem);
     else f3_big_front<10>(d, pos, smem);
 }
@@ -2360,24 +2374,30 @@ __global__ void __launch_bounds__(256, 2) k_backsolve3_tab(DevGraph d, const int
     if (kind == WG_WAVES || kind == WG_BLOCK4) { if (wave < cnt) bs3_wave_front<true>(d, pos - wave, smem, slot_doubles, wave, lane, ts_on); }     // root first: positions downwards
     else bs3_big_front<true>(d, pos, smem);
 }
-size_t factor_tab_lds_bytes(int max_front) {
-    size_t b = (size_t)MF_IMG * 4 * sizeof(double);
-    if (max_front > 63) b = std::max(b, (size_t)BigDims<7>::LDS_DOUBLES * sizeof(double));
-    if (max_front > 111) b = std::max(b, (size_t)BigDims<10>::LDS_DOUBLES * sizeof(double));
-    return b;
+// LDS of one workgroup of a table-driven launch, by kind (a launch takes the maximum over its workgroups: the host cuts the table
+// into launches of equal need, so that the many fronts just beyond a wave do not run at the occupancy of the ten-tile-row ones)
+size_t factor_tab_lds_bytes(int kind) {
+    switch (kind) {
+        case WG_BIG5: return (size_t)BigDims<5>::LDS_DOUBLES * sizeof(double);
+        case WG_BIG7: return (size_t)BigDims<7>::LDS_DOUBLES * sizeof(double);
+        case WG_BIG10: return (size_t)BigDims<10>::LDS_DOUBLES * sizeof(double);
+        default: return (size_t)MF_IMG * 4 * sizeof(double);
+    }
 }
-void launch_factor_tab(const DevGraph &d, const int2 *wgt, int n_wg, int leaf_launch_preceded, int max_front, hipStream_t st) {
+size_t backsolve_tab_lds_bytes(int kind, int f_or_slot_f, int npiv_small) {      // waves: the slot of the largest small front; big: the front's own need
+    if (kind == WG_WAVES || kind == WG_BLOCK4) { const int slot = ((((f_or_slot_f + 1) | 1) * std::max(npiv_small, 1)) + 1) & ~1; return (size_t)slot * 4 * sizeof(double); }
+    return (size_t)bs3_big_lds_doubles(f_or_slot_f) * sizeof(double);
+}
+void launch_factor_tab(const DevGraph &d, const int2 *wgt, int n_wg, int leaf_launch_preceded, size_t lds_bytes, hipStream_t st) {
     if (n_wg <= 0) return;
     allow_max_lds((const void *)k_factor3_tab);
-    hipLaunchKernelGGL(k_factor3_tab, dim3(n_wg), dim3(256), factor_tab_lds_bytes(max_front), st, d, wgt, leaf_launch_preceded);
+    hipLaunchKernelGGL(k_factor3_tab, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, leaf_launch_preceded);
 }
-void launch_backsolve_tab(const DevGraph &d, const int2 *wgt, int n_wg, int max_npiv_small, int max_f_small, int max_front, hipStream_t st) {
+void launch_backsolve_tab(const DevGraph &d, const int2 *wgt, int n_wg, int max_npiv_small, int max_f_small, size_t lds_bytes, hipStream_t st) {
     if (n_wg <= 0) return;
     const int slot = ((((max_f_small + 1) | 1) * std::max(max_npiv_small, 1)) + 1) & ~1;
-    size_t b = (size_t)slot * 4 * sizeof(double);
-    if (max_front > 63) b = std::max(b, (size_t)bs3_big_lds_doubles(max_front) * sizeof(double));
     allow_max_lds((const void *)k_backsolve3_tab);
-    hipLaunchKernelGGL(k_backsolve3_tab, dim3(n_wg), dim3(256), b, st, d, wgt, slot);
+    hipLaunchKernelGGL(k_backsolve3_tab, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, slot);
 }
 
 // ---- structure phase on the device: the ELL streams of the observation edges, permuted out of the insertion-order

@@ -137,8 +137,14 @@ struct Builder {
           nb = 3 * (int)seen_p.size() + 2 * bc; }
         std::vector<int32_t> sep_poses, cut, sep_cones, orphans;
         std::vector<std::vector<int32_t>> part_cones;
+        // the cluster front must fit a wave (63 scalars) where that is possible at all; with 16-24 cones in view (frames of the
+        // reference's coneMappingThreshold) the boundary alone is ~60 scalars, every front is a workgroup front anyway
+        // and the bound becomes the 7-tile-row instance's 111 — otherwise such a range falls back to binary splits and
+        // leaves level after level of ONE-pose separators (3 pivots each) with 60-100 boundary rows
+        const int p_first = p;
+        int limit = 63;
         for (;; --p) {
-            if (p <= 2) return false;
+            if (p <= 2) { if (limit == 63 && opt.big_cluster_front > 63) { limit = opt.big_cluster_front; p = p_first + 1; continue; } return false; }
             sep_poses.clear(); cut.clear(); sep_cones.clear(); orphans.clear();
             // split poses: the unassigned ones at ranks (un * k) / p, k = 1 .. p - 1; part k = positions (cut[k], cut[k + 1])
             cut.push_back(a - 1);
@@ -156,7 +162,7 @@ struct Builder {
             for (int l : cones) { int hit = -1, n = 0;
                 for (int k = 0; k < np && n < 2; ++k) if (has_observer(l, cut[k] + 1, cut[k + 1])) { hit = k; ++n; }
                 if (n >= 2) sep_cones.push_back(l); else if (n == 1) part_cones[hit].push_back(l); else orphans.push_back(l); }
-            if (3 * (int)sep_poses.size() + 2 * (int)sep_cones.size() + nb <= 63) break;       // the cluster front fits a wave
+            if (3 * (int)sep_poses.size() + 2 * (int)sep_cones.size() + nb <= limit) break;    // the cluster front fits a wave (or, second pass, a 7-tile-row workgroup)
             for (int m : sep_poses) assigned[m] = 0;                // too big: fewer parts (their larger pieces are dissected further)
         }
         const int np = (int)cut.size() - 1;
@@ -463,6 +469,14 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     plan.level_fronts.resize(S);
     { std::vector<int32_t> fill(plan.level_start.begin(), plan.level_start.end() - 1);
       for (int s = 0; s < S; ++s) plan.level_fronts[fill[plan.fronts[s].level]++] = s; }
+    // fronts beyond a wave (f > 63) are launched by size class (5 / 7 / 10 tile rows, each with its own LDS need): keep the classes
+    // of a level together.  Stable, so a plan without such fronts keeps its order.
+    if (plan.max_front > 63) {
+        auto cls = [&](int s) { const int f = plan.fronts[s].npiv + plan.fronts[s].nbnd; return f <= 63 ? 0 : (f <= 79 ? 1 : (f <= 111 ? 2 : 3)); };
+        for (int l = 0; l < nlev; ++l)
+            std::stable_sort(plan.level_fronts.begin() + plan.level_start[l], plan.level_fronts.begin() + plan.level_start[l + 1],
+                             [&](int a, int b) { return cls(a) < cls(b); });
+    }
     GS_PT(6);
     // ---- pose-window shards: rank r owns the subtrees whose poses all lie in the r-th contiguous
     // window of the free-pose sequence; every front above them is "shared" (owner -1): the window-boundary
