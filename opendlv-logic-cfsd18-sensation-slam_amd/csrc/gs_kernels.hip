@@ -230,7 +230,7 @@ __device__ __forceinline__ void quad_pl(double px, double py, double c, double s
 // device-scope store (sc1): see st_off_wt below
 template <class Tp> __device__ __forceinline__ void st_wt(Tp *ptr, Tp v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #ifndef LIN_NT
-#define LIN_NT 1
+#define LIN_NT 0
 #endif
 #if LIN_NT & 4
 #define ST_O(ptr, v) st_wt(ptr, v)
@@ -416,6 +416,8 @@ __global__ void __launch_bounds__(256) k_linearize_lm_gather(DevGraph d) {
 //      items in a fixed order into the per-(wave tile, landmark) partial slot.
 static constexpr int LIN_R = 4;                   // == gs::LIN_R: observation slots per lane
 #ifndef LIN_WAVES_PER_SIMD
+#define LIN_WAVES_PER_SIMD 4
+#endif
 // base[byte_off / sizeof(T)] with a wave-uniform base and a 32-bit per-lane byte offset: compiles to the
 // "SGPR base + VGPR offset" global addressing form, so no 64-bit per-lane address has to live in VGPRs.
 template <class Tp> __device__ __forceinline__ Tp ld_off(const Tp *base, uint32_t byte_off) {
@@ -436,8 +438,6 @@ template <class Tp> __device__ __forceinline__ void st_off_nt(Tp *base, uint32_t
 template <class Tp> __device__ __forceinline__ void st_off_wt(Tp *base, uint32_t byte_off, Tp v) {
     __hip_atomic_store(reinterpret_cast<Tp *>(reinterpret_cast<char *>(base) + byte_off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-#define LIN_WAVES_PER_SIMD 4
-#endif
 // LIN_NT bit 0: non-temporal loads of the read-once ELL streams, bit 1: non-temporal stores of the Hpl planes.
 // Measured on MI355X, cfg4 (105 MB per pass, fits the 256 MB Infinity Cache), microseconds per launch:
 //   back-to-back launches  nt=0 26.1  nt=1 30.4  nt=2 26.8  nt=3 29.8   (streams still cached from the last launch)
@@ -446,8 +446,13 @@ template <class Tp> __device__ __forceinline__ void st_off_wt(Tp *base, uint32_t
 // Re-measured with the final solver (L panels non-temporal): nt=0 30.7 us in-iteration but the factor phase after it
 // 252 us and 2540 it/s; nt=1 31.7 us, factor 244 us, 2600 it/s — streaming the read-once inputs past the caches is
 // worth more to the kernels that follow than to this one.
+// Round 3, re-measured with this round's solver (scripts/r3_f.sh, same box, whole iterations; microseconds lin / factor, it/s):
+//   cfg4  nt=0 28.5 / 170, 3638   nt=1 32.0 / 170, 3590   nt=3 32.5 / 173, 3545   nt=5 (write-through stores) 32.0 / 170, 3598
+//   cfg5  nt=0 209 / 960, 626     nt=1 209 / 965, 622     nt=5 207 / 972, 622
+// the factor phase no longer gains from streamed inputs (its own traffic is streamed now), the pass itself loses 3.5 us at
+// cfg4 with them: plain loads.
 #ifndef LIN_NT
-#define LIN_NT 1
+#define LIN_NT 0
 #endif
 #if LIN_NT & 1
 #define LD_S ld_off_nt
