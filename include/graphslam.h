@@ -111,6 +111,9 @@ typedef struct gs_stats {
     int32_t factor_variant;     /* the front kernels this plan runs on (gs_config.factor_variant after the per-plan rules): 3 = LDL^T on
                                    the fp64 matrix cores (a wave per front up to 63 scalars, a workgroup per front up to 159), 4 = block VALU */
     int32_t n_big_fronts;       /* fronts of more than 63 scalars (variant 3: the ones that get a workgroup) */
+    int64_t device_bytes;       /* HBM this handle's plan and graph occupy (the chunks its arrays are carved from) */
+    int32_t n_own_fronts, n_shared_fronts;   /* pose-window shards: fronts this rank factorises / the shared top (world 1: all, 0) */
+    double  ms_plan_host;       /* share of ms_structure spent building the plan on the host */
 } gs_stats;
 
 int  gs_version(void);                               /* major*100+minor */

@@ -44,9 +44,9 @@ template <class T> static int dev_alloc(gs_graph *g, T **ptr, size_t count) {
         while (want < bytes) want <<= 1;
         void *p = nullptr;
         HIP_TRY(hipMalloc(&p, want));
-        g->allocs.push_back(p);
+        g->allocs.push_back(p); g->pool_total += want;
         g->pool_base = (char *)p; g->pool_size = want; g->pool_off = 0;
-        g->pool_next = std::min<size_t>(want << 1, (size_t)1 << 30);
+        g->pool_next = std::min<size_t>(want << 1, (size_t)128 << 20);      // chunks of at most 128 MB (a larger single array gets its own): little slack in the footprint
     }
     *ptr = (T *)(g->pool_base + g->pool_off);
     g->pool_off += bytes;
@@ -61,7 +61,7 @@ template <class T, class A> static int dev_upload(gs_graph *g, T **ptr, const st
 static void dev_free_all(gs_graph *g) {
     for (void *p : g->allocs) hipFree(p);
     g->allocs.clear();
-    g->pool_base = nullptr; g->pool_size = g->pool_off = 0; g->pool_next = 0;
+    g->pool_base = nullptr; g->pool_size = g->pool_off = 0; g->pool_next = 0; g->pool_total = 0;
     g->d = DevGraph();
     g->dev_valid = false;
 }
@@ -372,6 +372,7 @@ struct RawUpload {
     ~RawUpload() { if (th.joinable()) th.join(); }                  // an exception (bad_alloc in the plan build) must not meet a joinable thread: std::terminate
     int32_t *pl_l = nullptr; double *pl_z = nullptr, *pl_info = nullptr;
     std::vector<double> zinv;
+    uvec<int32_t> ell_l; uvec<double> ell_z, ell_w;               // pose-window shards: the ELL streams, filled on the host (they must outlive the copies: upload_graph ends with a sync)
 };
 static int upload_raw_begin(gs_graph *g, RawUpload &R) {
     const HostGraph &h = g->h; DevGraph &d = g->d;
@@ -380,9 +381,12 @@ static int upload_raw_begin(gs_graph *g, RawUpload &R) {
     if ((rc = dev_alloc(g, &d.pose_est, N * 3)) != GS_OK || (rc = dev_alloc(g, &d.lm_est, M * 2)) != GS_OK ||
         (rc = dev_alloc(g, &d.pose_fixed, N)) != GS_OK || (rc = dev_alloc(g, &d.lm_fixed, M)) != GS_OK ||
         (rc = dev_alloc(g, &d.pose_cs, N * 2)) != GS_OK || (rc = dev_alloc(g, &d.pp_zinv, Epp * 5)) != GS_OK ||
-        (rc = dev_alloc(g, &d.pp_info, Epp * 6)) != GS_OK || (rc = dev_alloc(g, &R.pl_l, Epl)) != GS_OK ||
-        (rc = dev_alloc(g, &R.pl_z, Epl * 2)) != GS_OK || (rc = dev_alloc(g, &R.pl_info, Epl * 3)) != GS_OK) return rc;
-    R.th = std::thread([g, &R, N, M, Epp, Epl] {
+        (rc = dev_alloc(g, &d.pp_info, Epp * 6)) != GS_OK) return rc;
+    // the observation edges as inserted travel now only on a single GPU; a pose-window shard uploads the ones it evaluates, in
+    // device layout, once the plan says which they are (upload_graph)
+    const bool raw_pl = g->world <= 1;
+    if (raw_pl && ((rc = dev_alloc(g, &R.pl_l, Epl)) != GS_OK || (rc = dev_alloc(g, &R.pl_z, Epl * 2)) != GS_OK || (rc = dev_alloc(g, &R.pl_info, Epl * 3)) != GS_OK)) return rc;
+    R.th = std::thread([g, &R, N, M, Epp, Epl, raw_pl] {
         const HostGraph &h = g->h; DevGraph &d = g->d;
         auto cp = [&](void *dst, const void *src, size_t bytes) {
             if (R.rc != GS_OK || bytes == 0) return;
@@ -391,8 +395,8 @@ static int upload_raw_begin(gs_graph *g, RawUpload &R) {
         if (hipSetDevice(g->device) != hipSuccess) { R.rc = GS_ERR_HIP; R.err = "hipSetDevice failed on the upload thread"; return; }
         cp(d.pose_est, h.pose_est.data(), N * 3 * sizeof(double)); cp(d.lm_est, h.lm_est.data(), M * 2 * sizeof(double));
         cp(d.pose_fixed, h.pose_fixed.data(), N); cp(d.lm_fixed, h.lm_fixed.data(), M);
-        cp(R.pl_l, h.pl_l.data(), Epl * sizeof(int32_t)); cp(R.pl_z, h.pl_z.data(), Epl * 2 * sizeof(double));
-        cp(R.pl_info, h.pl_info.data(), Epl * 3 * sizeof(double));
+        if (raw_pl) { cp(R.pl_l, h.pl_l.data(), Epl * sizeof(int32_t)); cp(R.pl_z, h.pl_z.data(), Epl * 2 * sizeof(double));
+            cp(R.pl_info, h.pl_info.data(), Epl * 3 * sizeof(double)); }
         cp(d.pp_info, h.pp_info.data(), Epp * 6 * sizeof(double));            // odometry edges keep their insertion order on the device
         R.zinv.resize(Epp * 5);
         for (size_t k = 0; k < Epp; ++k) { double inv[3]; se2_inverse_host(&h.pp_z[3 * k], inv);
@@ -414,13 +418,24 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
     // estimates, fixed flags, odometry edges and the insertion-order observation arrays are in HBM already (RawUpload)
     launch_pose_trig(d, g->stream);
     UP(pose_gidx, P.pose_gidx); UP(lm_gidx, P.lm_gidx);
-    d.ell_T = P.ell_T; d.ell_R = P.ell_R; d.ell_len = P.ell_len;
-    { const size_t L = (size_t)P.ell_len;                            // ELL streams: permuted on the device (k_build_ell)
-      int32_t *ins = nullptr, *prank = nullptr;
-      if ((rc = dev_upload(g, &ins, P.ell_ins)) != GS_OK) return rc;
-      if (P.world > 1 && (rc = dev_upload(g, &prank, P.pl_rank)) != GS_OK) return rc;
+    d.ell_T = P.ell_T; d.ell_R = P.ell_R; d.ell_len = P.ell_len; d.ell_p0 = P.ell_p0; d.ell_np = P.ell_np;
+    { const size_t L = (size_t)P.ell_len;
       if ((rc = dev_alloc(g, &d.ell_l, L)) != GS_OK || (rc = dev_alloc(g, &d.ell_z, 2 * L)) != GS_OK || (rc = dev_alloc(g, &d.ell_w, 3 * L)) != GS_OK) return rc;
-      launch_build_ell((int64_t)L, ins, raw.pl_l, raw.pl_z, raw.pl_info, prank, P.rank, d.ell_l, d.ell_z, d.ell_w, g->stream); }
+      if (P.world <= 1) {                                            // ELL streams: permuted on the device out of the arrays that travelled during the plan build (k_build_ell)
+          int32_t *ins = nullptr;
+          if ((rc = dev_upload(g, &ins, P.ell_ins)) != GS_OK) return rc;
+          launch_build_ell((int64_t)L, ins, raw.pl_l, raw.pl_z, raw.pl_info, nullptr, P.rank, d.ell_l, d.ell_z, d.ell_w, g->stream);
+      } else {                                                       // pose-window shard: only the poses it sweeps are laid out; the streams are filled on the host
+          raw.ell_l.resize(L); raw.ell_z.resize(2 * L); raw.ell_w.resize(3 * L);        // (threads) with the edges this rank evaluates, the others stay empty (l = -1)
+          parallel_chunks((int64_t)L, 16384, [&](int64_t b, int64_t e2, int) {
+              for (int64_t e = b; e < e2; ++e) { int k = P.ell_ins[(size_t)e]; if (k >= 0 && P.pl_rank[k] != P.rank) k = -1;
+                  raw.ell_l[e] = k >= 0 ? h.pl_l[k] : -1;
+                  raw.ell_z[e] = k >= 0 ? h.pl_z[2 * (size_t)k] : 0.0; raw.ell_z[L + e] = k >= 0 ? h.pl_z[2 * (size_t)k + 1] : 0.0;
+                  raw.ell_w[e] = k >= 0 ? h.pl_info[3 * (size_t)k] : 0.0; raw.ell_w[L + e] = k >= 0 ? h.pl_info[3 * (size_t)k + 1] : 0.0;
+                  raw.ell_w[2 * L + e] = k >= 0 ? h.pl_info[3 * (size_t)k + 2] : 0.0; } });
+          HIP_TRY(hipMemcpyAsync(d.ell_l, raw.ell_l.data(), L * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
+          HIP_TRY(hipMemcpyAsync(d.ell_z, raw.ell_z.data(), 2 * L * sizeof(double), hipMemcpyHostToDevice, g->stream));
+          HIP_TRY(hipMemcpyAsync(d.ell_w, raw.ell_w.data(), 3 * L * sizeof(double), hipMemcpyHostToDevice, g->stream)); } }
     GS_UT("estimates+edges");
     UP(lm_start, P.lm_start); UP(lm_edges, P.lm_edges); UP(ppadj_start, P.ppadj_start);
     { std::vector<int32_t> inc = P.ppinc;                                 // incidences of edges another rank evaluates: edge = -1
@@ -434,15 +449,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
         d.n_wtiles = P.n_wtiles; d.n_groups = (int32_t)P.grp_lm.size();
         UP(wt_desc, P.wt_desc); UP(grp_pos_start, P.grp_pos_start); UP(grp_slot, P.grp_slot); UP(lm_grp_start, P.lm_grp_start);
         UP(ell_dst, P.ell_dst);
-        d.wt_lo = 0; d.wt_hi = P.n_wtiles;
-        if (P.world > 1) {                                                // the wave tiles this shard has any edge in
-            const int PW = 64 / P.ell_T; int lo = P.n_wtiles, hi = 0;
-            for (int p = 0; p < N; ++p) { bool any = false;
-                for (int s = P.pl_start[p]; s < P.pl_start[p + 1] && !any; ++s) any = P.pl_rank[P.pl_order[s]] == P.rank;
-                for (int q = P.ppadj_start[p]; q < P.ppadj_start[p + 1] && !any; ++q) any = P.pp_rank[P.ppadj[q] >> 1] == P.rank;
-                if (any) { lo = std::min(lo, p / PW); hi = std::max(hi, p / PW + 1); } }
-            d.wt_lo = std::min(lo, hi); d.wt_hi = hi;
-        }
+        d.wt_lo = P.wt_lo; d.wt_hi = P.wt_hi;                             // the wave tiles this shard has any edge in (gs_plan.cpp)
     } else if (P.world > 1) return fail(GS_ERR_INVALID, "pose-window shards need the fused linearisation layout (<= 32 observations per pose)");
     // block-sparse H and b live in ONE arena (the variant-3 front assembly addresses every scalar by its offset in it)
     int64_t arena_off[8], arena_doubles = 0;
@@ -842,7 +849,9 @@ static void fill_plan_stats(gs_graph *g, gs_stats *s) {
     s->fell_back = g->fell_back ? 1 : 0;
     s->factor_variant = g->dev_valid ? (g->d.factor_variant == 0 ? 4 : g->d.factor_variant) : 0;
     s->n_big_fronts = 0;
-    for (const Front &F : P.fronts) s->n_big_fronts += (F.npiv + F.nbnd > 63);
+    for (const Front &F : P.fronts) s->n_big_fronts += (!F.opaque && F.npiv + F.nbnd > 63);
+    s->device_bytes = (int64_t)g->pool_total; s->ms_plan_host = P.ms_build;
+    s->n_own_fronts = (int32_t)P.level_fronts_owned.size(); s->n_shared_fronts = (int32_t)P.level_fronts_shared.size();
 }
 
 extern "C" int gs_get_stats(gs_graph *g, gs_stats *s) {
@@ -997,7 +1006,8 @@ extern "C" int gs_export_system(gs_graph *g, double *Hpp_diag, double *Hll_diag,
     if (Hpp_diag) for (size_t p = 0; p < N; ++p) for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Hpp_diag[9 * p + 3 * r + c] = t0[sym3[r][c] * N + p];
     if (Hll_diag) for (size_t l = 0; l < M; ++l) for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) Hll_diag[4 * l + 2 * r + c] = t1[sym2[r][c] * M + l];
     if (Hpp_off) for (size_t k = 0; k < Epp; ++k) for (int c = 0; c < 9; ++c) Hpp_off[9 * k + c] = t2[c * Epp + k];
-    if (Hpl) for (size_t k = 0; k < Epl; ++k) for (int c = 0; c < 6; ++c) Hpl[6 * k + c] = t3[c * L + (size_t)g->plan.ell_of_ins[k]];   // insertion order
+    if (Hpl) for (size_t k = 0; k < Epl; ++k) { const int32_t e = g->plan.ell_of_ins[k];                 // insertion order; an edge outside this rank's layout: zeros
+        for (int c = 0; c < 6; ++c) Hpl[6 * k + c] = e >= 0 ? t3[c * L + (size_t)e] : 0.0; }
     if (b_pose) for (size_t p = 0; p < N; ++p) for (int c = 0; c < 3; ++c) b_pose[3 * p + c] = t4[c * N + p];
     if (b_lm) for (size_t l = 0; l < M; ++l) for (int c = 0; c < 2; ++c) b_lm[2 * l + c] = t5[c * M + l];
     if (pp_order) std::memcpy(pp_order, g->plan.pp_order.data(), g->plan.pp_order.size() * sizeof(int32_t));

@@ -33,6 +33,7 @@ struct DevGraph {
     int32_t *pose_gidx = nullptr, *lm_gidx = nullptr;          // first scalar in elimination order, -1 fixed
     // observation edges, ELL
     int32_t ell_T = 1, ell_R = 1; int64_t ell_len = 0;
+    int32_t ell_p0 = 0, ell_np = 0;                             // the layout covers poses [ell_p0, ell_p0 + ell_np): all (single GPU) or the ones this rank sweeps; plane stride T * ell_np
     int32_t *ell_l = nullptr; double *ell_z = nullptr, *ell_w = nullptr;
     // odometry edges; the measurement is stored inverted (g2o keeps _inverseMeasurement) with its cos/sin
     double *pp_zinv = nullptr, *pp_info = nullptr;              // zinv [E][5], info [E][6]

@@ -61,6 +61,7 @@ struct Front {
     int32_t piv0 = 0;               // first pivot's index in the elimination order (pivots contiguous)
     int32_t parent = -1, level = 0;
     int32_t owner = 0;              // rank that factorises it (multi-GPU); -1 = shared top of the tree
+    int32_t opaque = 0;             // pose-window shards: a whole subtree of ANOTHER rank, kept as one supernode (vertices + boundary only: no records, no storage)
     int64_t bnd_off = 0;            // into Plan::bnd_rows  (elimination indices of boundary rows, ascending)
     int64_t map_off = 0;            // into Plan::child_map (this front's boundary rows -> rows of parent's front)
     int64_t L_off = 0;              // doubles: (f+1) x npiv column-major, ld = f+1 (last row = forward-solved rhs)
@@ -83,12 +84,14 @@ struct Plan {
     // CSR: pose -> incident pp edges (sorted position * 2 + role; role 0 = i endpoint)
     std::vector<int32_t> ppadj_start, ppadj;
     // ELL layout of the observation edges on the device: T lanes per pose, R slots per lane
-    int32_t ell_T = 1, ell_R = 1; int64_t ell_len = 0;
+    int32_t ell_T = 1, ell_R = 1; int64_t ell_len = 0;   // ell_len = R * T * ell_np + 1 (the last entry: a permanent empty slot)
+    int32_t ell_p0 = 0, ell_np = 0;                       // the poses the layout covers: [ell_p0, ell_p0 + ell_np) — all of them (world 1) or the ones this rank sweeps
     std::vector<int32_t> ell_ins;                         // [ell_len] ELL index -> insertion index (-1 = empty slot)
-    std::vector<int32_t> ell_of_ins;                      // insertion index -> ELL index
+    std::vector<int32_t> ell_of_ins;                      // insertion index -> ELL index (-1: the edge's pose is outside the layout)
     std::vector<int32_t> ppinc;                           // [Q][4] edge, role, i, j per (pose, odometry edge) incidence
     // wave tiles of the fused A5-A7 kernel (valid when lin_ell_ok): one wave = 64/T consecutive poses
     bool lin_ell_ok = false; int32_t n_wtiles = 0;
+    int32_t wt_lo = 0, wt_hi = 0;                         // the wave tiles this rank sweeps (world 1: all)
     std::vector<int32_t> wt_grp_start;                    // [WT+1] landmark groups of a wave tile
     std::vector<int32_t> wt_desc;                         // [WT][4] first group, #groups, first position, #positions
     std::vector<int32_t> grp_lm, grp_pos_start, grp_pos;  // group -> landmark, wave-local positions (slot*64 + lane)

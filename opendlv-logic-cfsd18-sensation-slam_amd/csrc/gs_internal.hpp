@@ -22,7 +22,7 @@ struct gs_graph {
     uint64_t plan_version = ~0ull;          // h.structure_version the plan was built for
     gs::DevGraph d;
     std::vector<void *> allocs;             // every device allocation of this handle (chunks the plan's arrays are carved from)
-    char *pool_base = nullptr; size_t pool_size = 0, pool_off = 0, pool_next = 0;
+    char *pool_base = nullptr; size_t pool_size = 0, pool_off = 0, pool_next = 0, pool_total = 0;
     bool dev_valid = false;                 // device mirrors the host graph + plan
     bool dev_estimates_newer = false;       // estimates in HBM are ahead of the host copy
     uint64_t dev_estimate_version = 0;

@@ -351,9 +351,10 @@ __global__ void __launch_bounds__(256) k_linearize_pose_gather(DevGraph d) {
         double s, c; sincos(d.pose_est[3 * p + 2], &s, &c);
         const bool fp = d.pose_fixed[p];
         double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-        const int64_t L = d.ell_len, S = (int64_t)d.ell_T * d.N;
-        for (int sl = 0; sl < d.ell_R * d.ell_T; ++sl) {
-            const int64_t e = (int64_t)(sl / d.ell_T) * S + (int64_t)d.ell_T * p + (sl % d.ell_T);
+        const int64_t L = d.ell_len, S = (int64_t)d.ell_T * d.ell_np;
+        const bool laid_out = p >= d.ell_p0 && p < d.ell_p0 + d.ell_np;      // pose-window shards: the layout covers the poses this rank sweeps
+        for (int sl = 0; laid_out && sl < d.ell_R * d.ell_T; ++sl) {
+            const int64_t e = (int64_t)(sl / d.ell_T) * S + (int64_t)d.ell_T * (p - d.ell_p0) + (sl % d.ell_T);
             const int l = d.ell_l[e];
             if (l < 0) continue;
             PlQuad q;
@@ -389,10 +390,10 @@ __global__ void __launch_bounds__(256) k_linearize_lm_gather(DevGraph d) {
     double h00 = 0, h01 = 0, h11 = 0, b0 = 0, b1 = 0;
     if (!d.lm_fixed[l]) {
         const double lx = d.lm_est[2 * l], ly = d.lm_est[2 * l + 1];
-        const int64_t L = d.ell_len, S = (int64_t)d.ell_T * d.N;
+        const int64_t L = d.ell_len, S = (int64_t)d.ell_T * d.ell_np;
         for (int q = d.lm_start[l]; q < d.lm_start[l + 1]; ++q) {
             const int64_t e = d.lm_edges[q];
-            const int p = (int)((e % S) / d.ell_T);
+            const int p = d.ell_p0 + (int)((e % S) / d.ell_T);
             double s, c; sincos(d.pose_est[3 * p + 2], &s, &c);
             PlQuad r;
             quad_pl(d.pose_est[3 * p], d.pose_est[3 * p + 1], c, s, lx, ly, d.ell_z[e], d.ell_z[L + e],
@@ -490,11 +491,11 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
     LTS(0);
     const int p = wt * PW + lane / T, h = lane % T;
     const bool live = p < d.N;
-    const int64_t L = d.ell_len, S = (int64_t)T * d.N;
+    const int64_t L = d.ell_len, S = (int64_t)T * d.ell_np;         // the layout starts at pose ell_p0 = wt_lo * PW (pose-window shards: the swept tiles only)
     const int R = d.ell_R;
     // ---- first round trip: pose state, incidence range, tile descriptor AND the streams of slots 0-1 — none of these
     // addresses depends on a loaded value, so everything is issued before the first wait
-    const uint32_t off8 = (uint32_t)(T * p + h) * 8u;             // byte offset of this lane's edge inside one ELL slot plane (< 4 GiB: host-checked)
+    const uint32_t off8 = (uint32_t)(T * (p - d.ell_p0) + h) * 8u;   // byte offset of this lane's edge inside one ELL slot plane (< 4 GiB: host-checked)
     const uint32_t plane8 = (uint32_t)S * 8u;
     struct Slots { int l[2]; uint32_t dst[2]; double zx[2], zy[2], w00[2], w01[2], w11[2]; };
     auto load_slots = [&](int c, Slots &e) {

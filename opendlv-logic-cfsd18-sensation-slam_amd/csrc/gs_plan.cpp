@@ -50,7 +50,9 @@ struct Builder {
     // ND helpers
     std::vector<int32_t> cone_obs_start, cone_obs;   // per free landmark: sorted free-pose positions
     std::vector<uint8_t> assigned;
+    std::vector<uint8_t> opaque_pose;                // pose-window shards: the pose belongs to an opaque supernode (a whole subtree of another rank)
     std::vector<std::vector<int32_t>> sn;            // supernodes (vertex lists) in elimination order
+    int window(int fpos) const { return (int)((int64_t)fpos * std::max(1, opt.world) / std::max(1, nfp)); }
 
     explicit Builder(const HostGraph &gg, const PlanOptions &o) : g(gg), opt(o) {}
 
@@ -67,10 +69,7 @@ struct Builder {
     // and observation edges, landmark -> its edges): every vertex fills its own range, so the build runs on all host
     // threads.  Order inside a vertex: odometry edges (insertion order), then observation edges (insertion order for a
     // pose, pose order for a landmark).
-    void build_adjacency(const Plan &P) {
-        const int N = g.n_poses(); const int T = P.ell_T; const int64_t SN = (int64_t)T * N;
-        int tsh = 0; while ((1 << tsh) < T) ++tsh;                   // T is 1, 2, 4 or 8
-        auto pose_of_ell = [&](int64_t e) { while (e >= SN) e -= SN; return (int)(e >> tsh); };      // slot plane = at most R - 1 subtractions
+    void build_adjacency(const Plan &P, const std::vector<int32_t> &lm_k) {
         inc_start.assign(nv + 1, 0);
         parallel_chunks(nv, 4096, [&](int64_t b0, int64_t e0, int) {
             for (int v = (int)b0; v < (int)e0; ++v) { int n = 0;
@@ -79,13 +78,15 @@ struct Builder {
                         n += fp_of_pose[(code & 1) ? g.pp_i[k] : g.pp_j[k]] >= 0; }
                     for (int s = P.pl_start[p]; s < P.pl_start[p + 1]; ++s) n += fl_of_lm[g.pl_l[P.pl_order[s]]] >= 0;
                 } else { const int l = lm_of_fl[v - nfp];
-                    for (int q = P.lm_start[l]; q < P.lm_start[l + 1]; ++q) n += fp_of_pose[pose_of_ell(P.lm_edges[q])] >= 0; }
+                    for (int q = P.lm_start[l]; q < P.lm_start[l + 1]; ++q) n += fp_of_pose[g.pl_p[lm_k[q]]] >= 0; }
                 inc_start[v + 1] = n; } });
         for (int v = 0; v < nv; ++v) inc_start[v + 1] += inc_start[v];
         inc_store.reset(new Inc[(size_t)inc_start[nv] + 1]); inc = inc_store.get();
         cone_obs_start.assign(nfl + 1, 0);
         for (int l = 0; l < nfl; ++l) cone_obs_start[l + 1] = cone_obs_start[l] + (inc_start[nfp + l + 1] - inc_start[nfp + l]);
         cone_obs.resize(cone_obs_start[nfl]);
+        // an observation edge is named by its INSERTION index here (epos); the assembly records are translated to the device
+        // layout once it exists
         parallel_chunks(nv, 4096, [&](int64_t b0, int64_t e0, int) {
             for (int v = (int)b0; v < (int)e0; ++v) { Inc *o = &inc[inc_start[v]];
                 if (v < nfp) { const int p = pose_of_fp[v];
@@ -93,10 +94,10 @@ struct Builder {
                         const int other = fp_of_pose[role ? g.pp_i[k] : g.pp_j[k]];
                         if (other >= 0) *o++ = {other, k, role}; }
                     for (int s = P.pl_start[p]; s < P.pl_start[p + 1]; ++s) { const int k = P.pl_order[s], fl = fl_of_lm[g.pl_l[k]];
-                        if (fl >= 0) *o++ = {nfp + fl, P.ell_of_ins[k], 2}; }
+                        if (fl >= 0) *o++ = {nfp + fl, k, 2}; }
                 } else { const int lf = v - nfp, l = lm_of_fl[lf]; int32_t *co = &cone_obs[cone_obs_start[lf]];
-                    for (int q = P.lm_start[l]; q < P.lm_start[l + 1]; ++q) { const int e = P.lm_edges[q]; const int fp = fp_of_pose[pose_of_ell(e)];
-                        if (fp >= 0) { *o++ = {fp, e, 3}; *co++ = fp; } }
+                    for (int q = P.lm_start[l]; q < P.lm_start[l + 1]; ++q) { const int k = lm_k[q]; const int fp = fp_of_pose[g.pl_p[k]];
+                        if (fp >= 0) { *o++ = {fp, k, 3}; *co++ = fp; } }
                     std::sort(&cone_obs[cone_obs_start[lf]], co); }      // landmark observer lists (free-pose positions, ascending)
             } });
     }
@@ -179,6 +180,19 @@ struct Builder {
     void nd(int a, int b, std::vector<int32_t> &cones, SnList &out, int depth) {
         int un = 0;
         for (int i = a; i < b; ++i) un += !assigned[i];
+        // pose-window shards: a range that lies in ONE window of ANOTHER rank is that rank's business — here it stays one opaque
+        // supernode (its poses + the cones alive in it): the symbolic factorisation gives it the boundary the owner's whole
+        // subtree has (the rows of the shared fronts above are the same on every rank), nothing below it is planned, stored or
+        // uploaded on this rank.  A rank plans its own window and the shared top: 1 / world of the dissection.
+        if (opt.world > 1 && un > 0) {
+            int first = -1, last = -1;
+            for (int i = a; i < b; ++i) if (!assigned[i]) { if (first < 0) first = i; last = i; }
+            if (window(first) == window(last) && window(first) != opt.rank) {
+                std::vector<int32_t> verts; verts.reserve((size_t)un + 2 * cones.size());
+                for (int i = a; i < b; ++i) if (!assigned[i]) { verts.push_back(i); assigned[i] = 1; opaque_pose[i] = 1; }
+                for (int l : cones) verts.push_back(nfp + l);
+                emit(out, std::move(verts));
+                return; } }
         if (un <= opt.leaf_poses) {
             std::vector<int32_t> verts;
             for (int i = a; i < b; ++i) if (!assigned[i]) { verts.push_back(i); assigned[i] = 1; }
@@ -238,49 +252,23 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     const int N = g.n_poses(), M = g.n_lms(), Epl = g.n_pl(), Epp = g.n_pp();
 
     GS_PT(0);
-    // ---- device layout of the observation edges: ELL, T lanes per pose -------------------------------
-    // pl_start/pl_order: edges grouped by pose (stable) on the host.  On the device the s-th edge of pose p
-    // sits at  idx = (s / T) * (T*N) + T*p + (s % T):  the T lanes of a pose each own up to R = ceil(Kmax/T)
-    // edges (slots i = 0..R-1), consecutive lanes read consecutive addresses in every slot, and the loads of
-    // all R slots of a thread are independent (memory-level parallelism instead of occupancy).  T is the
-    // smallest power of two with R <= 4; graphs with a pose of more than 32 observations use T = 8 and a
-    // larger R, which only the gather kernels handle.
+    // ---- edges grouped by pose and by landmark (insertion indices; the device layout of the observation edges follows the shard
+    // assignment further down: a rank lays out the poses it sweeps only)
     plan.pl_start.assign(N + 1, 0);
     for (int k = 0; k < Epl; ++k) plan.pl_start[g.pl_p[k] + 1]++;
     for (int p = 0; p < N; ++p) plan.pl_start[p + 1] += plan.pl_start[p];
     plan.pl_order.resize(Epl);
-    std::vector<int32_t> pl_pos_of_ins(Epl);
     { std::vector<int32_t> fill(plan.pl_start.begin(), plan.pl_start.end() - 1);
-      for (int k = 0; k < Epl; ++k) { int pos = fill[g.pl_p[k]]++; plan.pl_order[pos] = k; pl_pos_of_ins[k] = pos; } }
+      for (int k = 0; k < Epl; ++k) plan.pl_order[fill[g.pl_p[k]]++] = k; }
     plan.pp_order.resize(Epp);
     for (int k = 0; k < Epp; ++k) plan.pp_order[k] = k;
-    int kmax = 0;
-    for (int p = 0; p < N; ++p) kmax = std::max(kmax, plan.pl_start[p + 1] - plan.pl_start[p]);
-    int T = 1;
-    while (T < 8 && (kmax + T - 1) / T > LIN_R) T *= 2;
-    // fewer, fatter lanes give more loads in flight per wave, but the chip wants >= ~3 waves per SIMD
-    // (1024 SIMDs): small graphs take more lanes per pose (measured on MI355X: 100k poses T=2 30 us vs T=4 40 us;
-    // 10k poses T=2 13.6 us vs T=4 8.5 us)
-    while (T < 8 && (int64_t)N * T / 64 < 3072) T *= 2;
-    if (opt.ell_lanes == 1 || opt.ell_lanes == 2 || opt.ell_lanes == 4 || opt.ell_lanes == 8) T = opt.ell_lanes;   // tuning override (too few lanes => gather kernels)
-    const int R = std::max(1, (kmax + T - 1) / T);
-    plan.ell_T = T; plan.ell_R = R; plan.ell_len = (int64_t)R * T * N;
-    plan.lin_ell_ok = R <= LIN_R;
-    plan.ell_ins.assign((size_t)plan.ell_len, -1);
-    plan.ell_of_ins.resize(Epl);
-    for (int p = 0; p < N; ++p)
-        for (int s = 0; s < plan.pl_start[p + 1] - plan.pl_start[p]; ++s) {
-            const int64_t idx = (int64_t)(s / T) * ((int64_t)T * N) + (int64_t)T * p + (s % T);
-            const int k = plan.pl_order[plan.pl_start[p] + s];
-            plan.ell_ins[(size_t)idx] = k; plan.ell_of_ins[k] = (int32_t)idx;
-        }
-    // landmark -> ELL indices of its edges (pose order)
+    // landmark -> its edges (insertion indices, pose order); turned into ELL indices at the end (lm_edges, single GPU only)
     plan.lm_start.assign(M + 1, 0);
     for (int k = 0; k < Epl; ++k) plan.lm_start[g.pl_l[k] + 1]++;
     for (int l = 0; l < M; ++l) plan.lm_start[l + 1] += plan.lm_start[l];
-    plan.lm_edges.resize(Epl);
+    std::vector<int32_t> lm_k(Epl);
     { std::vector<int32_t> fill(plan.lm_start.begin(), plan.lm_start.end() - 1);
-      for (int pos = 0; pos < Epl; ++pos) { int k = plan.pl_order[pos]; plan.lm_edges[fill[g.pl_l[k]]++] = plan.ell_of_ins[k]; } }
+      for (int pos = 0; pos < Epl; ++pos) { const int k = plan.pl_order[pos]; lm_k[fill[g.pl_l[k]]++] = k; } }
     // pose -> incident pp edges, and the flattened incidence records {edge, role, i, j}
     plan.ppadj_start.assign(N + 1, 0);
     for (int k = 0; k < Epp; ++k) { plan.ppadj_start[g.pp_i[k] + 1]++; plan.ppadj_start[g.pp_j[k] + 1]++; }
@@ -293,66 +281,11 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         plan.ppinc[4 * q] = k; plan.ppinc[4 * q + 1] = code & 1; plan.ppinc[4 * q + 2] = g.pp_i[k]; plan.ppinc[4 * q + 3] = g.pp_j[k]; }
 
     GS_PT(1);
-    // ---- wave tiles of the fused A5-A7 kernel: one wave = 64/T consecutive poses.  Per wave tile the distinct
-    // landmarks it touches ("groups") with the wave-local positions (slot*64 + lane) of their edges.  Partial-sum
-    // slots are ordered by (landmark, wave tile): the finalize pass reads one contiguous run per landmark and the
-    // summation order is fixed => bitwise reproducible without atomics.
-    if (plan.lin_ell_ok) {
-        const int PW = 64 / T, WT = (N + PW - 1) / PW;
-        plan.n_wtiles = WT;
-        plan.wt_grp_start.assign(WT + 1, 0);
-        plan.ell_dst.assign((size_t)plan.ell_len, (uint16_t)0xFFFF);
-        // every wave tile is independent: chunks of tiles on the host threads, each into its own lists, stitched afterwards
-        const int C = chunk_count(WT, 256);
-        struct TileOut { std::vector<int32_t> grp_lm, grp_pos_start, grp_pos, tile_groups; };
-        std::vector<TileOut> outs(C);
-        std::vector<int64_t> cb(C + 1, 0);
-        for (int c = 0; c <= C; ++c) cb[c] = (int64_t)WT * c / C;
-        parallel_chunks(C, 1, [&](int64_t c0, int64_t c1, int) {
-            for (int c = (int)c0; c < (int)c1; ++c) { TileOut &O = outs[c];
-                std::vector<std::pair<int32_t, int32_t>> tmp;          // (landmark, local position)
-                for (int w = (int)cb[c]; w < (int)cb[c + 1]; ++w) {
-                    tmp.clear();
-                    for (int lane = 0; lane < 64; ++lane) { const int p = w * PW + lane / T, h = lane % T;
-                        if (p >= N) break;
-                        for (int i = 0; i < R; ++i) { const int s2 = i * T + h;
-                            if (s2 < plan.pl_start[p + 1] - plan.pl_start[p]) tmp.emplace_back(g.pl_l[plan.pl_order[plan.pl_start[p] + s2]], i * 64 + lane); } }
-                    std::sort(tmp.begin(), tmp.end());
-                    int ng = 0;
-                    for (size_t i = 0; i < tmp.size(); ++i) {
-                        if (i == 0 || tmp[i].first != tmp[i - 1].first) { O.grp_lm.push_back(tmp[i].first); O.grp_pos_start.push_back((int32_t)O.grp_pos.size()); ++ng; }
-                        O.grp_pos.push_back(tmp[i].second);
-                        plan.ell_dst[(size_t)((int64_t)(tmp[i].second >> 6) * ((int64_t)T * N) + (int64_t)w * 64 + (tmp[i].second & 63))] = (uint16_t)i;
-                    }
-                    O.tile_groups.push_back(ng);
-                } } });
-        { size_t ng = 0, np2 = 0; for (auto &O : outs) { ng += O.grp_lm.size(); np2 += O.grp_pos.size(); }
-          plan.grp_lm.reserve(ng); plan.grp_pos_start.reserve(ng + 1); plan.grp_pos.reserve(np2);
-          int w = 0;
-          for (auto &O : outs) { const int32_t pos0 = (int32_t)plan.grp_pos.size();
-              plan.grp_lm.insert(plan.grp_lm.end(), O.grp_lm.begin(), O.grp_lm.end());
-              for (int32_t v : O.grp_pos_start) plan.grp_pos_start.push_back(pos0 + v);
-              plan.grp_pos.insert(plan.grp_pos.end(), O.grp_pos.begin(), O.grp_pos.end());
-              for (int n : O.tile_groups) { plan.wt_grp_start[w + 1] = plan.wt_grp_start[w] + n; ++w; } } }
-        plan.grp_pos_start.push_back((int32_t)plan.grp_pos.size());
-        plan.wt_desc.resize((size_t)WT * 4);
-        for (int w = 0; w < WT; ++w) { const int a = plan.wt_grp_start[w], b = plan.wt_grp_start[w + 1];
-            plan.wt_desc[4 * (size_t)w] = a; plan.wt_desc[4 * (size_t)w + 1] = b - a;
-            plan.wt_desc[4 * (size_t)w + 2] = plan.grp_pos_start[a]; plan.wt_desc[4 * (size_t)w + 3] = plan.grp_pos_start[b] - plan.grp_pos_start[a]; }
-        const int G = (int)plan.grp_lm.size();
-        plan.lm_grp_start.assign(M + 1, 0);
-        for (int q = 0; q < G; ++q) plan.lm_grp_start[plan.grp_lm[q] + 1]++;
-        for (int l = 0; l < M; ++l) plan.lm_grp_start[l + 1] += plan.lm_grp_start[l];
-        plan.grp_slot.resize(G);
-        std::vector<int32_t> fill(plan.lm_grp_start.begin(), plan.lm_grp_start.end() - 1);
-        for (int q = 0; q < G; ++q) plan.grp_slot[q] = fill[plan.grp_lm[q]]++;
-    }
-
     GS_PT(2);
     // ---- elimination order by nested dissection ----
-    B.build_adjacency(plan);
+    B.build_adjacency(plan, lm_k);
     GS_PT(21);
-    B.assigned.assign(B.nfp, 0);
+    B.assigned.assign(B.nfp, 0); B.opaque_pose.assign(B.nfp, 0);
     { std::vector<int32_t> all(B.nfl); for (int l = 0; l < B.nfl; ++l) all[l] = l; B.nd(0, B.nfp, all, B.sn, 0); }
     const int S = (int)B.sn.size();
     std::vector<int32_t> sn_of(B.nv, -1), vpos(B.nv, -1), gidx(B.nv, -1);
@@ -395,8 +328,9 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
             F.parent = parent[s]; F.piv0 = gidx[B.sn[s][0]];
             for (int v : B.sn[s]) F.npiv += B.dim(v);
             for (int w : bndv[s]) F.nbnd += B.dim(w);
+            F.opaque = (B.sn[s][0] < B.nfp && B.opaque_pose[B.sn[s][0]]) ? 1 : 0;     // (an opaque supernode lists its poses first)
             int n = 0;
-            for (int v : B.sn[s]) { ++n;
+            if (!F.opaque) for (int v : B.sn[s]) { ++n;
                 for (int q = B.inc_start[v]; q < B.inc_start[v + 1]; ++q) n += vpos[B.inc[q].other] > vpos[v]; }     // the earlier endpoint owns the block
             asm_n[s] = n;
         } });
@@ -409,10 +343,12 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
           for (int c : kids[s]) F.level = std::max(F.level, plan.fronts[c].level + 1);
           F.child_off = (int32_t)plan.children.size(); F.child_cnt = (int32_t)kids[s].size();
           for (int c : kids[s]) plan.children.push_back(c);
-          plan.max_front = std::max(plan.max_front, F.npiv + F.nbnd);
           F.asm_off = (int32_t)na; F.asm_cnt = asm_n[s]; na += asm_n[s];
-          F.L_off = plan.l_doubles; plan.l_doubles += (int64_t)(F.npiv + F.nbnd + 1) * F.npiv;
-          F.U_off = plan.u_doubles; plan.u_doubles += (int64_t)(F.nbnd + 1) * F.nbnd;
+          F.L_off = plan.l_doubles; F.U_off = plan.u_doubles;
+          if (F.opaque) continue;                                     // another rank's subtree: no factor, no update matrix, no share in the sizes
+          plan.max_front = std::max(plan.max_front, F.npiv + F.nbnd);
+          plan.l_doubles += (int64_t)(F.npiv + F.nbnd + 1) * F.npiv;
+          plan.u_doubles += (int64_t)(F.nbnd + 1) * F.nbnd;
           for (int k = 0; k < F.npiv; ++k) { int64_t r2 = F.npiv + F.nbnd + 1 - k; plan.factor_flops += r2 * r2; }
       }
       if (na >= ((int64_t)1 << 31)) { err = "too many assembly records"; return false; }
@@ -432,7 +368,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
                 for (int w : bndv[c]) for (int t = 0; t < B.dim(w); ++t) *o++ = loc[w] + t; }
             // original entries
             recs.clear();
-            for (int v : B.sn[s]) {
+            if (!F.opaque) for (int v : B.sn[s]) {
                 if (v < B.nfp) recs.push_back({ASM_POSE_DIAG, B.pose_of_fp[v], loc[v], loc[v]});
                 else recs.push_back({ASM_LM_DIAG, B.lm_of_fl[v - B.nfp], loc[v], loc[v]});
                 for (int q = B.inc_start[v]; q < B.inc_start[v + 1]; ++q) { const auto &e = B.inc[q];
@@ -530,11 +466,123 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
             plan.level_start_shared[l + 1] = (int32_t)plan.level_fronts_shared.size();
         }
         plan.n_shared_fronts = (int32_t)plan.level_fronts_shared.size();
+        // exchange slots in ELIMINATION order of the shared fronts: the one order every rank agrees on (levels differ between
+        // ranks — a rank sees the other ranks' subtrees as single supernodes)
         plan.x_off.assign(S, -1);
-        for (int s : plan.level_fronts_shared) { const Front &F = plan.fronts[s]; const int64_t f = F.npiv + F.nbnd;
+        for (int s = 0; s < S; ++s) if (plan.fronts[s].owner < 0) { const Front &F = plan.fronts[s]; const int64_t f = F.npiv + F.nbnd;
             plan.x_off[s] = plan.exchange_doubles; plan.exchange_doubles += (f + 1) * f; }
         plan.exchange_doubles += 2;                // tail: [0] the ranks' failure flags (summed by the same all-reduce), [1] spare
     }
+    // ---- wave tiles of the fused A5-A7 kernel: one wave = 64/T consecutive poses.  Per wave tile the distinct
+    // landmarks it touches ("groups") with the wave-local positions (slot*64 + lane) of their edges.  Partial-sum
+    // slots are ordered by (landmark, wave tile): the finalize pass reads one contiguous run per landmark and the
+    // summation order is fixed => bitwise reproducible without atomics.
+    // ---- device layout of the observation edges: ELL, T lanes per pose, over the poses THIS RANK SWEEPS ------------------
+    // (after the shard assignment: a rank lays out, uploads and linearises the pose range [ell_p0, ell_p0 + ell_np) that holds its
+    // edges — its window plus the boundary poses of the shared top — and nothing of the other windows: 1 / world of the edge
+    // streams, of the H_pl blocks and of this phase.  World 1: every pose.)
+    // The s-th edge of pose p sits at  idx = (s / T) * (T * np) + T * (p - p0) + (s % T):  the T lanes of a pose each own up to
+    // R = ceil(Kmax / T) edges (slots i = 0 .. R-1), consecutive lanes read consecutive addresses in every slot, and the loads of
+    // all R slots of a thread are independent (memory-level parallelism instead of occupancy).  T is the smallest power of two
+    // with R <= 4; graphs with a pose of more than 32 observations use T = 8 and a larger R, which only the gather kernels
+    // handle.  The LAST entry of the layout is a permanent empty slot: the assembly record of an edge another rank evaluates
+    // points there (its block reads as zero).
+    int plo = 0, phi = N;
+    if (plan.world > 1) { plo = N; phi = 0;
+        for (int p = 0; p < N; ++p) { bool any = false;
+            for (int s2 = plan.pl_start[p]; s2 < plan.pl_start[p + 1] && !any; ++s2) any = plan.pl_rank[plan.pl_order[s2]] == plan.rank;
+            for (int q = plan.ppadj_start[p]; q < plan.ppadj_start[p + 1] && !any; ++q) any = plan.pp_rank[plan.ppadj[q] >> 1] == plan.rank;
+            if (any) { plo = std::min(plo, p); phi = std::max(phi, p + 1); } }
+        if (phi <= plo) { plo = 0; phi = 0; } }
+    int kmax = 0;
+    for (int p = 0; p < N; ++p) kmax = std::max(kmax, plan.pl_start[p + 1] - plan.pl_start[p]);
+    int T = 1;
+    while (T < 8 && (kmax + T - 1) / T > LIN_R) T *= 2;
+    // fewer, fatter lanes give more loads in flight per wave, but the chip wants >= ~3 waves per SIMD
+    // (1024 SIMDs): small graphs take more lanes per pose (measured on MI355X: 100k poses T=2 30 us vs T=4 40 us;
+    // 10k poses T=2 13.6 us vs T=4 8.5 us)
+    while (T < 8 && (int64_t)std::max(phi - plo, 1) * T / 64 < 3072) T *= 2;
+    if (opt.ell_lanes == 1 || opt.ell_lanes == 2 || opt.ell_lanes == 4 || opt.ell_lanes == 8) T = opt.ell_lanes;   // tuning override (too few lanes => gather kernels)
+    const int R = std::max(1, (kmax + T - 1) / T);
+    const int PW = 64 / T, WT = (N + PW - 1) / PW;
+    plan.wt_lo = plo / PW; plan.wt_hi = (phi + PW - 1) / PW;        // whole wave tiles
+    const int p0 = plan.wt_lo * PW, p1 = std::min(N, plan.wt_hi * PW), np_ = std::max(p1 - p0, 0);
+    plan.ell_T = T; plan.ell_R = R; plan.ell_p0 = p0; plan.ell_np = np_;
+    plan.ell_len = (int64_t)R * T * np_ + 1;
+    plan.lin_ell_ok = R <= LIN_R;
+    plan.ell_ins.assign((size_t)plan.ell_len, -1);
+    plan.ell_of_ins.assign(Epl, -1);
+    parallel_chunks(np_, 8192, [&](int64_t b0, int64_t e0, int) {
+        for (int p = p0 + (int)b0; p < p0 + (int)e0; ++p)
+            for (int s2 = 0; s2 < plan.pl_start[p + 1] - plan.pl_start[p]; ++s2) {
+                const int64_t idx = (int64_t)(s2 / T) * ((int64_t)T * np_) + (int64_t)T * (p - p0) + (s2 % T);
+                const int k = plan.pl_order[plan.pl_start[p] + s2];
+                plan.ell_ins[(size_t)idx] = k; plan.ell_of_ins[k] = (int32_t)idx; } });
+    // the assembly records named observation edges by insertion index so far
+    { const int32_t zero_slot = (int32_t)(plan.ell_len - 1);
+      parallel_chunks((int64_t)plan.asm_recs.size(), 65536, [&](int64_t b0, int64_t e0, int) {
+          for (int64_t t = b0; t < e0; ++t) { AsmRec &r = plan.asm_recs[(size_t)t];
+              if (r.kind == ASM_PL || r.kind == ASM_PL_T) { const int32_t e = plan.ell_of_ins[r.src]; r.src = e >= 0 ? e : zero_slot; } } }); }
+    // landmark -> ELL indices of its edges (the gather kernels: single GPU only)
+    plan.lm_edges.clear();
+    if (plan.world == 1) { plan.lm_edges.resize(Epl);
+        parallel_chunks(Epl, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t q = b0; q < e0; ++q) plan.lm_edges[(size_t)q] = plan.ell_of_ins[lm_k[(size_t)q]]; }); }
+    else plan.lm_edges.assign(1, 0);
+    // ---- wave tiles of the fused A5-A7 kernel: one wave = 64/T consecutive poses.  Per wave tile the distinct
+    // landmarks it touches ("groups") with the wave-local positions (slot*64 + lane) of their edges.  Partial-sum
+    // slots are ordered by (landmark, wave tile): the finalize pass reads one contiguous run per landmark and the
+    // summation order is fixed => bitwise reproducible without atomics.  Only the tiles [wt_lo, wt_hi) have groups.
+    if (plan.lin_ell_ok) {
+        plan.n_wtiles = WT;
+        plan.wt_grp_start.assign(WT + 1, 0);
+        plan.ell_dst.assign((size_t)plan.ell_len, (uint16_t)0xFFFF);
+        // every wave tile is independent: chunks of tiles on the host threads, each into its own lists, stitched afterwards
+        const int C = chunk_count(std::max(1, plan.wt_hi - plan.wt_lo), 256);
+        struct TileOut { std::vector<int32_t> grp_lm, grp_pos_start, grp_pos, tile_groups; };
+        std::vector<TileOut> outs(C);
+        std::vector<int64_t> cb(C + 1, 0);
+        for (int c = 0; c <= C; ++c) cb[c] = plan.wt_lo + (int64_t)(plan.wt_hi - plan.wt_lo) * c / C;
+        parallel_chunks(C, 1, [&](int64_t c0, int64_t c1, int) {
+            for (int c = (int)c0; c < (int)c1; ++c) { TileOut &O = outs[c];
+                std::vector<std::pair<int32_t, int32_t>> tmp;          // (landmark, local position)
+                for (int w = (int)cb[c]; w < (int)cb[c + 1]; ++w) {
+                    tmp.clear();
+                    for (int lane = 0; lane < 64; ++lane) { const int p = w * PW + lane / T, h = lane % T;
+                        if (p >= N) break;
+                        for (int i = 0; i < R; ++i) { const int s2 = i * T + h;
+                            if (s2 < plan.pl_start[p + 1] - plan.pl_start[p]) tmp.emplace_back(g.pl_l[plan.pl_order[plan.pl_start[p] + s2]], i * 64 + lane); } }
+                    std::sort(tmp.begin(), tmp.end());
+                    int ng = 0;
+                    for (size_t i = 0; i < tmp.size(); ++i) {
+                        if (i == 0 || tmp[i].first != tmp[i - 1].first) { O.grp_lm.push_back(tmp[i].first); O.grp_pos_start.push_back((int32_t)O.grp_pos.size()); ++ng; }
+                        O.grp_pos.push_back(tmp[i].second);
+                        plan.ell_dst[(size_t)((int64_t)(tmp[i].second >> 6) * ((int64_t)T * np_) + (int64_t)(w - plan.wt_lo) * 64 + (tmp[i].second & 63))] = (uint16_t)i;
+                    }
+                    O.tile_groups.push_back(ng);
+                } } });
+        { size_t ng = 0, np2 = 0; for (auto &O : outs) { ng += O.grp_lm.size(); np2 += O.grp_pos.size(); }
+          plan.grp_lm.reserve(ng); plan.grp_pos_start.reserve(ng + 1); plan.grp_pos.reserve(np2);
+          int w = plan.wt_lo;                                          // tiles below wt_lo have no groups: wt_grp_start stays 0 there
+          for (auto &O : outs) { const int32_t pos0 = (int32_t)plan.grp_pos.size();
+              plan.grp_lm.insert(plan.grp_lm.end(), O.grp_lm.begin(), O.grp_lm.end());
+              for (int32_t v : O.grp_pos_start) plan.grp_pos_start.push_back(pos0 + v);
+              plan.grp_pos.insert(plan.grp_pos.end(), O.grp_pos.begin(), O.grp_pos.end());
+              for (int n : O.tile_groups) { plan.wt_grp_start[w + 1] = plan.wt_grp_start[w] + n; ++w; } }
+          for (; w < WT; ++w) plan.wt_grp_start[w + 1] = plan.wt_grp_start[w]; }
+        plan.grp_pos_start.push_back((int32_t)plan.grp_pos.size());
+        plan.wt_desc.resize((size_t)WT * 4);
+        for (int w = 0; w < WT; ++w) { const int a = plan.wt_grp_start[w], b = plan.wt_grp_start[w + 1];
+            plan.wt_desc[4 * (size_t)w] = a; plan.wt_desc[4 * (size_t)w + 1] = b - a;
+            plan.wt_desc[4 * (size_t)w + 2] = plan.grp_pos_start[a]; plan.wt_desc[4 * (size_t)w + 3] = plan.grp_pos_start[b] - plan.grp_pos_start[a]; }
+        const int G = (int)plan.grp_lm.size();
+        plan.lm_grp_start.assign(M + 1, 0);
+        for (int q = 0; q < G; ++q) plan.lm_grp_start[plan.grp_lm[q] + 1]++;
+        for (int l = 0; l < M; ++l) plan.lm_grp_start[l + 1] += plan.lm_grp_start[l];
+        plan.grp_slot.resize(G);
+        std::vector<int32_t> fill(plan.lm_grp_start.begin(), plan.lm_grp_start.end() - 1);
+        for (int q = 0; q < G; ++q) plan.grp_slot[q] = fill[plan.grp_lm[q]]++;
+    }
+
     plan.valid = true;
     GS_PT(7);
     plan.ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

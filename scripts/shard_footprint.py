@@ -1,0 +1,25 @@
+"""Per-rank structure time and HBM footprint of the pose-window shards: ONE graph of world x cfg4 (the workload of bench.py
+--gpus world) as `world` rank handles on this one GPU, against a single-GPU cfg4 handle.  A rank plans and uploads its own
+window and the shared top; the other ranks' subtrees stay single supernodes in its plan."""
+import importlib, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("opendlv-logic-cfsd18-sensation-slam_amd")
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+name = sys.argv[2] if len(sys.argv) > 2 else "cfg4"
+Nw, Mw = pkg.track.CONFIGS[name]
+def build(N, M, rank=None):
+    t = pkg.track.generate(N, M); fe = pkg.Graph(); g = pkg.track.bench_graph(t, fe); fe.close()
+    G = pkg.Graph(); G.load_bench_graph(g)
+    if rank is not None: G.dist_configure(rank, world)
+    G.initialize_optimization(); G.initialize_optimization()      # second call: warm host threads / page cache, as in a running service
+    st = G.stats(); G.close(); return st
+s1 = build(Nw, Mw)
+print("single GPU %s: structure %.1f ms (plan %.1f), device %.1f MB, fronts %d" % (name, s1.ms_structure, s1.ms_plan_host, s1.device_bytes / 1e6, s1.n_fronts))
+out = {"single": dict(ms_structure=s1.ms_structure, ms_plan_host=s1.ms_plan_host, device_mb=s1.device_bytes / 1e6, fronts=s1.n_fronts), "ranks": []}
+for r in (0, world // 2, world - 1):
+    sr = build(Nw * world, Mw * world, r)
+    print("rank %d of %d on %d x %s: structure %.1f ms (plan %.1f) = %.2fx, device %.1f MB = %.2fx, own fronts %d + shared %d of %d supernodes"
+          % (r, world, world, name, sr.ms_structure, sr.ms_plan_host, sr.ms_structure / s1.ms_structure, sr.device_bytes / 1e6, sr.device_bytes / s1.device_bytes,
+             sr.n_own_fronts, sr.n_shared_fronts, sr.n_fronts))
+    out["ranks"].append(dict(rank=r, ms_structure=sr.ms_structure, ms_plan_host=sr.ms_plan_host, device_mb=sr.device_bytes / 1e6, own=sr.n_own_fronts, shared=sr.n_shared_fronts))
+os.makedirs("gpurun_out", exist_ok=True); json.dump(out, open("gpurun_out/shard_footprint_%dx%s.json" % (world, name), "w"), indent=1)

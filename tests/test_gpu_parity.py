@@ -705,6 +705,7 @@ def test_cfg5_single_handle_properties_and_eight_pose_windows(pkg, po, frontend)
     G.linearize(); sysm = G.export_system()                      # H, b at the initial estimates
     done, st = G.optimize(1)
     assert done == 1 and st.numeric_failure == 0
+    st_single = G.stats()
     dp, dl = G.export_delta()
     r_single = normal_equation_residual(g, sysm, dp, dl)
     assert r_single < 1e-9, r_single
@@ -749,6 +750,14 @@ def test_cfg5_single_handle_properties_and_eight_pose_windows(pkg, po, frontend)
     for r in range(world):
         H = fresh(pkg, g); H.dist_configure(r, world); H.initialize_optimization(); ranks.append(H)
     assert ranks[0].dist_exchange_doubles() > 2
+    # a rank plans and holds ITS window and the shared top: fronts, HBM and structure time ~1/8 of the single handle's
+    for H in ranks:
+        sr = H.stats()
+        assert sr.n_own_fronts + sr.n_shared_fronts < 0.15 * st_single.n_fronts and sr.n_fronts < sr.n_own_fronts + sr.n_shared_fronts + 3 * world
+        assert sr.device_bytes < 0.30 * st_single.device_bytes, (sr.device_bytes, st_single.device_bytes)
+    sr = ranks[world // 2].stats()
+    print("cfg5 as 8 pose windows: rank structure %.0f ms (plan %.0f), %.0f MB of HBM, %d own + %d shared fronts; single handle: %.0f ms (plan %.0f), %.0f MB, %d fronts"
+          % (sr.ms_structure, sr.ms_plan_host, sr.device_bytes / 1e6, sr.n_own_fronts, sr.n_shared_fronts, st_single.ms_structure, st_single.ms_plan_host, st_single.device_bytes / 1e6, st_single.n_fronts))
     def merged(fn, width_p, width_l):
         A = np.zeros((N, width_p)); B = np.zeros((Mg, width_l)); cp = np.zeros(N); cl = np.zeros(Mg); shared = np.ones(N, dtype=bool)
         for H in ranks:

@@ -123,3 +123,28 @@ def test_plan_is_the_same_for_any_number_of_host_threads(pkg):
         assert r.returncode == 0, r.stderr[-1000:]
         digests.add(r.stdout.strip().splitlines()[-1])
     assert len(digests) == 1, digests
+
+
+def test_a_rank_plans_its_own_window_and_the_shared_top_only(pkg, bench_graphs):
+    """Pose-window shards: the other ranks' subtrees stay single (opaque) supernodes in a rank's plan — vertices and boundary,
+    no records, no storage — and the observation edges are laid out for the poses the rank sweeps only.  Fronts, factor
+    storage and edge layout of a rank are ~1 / world of the single-GPU plan; the exchange layout (slots of the shared
+    fronts, in elimination order) is the same on every rank."""
+    _, g = bench_graphs(10000, 2000)
+    G = host_graph(pkg, g); one = G.plan_build_host(); P1 = Plan(G.plan_export()); G.close()
+    world = 8
+    slots = None
+    for r in range(world):
+        G = host_graph(pkg, g); G.dist_configure(r, world); info = G.plan_build_host(); P = Plan(G.plan_export()); G.close()
+        P.check_invariants()
+        own = int((P.owner == r).sum()); shared = int((P.owner < 0).sum()); foreign = int((P.owner >= 0).sum()) - own
+        assert own <= 1.3 * one.n_fronts / world + 8 and shared <= 3 * world and foreign <= 3 * world        # each other window: one or two opaque supernodes
+        assert info.l_doubles <= 1.3 * one.l_doubles / world + 10000 and info.max_front <= 63                  # the opaque ones do not count
+        assert P.ell_len <= 1.3 * P1.ell_len / world + 4096                                                   # edges laid out for the swept poses only
+        mine = (P.pl_rank == r)
+        laid = np.zeros(len(mine), dtype=bool); laid[P.ell_ins[P.ell_ins >= 0]] = True
+        assert np.all(laid[mine])                                                                             # every edge the rank evaluates has a slot
+        sl = [(int(P.npiv[s]), int(P.nbnd[s]), int(P.x_off[s])) for s in range(P.n_fronts) if P.owner[s] < 0]
+        assert slots is None or sl == slots                                                                   # same shared fronts, same slots, on every rank
+        slots = sl
+    assert len(slots) >= world - 1
