@@ -196,7 +196,7 @@ def main():
     if dist_mode:
         if backend != "gloo":
             xbuf = torch.zeros(max(G.dist_exchange_doubles(), 1), dtype=torch.float64, device="cuda")
-            if world > 1:
+            if G.dist_exchange_doubles() > 0:       # (a group of one rank has no shared fronts: nothing to hand over)
                 G.dist_set_exchange_buffer(xbuf.data_ptr())
 
     def step():

@@ -1447,7 +1447,9 @@ __device__ __forceinline__ bool f3_panel_step(bool &bad, v4d (&acc)[NT * (NT + 1
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[j] = Pn[lane * 4 + j];
     f3_panel_pivots(k0, bad, p, dd, npiv, lane);
-    if (lane <= f) {                                                // the panel's columns of L (rows < col are 0, the diagonal is 1), one masked region
+    // the panel's columns of L (the diagonal is 1), one masked region.  Rows above the panel are zero and nobody reads them (the
+    // backward solve uses a column from its diagonal down): not stored — whole 64-byte groups of them, a fifth of a leaf's L bytes
+    if (lane >= (k0 & ~7) && lane <= f) {
         double *Lc = L + (int64_t)k0 * (f + 1) + lane;
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (k0 + j < npiv) F3_ST_L(Lc + (int64_t)j * (f + 1), p[j]);
@@ -1554,7 +1556,7 @@ __device__ __forceinline__ bool f3_block_panel(int B, bool &bad, v4d (&acc)[3], 
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[j] = Pb[lane * 4 + j];
     f3_panel_pivots(k0, bad, p, dd, npiv, lane);
-    if (wave == 0 && lane <= f) {
+    if (wave == 0 && lane >= (k0 & ~7) && lane <= f) {             // (rows above the panel: zero, never read, not stored)
         double *Lc = L + (int64_t)k0 * (f + 1) + lane;
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (k0 + j < npiv) F3_ST_L(Lc + (int64_t)j * (f + 1), p[j]);
@@ -2017,7 +2019,8 @@ __device__ __forceinline__ void bs3_wave_front(const DevGraph &d, int pos, doubl
     for (int c0 = 0; c0 < npiv; c0 += 32) {                          // 32 column loads in flight per lane: one round trip for npiv <= 32
         double t[32];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) t[j] = F3_LD_L(&L[(int64_t)min(c0 + j, npiv - 1) * ldl + lrow]);
+        for (int j = 0; j < 32; ++j) { const int c = min(c0 + j, npiv - 1);      // rows above the diagonal are not stored: those lanes re-read the diagonal's 64-byte group
+            t[j] = F3_LD_L(&L[(int64_t)c * ldl + max(lrow, min(c & ~7, f))]); }
 #pragma unroll
         for (int j = 0; j < 32; ++j) if (c0 + j < npiv && lane <= f) S[(c0 + j) * lds + lane] = t[j];
     }
@@ -2171,7 +2174,7 @@ __device__ __forceinline__ bool f3_big_panel(int B, bool &bad, v4d (&acc)[BigDim
     }
     if (wave == 0) {
 #pragma unroll
-        for (int m = 0; m < D::NR; ++m) if (lane + 64 * m <= f) {
+        for (int m = 0; m < D::NR; ++m) if (lane + 64 * m >= (k0 & ~7) && lane + 64 * m <= f) {      // (rows above the panel: zero, never read, not stored)
             double *Lc = L + (int64_t)k0 * (f + 1) + lane + 64 * m;
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (k0 + j < npiv) F3_ST_L(Lc + (int64_t)j * (f + 1), p[m][j]); }
@@ -2725,30 +2728,41 @@ __global__ void __launch_bounds__(256) k_update(DevGraph d) {
     const int conv_it = d.fail[2];
     const bool stop = d.fail[0] != 0 || peer_failed || (conv_it != 0 && conv_it < d.iter);
     if (t == 0) { if (stop) { if (peer_failed) atomicMax(d.fail, 3); } else atomicAdd(d.fail + 1, 1); }
-    // pose-window shards: a rank only tracks the vertices of its own subtrees and of the shared top
+    // pose-window shards: a rank only tracks the vertices of its own subtrees and of the shared top.
+    // One thread per SCALAR of the estimates (3 N pose scalars, then 2 M landmark scalars): the estimate, the increment record and
+    // the solution vector are read and written as fully coalesced 8-byte streams (a thread per vertex touched them with a 24-byte
+    // stride: 1.0 TB/s at 1M poses); the lane that holds a pose's angle normalises it and refreshes the pose's cos / sin.
     if (stop) { }
-    else if (t < d.N) {
-        int g = d.pose_known[t] ? d.pose_gidx[t] : -1;
-        double dx = 0, dy = 0, dt = 0;
-        if (g >= 0) { dx = d.xe[g]; dy = d.xe[g + 1]; dt = d.xe[g + 2];
-            d.pose_est[3 * t] += dx; d.pose_est[3 * t + 1] += dy;
-            const double th = normalize_theta(d.pose_est[3 * t + 2] + dt);
-            d.pose_est[3 * t + 2] = th;
-            double sn, cs; sincos(th, &sn, &cs); d.pose_cs[2 * t] = cs; d.pose_cs[2 * t + 1] = sn; }
-        d.dpose[3 * t] = dx; d.dpose[3 * t + 1] = dy; d.dpose[3 * t + 2] = dt;
-    } else if (t < d.N + d.M) {
-        int l = t - d.N, g = d.lm_known[l] ? d.lm_gidx[l] : -1;
-        double dx = 0, dy = 0;
-        if (g >= 0) { dx = d.xe[g]; dy = d.xe[g + 1]; d.lm_est[2 * l] += dx; d.lm_est[2 * l + 1] += dy; }
-        d.dlm[2 * l] = dx; d.dlm[2 * l + 1] = dy;
+    else if (t < 3 * d.N) {
+        const int p = t / 3, c = t - 3 * p;
+        const int g = d.pose_known[p] ? d.pose_gidx[p] : -1;
+        double dx = 0.0;
+        if (g >= 0) { dx = d.xe[g + c];
+            double v = d.pose_est[t] + dx;
+            if (c == 2) { v = normalize_theta(v); double sn, cs; sincos(v, &sn, &cs); reinterpret_cast<double2 *>(d.pose_cs)[p] = make_double2(cs, sn); }
+            d.pose_est[t] = v; }
+        d.dpose[t] = dx;
+    } else if (t < 3 * d.N + 2 * d.M) {
+        const int u = t - 3 * d.N, l = u >> 1, c = u & 1;
+        const int g = d.lm_known[l] ? d.lm_gidx[l] : -1;
+        double dx = 0.0;
+        if (g >= 0) { dx = d.xe[g + c]; d.lm_est[u] += dx; }
+        d.dlm[u] = dx;
     }
     // fused linearisation leaves one chi2 partial per wave tile: total them here (fixed order), no extra launch
     if (blockIdx.x == gridDim.x - 1) {
         __shared__ double red[8];
         double tot = 0.0;
         if (d.n_wtiles > 0) {
+            // (sixteen loads in flight per thread, added in the same order as one at a time: a thread's chain of dependent
+            // load -> add was the whole duration of this kernel — 80 us at 1M poses, 7 of its 10 us at 100k)
             double s = 0.0;
-            for (int k = threadIdx.x; k < d.n_wtiles; k += 256) s += d.chi2_partial[k];
+            for (int k0 = threadIdx.x; k0 < d.n_wtiles; k0 += 256 * 16) {
+                double v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { const int k = k0 + 256 * j; v[j] = k < d.n_wtiles ? d.chi2_partial[k] : 0.0; }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) if (k0 + 256 * j < d.n_wtiles) s += v[j]; }
             tot = block_sum(s, red);
             if (threadIdx.x == 0) d.chi2[0] = tot;
         } else if (threadIdx.x == 0) tot = d.chi2[0];              // gather kernels: k_reduce_chi2 totalled it already
@@ -2762,7 +2776,7 @@ __global__ void __launch_bounds__(256) k_update(DevGraph d) {
     }
 }
 void launch_update(const DevGraph &d, hipStream_t st) {
-    int n = d.N + d.M;
+    int n = 3 * d.N + 2 * d.M;
     if (n > 0) hipLaunchKernelGGL(k_update, dim3((n + 255) / 256), dim3(256), 0, st, d);
 }
 
