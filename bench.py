@@ -170,10 +170,20 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        if backend == "gloo":
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # RCCL and gloo print banners ("RCCL version : ...", "[Gloo] Rank 0 is connected ...") on STDOUT when the first communicator
+        # comes up: send them to stderr — stdout carries exactly one line, the JSON record
+        sys.stdout.flush(); saved_stdout = os.dup(1); os.dup2(2, 1)
+        try:
+            if backend == "gloo":
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            w0 = torch.zeros(1, dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
+            dist.all_reduce(w0); dist.barrier()                  # the first collective creates the communicator
+            if backend != "gloo":
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush(); os.dup2(saved_stdout, 1); os.close(saved_stdout)
     pkg = importlib.import_module("opendlv-logic-cfsd18-sensation-slam_amd")
 
     Nw, Mw = pkg.track.CONFIGS[args.workload]     # one pose window = the single-GPU workload

@@ -417,6 +417,14 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
 #define UP(dst, vec) if ((rc = dev_upload(g, &d.dst, vec)) != GS_OK) return rc
     // estimates, fixed flags, odometry edges and the insertion-order observation arrays are in HBM already (RawUpload)
     launch_pose_trig(d, g->stream);
+    // GS_HOST_TRIG=1 (an experiment, scripts/parity_spread.py): the cos / sin of the INITIAL pose angles from the host's libm
+    // instead of the device's — what the CPU oracle linearises with — to tell how much of the first increment's distance
+    // to the CPU paths is the last bit of two transcendental functions
+    if (const char *e = std::getenv("GS_HOST_TRIG")) if (std::atoi(e) != 0 && N > 0) {
+        std::vector<double> cs(2 * (size_t)N);
+        for (int p = 0; p < N; ++p) { cs[2 * (size_t)p] = std::cos(h.pose_est[3 * (size_t)p + 2]); cs[2 * (size_t)p + 1] = std::sin(h.pose_est[3 * (size_t)p + 2]); }
+        HIP_TRY(hipMemcpyAsync(d.pose_cs, cs.data(), cs.size() * sizeof(double), hipMemcpyHostToDevice, g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream)); }
     UP(pose_gidx, P.pose_gidx); UP(lm_gidx, P.lm_gidx);
     d.ell_T = P.ell_T; d.ell_R = P.ell_R; d.ell_len = P.ell_len; d.ell_p0 = P.ell_p0; d.ell_np = P.ell_np;
     { const size_t L = (size_t)P.ell_len;

@@ -181,7 +181,9 @@ void launch_frame_frontend(int k, const double *in, double lidar, int n_map, con
 // EdgeSE2PointXY with the pose's cos/sin already known: error, Jacobian rows A0/A1 (2x3); B = R(theta)^T
 __device__ __forceinline__ void edge_pl(double px, double py, double c, double s, double lx, double ly, double zx, double zy,
                                         double &ex, double &ey, double A0[3], double A1[3]) {
+#if !GS_G2O_ORDER
     double dx = lx - px, dy = ly - py;
+#endif
 #if GS_G2O_ORDER
     {   // g2o EdgeSE2PointXY::computeError: (x_p^-1 * l) - z with SE2::inverse() = (R^T (-t), -theta) and SE2 * point =
         // R p + t, in g2o's operation order and without fused multiply-adds: at kilometre coordinates the two products
@@ -195,8 +197,21 @@ __device__ __forceinline__ void edge_pl(double px, double py, double c, double s
     ex = (c * dx + s * dy) - zx;
     ey = (-s * dx + c * dy) - zy;
 #endif
-    A0[0] = -c; A0[1] = -s; A0[2] = c * dy - s * dx;
-    A1[0] = s;  A1[1] = -c; A1[2] = -s * dy - c * dx;
+    A0[0] = -c; A0[1] = -s; A1[0] = s;  A1[1] = -c;
+#if GS_G2O_ORDER
+    {   // g2o EdgeSE2PointXY::linearizeOplus writes the lever-arm entries as  a1 y2 - a1 y1 - a3 x2 + a3 x1  and
+        // -a3 y2 + a3 y1 - a1 x2 + a1 x1  (a1 = cos, a3 = sin; left to right, every product rounded): at kilometre coordinates that
+        // is 1e-13 of relative rounding in H_pp and H_pl which "differences first" does not have — and cond(H) ~ 1e13 on a 25 km lap
+        // turns exactly that 1e-13 into the per-cent of the first increment by which the GPU path stood apart from every CPU path
+        // (measured: profiles/r03_parity_spread_cfg4*.json).  The reference's numbers are the bar: same order, no contraction.
+#pragma clang fp contract(off)
+        A0[2] = ((c * ly - c * py) - s * lx) + s * px;
+        A1[2] = (((-s) * ly + s * py) - c * lx) + c * px;
+    }
+#else
+    A0[2] = c * dy - s * dx;
+    A1[2] = -s * dy - c * dx;
+#endif
 }
 
 // One observation edge: everything constructQuadraticForm produces, packed symmetric.
@@ -1382,6 +1397,9 @@ __device__ __forceinline__ void f3_child_tail(double *img, const double *Uc, int
 #ifndef F3_RCP_NEWTON
 #define F3_RCP_NEWTON 2
 #endif
+#ifndef F3_EXACT_DIV
+#define F3_EXACT_DIV 0
+#endif
 __device__ __forceinline__ double rcp_f64(double x) {             // reciprocal to ~1 ulp: hardware seed + Newton steps
     double r = __builtin_amdgcn_rcp(x);
     double e = fma(-x, r, 1.0); r = fma(r, e, r);
@@ -1405,8 +1423,12 @@ __device__ __forceinline__ void f3_panel_pivots(int k0, bool &bad, double (&p)[4
         if (is_pivot) {
             const double piv = lane_bcast(p[j], col);
             bad = bad || !(fabs(piv) > 0.0);                        // LDL^T: a ZERO pivot fails (Eigen 3.3.4 SimplicialCholesky_impl.h:172-176: d == 0), a negative one does not; NaN is reported too
+#if F3_EXACT_DIV                                                     // (experiment: a division per entry instead of one reciprocal per pivot — scripts/r3_j.sh)
+            const double lj = (lane >= col) ? p[j] / piv : 0.0;
+#else
             const double inv = rcp_f64(piv);
             const double lj = (lane >= col) ? p[j] * inv : 0.0;    // row col itself gets d / d = 1: a dead row in every later use
+#endif
 #pragma unroll
             for (int j2 = j + 1; j2 < 4; ++j2) { const double c2 = lane_bcast(p[j], k0 + j2); p[j2] -= lj * c2; }
             p[j] = lj;

@@ -13,7 +13,7 @@ from oracle import pyoracle as po
 pkg = importlib.import_module("opendlv-logic-cfsd18-sensation-slam_amd")
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
 tag = sys.argv[2] if len(sys.argv) > 2 else "default"
-iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10      # 1: first increment only
 N, M = pkg.track.CONFIGS[name]
 t = pkg.track.generate(N, M); g = pkg.track.bench_graph(t, po.OracleFrontend())
 out = {"config": name, "tag": tag, "library": os.environ.get("GS_LIB", "default build"), "iterations": iters}

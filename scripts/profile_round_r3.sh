@@ -1,0 +1,44 @@
+#!/bin/bash
+# Round 3: one GPU session that regenerates every measurement DESIGN.md / profiles/r03_* cite.
+set -o pipefail
+TAG=r03
+O=gpurun_out/$TAG; mkdir -p $O
+B=$PWD/opendlv-logic-cfsd18-sensation-slam_amd/csrc/build
+step() { echo "== $1 ($(date +%T))"; }
+step bench_cfg4; timeout -k 10 900 python bench.py > $O/bench_cfg4_n1.json 2> $O/bench_cfg4.err; echo "bench cfg4 exit=$?"
+step bench_cfg3; timeout -k 10 300 python bench.py --workload cfg3 --steps 400 --warmup 40 --no-extra-configs > $O/bench_cfg3_n1.json 2> $O/bench_cfg3.err; echo "bench cfg3 exit=$?"
+step bench_cfg5; timeout -k 10 600 python bench.py --workload cfg5 --steps 40 --warmup 5 --cpu-iters 2 --no-extra-configs > $O/bench_cfg5_n1.json 2> $O/bench_cfg5.err; echo "bench cfg5 exit=$?"
+step bench_forced_dist; GS_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --no-cpu --no-extra-configs --steps 200 --warmup 20 > $O/bench_cfg4_rccl_group_of_one.json 2> $O/bench_fd.err; echo "forced-dist exit=$?"
+step bench_plain; timeout -k 10 300 python bench.py --no-cpu --no-extra-configs --steps 200 --warmup 20 > $O/bench_cfg4_plain_200.json 2> $O/bench_pl.err; echo "plain exit=$?"
+step gloo2; GS_BENCH_BACKEND=gloo timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 50 --warmup 5 > $O/bench_2rank_gloo_rehearsal_one_gpu.json 2> $O/bench2.err; echo "gloo2 exit=$?"
+step gloo4_cfg5_shard; GS_BENCH_BACKEND=gloo timeout -k 10 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 4 --workload cfg5 --shard --steps 10 --warmup 2 > $O/bench_cfg5_shard_4rank_gloo_rehearsal_one_gpu.json 2> $O/bench4s.err; echo "gloo4 shard exit=$?"
+step structure; GS_PLAN_TIMING=1 timeout -k 10 200 python scripts/iter_loop.py cfg4 1 2>&1 | grep -E "upload|plan phase" > $O/structure_phase_breakdown_cfg4.txt
+step levels; GS_LIB=$B/var_ts/libgraphslam_hip.so timeout -k 10 200 python scripts/level_times.py cfg4 > $O/level_completion_times_cfg4.txt 2>&1
+GS_LIB=$B/var_ts/libgraphslam_hip.so timeout -k 10 300 python scripts/level_times.py cfg5 > $O/level_completion_times_cfg5.txt 2>&1
+GS_LIB=$B/var_ts/libgraphslam_hip.so timeout -k 10 300 python scripts/level_times.py cfg4 24 > $O/level_completion_times_cfg4_K24.txt 2>&1
+step wide_view; timeout -k 10 300 python scripts/wide_view.py cfg4 8 16 24 > $O/wide_view_tracks_cfg4.txt 2>&1; cat $O/wide_view_tracks_cfg4.txt
+step shard_footprint; timeout -k 10 600 python scripts/shard_footprint.py 8 cfg4 > $O/shard_footprint_8xcfg4.txt 2>&1; cat $O/shard_footprint_8xcfg4.txt
+step spreads; timeout -k 10 400 python scripts/parity_spread.py cfg4 r03 > $O/parity_spread_cfg4.log 2>&1; grep -h " vs \|b_pose" $O/parity_spread_cfg4.log | cut -c1-220
+timeout -k 10 600 python scripts/parity_spread.py cfg5 r03 > $O/parity_spread_cfg5.log 2>&1; grep -h " vs \|b_pose" $O/parity_spread_cfg5.log | cut -c1-220
+step pmc_iter; bash scripts/pmc_iter.sh $TAG cfg4 5 > /dev/null; cp gpurun_out/pmc_$TAG.txt $O/iteration_hbm_traffic_cfg4.txt
+bash scripts/pmc_iter.sh ${TAG}c5 cfg5 3 > /dev/null; cp gpurun_out/pmc_${TAG}c5.txt $O/iteration_hbm_traffic_cfg5.txt
+step pmc_groups; bash scripts/pmc_groups.sh ${TAG}mix cfg4 3 "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVE_CYCLES" "SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" > $O/solver_pmc_instruction_mix_cfg4.txt 2>&1
+# texture-addresser counters, ONE small group per pass (a pass with the whole family is refused: "Request exceeds the capabilities of the hardware to collect")
+(cd /tmp && rocprofv3 --list-avail 2>/dev/null | grep -oE "\bTA_[A-Z_0-9a-z]+" | sort -u > $GRAFT_REPO_ROOT/$O/ta_counters_available.txt)
+bash scripts/pmc_groups.sh ${TAG}ta cfg4 3 "TA_BUSY_avr TA_TA_BUSY_sum" "TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum" "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" "TA_BUFFER_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum" > $O/solver_pmc_ta_groups_cfg4.txt 2>&1
+grep -l "exceeds\|signal\|failed" gpurun_out/pmcg_${TAG}ta/*.log 2>/dev/null | while read f; do echo "--- $f"; grep -m3 "exceeds\|signal\|Could not" $f; done >> $O/solver_pmc_ta_groups_cfg4.txt
+step rocprof; cd /tmp && export TMPDIR=/tmp
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu --no-extra-configs > $GRAFT_REPO_ROOT/$O/rocprof_bench.log 2>&1; echo "rocprof exit=$?"
+cd $GRAFT_REPO_ROOT
+f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/bench_cfg4_kernel_stats.csv && head -14 "$f"
+find gpurun_out/prof_$TAG -name "*kernel_trace.csv" -size +20M -delete
+step done
+for c in cfg3 cfg4 cfg5; do python - <<PY
+import json
+try:
+    d = json.load(open("$O/bench_${c}_n1.json"))
+    print("$c", round(d["value"]), "it/s", "lin frac", round(d["roofline"]["frac"], 3), "b2b", round(d["roofline"].get("achieved_back_to_back", 0) / 8000, 3), d.get("phases_ms"), "cpu", d.get("cpu_baseline", {}) and round(d["cpu_baseline"]["value"], 2))
+except Exception as e:
+    print("$c", "no json:", e)
+PY
+done
