@@ -705,25 +705,26 @@ static int build_big_tables(gs_graph *g, const gs_graph::LevelSet &ls) {
     g->wg_f.clear(); g->wg_b.clear(); g->seg_f.clear(); g->seg_b.clear();
     g->small_max_npiv = 1; g->small_max_f = 1;
     for (const Front &F : P.fronts) if (F.npiv + F.nbnd <= 63) { g->small_max_npiv = std::max(g->small_max_npiv, (int)F.npiv); g->small_max_f = std::max(g->small_max_f, F.npiv + F.nbnd); }
-    auto push = [&](std::vector<int32_t> &tab, std::vector<gs_graph::WgSeg> &segs, int pos, int kind_cnt, int level, size_t lds) {
+    auto push = [&](std::vector<int32_t> &tab, std::vector<gs_graph::WgSeg> &segs, int pos, int kind_cnt, int level, size_t lds, int cls) {
         const int e = (int)tab.size() / 2; tab.push_back(pos); tab.push_back(kind_cnt);
-        if (!segs.empty() && segs.back().level == level && segs.back().lds == lds) ++segs.back().count; else segs.push_back({e, 1, level, lds}); };
+        if (!segs.empty() && segs.back().level == level && segs.back().lds == lds && segs.back().cls == cls) ++segs.back().count; else segs.push_back({e, 1, level, lds, cls}); };
+    auto fcls = [](int kind) { return kind == 4 ? 0 : (kind == 3 ? 2 : 1); };       // factor kernel class: fronts of 64-79 | small fronts and 80-111 | 112-159
     const int first = std::max(g->leaf_n, 0), first_block = total - std::max(g->block_n, 0);
     for (int l = 0; l < nlev; ++l)
         for (int q = std::max(ls.start[l], first); q < ls.start[l + 1]; ) {
             const int f = f_of(q);
-            if (f > 63) { const int k = big_kind(f); push(g->wg_f, g->seg_f, q, k, l, factor_tab_lds_bytes(k)); ++q; }
-            else if (q >= first_block) { push(g->wg_f, g->seg_f, q, 1 | (1 << 8), l, factor_tab_lds_bytes(1)); ++q; }
+            if (f > 63) { const int k = big_kind(f); push(g->wg_f, g->seg_f, q, k, l, factor_tab_lds_bytes(k), fcls(k)); ++q; }
+            else if (q >= first_block) { push(g->wg_f, g->seg_f, q, 1 | (1 << 8), l, factor_tab_lds_bytes(1), 1); ++q; }
             else { int cnt = 1; while (cnt < 4 && q + cnt < ls.start[l + 1] && q + cnt < first_block && f_of(q + cnt) <= 63) ++cnt;
-                push(g->wg_f, g->seg_f, q, 0 | (cnt << 8), l, factor_tab_lds_bytes(0)); q += cnt; } }
+                push(g->wg_f, g->seg_f, q, 0 | (cnt << 8), l, factor_tab_lds_bytes(0), 1); q += cnt; } }
     for (int l = nlev - 1; l >= 0; --l)
         for (int q = ls.start[l + 1] - 1; q >= ls.start[l]; ) {
             const int f = f_of(q);
             if (f > 63) { // LDS by the size class of the front (the largest front of the class), so that runs of one class share a launch
                 const int k = big_kind(f), fc = k == 4 ? 79 : (k == 2 ? 111 : 159);
-                push(g->wg_b, g->seg_b, q, k, l, backsolve_tab_lds_bytes(k, fc, 0)); --q; }
+                push(g->wg_b, g->seg_b, q, k, l, backsolve_tab_lds_bytes(k, fc, 0), 1); --q; }
             else { int cnt = 1; while (cnt < 4 && q - cnt >= ls.start[l] && f_of(q - cnt) <= 63) ++cnt;
-                push(g->wg_b, g->seg_b, q, 0 | (cnt << 8), l, backsolve_tab_lds_bytes(0, g->small_max_f, g->small_max_npiv)); q -= cnt; } }
+                push(g->wg_b, g->seg_b, q, 0 | (cnt << 8), l, backsolve_tab_lds_bytes(0, g->small_max_f, g->small_max_npiv), 0); q -= cnt; } }
     int rc;
     if ((rc = dev_alloc(g, (int32_t **)&g->d_wg_f, g->wg_f.size())) != GS_OK || (rc = dev_alloc(g, (int32_t **)&g->d_wg_b, g->wg_b.size())) != GS_OK) return rc;
     HIP_TRY(hipMemcpyAsync(g->d_wg_f, g->wg_f.data(), g->wg_f.size() * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));     // the host vectors live on the handle
@@ -735,8 +736,8 @@ static int build_big_tables(gs_graph *g, const gs_graph::LevelSet &ls) {
 template <class Launch> static void for_each_run(const std::vector<gs_graph::WgSeg> &segs, bool across_levels, Launch &&fn) {
     for (size_t i = 0; i < segs.size(); ) {
         size_t j = i + 1; int n = segs[i].count;
-        while (j < segs.size() && segs[j].lds == segs[i].lds && (across_levels || segs[j].level == segs[i].level)) { n += segs[j].count; ++j; }
-        fn(segs[i].first, n, segs[i].lds);
+        while (j < segs.size() && segs[j].lds == segs[i].lds && segs[j].cls == segs[i].cls && (across_levels || segs[j].level == segs[i].level)) { n += segs[j].count; ++j; }
+        fn(segs[i].first, n, segs[i].lds, segs[i].cls);
         i = j; }
 }
 static void enqueue_factor_big(gs_graph *g, const gs_graph::LevelSet &ls, bool tree) {
@@ -744,11 +745,11 @@ static void enqueue_factor_big(gs_graph *g, const gs_graph::LevelSet &ls, bool t
     if (g->leaf_n > 0) launch_factor_tree(g->d, g->leaf_n, g->leaf_slot, g->leaf_max_f, g->leaf_n, 0, g->stream);       // the leaf instance alone
     // "no flags to wait for at level 1" holds only if EVERY leaf went through the leaf launch (big leaves share the table launch with their parents)
     const int leaf_pre = (g->leaf_n > 0 && g->leaf_n == ls.start[1]) ? 1 : 0;
-    for_each_run(g->seg_f, tree, [&](int first, int n, size_t lds) { launch_factor_tab(g->d, g->d_wg_f + first, n, leaf_pre, lds, g->stream); });
+    for_each_run(g->seg_f, tree, [&](int first, int n, size_t lds, int cls) { launch_factor_tab(g->d, g->d_wg_f + first, n, leaf_pre, lds, cls, g->stream); });
 }
 static void enqueue_backsolve_big(gs_graph *g, const gs_graph::LevelSet &, bool tree) {
     if (!g->d_wg_b) return;
-    for_each_run(g->seg_b, tree, [&](int first, int n, size_t lds) { launch_backsolve_tab(g->d, g->d_wg_b + first, n, g->small_max_npiv, g->small_max_f, lds, g->stream); });
+    for_each_run(g->seg_b, tree, [&](int first, int n, size_t lds, int cls) { launch_backsolve_tab(g->d, g->d_wg_b + first, n, g->small_max_npiv, g->small_max_f, lds, cls, g->stream); });
 }
 static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int base, int mode) {
     const int nlev = (int)ls.start.size() - 1;

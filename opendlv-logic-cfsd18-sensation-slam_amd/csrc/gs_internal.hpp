@@ -49,7 +49,7 @@ struct gs_graph {
     int default_factor_variant = 0;         // see upload_graph
     // plans that hold a front of more than 63 scalars: table-driven whole-tree launches (workgroup -> {level position, kind | count << 8}),
     // built once per plan; *_level[l] = first table entry of level l (one launch per level after a fallback)
-    struct WgSeg { int first, count, level; size_t lds; };           // a run of table entries of one level with the same LDS need
+    struct WgSeg { int first, count, level; size_t lds; int cls; };  // a run of table entries of one level with the same LDS need and kernel class
     std::vector<WgSeg> seg_f, seg_b;
     std::vector<int32_t> wg_f, wg_b;
     int2 *d_wg_f = nullptr, *d_wg_b = nullptr; int small_max_npiv = 0, small_max_f = 0;

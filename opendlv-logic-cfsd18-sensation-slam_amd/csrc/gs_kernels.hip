@@ -2208,7 +2208,11 @@ __device__ __forceinline__ bool f3_big_panel(int B, bool &bad, v4d (&acc)[BigDim
         for (int j = 0; j < 4; ++j) Pw[(lane + 64 * m) * 4 + j] = p[m][j]; }
     const double dk = lr == 0 ? dd[0] : (lr == 1 ? dd[1] : (lr == 2 ? dd[2] : dd[3]));
     // (static tile coordinates — every wave walking all NT (NT + 1) / 2 tiles with a uniform test each, operands preloaded per tile
-    // row — were measured SLOWER: 548 against 596 it/s on the 24-cones-in-view track; the code is three times the size)
+    // row — were measured SLOWER: 548 against 596 it/s on the 24-cones-in-view track; the code is three times the size.  So were
+    // tile ROWS per wave (accumulator [r][J] = tile (w + 4 r, J), all register indices compile-time, operands read once per tile
+    // row): 3.2 us per panel of a 153-scalar front against 2.3 — thirty uniform tests per loop at ~25 cycles each —, and the same
+    // with one jump on the tile column instead of the tests: 4.2 us, ten copies of the loop thrash the instruction cache.  The
+    // panel of a ten-tile-row front is 1.0 us of matrix cores (14 tiles per wave at 67 ns), 0.5 of pivots, 0.6 of LDS round trips.)
 #pragma unroll
     for (int s = 0; s < D::TPW; ++s) { const int t = 4 * s + wave, I = f3_tile_row_any(t), J = t - ((I * (I + 1)) >> 1);
         if (t < D::NTILE && J >= J0 && 16 * I <= f) {
@@ -2223,6 +2227,9 @@ __device__ __forceinline__ void f3_big_front(const DevGraph &d, int pos, double 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const F3 fr = f3_load(d.f3_desc, pos, lane);
     const int npiv = fr.npiv, f = npiv + fr.nbnd;
+    const bool ts_on = (d.dbg & 16) && pos == (d.dbg >> 8);          // GS_DBG = 16 | position << 8: phase timestamps of this front (scripts/big_probe.py)
+#define BIG_TS(i) do { if (ts_on) { __builtin_amdgcn_s_waitcnt(0); if (tid == 0) d.dbg_ts[i] = wall_clock64(); } } while (0)
+    BIG_TS(0);
     for (int r = tid; r < npiv; r += 256) d.xe[fr.piv0 + r] = f3_unset();        // this front's solution rows: not written yet
     double *img = smem, *Pn = smem + D::IMG, *Pw = Pn + 2 * D::PANEL + wave * D::PANEL;
     int32_t *tab = reinterpret_cast<int32_t *>(Pn + 6 * D::PANEL);
@@ -2261,6 +2268,7 @@ __device__ __forceinline__ void f3_big_front(const DevGraph &d, int pos, double 
               const int4 r = reinterpret_cast<const int4 *>(d.asm3)[fr.asm_off + t];
               double w[9]; asm3_load(d, r.x, r.y, w); asm3_put<true>(P, r.x, r.z, r.w, w); }
           __syncthreads(); } }
+    BIG_TS(1);
     // ---- the children, by source, in list order: table to LDS, the child's flag, its packed update matrix in storage order
     bool okw = true;
     for (int e = 0; e < fr.nchild; ++e) {
@@ -2282,6 +2290,7 @@ __device__ __forceinline__ void f3_big_front(const DevGraph &d, int pos, double 
         __syncthreads();
     }
     if (!okw && tid == 0) atomicMax(d.fail, 2);
+    BIG_TS(2);
     // ---- accumulators: wave w holds tiles w, w + 4, ...
     v4d acc[D::TPW];
 #pragma unroll
@@ -2291,7 +2300,9 @@ __device__ __forceinline__ void f3_big_front(const DevGraph &d, int pos, double 
     double *L = d.Lbuf + fr.L_off;
     bool go = true, bad = false;
 #pragma clang loop unroll(disable)
-    for (int B = 0; B < 4 * NT && go; ++B) go = f3_big_panel<NT>(B, bad, acc, Pn, Pw, L, npiv, f, wave, lane);
+    BIG_TS(3);
+    for (int B = 0; B < 4 * NT && go; ++B) { go = f3_big_panel<NT>(B, bad, acc, Pn, Pw, L, npiv, f, wave, lane); if (B < 16) BIG_TS(4 + B); }
+    BIG_TS(20);
     if (d.inject_iter != 0 && d.iter == d.inject_iter && pos == 0 && tid == 0) atomicMax(d.fail, d.inject_code);   // gs_debug_fail_at_iteration
     if (bad && tid == 0) atomicMax(d.fail, 1);
     // ---- Schur complement out through the image, contiguous write-through stores
@@ -2311,6 +2322,8 @@ __device__ __forceinline__ void f3_big_front(const DevGraph &d, int pos, double 
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __hip_atomic_store(d.done_f + fr.s, d.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    BIG_TS(21);
+#undef BIG_TS
 }
 // LDS of the backward solve of a big front: boundary values, right-hand side, L21 (column-major as stored) and L11 strictly
 // lower, packed by ROWS (row r holds its r columns at r (r - 1) / 2): f^2 / 2 doubles at most
@@ -2385,25 +2398,31 @@ __device__ __forceinline__ void bs3_big_front(const DevGraph &d, int pos, double
 // Table-driven launches (plans that hold a big front): workgroup b takes wgt[b] = {first level position, kind | count << 8} — up to
 // four small fronts a wave each, a small front on four waves, or a big front.  Factor: the table follows the level positions
 // (children in earlier workgroups); backward solve: the reverse (ancestors in earlier workgroups).
-__global__ void __launch_bounds__(256, 2) k_factor3_tab(DevGraph d, const int2 *__restrict__ wgt, int leaf_launch_preceded) {
+// CLASS: the launches are cut by LDS need, and each class is its own kernel so that the many fronts just beyond a wave do not
+// inherit the registers (and with them the occupancy) of the others: 0 = fronts of 64-79 scalars (three workgroups per CU),
+// 1 = small fronts (a wave or four each) and fronts of 80-111 (two per CU), 2 = fronts of 112-159 (one per CU)
+template <int CLASS>
+__global__ void __launch_bounds__(256, CLASS == 0 ? 3 : (CLASS == 1 ? 2 : 1)) k_factor3_tab(DevGraph d, const int2 *__restrict__ wgt, int leaf_launch_preceded) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int2 e = wgt[blockIdx.x];
     const int pos = __builtin_amdgcn_readfirstlane(e.x), kind = __builtin_amdgcn_readfirstlane(e.y) & 0xff, cnt = __builtin_amdgcn_readfirstlane(e.y) >> 8;
-    if (kind == WG_WAVES) { if (wave < cnt) f3_wave_front<true, false, 4>(d, pos + wave, FRONT_OWN, leaf_launch_preceded, smem, wave, lane, false, false); }
-    else if (kind == WG_BLOCK4) f3_block_front(d, pos, leaf_launch_preceded, smem, false);
-    else if (kind == WG_BIG5) f3_big_front<5>(d, pos, smem);
-    else if (kind == WG_BIG7) f3_big_front<7>(d, pos, smem);
-    else f3_big_front<10>(d, pos, smem);
+    if constexpr (CLASS == 0) { f3_big_front<5>(d, pos, smem); }
+    else if constexpr (CLASS == 2) { f3_big_front<10>(d, pos, smem); }
+    else {
+        if (kind == WG_WAVES) { if (wave < cnt) f3_wave_front<true, false, 4>(d, pos + wave, FRONT_OWN, leaf_launch_preceded, smem, wave, lane, false, false); }
+        else if (kind == WG_BLOCK4) f3_block_front(d, pos, leaf_launch_preceded, smem, false);
+        else f3_big_front<7>(d, pos, smem);
+    }
 }
-__global__ void __launch_bounds__(256, 2) k_backsolve3_tab(DevGraph d, const int2 *__restrict__ wgt, int slot_doubles) {
+template <bool BIG>      // BIG: a launch of big fronts only (few registers: as many workgroups per CU as the LDS allows); else small fronts, a wave each
+__global__ void __launch_bounds__(256, BIG ? 4 : 2) k_backsolve3_tab(DevGraph d, const int2 *__restrict__ wgt, int slot_doubles) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int2 e = wgt[blockIdx.x];
-    const int pos = __builtin_amdgcn_readfirstlane(e.x), kind = __builtin_amdgcn_readfirstlane(e.y) & 0xff, cnt = __builtin_amdgcn_readfirstlane(e.y) >> 8;
-    const bool ts_on = false;
-    if (kind == WG_WAVES || kind == WG_BLOCK4) { if (wave < cnt) bs3_wave_front<true>(d, pos - wave, smem, slot_doubles, wave, lane, ts_on); }     // root first: positions downwards
-    else bs3_big_front<true>(d, pos, smem);
+    const int pos = __builtin_amdgcn_readfirstlane(e.x), cnt = __builtin_amdgcn_readfirstlane(e.y) >> 8;
+    if constexpr (BIG) bs3_big_front<true>(d, pos, smem);
+    else { if (wave < cnt) bs3_wave_front<true>(d, pos - wave, smem, slot_doubles, wave, lane, false); }     // root first: positions downwards
 }
 // LDS of one workgroup of a table-driven launch, by kind (a launch takes the maximum over its workgroups: the host cuts the table
 // into launches of equal need, so that the many fronts just beyond a wave do not run at the occupancy of the ten-tile-row ones)
@@ -2419,16 +2438,22 @@ size_t backsolve_tab_lds_bytes(int kind, int f_or_slot_f, int npiv_small) {     
     if (kind == WG_WAVES || kind == WG_BLOCK4) { const int slot = ((((f_or_slot_f + 1) | 1) * std::max(npiv_small, 1)) + 1) & ~1; return (size_t)slot * 4 * sizeof(double); }
     return (size_t)bs3_big_lds_doubles(f_or_slot_f) * sizeof(double);
 }
-void launch_factor_tab(const DevGraph &d, const int2 *wgt, int n_wg, int leaf_launch_preceded, size_t lds_bytes, hipStream_t st) {
-    if (n_wg <= 0) return;
-    allow_max_lds((const void *)k_factor3_tab);
-    hipLaunchKernelGGL(k_factor3_tab, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, leaf_launch_preceded);
+void launch_factor_tab(const DevGraph &d, const int2 *wgt, int n_wg, int leaf_launch_preceded, size_t lds_bytes, int cls, hipStream_t st) {
+    if (n_wg <= 0) return;                                           // (a launch holds workgroups of ONE class: the host cut the table that way)
+    if (cls == 0) { allow_max_lds((const void *)k_factor3_tab<0>);
+        hipLaunchKernelGGL(k_factor3_tab<0>, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, leaf_launch_preceded); }
+    else if (cls == 2) { allow_max_lds((const void *)k_factor3_tab<2>);
+        hipLaunchKernelGGL(k_factor3_tab<2>, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, leaf_launch_preceded); }
+    else { allow_max_lds((const void *)k_factor3_tab<1>);
+        hipLaunchKernelGGL(k_factor3_tab<1>, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, leaf_launch_preceded); }
 }
-void launch_backsolve_tab(const DevGraph &d, const int2 *wgt, int n_wg, int max_npiv_small, int max_f_small, size_t lds_bytes, hipStream_t st) {
+void launch_backsolve_tab(const DevGraph &d, const int2 *wgt, int n_wg, int max_npiv_small, int max_f_small, size_t lds_bytes, int cls, hipStream_t st) {
     if (n_wg <= 0) return;
     const int slot = ((((max_f_small + 1) | 1) * std::max(max_npiv_small, 1)) + 1) & ~1;
-    allow_max_lds((const void *)k_backsolve3_tab);
-    hipLaunchKernelGGL(k_backsolve3_tab, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, slot);
+    if (cls == 1) { allow_max_lds((const void *)k_backsolve3_tab<true>);
+        hipLaunchKernelGGL(k_backsolve3_tab<true>, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, slot); }
+    else { allow_max_lds((const void *)k_backsolve3_tab<false>);
+        hipLaunchKernelGGL(k_backsolve3_tab<false>, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, slot); }
 }
 
 // ---- structure phase on the device: the ELL streams of the observation edges, permuted out of the insertion-order
