@@ -1619,7 +1619,7 @@ __device__ __forceinline__ void f3_block_scatter(double *img, const double *Uc, 
         const double v = ld_off_coh(Uc, (uint32_t)min(idx, usz) * 8u);
         img[idx < usz ? pl : 1] += v; }
 }
-__device__ __forceinline__ void f3_block_front(const DevGraph &d, int pos, int leaf_slot, double *smem, bool ts_on) {
+__device__ __forceinline__ void f3_block_front(const DevGraph &d, int pos, int mode, int leaf_slot, double *smem, bool ts_on) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 #define F3B_TS(i) do { if (ts_on) { __builtin_amdgcn_s_waitcnt(0); if (tid == 0) d.dbg_ts[i] = wall_clock64(); } } while (0)
     F3B_TS(0);
@@ -1635,7 +1635,10 @@ __device__ __forceinline__ void f3_block_front(const DevGraph &d, int pos, int l
         own[k] = min(f3_img_rowpart(npiv + (rc[k] & 0xff)) + f3_img_colpart(npiv + (rc[k] >> 8)), MF_IMG - 1);
         asm volatile("" : "+v"(own[k])); }
     // ---- records (scalar records come in multiples of 64: a wave's 64 are all there or none)
-    const int nsc = fr.sc_cnt, nlm = fr.lm_cnt;
+    // mode TOP (the shared top of a sharded graph): the originals AND the contributions of the ranks' own subtrees arrive summed in
+    // the front's exchange slot; only the shared children are gathered
+    const bool top = mode == FRONT_TOP;
+    const int nsc = top ? 0 : fr.sc_cnt, nlm = top ? 0 : fr.lm_cnt;
     const int2 *sc3 = reinterpret_cast<const int2 *>(d.sc3) + fr.sc_off;
     int2 sc[2];
 #pragma unroll
@@ -1647,7 +1650,11 @@ __device__ __forceinline__ void f3_block_front(const DevGraph &d, int pos, int l
     for (int k = 0; k < 10; ++k) img[256 * k + tid] = 0.0;
     __syncthreads();
     // ---- the original values
-    {
+    if (top) {
+        const double *X = d.exchange + fr.x_off;                     // slot layout: (f+1) x f column-major, ld = f+1
+        for (int c = wave; c < f; c += 4) if (lane >= c && lane <= f) P.at(lane, c) = X[c * (f + 1) + lane];
+        __syncthreads();
+    } else {
         double val[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) if (256 * u + 64 * wave < nsc) val[u] = F3_LD_VAL(d.H_arena, (uint32_t)sc[u].x * 8u);
@@ -1691,24 +1698,24 @@ __device__ __forceinline__ void f3_block_front(const DevGraph &d, int pos, int l
         bool okw = true;
         for (int e = 0; e < fr.nchild; e += 2) {
             const bool hasB = e + 1 < fr.nchild;
-            int tA, a_id, a_uoff, a_usz, tB, b_id, b_uoff, b_usz;
-            if (e == 0) { tA = tab0; a_id = fr.c_id[0]; a_uoff = fr.c_uoff[0]; a_usz = fr.c_usize[0];
-                          tB = tab1; b_id = fr.c_id[1]; b_uoff = fr.c_uoff[1]; b_usz = fr.c_usize[1]; }
+            int tA, a_id, a_uoff, a_usz, a_own, tB, b_id, b_uoff, b_usz, b_own;
+            if (e == 0) { tA = tab0; a_id = fr.c_id[0]; a_uoff = fr.c_uoff[0]; a_usz = fr.c_usize[0]; a_own = fr.c_owner[0];
+                          tB = tab1; b_id = fr.c_id[1]; b_uoff = fr.c_uoff[1]; b_usz = fr.c_usize[1]; b_own = fr.c_owner[1]; }
             else { const int eb = hasB ? e + 1 : e;
                 const int XS = d.f3x_stride, XH = XS - 8;            // per-child stride of f3_x (72, or 168 when the plan holds a big front), header behind the table
                 tA = xt[e * XS + lane]; const int hA = xt[e * XS + XH + (lane & 7)]; tB = xt[eb * XS + lane]; const int hB = xt[eb * XS + XH + (lane & 7)];
-                a_id = __builtin_amdgcn_readlane(hA, 0); a_uoff = __builtin_amdgcn_readlane(hA, 1); a_usz = __builtin_amdgcn_readlane(hA, 2);
-                b_id = __builtin_amdgcn_readlane(hB, 0); b_uoff = __builtin_amdgcn_readlane(hB, 1); b_usz = __builtin_amdgcn_readlane(hB, 2); }
+                a_id = __builtin_amdgcn_readlane(hA, 0); a_uoff = __builtin_amdgcn_readlane(hA, 1); a_usz = __builtin_amdgcn_readlane(hA, 2); a_own = __builtin_amdgcn_readlane(hA, 3);
+                b_id = __builtin_amdgcn_readlane(hB, 0); b_uoff = __builtin_amdgcn_readlane(hB, 1); b_usz = __builtin_amdgcn_readlane(hB, 2); b_own = __builtin_amdgcn_readlane(hB, 3); }
+            const bool onA = !(top && a_own >= 0), onB = hasB && !(top && b_own >= 0);      // (uniform) a rank's own subtree: its update matrix came with the exchange slot
             int dA[4], dB[4]; double sA[4], sB[4];
-            f3_block_places(tA, rc, a_usz, tid, dA);
-            if (hasB) f3_block_places(tB, rc, b_usz, tid, dB);
-            if (!plain) okw = f3_wait_flag(d.done_f + a_id, d.epoch, d.fail) && okw;
-            f3_block_loads(d.Uimg + a_uoff, a_usz, tid, sA);
-            if (hasB) { if (!plain) okw = f3_wait_flag(d.done_f + b_id, d.epoch, d.fail) && okw;
+            if (onA) f3_block_places(tA, rc, a_usz, tid, dA);
+            if (onB) f3_block_places(tB, rc, b_usz, tid, dB);
+            if (onA) { if (!plain) okw = f3_wait_flag(d.done_f + a_id, d.epoch, d.fail) && okw;
+                f3_block_loads(d.Uimg + a_uoff, a_usz, tid, sA); }
+            if (onB) { if (!plain) okw = f3_wait_flag(d.done_f + b_id, d.epoch, d.fail) && okw;
                 f3_block_loads(d.Uimg + b_uoff, b_usz, tid, sB); }
-            f3_block_scatter(img, d.Uimg + a_uoff, a_usz, tA, tid, dA, sA);
-            __syncthreads();
-            if (hasB) { f3_block_scatter(img, d.Uimg + b_uoff, b_usz, tB, tid, dB, sB); __syncthreads(); }
+            if (onA) { f3_block_scatter(img, d.Uimg + a_uoff, a_usz, tA, tid, dA, sA); __syncthreads(); }
+            if (onB) { f3_block_scatter(img, d.Uimg + b_uoff, b_usz, tB, tid, dB, sB); __syncthreads(); }
         }
         if (!okw && tid == 0) atomicMax(d.fail, 2);
     }
@@ -2018,7 +2025,7 @@ __global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(D
     if constexpr (TREE && !LEAF) {
         const int wave_blocks = (n_wave_fronts + 3) >> 2;
         if ((int)blockIdx.x >= wave_blocks) { const int pos = level_off + n_wave_fronts + ((int)blockIdx.x - wave_blocks);
-            f3_block_front(d, pos, leaf_slot, smem, (d.dbg & 16) && pos == (d.dbg >> 8)); return; }
+            f3_block_front(d, pos, mode, leaf_slot, smem, (d.dbg & 16) && pos == (d.dbg >> 8)); return; }
     }
     const int fi = blockIdx.x * 4 + wave;
     if (fi >= (TREE && !LEAF ? n_wave_fronts : count)) return;      // whole wave leaves; no block barrier below
@@ -2411,7 +2418,7 @@ __global__ void __launch_bounds__(256, CLASS == 0 ? 3 : (CLASS == 1 ? 2 : 1)) k_
     else if constexpr (CLASS == 2) { f3_big_front<10>(d, pos, smem); }
     else {
         if (kind == WG_WAVES) { if (wave < cnt) f3_wave_front<true, false, 4>(d, pos + wave, FRONT_OWN, leaf_launch_preceded, smem, wave, lane, false, false); }
-        else if (kind == WG_BLOCK4) f3_block_front(d, pos, leaf_launch_preceded, smem, false);
+        else if (kind == WG_BLOCK4) f3_block_front(d, pos, FRONT_OWN, leaf_launch_preceded, smem, false);
         else f3_big_front<7>(d, pos, smem);
     }
 }
@@ -2624,7 +2631,8 @@ void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int leaf_m
 void launch_factor_tree_top(const DevGraph &d, int first, int count, hipStream_t st) {
     if (count <= 0) return;
     allow_max_lds((const void *)k_factor3<true, false>);
-    hipLaunchKernelGGL((k_factor3<true, false>), dim3((count + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, first, count, FRONT_TOP, 0, count);
+    // every shared front four waves (the chain of the top levels is all there is to this launch): n_wave_fronts = 0
+    hipLaunchKernelGGL((k_factor3<true, false>), dim3(count), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, first, count, FRONT_TOP, 0, 0);
 }
 void launch_backsolve_tree(const DevGraph &d, int first, int count, int max_npiv, int max_f, hipStream_t st) {
     if (count <= 0) return;                                          // positions [first, first + count), root first
