@@ -87,8 +87,9 @@ def linearize_roofline_of(pkg, name, device, reps=10):
     G = pkg.Graph(device=device); G.load_bench_graph(g); G.initialize_optimization()
     ph = G.time_iterations(reps); b2b = G.time_linearize(reps); B = G.linearize_bytes()
     G.close()
-    inside = B / (ph.ms_linearize * 1e-3) / 1e9
-    return dict(algorithmic_bytes=B, ms_per_launch=ph.ms_linearize, achieved=inside, frac=inside / HBM_PEAK_GBS,
+    lin = ph.ms_linearize_kernel if ph.ms_linearize_kernel > 0 else ph.ms_linearize      # the kernel's own begin -> end (events attached to its dispatch)
+    inside = B / (lin * 1e-3) / 1e9
+    return dict(algorithmic_bytes=B, ms_per_launch=lin, ms_event_to_event=ph.ms_linearize, achieved=inside, frac=inside / HBM_PEAK_GBS,
                 ms_per_launch_back_to_back=b2b, frac_back_to_back=B / (b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 iteration_ms=ph.ms_total, iterations_per_s=1e3 / ph.ms_total)
 
@@ -296,14 +297,16 @@ def main():
         phases = G.time_iterations(20)
         out["phases_ms"] = dict(linearize=phases.ms_linearize, factor=phases.ms_factor, backsolve=phases.ms_backsolve,
                                 update=phases.ms_update, structure_once=plan.ms_structure)
-        # the roofline entry is the kernel AS IT RUNS INSIDE the Gauss-Newton iteration (HIP events around the phase, same
-        # launch sequence as the timed region): its inputs are cold there.  Back-to-back launches of the same kernel find
-        # cfg4's 105 MB still in the 256 MB Infinity Cache and are reported beside it, not as `achieved`.
-        # (an EMPTY event-to-event interval on the stream measures 4-5 us, reported as phases_ms.event_overhead, but it is
-        # not contained in the phase times: the rocprof kernel trace of this command shows the same in-iteration launch
-        # duration as the raw phase time — 127 launches averaging 29.9 us = 77 in-iteration at 31.5 + 50 back to back at
-        # 27.4 — so nothing is subtracted)
-        lin_in = phases.ms_linearize
+        # the roofline entry is the kernel AS IT RUNS INSIDE the Gauss-Newton iteration (same launch sequence as the timed region: its
+        # inputs are cold there).  Back-to-back launches of the same kernel find cfg4's 105 MB still in the 256 MB Infinity Cache and
+        # are reported beside it, not as `achieved`.
+        # Duration = HIP start / stop events attached to the kernel's OWN dispatch (hipExtLaunchKernelGGL, on the stream it is launched
+        # on) in iterations that carry no other event — the launch sequence of the timed region: begin -> end as the command processor
+        # stamps the dispatch, the quantity a rocprofv3 kernel trace reports.  Measured on one box (profiles/r03_linearize_duration_*):
+        # attached 29.7 us, the trace's in-iteration launches 28.4 us (a mean over these and the phase-timed iterations), events
+        # recorded around the phase 30.8 us (ms_event_to_event: also holds the hand-over from k_update), and 27.3 us when an event
+        # boundary precedes the launch (the previous kernel has then drained before the dispatch is stamped).
+        lin_in = phases.ms_linearize_kernel if phases.ms_linearize_kernel > 0 else phases.ms_linearize
         out["phases_ms"]["event_overhead"] = phases.ms_event_overhead
         # ---- the solver (A8) against its own bytes: every L and update-matrix double is written once and read once, every
         # block of H read once.  Dependent latency bounds it, not bandwidth; the entry says by how much, and how close the
@@ -330,9 +333,9 @@ def main():
                              bound="dependent latency of the elimination tree (levels in sequence), instruction issue in the leaf level; not HBM",
                              note="algorithmic_bytes = 2 x (L + update matrices) + H blocks read once")
         inside = alg_bytes / (lin_in * 1e-3) / 1e9
-        out["roofline"].update(achieved=inside, frac=inside / HBM_PEAK_GBS, ms_per_launch=lin_in,
+        out["roofline"].update(achieved=inside, frac=inside / HBM_PEAK_GBS, ms_per_launch=lin_in, ms_event_to_event=phases.ms_linearize,
                                achieved_back_to_back=achieved, ms_per_launch_back_to_back=lin_ms,
-                               note="HIP events around the linearisation phase inside full iterations (cold inputs); "
+                               note="HIP start/stop events attached to the kernel's dispatch inside full iterations (cold inputs), mean of 20 launches; ms_event_to_event = events recorded around the phase (holds the hand-over from the previous kernel too); "
                                     "achieved_back_to_back = the same kernel launched 50x in a row (inputs cached)")
     if rank == 0 and world == 1 and not args.no_cpu:
         og, cb = cpu_baseline(pkg, g, args.cpu_iters)

@@ -114,6 +114,8 @@ typedef struct gs_stats {
     int64_t device_bytes;       /* HBM this handle's plan and graph occupy (the chunks its arrays are carved from) */
     int32_t n_own_fronts, n_shared_fronts;   /* pose-window shards: fronts this rank factorises / the shared top (world 1: all, 0) */
     double  ms_plan_host;       /* share of ms_structure spent building the plan on the host */
+    double  ms_linearize_kernel; /* gs_time_iterations: the A5-A7 kernel's own begin -> end per launch, from events attached to its dispatch (ms_linearize
+                                    is event to event on the stream: it also holds the hand-over from the previous kernel) */
 } gs_stats;
 
 int  gs_version(void);                               /* major*100+minor */

@@ -51,7 +51,8 @@ class Stats(C.Structure):
                 ("ms_backsolve", C.c_double), ("ms_update", C.c_double), ("ms_total", C.c_double),
                 ("factor_flops", C.c_int64), ("factor_bytes", C.c_int64), ("ms_event_overhead", C.c_double),
                 ("fell_back", C.c_int32), ("first_failure", C.c_int32), ("factor_variant", C.c_int32), ("n_big_fronts", C.c_int32),
-                ("device_bytes", C.c_int64), ("n_own_fronts", C.c_int32), ("n_shared_fronts", C.c_int32), ("ms_plan_host", C.c_double)]
+                ("device_bytes", C.c_int64), ("n_own_fronts", C.c_int32), ("n_shared_fronts", C.c_int32), ("ms_plan_host", C.c_double),
+                ("ms_linearize_kernel", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -816,7 +816,7 @@ static void enqueue_backsolve_levels(gs_graph *g, const gs_graph::LevelSet &ls, 
 static void enqueue_local(gs_graph *g, bool timed) {
     ++g->d.iter;                                                     // kernels see the iteration they belong to (fault injection, gs_debug_fail_at_iteration)
     if (timed) hipEventRecord(g->ev[0], g->stream);
-    launch_linearize(g->d, g->stream);
+    launch_linearize(g->d, g->stream, g->ev_lin[0], g->ev_lin[1]);   // (null outside gs_time_iterations' second pass)
     if (timed) hipEventRecord(g->ev[1], g->stream);
     enqueue_factor_levels(g, g->own, 0, 0);
     const int nshared = (int)g->plan.level_fronts_shared.size();
@@ -1048,24 +1048,36 @@ extern "C" int gs_time_iterations(gs_graph *g, int32_t reps, gs_stats *s) {
     // all repetitions are enqueued back to back like the iterations of gs_optimize (no host round trip in between);
     // every repetition has its own five phase events plus a sixth right behind the fifth: that empty interval is what
     // one event boundary costs on this stream (ms_event_overhead), i.e. how much of each phase time is the measurement
-    std::vector<hipEvent_t> evs((size_t)reps * 6);
+    // ... then `reps` more iterations with a start / stop pair attached to the linearisation kernel's own dispatch (hipExtLaunchKernelGGL):
+    // its begin -> end as a kernel trace reports it, without the hand-over from k_update that the event-to-event interval also holds
+    std::vector<hipEvent_t> evs((size_t)reps * 8);
     for (auto &e : evs) HIP_TRY(hipEventCreate(&e));
     hipEvent_t saved[5]; for (int k = 0; k < 5; ++k) saved[k] = g->ev[k];
     for (int r = 0; r < reps; ++r) {
-        for (int k = 0; k < 5; ++k) g->ev[k] = evs[(size_t)r * 6 + k];
+        for (int k = 0; k < 5; ++k) g->ev[k] = evs[(size_t)r * 8 + k];
         enqueue_iteration(g, true);
-        hipEventRecord(evs[(size_t)r * 6 + 5], g->stream);
+        hipEventRecord(evs[(size_t)r * 8 + 5], g->stream);
     }
     for (int k = 0; k < 5; ++k) g->ev[k] = saved[k];
+    // second pass, nothing recorded between the phases (a dispatch with events attached lengthens the event-to-event interval
+    // around it by ~10 us: the two measurements do not share iterations)
+    for (int r = 0; r < reps; ++r) {
+        g->ev_lin[0] = evs[(size_t)r * 8 + 6]; g->ev_lin[1] = evs[(size_t)r * 8 + 7];
+        enqueue_iteration(g, false);
+    }
+    g->ev_lin[0] = g->ev_lin[1] = nullptr;
     HIP_TRY(hipStreamSynchronize(g->stream));
-    double ovh = 0.0;
-    for (int r = 0; r < reps; ++r) { const hipEvent_t *e = &evs[(size_t)r * 6];
-        float a = 0, b = 0, c = 0, dd = 0, o = 0;
+    double ovh = 0.0, link = 0.0; int nlink = 0;
+    for (int r = 0; r < reps; ++r) { const hipEvent_t *e = &evs[(size_t)r * 8];
+        float a = 0, b = 0, c = 0, dd = 0, o = 0, lk = 0;
         hipEventElapsedTime(&a, e[0], e[1]); hipEventElapsedTime(&b, e[1], e[2]);
         hipEventElapsedTime(&c, e[2], e[3]); hipEventElapsedTime(&dd, e[3], e[4]); hipEventElapsedTime(&o, e[4], e[5]);
+        if (hipEventElapsedTime(&lk, e[6], e[7]) == hipSuccess && lk > 0) { link += lk; ++nlink; }     // (the gather path launches several kernels: no pair)
         s->ms_linearize += a; s->ms_factor += b; s->ms_backsolve += c; s->ms_update += dd; ovh += o; }
+    (void)hipGetLastError();
     for (auto &e : evs) hipEventDestroy(e);
     s->ms_linearize /= reps; s->ms_factor /= reps; s->ms_backsolve /= reps; s->ms_update /= reps; s->ms_event_overhead = ovh / reps;
+    s->ms_linearize_kernel = nlink > 0 ? link / nlink : 0.0;
     s->ms_total = s->ms_linearize + s->ms_factor + s->ms_backsolve + s->ms_update; s->iterations = reps;
     hipMemcpyAsync(g->d.pose_est, sp, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToDevice, g->stream);
     launch_pose_trig(g->d, g->stream);

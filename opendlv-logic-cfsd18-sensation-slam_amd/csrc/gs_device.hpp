@@ -83,7 +83,7 @@ struct DevGraph {
 };
 
 // launchers (gs_kernels.hip); all asynchronous on `st`
-void launch_linearize(const DevGraph &d, hipStream_t st);       // fused ELL kernel when wave tiles exist, else gather kernels
+void launch_linearize(const DevGraph &d, hipStream_t st, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);   // start / stop: events attached to the dispatch itself       // fused ELL kernel when wave tiles exist, else gather kernels
 void launch_linearize_gather(const DevGraph &d, hipStream_t st);
 void launch_linearize_finalize(const DevGraph &d, hipStream_t st);   // H_ll, b_l, chi2 total from the fused kernel's partials
 void launch_chi2_only(const DevGraph &d, hipStream_t st);

@@ -28,6 +28,7 @@ struct gs_graph {
     uint64_t dev_estimate_version = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
     hipEvent_t ev[8]{};
+    hipEvent_t ev_lin[2]{};                 // timed iterations: start / stop attached to the linearisation dispatch (null: none)
     LevelSet own, shared;                   // this rank's fronts / the shared top (pose-window shards)
     int shared_base = 0;                    // offset of the shared list inside d.level_fronts
     int leaf_max_f = 0;                     // largest leaf front (<= 47: the three-tile-row leaf instance)

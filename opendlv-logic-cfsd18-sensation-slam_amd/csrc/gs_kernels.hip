@@ -15,6 +15,7 @@
 //
 // All fp64; every sum has a fixed order (no floating-point atomics) so results are bitwise reproducible.
 #include "gs_device.hpp"
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <mutex>
 #include <set>
@@ -660,15 +661,18 @@ void launch_linearize_finalize(const DevGraph &d, hipStream_t st) {
     if (d.n_wtiles > 0)
         hipLaunchKernelGGL(k_linearize_finalize, dim3(max(1, (d.M + 255) / 256)), dim3(256), 0, st, d, d.n_wtiles);
 }
-void launch_linearize(const DevGraph &d, hipStream_t st) {
+// start / stop (optional): HIP events attached to THIS dispatch (hipExtLaunchKernelGGL) — the kernel's own begin and end as the
+// command processor stamps them, what a kernel trace reports; an event recorded before / after the launch also holds the
+// hand-over from the previous kernel of the stream
+void launch_linearize(const DevGraph &d, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
     if (d.n_wtiles <= 0) { launch_linearize_gather(d, st); return; }
     if (d.wt_hi <= d.wt_lo) return;
     const dim3 grid((d.wt_hi - d.wt_lo + 3) / 4), block(256);
     switch (d.ell_T) {
-        case 1: hipLaunchKernelGGL(k_linearize_ell<1>, grid, block, 0, st, d); break;
-        case 2: hipLaunchKernelGGL(k_linearize_ell<2>, grid, block, 0, st, d); break;
-        case 4: hipLaunchKernelGGL(k_linearize_ell<4>, grid, block, 0, st, d); break;
-        default: hipLaunchKernelGGL(k_linearize_ell<8>, grid, block, 0, st, d); break;
+        case 1: hipExtLaunchKernelGGL(k_linearize_ell<1>, grid, block, 0, st, start, stop, 0, d); break;
+        case 2: hipExtLaunchKernelGGL(k_linearize_ell<2>, grid, block, 0, st, start, stop, 0, d); break;
+        case 4: hipExtLaunchKernelGGL(k_linearize_ell<4>, grid, block, 0, st, start, stop, 0, d); break;
+        default: hipExtLaunchKernelGGL(k_linearize_ell<8>, grid, block, 0, st, start, stop, 0, d); break;
     }
 }
 void launch_chi2_only(const DevGraph &d, hipStream_t st) {
