@@ -116,6 +116,8 @@ typedef struct gs_stats {
     double  ms_plan_host;       /* share of ms_structure spent building the plan on the host */
     double  ms_linearize_kernel; /* gs_time_iterations: the A5-A7 kernel's own begin -> end per launch, from events attached to its dispatch (ms_linearize
                                     is event to event on the stream: it also holds the hand-over from the previous kernel) */
+    int32_t n_growths;          /* append-only growth steps the current plan has absorbed since the last full structure phase (0: none) */
+    int32_t reserved2;
 } gs_stats;
 
 int  gs_version(void);                               /* major*100+minor */
@@ -257,6 +259,15 @@ typedef struct gs_plan_info {
 } gs_plan_info;
 /* builds the plan on the host only (no HIP), usable without a device */
 int  gs_plan_build_host(gs_graph *g, gs_plan_info *info);
+/* Append-only growth (reference src/slam.cpp:433-459, 537-550 add one pose vertex, its odometry edge and its observation edges per
+ * keyframe; g2o's initializeOptimization rebuilds everything, :480).  When the only changes since the last structure phase are new poses
+ * with their edges (observation edges to EXISTING landmarks; at most 16 poses / 512 + 64 edges since the last full phase; every front stays
+ * <= 63 scalars), gs_initialize_optimization / gs_optimize keep the plan: the new poses become pivots of the root front, the fronts between a
+ * neighbour's front and the root gain them as boundary rows, and only those fronts' tables are rebuilt (csrc/gs_plan.cpp grow_plan,
+ * csrc/gs_api.cpp upload_growth).  Anything else (new landmark, fixed flag, GS_GROW=0 in the environment) is a full structure phase.
+ * gs_plan_growths: steps absorbed by the current plan; gs_growth_refusal: why the last change was NOT absorbed ("" if it was). */
+int  gs_plan_growths(gs_graph *g);
+const char *gs_growth_refusal(gs_graph *g);
 /* flat int32 dump of the plan, see csrc/gs_plan.hpp for the layout; call with out==NULL
  * to get the required length in *out_len. */
 int  gs_plan_export(gs_graph *g, int32_t *out, int64_t *out_len);

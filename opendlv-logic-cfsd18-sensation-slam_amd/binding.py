@@ -52,7 +52,7 @@ class Stats(C.Structure):
                 ("factor_flops", C.c_int64), ("factor_bytes", C.c_int64), ("ms_event_overhead", C.c_double),
                 ("fell_back", C.c_int32), ("first_failure", C.c_int32), ("factor_variant", C.c_int32), ("n_big_fronts", C.c_int32),
                 ("device_bytes", C.c_int64), ("n_own_fronts", C.c_int32), ("n_shared_fronts", C.c_int32), ("ms_plan_host", C.c_double),
-                ("ms_linearize_kernel", C.c_double)]
+                ("ms_linearize_kernel", C.c_double), ("n_growths", C.c_int32), ("reserved2", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -145,6 +145,7 @@ def lib():
     L.gs_time_iterations.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
     L.gs_plan_build_host.argtypes = [vp, C.POINTER(PlanInfo)]
     L.gs_plan_export.argtypes = [vp, _ip, C.POINTER(C.c_int64)]
+    L.gs_plan_growths.argtypes = [vp]; L.gs_growth_refusal.argtypes = [vp]; L.gs_growth_refusal.restype = C.c_char_p
     L.gs_polar_to_xy_batch.argtypes = [vp, C.c_int32, _dp, _dp, _dp, _dp]
     L.gs_cone_to_global_batch.argtypes = [vp, C.c_int32, _dp, C.c_int32, _ip, _dp, _dp]
     L.gs_associate_batch.argtypes = [vp, C.c_int32, _dp, C.c_int32, _ip, _dp, C.c_int32, _dp, _ip,
@@ -395,6 +396,14 @@ class Graph:
     # ---- host-only plan (no device work)
     def plan_build_host(self):
         info = PlanInfo(); self._check(self.L.gs_plan_build_host(self.h, C.byref(info))); return info
+
+    def plan_growths(self):
+        """append-only growth steps the current plan has absorbed (0: the plan is a full build)"""
+        return self._check(self.L.gs_plan_growths(self.h))
+
+    def growth_refusal(self):
+        """why the last structure change was not absorbed by growing the plan ('' if it was)"""
+        return self.L.gs_growth_refusal(self.h).decode()
 
     def plan_export(self):
         n = C.c_int64(0)

@@ -64,6 +64,7 @@ static void dev_free_all(gs_graph *g) {
     g->pool_base = nullptr; g->pool_size = g->pool_off = 0; g->pool_next = 0; g->pool_total = 0;
     g->d = DevGraph();
     g->dev_valid = false;
+    g->room = gs_graph::GrowRoom(); g->d_bf = g->d_xrow = g->d_patch = g->d_list = nullptr;
 }
 
 static int ensure_device(gs_graph *g) {
@@ -169,7 +170,7 @@ extern "C" int gs_add_landmark(gs_graph *g, int32_t id, const double est[2]) {
     int rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
     g->h.lm_index[id] = g->h.n_lms();
     g->h.lm_id.push_back(id); g->h.lm_est.insert(g->h.lm_est.end(), est, est + 2); g->h.lm_fixed.push_back(0);
-    ++g->h.structure_version;
+    ++g->h.structure_version; ++g->h.reshape_version;
     return GS_OK;
 }
 static bool sym_ok(const double *m, int n) {
@@ -233,7 +234,7 @@ extern "C" int gs_set_fixed_pose(gs_graph *g, int32_t id, int32_t fixed) {
     auto a = g->h.pose_index.find(id);
     if (a == g->h.pose_index.end()) return fail(GS_ERR_UNKNOWN_ID, "unknown pose id");
     uint8_t f = fixed != 0;
-    if (g->h.pose_fixed[a->second] != f) { g->h.pose_fixed[a->second] = f; ++g->h.structure_version; }
+    if (g->h.pose_fixed[a->second] != f) { g->h.pose_fixed[a->second] = f; ++g->h.structure_version; ++g->h.reshape_version; }
     return GS_OK;
 }
 extern "C" int gs_set_fixed_landmark(gs_graph *g, int32_t id, int32_t fixed) {
@@ -241,7 +242,7 @@ extern "C" int gs_set_fixed_landmark(gs_graph *g, int32_t id, int32_t fixed) {
     auto a = g->h.lm_index.find(id);
     if (a == g->h.lm_index.end()) return fail(GS_ERR_UNKNOWN_ID, "unknown landmark id");
     uint8_t f = fixed != 0;
-    if (g->h.lm_fixed[a->second] != f) { g->h.lm_fixed[a->second] = f; ++g->h.structure_version; }
+    if (g->h.lm_fixed[a->second] != f) { g->h.lm_fixed[a->second] = f; ++g->h.structure_version; ++g->h.reshape_version; }
     return GS_OK;
 }
 extern "C" int gs_set_pose_estimate(gs_graph *g, int32_t id, const double est[3]) {
@@ -267,7 +268,7 @@ extern "C" int gs_set_landmark_estimate(gs_graph *g, int32_t id, const double es
 static int pull_estimates_if_needed(gs_graph *g) {
     if (!g->dev_valid || !g->dev_estimates_newer) return GS_OK;
     int rc = ensure_device(g); if (rc != GS_OK) return rc;
-    const int N = g->d.N, M = g->d.M;
+    const int N = g->d.N + g->d.tN, M = g->d.M;          // (tail poses of a grown plan follow the base ones in the same array)
     if (N > 0) HIP_TRY(hipMemcpyAsync(g->h.pose_est.data(), g->d.pose_est, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
     if (M > 0) HIP_TRY(hipMemcpyAsync(g->h.lm_est.data(), g->d.lm_est, (size_t)M * 2 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
@@ -378,10 +379,13 @@ static int upload_raw_begin(gs_graph *g, RawUpload &R) {
     const HostGraph &h = g->h; DevGraph &d = g->d;
     const size_t N = h.n_poses(), M = h.n_lms(), Epp = h.n_pp(), Epl = h.n_pl();
     int rc;
-    if ((rc = dev_alloc(g, &d.pose_est, N * 3)) != GS_OK || (rc = dev_alloc(g, &d.lm_est, M * 2)) != GS_OK ||
-        (rc = dev_alloc(g, &d.pose_fixed, N)) != GS_OK || (rc = dev_alloc(g, &d.lm_fixed, M)) != GS_OK ||
-        (rc = dev_alloc(g, &d.pose_cs, N * 2)) != GS_OK || (rc = dev_alloc(g, &d.pp_zinv, Epp * 5)) != GS_OK ||
-        (rc = dev_alloc(g, &d.pp_info, Epp * 6)) != GS_OK) return rc;
+    // room for the tail of a grown plan (gs::grow_plan) behind the per-pose and per-odometry-edge arrays
+    const size_t TP = TAIL_POSES, TPP = TAIL_PP;
+    if ((rc = dev_alloc(g, &d.pose_est, (N + TP) * 3)) != GS_OK || (rc = dev_alloc(g, &d.lm_est, M * 2)) != GS_OK ||
+        (rc = dev_alloc(g, &d.pose_fixed, N + TP)) != GS_OK || (rc = dev_alloc(g, &d.lm_fixed, M)) != GS_OK ||
+        (rc = dev_alloc(g, &d.pose_cs, (N + TP) * 2)) != GS_OK || (rc = dev_alloc(g, &d.pp_zinv, (Epp + TPP) * 5)) != GS_OK ||
+        (rc = dev_alloc(g, &d.pp_info, (Epp + TPP) * 6)) != GS_OK) return rc;
+    HIP_TRY(hipMemsetAsync(d.pose_fixed + N, 0, TP, g->stream));
     // the observation edges as inserted travel now only on a single GPU; a pose-window shard uploads the ones it evaluates, in
     // device layout, once the plan says which they are (upload_graph)
     const bool raw_pl = g->world <= 1;
@@ -425,7 +429,10 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
         for (int p = 0; p < N; ++p) { cs[2 * (size_t)p] = std::cos(h.pose_est[3 * (size_t)p + 2]); cs[2 * (size_t)p + 1] = std::sin(h.pose_est[3 * (size_t)p + 2]); }
         HIP_TRY(hipMemcpyAsync(d.pose_cs, cs.data(), cs.size() * sizeof(double), hipMemcpyHostToDevice, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream)); }
-    UP(pose_gidx, P.pose_gidx); UP(lm_gidx, P.lm_gidx);
+    g->room = gs_graph::GrowRoom(); d.tN = d.tEpp = d.tEpl = 0; d.tcapN = TAIL_POSES; d.tcapEpp = TAIL_PP; d.tcapEpl = TAIL_PL;
+    if ((rc = dev_alloc(g, &d.pose_gidx, (size_t)N + TAIL_POSES)) != GS_OK) return rc;              // (room for a grown plan's tail poses)
+    if (N > 0) HIP_TRY(hipMemcpyAsync(d.pose_gidx, P.pose_gidx.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
+    UP(lm_gidx, P.lm_gidx);
     d.ell_T = P.ell_T; d.ell_R = P.ell_R; d.ell_len = P.ell_len; d.ell_p0 = P.ell_p0; d.ell_np = P.ell_np;
     { const size_t L = (size_t)P.ell_len;
       if ((rc = dev_alloc(g, &d.ell_l, L)) != GS_OK || (rc = dev_alloc(g, &d.ell_z, 2 * L)) != GS_OK || (rc = dev_alloc(g, &d.ell_w, 3 * L)) != GS_OK) return rc;
@@ -460,20 +467,24 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
         d.wt_lo = P.wt_lo; d.wt_hi = P.wt_hi;                             // the wave tiles this shard has any edge in (gs_plan.cpp)
     } else if (P.world > 1) return fail(GS_ERR_INVALID, "pose-window shards need the fused linearisation layout (<= 32 observations per pose)");
     // block-sparse H and b live in ONE arena (the variant-3 front assembly addresses every scalar by its offset in it)
-    int64_t arena_off[8], arena_doubles = 0;
-    { const int64_t sizes[7] = {(int64_t)N * 6, (int64_t)N * 3, (int64_t)Epp * 9, (int64_t)P.ell_len * 6, (int64_t)d.n_groups * 5, (int64_t)M * 3, (int64_t)M * 2};
+    int64_t arena_off[12], arena_doubles = 0;
+    { // (the last four parts: the blocks of a grown plan's tail — diagonal blocks and rhs of tail poses, off-diagonal blocks of tail edges)
+      const int64_t sizes[11] = {(int64_t)N * 6, (int64_t)N * 3, (int64_t)Epp * 9, (int64_t)P.ell_len * 6, (int64_t)d.n_groups * 5, (int64_t)M * 3, (int64_t)M * 2,
+                                 (int64_t)TAIL_POSES * 6, (int64_t)TAIL_POSES * 3, (int64_t)TAIL_PP * 9, (int64_t)TAIL_PL * 6};
       arena_off[0] = 0;
-      for (int k = 0; k < 7; ++k) arena_off[k + 1] = arena_off[k] + ((sizes[k] + 1) & ~(int64_t)1);       // 16-byte aligned parts
-      if (arena_off[7] >= ((int64_t)1 << 31)) return fail(GS_ERR_INVALID, "graph too large for 32-bit arena offsets");
-      arena_doubles = arena_off[7];
-      AL(H_arena, (size_t)arena_off[7] + 2);
+      for (int k = 0; k < 11; ++k) arena_off[k + 1] = arena_off[k] + ((sizes[k] + 1) & ~(int64_t)1);       // 16-byte aligned parts
+      if (arena_off[11] >= ((int64_t)1 << 31)) return fail(GS_ERR_INVALID, "graph too large for 32-bit arena offsets");
+      arena_doubles = arena_off[11];
+      AL(H_arena, (size_t)arena_off[11] + 2);
       // blocks of edges / tiles this rank never evaluates must read as zero
-      ZERO(H_arena, (size_t)arena_off[7] + 2);
+      ZERO(H_arena, (size_t)arena_off[11] + 2);
+      d.t_Hpp_diag = d.H_arena + arena_off[7]; d.t_b_pose = d.H_arena + arena_off[8]; d.t_Hpp_off = d.H_arena + arena_off[9]; d.t_Hpl = d.H_arena + arena_off[10];
+      AL(t_pp_ij, (size_t)TAIL_PP * 2); AL(t_pl, (size_t)TAIL_PL * 2); AL(t_pl_z, (size_t)TAIL_PL * 2); AL(t_pl_w, (size_t)TAIL_PL * 3);
       // (the fused linearisation kernel stores Hpp_diag's 6 planes and b_pose's 3 as 9 contiguous planes: 6N is even, no padding between)
       d.Hpp_diag = d.H_arena + arena_off[0]; d.b_pose = d.H_arena + arena_off[1]; d.Hpp_off = d.H_arena + arena_off[2];
       d.Hpl = d.H_arena + arena_off[3]; d.lm_part = d.H_arena + arena_off[4]; d.Hll_diag = d.H_arena + arena_off[5]; d.b_lm = d.H_arena + arena_off[6]; }
     d.n_chi2_partial = std::max((N + 255) / 256, d.n_wtiles);
-    AL(chi2_partial, d.n_chi2_partial); AL(chi2, 80); ZERO(chi2_partial, d.n_chi2_partial);
+    AL(chi2_partial, d.n_chi2_partial + 1); AL(chi2, 80); ZERO(chi2_partial, d.n_chi2_partial + 1);     // (+1: the partial of a grown plan's tail)
     UP(pose_known, P.pose_known); UP(lm_known, P.lm_known);
     GS_UT("tiles+arena");
     // plan
@@ -483,7 +494,16 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
           o.asm_dup = F.asm_dup; o.child_off = F.child_off; o.child_cnt = F.child_cnt; o.owner = F.owner; o.level = F.level; o.pad0 = 0;
           o.bnd_off = F.bnd_off; o.map_off = F.map_off; o.L_off = F.L_off; o.U_off = F.U_off; }
       UP(fronts, df); d.n_fronts = (int32_t)df.size(); }
-    UP(bnd_rows, P.bnd_rows); UP(child_map, P.child_map); UP(children, P.children);
+    // boundary rows, child maps and assembly records with room behind them: a growth step re-writes the runs of the fronts it changes there
+    constexpr size_t ROOM_ROWS = 64 * 1024, ROOM_RECS = 96 * 1024;
+    { auto up_room = [&](int32_t **dst, const int32_t *src, size_t n, size_t room) -> int {
+          int r2 = dev_alloc(g, dst, n + room); if (r2 != GS_OK) return r2;
+          if (n) { hipError_t e = hipMemcpyAsync(*dst, src, n * sizeof(int32_t), hipMemcpyHostToDevice, g->stream); if (e != hipSuccess) return fail(GS_ERR_HIP, hipGetErrorString(e)); }
+          return GS_OK; };
+      if ((rc = up_room(&d.bnd_rows, P.bnd_rows.data(), P.bnd_rows.size(), ROOM_ROWS)) != GS_OK) return rc;
+      if ((rc = up_room(&d.child_map, P.child_map.data(), P.child_map.size(), ROOM_ROWS)) != GS_OK) return rc;
+      g->room.cap_bnd = (int64_t)(P.bnd_rows.size() + ROOM_ROWS); g->room.cap_map = (int64_t)(P.child_map.size() + ROOM_ROWS); }
+    UP(children, P.children);
     { std::vector<int32_t> cd(P.children.size() * 4);
       for (size_t q = 0; q < P.children.size(); ++q) { const Front &C = P.fronts[P.children[q]];
           cd[4 * q] = P.children[q]; cd[4 * q + 1] = C.npiv | (C.nbnd << 16); cd[4 * q + 2] = C.owner; cd[4 * q + 3] = (int32_t)C.map_off; }
@@ -497,10 +517,10 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
         d.xfail_off = P.exchange_doubles - 2;                             // the ranks' failure flags ride at the tail of the exchange buffer
         if (!g->exchange_external) { AL(exchange, P.exchange_doubles); ZERO(exchange, P.exchange_doubles); }
         else d.exchange = g->exchange; }
-    { std::vector<int32_t> recs(P.asm_recs.size() * 4);
-      for (size_t t = 0; t < P.asm_recs.size(); ++t) { recs[4 * t] = P.asm_recs[t].kind; recs[4 * t + 1] = P.asm_recs[t].src;
-          recs[4 * t + 2] = P.asm_recs[t].r0; recs[4 * t + 3] = P.asm_recs[t].c0; }
-      UP(asm_recs, recs); }
+    { static_assert(sizeof(AsmRec) == 16, "AsmRec is uploaded as 4 int32");
+      if ((rc = dev_alloc(g, &d.asm_recs, (P.asm_recs.size() + ROOM_RECS) * 4)) != GS_OK) return rc;
+      if (!P.asm_recs.empty()) HIP_TRY(hipMemcpyAsync(d.asm_recs, P.asm_recs.data(), P.asm_recs.size() * sizeof(AsmRec), hipMemcpyHostToDevice, g->stream));
+      g->room.cap_asm = (int64_t)(P.asm_recs.size() + ROOM_RECS); }
     GS_UT("plan arrays");
     // factor kernel variant (gs_config.factor_variant, GS_FACTOR_VARIANT overrides): 0 = default = 3 when every front
     // fits 63 scalars, else 4.  3 = wave-per-front LDL^T on the fp64 matrix cores, latency-shaped; 2 = wave-per-front
@@ -525,8 +545,12 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
             for (size_t f0 = 0; f0 < P.fronts.size(); ++f0) { const int nb = P.fronts[f0].nbnd;
                 u3_off[f0] = (int32_t)tot; u3_size[f0] = (nb * (nb + 1)) / 2 + nb; tot += ((u3_size[f0] + 2 + 1) & ~1);
                 if (tot >= ((int64_t)1 << 31)) return fail(GS_ERR_INVALID, "update-matrix arena beyond 32-bit offsets"); }
-            AL(Uimg, (size_t)tot + 2); ZERO(Uimg, (size_t)tot + 2); }
+            constexpr int64_t ROOM_U = (int64_t)1 << 20;          // doubles: the update matrices of fronts a growth step enlarges move here
+            if (tot + ROOM_U >= ((int64_t)1 << 31)) return fail(GS_ERR_INVALID, "update-matrix arena beyond 32-bit offsets");
+            AL(Uimg, (size_t)(tot + ROOM_U) + 2); ZERO(Uimg, (size_t)(tot + ROOM_U) + 2);
+            g->room.used_U = tot; g->room.cap_U = tot + ROOM_U; }
           UP(u3_off, u3_off); UP(u3_size, u3_size);
+          g->u3_off_host = u3_off; g->u3_size_host = u3_size;
           AL(done_f, P.fronts.size()); ZERO(done_f, P.fronts.size());
           d.epoch = 0; d.tree = 1; g->fell_back = false;              // whole-tree launches for this rank's own subtrees (GS_TREE=0: one launch per level)
           if (const char *e = std::getenv("GS_TREE")) d.tree = std::atoi(e) != 0 ? 1 : 0;
@@ -534,8 +558,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
           const bool fused = P.lin_ell_ok && d.n_wtiles > 0;
           // block assembly records: the plan's, as they are (AsmRec = 4 ints); landmark-diagonal records of the fused
           // linearisation get their partial-slot range patched in by a kernel
-          static_assert(sizeof(AsmRec) == 16, "AsmRec is uploaded as 4 int32");
-          if ((rc = dev_alloc(g, &d.asm3, P.asm_recs.size() * 4)) != GS_OK) return rc;
+          if ((rc = dev_alloc(g, &d.asm3, (P.asm_recs.size() + ROOM_RECS) * 4)) != GS_OK) return rc;
           if (!P.asm_recs.empty()) HIP_TRY(hipMemcpyAsync(d.asm3, P.asm_recs.data(), P.asm_recs.size() * sizeof(AsmRec), hipMemcpyHostToDevice, g->stream));
           if (fused) { for (int l = 0; l < M; ++l) if (P.lm_grp_start[l + 1] - P.lm_grp_start[l] >= (1 << 22)) return fail(GS_ERR_INVALID, "landmark seen from too many wave tiles");
               launch_patch_asm3((int64_t)P.asm_recs.size(), d.asm3, d.lm_grp_start, g->stream); }
@@ -554,10 +577,17 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
             for (size_t sidx = 0; sidx < S; ++sidx) { const Front &F = P.fronts[sidx]; int32_t *r = &bf[8 * sidx];
                 if (so >= ((int64_t)1 << 31) - 64) return fail(GS_ERR_INVALID, "too many assembly scalars");
                 r[0] = F.asm_off; r[1] = F.asm_cnt - F.asm_dup; r[2] = F.npiv + F.nbnd; r[3] = (int32_t)so; r[5] = (int32_t)lo; so += r[4]; lo += r[6]; }
-            AL(sc3, 2 * (size_t)so + 2); AL(lm3, 4 * (size_t)lo + 4);
+            constexpr int64_t ROOM_SC = (int64_t)1 << 19;         // scalar records of the fronts a growth step rebuilds
+            if (so + ROOM_SC >= ((int64_t)1 << 31) - 64) return fail(GS_ERR_INVALID, "too many assembly scalars");
+            AL(sc3, 2 * (size_t)(so + ROOM_SC) + 2); AL(lm3, 4 * (size_t)lo + 4);
+            g->room.used_sc = so; g->room.cap_sc = so + ROOM_SC;
             int32_t *bf_dev = nullptr; if ((rc = dev_upload(g, &bf_dev, bf)) != GS_OK) return rc;
+            g->d_bf = bf_dev; g->bf_host = bf;
             Sc3Args A; for (int k = 0; k < 8; ++k) A.off[k] = arena_off[k];
             A.L = P.ell_len; A.N = N; A.M = M; A.Epp = Epp; A.fused = fused ? 1 : 0;
+            for (int k = 0; k < 4; ++k) A.toff[k] = arena_off[7 + k];
+            A.tcapN = TAIL_POSES; A.tcapEpp = TAIL_PP; A.tcapEpl = TAIL_PL; A.pad = 0;
+            g->sc3_args = A;
             launch_build_sc3(bf_dev, d.asm3, d.sc3, d.lm3, (int)S, A, g->stream);
             GS_UT("sc3 build");
             // descriptors + children tables: one wave per level position (k_build_f3)
@@ -566,19 +596,28 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
             for (size_t q = 0; q < lf.size(); ++q) { xrow[q + 1] = xrow[q] + d.f3x_stride * P.fronts[lf[q]].child_cnt;
                 if (xrow[q + 1] >= (1 << 30)) return fail(GS_ERR_INVALID, "children table too large"); }
             int32_t *xrow_dev = nullptr; if ((rc = dev_upload(g, &xrow_dev, xrow)) != GS_OK) return rc;
+            g->d_xrow = xrow_dev;
+            g->pos_of_front.assign(P.fronts.size(), -1);
+            for (size_t q = 0; q < lf.size(); ++q) g->pos_of_front[lf[q]] = (int32_t)q;
+            if ((rc = dev_alloc(g, &g->d_patch, (size_t)1024 * 32)) != GS_OK || (rc = dev_alloc(g, &g->d_list, (size_t)2048)) != GS_OK) return rc;
             AL(f3_desc, lf.size() * (size_t)F3W); AL(f3_x, (size_t)xrow[lf.size()] + 168);
             launch_build_f3((int)lf.size(), d.level_fronts, d.fronts, d.children, d.child_map, d.u3_off, d.u3_size, bf_dev, xrow_dev,
                             P.world > 1 ? d.x_off : nullptr, d.f3_desc, d.f3_x, d.f3x_stride, g->stream);
+            // a growth step needs all of the above: variant 3, one GPU, every front on a wave, the fused linearisation layout
+            g->room.ok = P.world == 1 && P.max_front <= 63 && fused;
             GS_UT("f3 tables"); }
       } }
     GS_UT("f3 x+desc upload");
     AL(dbg_ts, 64); ZERO(dbg_ts, 64);
     AL(done_ts, 2 * P.fronts.size() + 2); ZERO(done_ts, 2 * P.fronts.size() + 2);
-    AL(Lbuf, P.l_doubles); AL(Ubuf, (d.factor_variant == 0 || d.factor_variant == 1) ? P.u_doubles : 1);      // variants 2 and 3 keep their update matrices in Uimg
-    AL(xe, P.n_scalar); AL(dpose, (size_t)N * 3); AL(dlm, (size_t)M * 2); AL(fail, 4);
+    { const int64_t room_L = g->room.ok ? ((int64_t)2 << 20) : 0;          // doubles: the L panels of fronts a growth step enlarges move here
+      AL(Lbuf, P.l_doubles + room_L); g->room.cap_L = P.l_doubles + room_L; }
+    AL(Ubuf, (d.factor_variant == 0 || d.factor_variant == 1) ? P.u_doubles : 1);      // variants 2 and 3 keep their update matrices in Uimg
+    AL(xe, P.n_scalar + 3 * TAIL_POSES); g->room.cap_xe = P.n_scalar + 3 * TAIL_POSES;
+    AL(dpose, ((size_t)N + TAIL_POSES) * 3); AL(dlm, (size_t)M * 2); AL(fail, 4);
     HIP_TRY(hipMemsetAsync(d.fail, 0, 4 * sizeof(int32_t), g->stream));
     HIP_TRY(hipMemsetAsync(d.chi2, 0, 80 * sizeof(double), g->stream));
-    HIP_TRY(hipMemsetAsync(d.dpose, 0, std::max<size_t>((size_t)N * 3, 1) * sizeof(double), g->stream));
+    HIP_TRY(hipMemsetAsync(d.dpose, 0, ((size_t)N + TAIL_POSES) * 3 * sizeof(double), g->stream));
     HIP_TRY(hipMemsetAsync(d.dlm, 0, std::max<size_t>((size_t)M * 2, 1) * sizeof(double), g->stream));
     // per-level launch parameters and the global workspace for fronts beyond the LDS limit
     const int nlev = (int)P.level_start.size() - 1;
@@ -612,6 +651,95 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
     return GS_OK;
 }
 
+// ---- append-only growth on the device (after gs::grow_plan changed the host plan): the new poses' and edges' data into the tail
+// arrays, the re-written runs of the changed fronts behind the plan arrays, those fronts' rows of the compact tables through one
+// patch buffer, then the device-side expansion (k_build_sc3, k_build_f3) for those fronts only.  Everything older stays where it
+// is.  Returns GS_ERR_CAPACITY when the room left by the full structure phase is used up (the caller rebuilds).
+static int upload_growth(gs_graph *g, const Growth &gr) {
+    const HostGraph &h = g->h; const Plan &P = g->plan; DevGraph &d = g->d;
+    if (!g->room.ok || d.factor_variant != 3) return fail(GS_ERR_CAPACITY, "growth: this plan was not uploaded with room to grow");
+    const int nf = (int)gr.fronts.size();
+    if (nf > 1024 || (int64_t)P.bnd_rows.size() > g->room.cap_bnd || (int64_t)P.child_map.size() > g->room.cap_map ||
+        (int64_t)P.asm_recs.size() > g->room.cap_asm || P.l_doubles > g->room.cap_L || P.n_scalar > g->room.cap_xe)
+        return fail(GS_ERR_CAPACITY, "growth: room behind the plan arrays used up");
+    const bool fused = g->sc3_args.fused != 0;
+    // update-matrix slots and scalar-record runs of the changed fronts
+    std::vector<int32_t> patch((size_t)nf * 32, 0), poslist(nf);
+    int64_t used_U = g->room.used_U, used_sc = g->room.used_sc;
+    for (int i = 0; i < nf; ++i) { const int s = gr.fronts[i]; const Front &F = P.fronts[s]; int32_t *r = &patch[(size_t)i * 32];
+        const int nb = F.nbnd; const int32_t usz = (nb * (nb + 1)) / 2 + nb;
+        int ns = 0;
+        for (int t = F.asm_off; t < F.asm_off + F.asm_cnt - F.asm_dup; ++t) { const int k = P.asm_recs[t].kind;
+            if (k == 0) ns += 9; else if (k == 1) { if (!fused) ns += 5; } else if (k <= 3) ns += 9; else ns += 6; }
+        const int32_t sc_cnt = (ns + 63) & ~63;
+        if (used_U + usz + 4 > g->room.cap_U || used_sc + sc_cnt > g->room.cap_sc) return fail(GS_ERR_CAPACITY, "growth: room behind the update matrices / scalar records used up");
+        DevFront o; o.npiv = F.npiv; o.nbnd = F.nbnd; o.piv0 = F.piv0; o.parent = F.parent; o.asm_off = F.asm_off; o.asm_cnt = F.asm_cnt;
+        o.asm_dup = F.asm_dup; o.child_off = F.child_off; o.child_cnt = F.child_cnt; o.owner = F.owner; o.level = F.level; o.pad0 = 0;
+        o.bnd_off = F.bnd_off; o.map_off = F.map_off; o.L_off = F.L_off; o.U_off = F.U_off;
+        r[0] = s; std::memcpy(r + 1, &o, sizeof(o));
+        r[21] = (int32_t)used_U; r[22] = usz; used_U += (usz + 2 + 1) & ~1;
+        const int32_t *b0 = &g->bf_host[8 * (size_t)s];
+        r[23] = F.asm_off; r[24] = F.asm_cnt - F.asm_dup; r[25] = F.npiv + F.nbnd; r[26] = (int32_t)used_sc; r[27] = sc_cnt; r[28] = b0[5]; r[29] = b0[6]; r[30] = 0;
+        used_sc += sc_cnt;
+        poslist[i] = g->pos_of_front[s];
+        if (poslist[i] < 0) return fail(GS_ERR_INVALID, "growth: front without a level position"); }
+    // ---- from here on the device changes
+    const int N0 = gr.first_pose, N1 = P.planned_N, E0 = gr.first_pp, E1 = P.planned_Epp, K0 = gr.first_pl, K1 = P.planned_Epl;
+    std::vector<double> zinv((size_t)(E1 - E0) * 5), plz((size_t)(K1 - K0) * 2), plw((size_t)(K1 - K0) * 3);
+    std::vector<int32_t> ppij((size_t)(E1 - E0) * 2), plpl((size_t)(K1 - K0) * 2);
+    auto H2D = [&](void *dst, const void *src, size_t bytes) -> int {
+        if (!bytes) return GS_OK;
+        hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g->stream);
+        return e == hipSuccess ? GS_OK : fail(GS_ERR_HIP, std::string("growth upload: ") + hipGetErrorString(e)); };
+    int rc;
+    if ((rc = H2D(d.pose_est + 3 * (size_t)N0, &h.pose_est[3 * (size_t)N0], (size_t)(N1 - N0) * 3 * sizeof(double))) != GS_OK) return rc;
+    if ((rc = H2D(d.pose_gidx + N0, &P.pose_gidx[N0], (size_t)(N1 - N0) * sizeof(int32_t))) != GS_OK) return rc;
+    launch_pose_trig_range(d, N0, N1 - N0, g->stream);
+    for (int k = E0; k < E1; ++k) { double inv[3]; se2_inverse_host(&h.pp_z[3 * (size_t)k], inv);
+        double *o = &zinv[5 * (size_t)(k - E0)]; o[0] = inv[0]; o[1] = inv[1]; o[2] = inv[2]; o[3] = std::cos(inv[2]); o[4] = std::sin(inv[2]);
+        ppij[2 * (size_t)(k - E0)] = h.pp_i[k]; ppij[2 * (size_t)(k - E0) + 1] = h.pp_j[k]; }
+    if ((rc = H2D(d.pp_zinv + 5 * (size_t)E0, zinv.data(), zinv.size() * sizeof(double))) != GS_OK) return rc;
+    if ((rc = H2D(d.pp_info + 6 * (size_t)E0, &h.pp_info[6 * (size_t)E0], (size_t)(E1 - E0) * 6 * sizeof(double))) != GS_OK) return rc;
+    if ((rc = H2D(d.t_pp_ij + 2 * (size_t)(E0 - P.base_Epp), ppij.data(), ppij.size() * sizeof(int32_t))) != GS_OK) return rc;
+    for (int k = K0; k < K1; ++k) { const size_t q = (size_t)(k - K0);
+        plpl[2 * q] = h.pl_p[k]; plpl[2 * q + 1] = h.pl_l[k]; plz[2 * q] = h.pl_z[2 * (size_t)k]; plz[2 * q + 1] = h.pl_z[2 * (size_t)k + 1];
+        for (int c = 0; c < 3; ++c) plw[3 * q + c] = h.pl_info[3 * (size_t)k + c]; }
+    { const size_t s0 = (size_t)(K0 - P.base_Epl);
+      if ((rc = H2D(d.t_pl + 2 * s0, plpl.data(), plpl.size() * sizeof(int32_t))) != GS_OK) return rc;
+      if ((rc = H2D(d.t_pl_z + 2 * s0, plz.data(), plz.size() * sizeof(double))) != GS_OK) return rc;
+      if ((rc = H2D(d.t_pl_w + 3 * s0, plw.data(), plw.size() * sizeof(double))) != GS_OK) return rc; }
+    // the re-written runs
+    if ((rc = H2D(d.bnd_rows + gr.bnd_from, &P.bnd_rows[(size_t)gr.bnd_from], (P.bnd_rows.size() - (size_t)gr.bnd_from) * sizeof(int32_t))) != GS_OK) return rc;
+    if ((rc = H2D(d.child_map + gr.map_from, &P.child_map[(size_t)gr.map_from], (P.child_map.size() - (size_t)gr.map_from) * sizeof(int32_t))) != GS_OK) return rc;
+    { const size_t na = P.asm_recs.size() - (size_t)gr.asm_from;
+      if (na) { if ((rc = H2D(d.asm_recs + 4 * gr.asm_from, &P.asm_recs[(size_t)gr.asm_from], na * sizeof(AsmRec))) != GS_OK) return rc;
+          if ((rc = H2D(d.asm3 + 4 * gr.asm_from, &P.asm_recs[(size_t)gr.asm_from], na * sizeof(AsmRec))) != GS_OK) return rc;
+          if (fused) launch_patch_asm3((int64_t)na, d.asm3 + 4 * gr.asm_from, d.lm_grp_start, g->stream); } }
+    // compact tables: the changed fronts' rows
+    if ((rc = H2D(g->d_patch, patch.data(), patch.size() * sizeof(int32_t))) != GS_OK) return rc;
+    launch_apply_front_patch(nf, g->d_patch, d.fronts, d.u3_off, d.u3_size, g->d_bf, g->stream);
+    if ((rc = H2D(g->d_list, gr.fronts.data(), (size_t)nf * sizeof(int32_t))) != GS_OK) return rc;
+    if ((rc = H2D(g->d_list + 1024, poslist.data(), (size_t)nf * sizeof(int32_t))) != GS_OK) return rc;
+    // device-side expansion for those fronts: scalar records, then descriptors + children tables (a changed front's parent is a
+    // changed front too: its copy of the child's row table is rebuilt with it)
+    launch_build_sc3(g->d_bf, d.asm3, d.sc3, d.lm3, nf, g->sc3_args, g->stream, g->d_list);
+    launch_build_f3(nf, d.level_fronts, d.fronts, d.children, d.child_map, d.u3_off, d.u3_size, g->d_bf, g->d_xrow, nullptr, d.f3_desc, d.f3_x, d.f3x_stride, g->stream, g->d_list + 1024);
+    d.n_scalar = P.n_scalar; d.tN = N1 - P.base_N; d.tEpp = E1 - P.base_Epp; d.tEpl = K1 - P.base_Epl;
+    HIP_TRY(hipStreamSynchronize(g->stream));                       // the staging vectors above go out of scope
+    { hipError_t e = hipGetLastError(); if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("growth: ") + hipGetErrorString(e)); }
+    // host mirrors and launch parameters
+    for (int i = 0; i < nf; ++i) { const int s = gr.fronts[i]; const int32_t *r = &patch[(size_t)i * 32];
+        g->u3_off_host[s] = r[21]; g->u3_size_host[s] = r[22]; for (int c = 0; c < 8; ++c) g->bf_host[8 * (size_t)s + c] = r[23 + c]; }
+    g->room.used_U = used_U; g->room.used_sc = used_sc;
+    { gs_graph::LevelSet &ls = g->own; const int nlev = (int)ls.start.size() - 1;
+      for (int l = 0; l < nlev; ++l) { ls.max_f[l] = ls.max_npiv[l] = ls.max_nbnd[l] = 0;
+          for (int q = ls.start[l]; q < ls.start[l + 1]; ++q) { const Front &F = P.fronts[P.level_fronts_owned[q]];
+              ls.max_f[l] = std::max(ls.max_f[l], F.npiv + F.nbnd); ls.max_npiv[l] = std::max(ls.max_npiv[l], F.npiv); ls.max_nbnd[l] = std::max(ls.max_nbnd[l], F.nbnd); } } }
+    g->leaf_n = -1; g->block_n = -1;                                // the leaf instance and its LDS slot are chosen again from the grown fronts
+    g->dev_estimate_version = h.estimate_version;
+    return GS_OK;
+}
+
 // The factor kernel a plan gets (gs_config.factor_variant, GS_FACTOR_VARIANT overrides): 0 = default = 3.
 //   3 = wave-per-front LDL^T on the fp64 matrix cores, latency-shaped; 2 = wave-per-front Cholesky on the matrix cores (first
 //   version); 1 = wave-per-front VALU; 4 = block-per-front VALU (any front size, 64-bit addressing throughout).
@@ -634,6 +762,7 @@ static int build_plan_host(gs_graph *g) {
     if (const char *e = std::getenv("GS_CLUSTER_WAYS")) o.cluster_ways = std::atoi(e);   // tuning override: 2 = binary dissection down to the leaves
     if (const char *e = std::getenv("GS_ELL_LANES")) o.ell_lanes = std::atoi(e);       // tuning knob: lanes per pose of the ELL layout
     if (const char *e = std::getenv("GS_BIG_CLUSTER")) o.big_cluster_front = std::atoi(e);   // tuning override: 0 = clusters only where they fit a wave
+    if (const char *e = std::getenv("GS_GROW_HEADROOM")) o.grow_headroom = std::atoi(e);   // tuning override: 0 = cluster fronts up to the full 63 scalars
     std::string err;
     if (!build_plan(g->h, o, g->plan, err)) { g->plan_version = ~0ull; return fail(GS_ERR_EMPTY, "plan: " + err); }
     g->plan_version = g->h.structure_version;
@@ -642,7 +771,17 @@ static int build_plan_host(gs_graph *g) {
 
 extern "C" int gs_plan_build_host(gs_graph *g, gs_plan_info *info) {
     if (!g) return fail(GS_ERR_INVALID, "null graph");
-    int rc = build_plan_host(g); if (rc != GS_OK) return rc;
+    int rc = GS_OK;
+    // a host-only handle absorbs appended poses / edges the way a device handle does (gs::grow_plan), so that the grown plan can be
+    // inspected and replayed without a GPU; GS_GROW=0 or any other change: full build
+    bool grown = false;
+    if (g->host_only && g->plan.valid && g->plan_version != ~0ull && g->plan_version != g->h.structure_version) {
+        bool on = true; if (const char *e = std::getenv("GS_GROW")) on = std::atoi(e) != 0;
+        Growth gr; std::string why;
+        if (on && grow_plan(g->h, g->plan, gr, why)) { grown = true; g->plan_version = g->h.structure_version; g->no_growth_reason.clear(); }
+        else g->no_growth_reason = on ? why : "GS_GROW=0";
+    }
+    if (!grown) { rc = build_plan_host(g); if (rc != GS_OK) return rc; }
     if (info) { const Plan &P = g->plan; info->n_scalar = P.n_scalar; info->n_fronts = (int32_t)P.fronts.size();
         info->n_levels = (int32_t)P.level_start.size() - 1; info->max_front = P.max_front; info->l_doubles = P.l_doubles;
         info->u_doubles = P.u_doubles; info->n_asm_blocks = (int64_t)P.asm_recs.size(); info->n_child_map = (int64_t)P.child_map.size(); }
@@ -650,6 +789,8 @@ extern "C" int gs_plan_build_host(gs_graph *g, gs_plan_info *info) {
     if (g->dev_valid && !g->host_only) { hipSetDevice(g->device); hipStreamSynchronize(g->stream); pull_estimates_if_needed(g); dev_free_all(g); }
     return GS_OK;
 }
+extern "C" int gs_plan_growths(gs_graph *g) { return g ? g->plan.n_growths : fail(GS_ERR_INVALID, "null graph"); }
+extern "C" const char *gs_growth_refusal(gs_graph *g) { return g ? g->no_growth_reason.c_str() : ""; }
 extern "C" int gs_plan_export(gs_graph *g, int32_t *out, int64_t *out_len) {
     if (!g || !out_len) return fail(GS_ERR_INVALID, "null argument");
     if (!g->plan.valid) return fail(GS_ERR_NOT_INITIALIZED, "no plan built");
@@ -666,6 +807,22 @@ extern "C" int gs_initialize_optimization(gs_graph *g) {
     auto t0 = std::chrono::steady_clock::now();
     rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
     HIP_TRY(hipStreamSynchronize(g->stream));
+    // append-only growth: poses / edges added since the plan was built enter the existing plan and device tables (gs::grow_plan,
+    // upload_growth); anything else — or GS_GROW=0 — rebuilds
+    g->no_growth_reason.clear();
+    if (g->dev_valid && g->plan.valid && g->plan_version != ~0ull && g->plan_version != g->h.structure_version) {
+        bool on = true; if (const char *e = std::getenv("GS_GROW")) on = std::atoi(e) != 0;
+        Growth gr; std::string why;
+        if (!on) g->no_growth_reason = "GS_GROW=0";
+        else if (!g->room.ok) g->no_growth_reason = "plan uploaded without room to grow";
+        else if (grow_plan(g->h, g->plan, gr, why)) {
+            rc = upload_growth(g, gr);
+            if (rc == GS_OK) { g->plan_version = g->h.structure_version;
+                g->ms_structure = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                return GS_OK; }
+            g->no_growth_reason = g_last_error;                     // (the plan object is rebuilt from scratch below)
+        } else g->no_growth_reason = why;
+    }
     dev_free_all(g);
     RawUpload raw;
     rc = upload_raw_begin(g, raw); if (rc != GS_OK) { if (raw.th.joinable()) raw.th.join(); dev_free_all(g); return rc; }
@@ -682,7 +839,7 @@ static int ensure_ready(gs_graph *g) {
     int rc = ensure_device(g); if (rc != GS_OK) return rc;
     if (!g->dev_valid || g->plan_version != g->h.structure_version) return gs_initialize_optimization(g);
     if (g->dev_estimate_version != g->h.estimate_version) {      // host-side setEstimate since the upload
-        const int N = g->d.N, M = g->d.M;
+        const int N = g->d.N + g->d.tN, M = g->d.M;
         if (N > 0) HIP_TRY(hipMemcpyAsync(g->d.pose_est, g->h.pose_est.data(), (size_t)N * 3 * sizeof(double), hipMemcpyHostToDevice, g->stream));
         if (M > 0) HIP_TRY(hipMemcpyAsync(g->d.lm_est, g->h.lm_est.data(), (size_t)M * 2 * sizeof(double), hipMemcpyHostToDevice, g->stream));
         launch_pose_trig(g->d, g->stream);
@@ -817,6 +974,7 @@ static void enqueue_local(gs_graph *g, bool timed) {
     ++g->d.iter;                                                     // kernels see the iteration they belong to (fault injection, gs_debug_fail_at_iteration)
     if (timed) hipEventRecord(g->ev[0], g->stream);
     launch_linearize(g->d, g->stream, g->ev_lin[0], g->ev_lin[1]);   // (null outside gs_time_iterations' second pass)
+    launch_linearize_tail(g->d, g->stream);                          // a grown plan's tail (no launch without one)
     if (timed) hipEventRecord(g->ev[1], g->stream);
     enqueue_factor_levels(g, g->own, 0, 0);
     const int nshared = (int)g->plan.level_fronts_shared.size();
@@ -859,7 +1017,7 @@ static void fill_plan_stats(gs_graph *g, gs_stats *s) {
     s->factor_variant = g->dev_valid ? (g->d.factor_variant == 0 ? 4 : g->d.factor_variant) : 0;
     s->n_big_fronts = 0;
     for (const Front &F : P.fronts) s->n_big_fronts += (!F.opaque && F.npiv + F.nbnd > 63);
-    s->device_bytes = (int64_t)g->pool_total; s->ms_plan_host = P.ms_build;
+    s->device_bytes = (int64_t)g->pool_total; s->ms_plan_host = P.ms_build; s->n_growths = P.n_growths;
     s->n_own_fronts = (int32_t)P.level_fronts_owned.size(); s->n_shared_fronts = (int32_t)P.level_fronts_shared.size();
 }
 
@@ -958,6 +1116,7 @@ extern "C" int gs_linearize(gs_graph *g) {
     if (!g) return fail(GS_ERR_INVALID, "null graph");
     int rc = ensure_ready(g); if (rc != GS_OK) return rc;
     launch_linearize(g->d, g->stream);
+    launch_linearize_tail(g->d, g->stream);
     launch_linearize_finalize(g->d, g->stream);              // stand-alone pass: materialise H_ll, b_l, chi2 for export
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("linearize: ") + hipGetErrorString(e));
@@ -999,6 +1158,7 @@ extern "C" int gs_export_system(gs_graph *g, double *Hpp_diag, double *Hll_diag,
                                 double *b_pose, double *b_lm, int32_t *pp_order, int32_t *pl_order) {
     if (!g) return fail(GS_ERR_INVALID, "null graph");
     if (!g->dev_valid) return fail(GS_ERR_NOT_INITIALIZED, "nothing linearised yet");
+    if (g->d.tN > 0) return fail(GS_ERR_INVALID, "the plan has grown by appended poses: their blocks live in the tail arenas, which this export does not read (gs_initialize_optimization with GS_GROW=0 rebuilds)");
     int rc = ensure_device(g); if (rc != GS_OK) return rc;
     const DevGraph &d = g->d;
     // the device keeps these arrays structure-of-arrays (and the diagonal blocks packed symmetric); the
@@ -1027,7 +1187,7 @@ extern "C" int gs_export_delta(gs_graph *g, double *dpose, double *dlm) {
     if (!g) return fail(GS_ERR_INVALID, "null graph");
     if (!g->dev_valid) return fail(GS_ERR_NOT_INITIALIZED, "no iteration run yet");
     int rc = ensure_device(g); if (rc != GS_OK) return rc;
-    if (dpose && g->d.N) HIP_TRY(hipMemcpyAsync(dpose, g->d.dpose, (size_t)g->d.N * 3 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    if (dpose && g->d.N) HIP_TRY(hipMemcpyAsync(dpose, g->d.dpose, (size_t)(g->d.N + g->d.tN) * 3 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
     if (dlm && g->d.M) HIP_TRY(hipMemcpyAsync(dlm, g->d.dlm, (size_t)g->d.M * 2 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     return GS_OK;
@@ -1036,7 +1196,7 @@ extern "C" int gs_time_iterations(gs_graph *g, int32_t reps, gs_stats *s) {
     if (!g || !s || reps <= 0) return fail(GS_ERR_INVALID, "bad argument");
     if (g->world > 1) return fail(GS_ERR_INVALID, "sharded graph: time the two halves from the caller");
     int rc = ensure_ready(g); if (rc != GS_OK) return rc;
-    const int N = g->d.N, M = g->d.M;
+    const int N = g->d.N + g->d.tN, M = g->d.M;
     double *sp = nullptr, *sl = nullptr;                        // save estimates
     HIP_TRY(hipMalloc((void **)&sp, std::max<size_t>((size_t)N * 3, 1) * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&sl, std::max<size_t>((size_t)M * 2, 1) * sizeof(double)));
@@ -1294,7 +1454,7 @@ extern "C" int gs_frame_frontend(gs_graph *g, const double pose[3], const double
 // ------------------------------------------------------------------ multi-GPU
 extern "C" int gs_dist_configure(gs_graph *g, int32_t rank, int32_t world) {
     if (!g || world < 1 || rank < 0 || rank >= world) return fail(GS_ERR_INVALID, "bad rank/world");
-    g->rank = rank; g->world = world; ++g->h.structure_version;
+    g->rank = rank; g->world = world; ++g->h.structure_version; ++g->h.reshape_version;
     return GS_OK;
 }
 extern "C" int64_t gs_dist_exchange_doubles(gs_graph *g) { return (g && g->plan.valid) ? g->plan.exchange_doubles : 0; }

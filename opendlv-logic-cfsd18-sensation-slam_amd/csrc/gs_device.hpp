@@ -75,6 +75,15 @@ struct DevGraph {
     int32_t *f3_desc = nullptr, *asm3 = nullptr, *pinv = nullptr, *sc3 = nullptr, *lm3 = nullptr, *u3_off = nullptr, *u3_size = nullptr;
     int32_t *done_f = nullptr; int32_t epoch = 0, tree = 0;     // whole-tree factor launches: per-front completion flags (= epoch when done); the backward solve polls xe itself
     double *H_arena = nullptr;                                  // Hpp_diag | b_pose | Hpp_off | Hpl | lm_part | Hll_diag | b_lm, one allocation
+    // append-only growth (grow_plan): the TAIL — poses / edges added after the plan was built.  N, Epp, Epl and ell_len above stay the
+    // BASE counts (they are the plane strides of the H blocks and the extent of the linearisation layout); a tail pose p >= N uses
+    // slot p - N, a tail odometry edge k >= Epp slot k - Epp, a tail observation edge the virtual layout index ell_len + slot.
+    // pose_est / pose_cs / pose_fixed / pose_gidx / dpose / pp_zinv / pp_info / xe are allocated with room for the tail.
+    int32_t tN = 0, tEpp = 0, tEpl = 0;                         // tail counts (0: no tail, nothing below is touched)
+    int32_t tcapN = 0, tcapEpp = 0, tcapEpl = 0;                // plane strides of the tail blocks
+    int32_t *t_pp_ij = nullptr;                                 // [tcapEpp][2] endpoints of the tail odometry edges
+    int32_t *t_pl = nullptr; double *t_pl_z = nullptr, *t_pl_w = nullptr;    // [tcapEpl][2] {pose, landmark}, [tcapEpl][2], [tcapEpl][3]
+    double *t_Hpp_diag = nullptr, *t_b_pose = nullptr, *t_Hpp_off = nullptr, *t_Hpl = nullptr;   // [6][tcapN] [3][tcapN] [9][tcapEpp] [6][tcapEpl], inside H_arena
     // pose-window shards (world == 1: everything is "own", no exchange)
     int32_t rank = 0, wt_lo = 0, wt_hi = 0;                     // this shard sweeps wave tiles [wt_lo, wt_hi)
     uint8_t *pose_known = nullptr, *lm_known = nullptr;         // vertex estimates tracked by this rank
@@ -105,15 +114,22 @@ void launch_associate_grid(int n, const double *poses, const int32_t *pose_of_ob
                            const double *map_xy, const int32_t *map_type, double thr, double type_tol, double minx, double miny,
                            double inv_cell, int nx, int ny, const int32_t *cell_start, const int32_t *cell_items, int32_t *out, hipStream_t st);
 // structure phase on the device: expand the block assembly records into scalar / landmark records (k_build_sc3)
-struct Sc3Args { int64_t off[8]; int64_t L; int32_t N, M, Epp, fused; };
-void launch_build_sc3(const int32_t *bf, const int32_t *asm3, int32_t *sc3, int32_t *lm3, int n_fronts, const Sc3Args &A, hipStream_t st);
+struct Sc3Args { int64_t off[8]; int64_t L; int32_t N, M, Epp, fused;
+                 int64_t toff[4]; int32_t tcapN, tcapEpp, tcapEpl, pad; };     // tail blocks (grow_plan): arena offsets of t_Hpp_diag, t_b_pose, t_Hpp_off, t_Hpl; plane strides
+// list != nullptr: only the fronts list[0 .. n_fronts) (growth)
+void launch_build_sc3(const int32_t *bf, const int32_t *asm3, int32_t *sc3, int32_t *lm3, int n_fronts, const Sc3Args &A, hipStream_t st, const int32_t *list = nullptr);
+void launch_linearize_tail(const DevGraph &d, hipStream_t st);  // the tail's edges: their blocks into the tail arenas, their shares of old vertices' diagonal blocks added in place
+void launch_pose_trig_range(const DevGraph &d, int first, int count, hipStream_t st);
+// growth: per-front patch records {front, DevFront (20 ints), u3_off, u3_size, bf[8]} = 32 ints each -> fronts / u3_off / u3_size / bf
+void launch_apply_front_patch(int n, const int32_t *patch, DevFront *fronts, int32_t *u3_off, int32_t *u3_size, int32_t *bf, hipStream_t st);
 void launch_build_ell(int64_t L, const int32_t *ell_ins, const int32_t *raw_l, const double *raw_z, const double *raw_info,
                       const int32_t *pl_rank, int rank, int32_t *ell_l, double *ell_z, double *ell_w, hipStream_t st);
 void launch_frame_frontend(int k, const double *in, double lidar, int n_map, const double *map_xy, const int32_t *map_type,
                            double thr, double type_tol, int signed_type, double *out_z, double *out_g, int32_t *out_idx, hipStream_t st);
+// list != nullptr: only the level positions list[0 .. nq) (growth)
 void launch_build_f3(int nq, const int32_t *lf, const DevFront *fronts, const int32_t *children, const int32_t *child_map,
                      const int32_t *u3_off, const int32_t *u3_size, const int32_t *bf, const int32_t *xrow_off, const int64_t *x_off,
-                     int32_t *f3_desc, int32_t *f3_x, int x_stride, hipStream_t st);
+                     int32_t *f3_desc, int32_t *f3_x, int x_stride, hipStream_t st, const int32_t *list = nullptr);
 // plans that hold a front of more than 63 scalars: table-driven whole-tree launches (workgroup -> {level position, kind | count << 8})
 void launch_factor_tab(const DevGraph &d, const int2 *wgt, int n_wg, int leaf_launch_preceded, size_t lds_bytes, int cls, hipStream_t st);      // cls: 0 fronts of 64-79, 1 small fronts + 80-111, 2 fronts of 112-159
 void launch_backsolve_tab(const DevGraph &d, const int2 *wgt, int n_wg, int max_npiv_small, int max_f_small, size_t lds_bytes, int cls, hipStream_t st);   // cls: 0 small fronts (a wave each), 1 big fronts

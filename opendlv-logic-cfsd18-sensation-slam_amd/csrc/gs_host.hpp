@@ -36,6 +36,7 @@ struct HostGraph {
     std::vector<int32_t> pp_i, pp_j; std::vector<double> pp_z /*[E*3]*/, pp_info /*[E*6] xx xy xt yy yt tt*/;
     std::vector<int32_t> pl_p, pl_l; std::vector<double> pl_z /*[E*2]*/, pl_info /*[E*3] xx xy yy*/;
     uint64_t structure_version = 0;     // bumped by every change that invalidates the plan
+    uint64_t reshape_version = 0;       // bumped by the changes a plan cannot absorb by growing: a fixed flag flipped, a landmark added, clear()
     uint64_t estimate_version = 0;      // bumped by host-side estimate writes
 
     int n_poses() const { return (int)pose_id.size(); }
@@ -116,11 +117,36 @@ struct Plan {
     std::vector<int32_t> level_start_shared, level_fronts_shared;  // shared top by level
     std::vector<int64_t> x_off;             // front -> offset of its slot in the exchange buffer (-1 not shared)
     double ms_build = 0;
+    // ---- append-only growth (grow_plan): what the LINEARISATION LAYOUT above covers are the base counts; poses / edges beyond them
+    // form the tail (their blocks live in the tail arenas of the device, gs_device.hpp)
+    int32_t base_N = 0, base_Epp = 0, base_Epl = 0;      // counts build_plan saw
+    int32_t planned_N = 0, planned_Epp = 0, planned_Epl = 0;   // counts the plan covers now (base + tail)
+    int32_t n_growths = 0;                               // grow_plan calls since build_plan
+    uint64_t reshape_version = 0;                        // HostGraph::reshape_version the plan was built at
 };
+
+// Tail capacities (device arenas are sized for them at every full structure phase)
+constexpr int TAIL_POSES = 16, TAIL_PL = 512, TAIL_PP = 64;
+
+// What one grow_plan call changed (the device patch works from this)
+struct Growth {
+    std::vector<int32_t> fronts;            // fronts whose size, storage, records or maps changed (ascending = elimination order; the root last)
+    int64_t bnd_from = 0, map_from = 0, asm_from = 0;     // Plan::bnd_rows / child_map / asm_recs entries from these on are new
+    int32_t first_pose = 0, first_pp = 0, first_pl = 0;   // the poses / edges this call took in: [first, planned)
+};
+
+// Append-only growth of a built plan (reference src/slam.cpp:433-459, 537-550: one more pose vertex, its odometry edge, its
+// observation edges): the new poses become extra pivots of the ROOT front — eliminated last — and every front on the path from
+// a neighbour's front to the root gains them as boundary rows.  Only those fronts change; the elimination tree, the levels, the
+// order and the linearisation layout of everything older stay.  Returns false (with the reason) when the change is not of
+// that kind or does not fit (new landmark, fixed flag flipped, a front would exceed 63 scalars, tail capacity, sharded plan ...):
+// the caller rebuilds.
+bool grow_plan(const HostGraph &g, Plan &plan, Growth &out, std::string &why_not);
 
 struct PlanOptions { int leaf_poses = 8; int world = 1; int rank = 0; int ell_lanes = 0;
                      int cluster_ways = 0;         // fan-out of the multi-way split above the leaves (0 = default 8, <= 2 = binary all the way down)
-                     int big_cluster_front = 111; };   // second-pass bound of a cluster front when 63 scalars cannot be met (<= 63: off)
+                     int big_cluster_front = 111;      // second-pass bound of a cluster front when 63 scalars cannot be met (<= 63: off)
+                     int grow_headroom = 6; };         // scalars a cluster front stays below the 63 of a wave: room for the boundary rows of two appended poses (grow_plan)
 
 constexpr int LIN_R = 4;               // observation slots per lane handled by the fused linearisation kernel
 

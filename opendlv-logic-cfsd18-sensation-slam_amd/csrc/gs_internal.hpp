@@ -55,6 +55,13 @@ struct gs_graph {
     std::vector<int32_t> wg_f, wg_b;
     int2 *d_wg_f = nullptr, *d_wg_b = nullptr; int small_max_npiv = 0, small_max_f = 0;
     bool fell_back = false;                 // a whole-tree launch gave up on a flag: this handle uses one launch per level until the next plan
+    // append-only growth (gs::grow_plan): the full structure phase leaves room behind the plan's arrays; a growth step re-writes the
+    // changed fronts' runs there and rebuilds those fronts' device tables.  used_* = entries taken so far, cap_* = allocated.
+    struct GrowRoom { int64_t cap_bnd = 0, cap_map = 0, cap_asm = 0, cap_sc = 0, used_sc = 0, cap_L = 0, cap_U = 0, used_U = 0, cap_xe = 0; bool ok = false; } room;
+    int32_t *d_bf = nullptr, *d_xrow = nullptr, *d_patch = nullptr, *d_list = nullptr;      // per-front counts / children-table offsets (kept for growth), patch + list staging
+    std::vector<int32_t> bf_host, u3_off_host, u3_size_host, pos_of_front;                  // host mirrors the patch is computed from
+    gs::Sc3Args sc3_args{};
+    std::string no_growth_reason;           // why the last structure change was not absorbed by growing (empty: it was, or nothing tried)
 };
 
 namespace gs {

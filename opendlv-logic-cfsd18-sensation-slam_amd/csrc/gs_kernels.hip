@@ -256,7 +256,8 @@ template <class Tp> __device__ __forceinline__ void st_wt(Tp *ptr, Tp v) { __hip
 template <bool WRITE_H>
 __device__ __forceinline__ double pp_incidence(const DevGraph &d, int k, int role, const double xi[3], const double xj[3],
                                                double ci, double si, const double zinv5[5], const double w[6],
-                                               bool fi, bool fj, double H[6], double b[3]) {
+                                               bool fi, bool fj, double H[6], double b[3], double *hoff = nullptr, int64_t hoff_stride = 0) {
+    // (hoff: where the off-diagonal block of an owned edge goes, plane stride hoff_stride; default = the edge's slot of Hpp_off)
     // Structure of the EdgeSE2 Jacobians (g2o EdgeSE2::linearizeOplus): with M = rot(z^-1) * R_i^T = [[m0, m1], [-m1, m0]],
     //   B = [[m0, m1, 0], [-m1, m0, 0], [0, 0, 1]],   A = [-B(:,0), -B(:,1), a2],  a2 = (a02, a12, -1),
     // so with G = B^T W B and wa2 = W a2 everything needed is G (6), wa2 (3) and three dot products:
@@ -299,8 +300,8 @@ __device__ __forceinline__ double pp_incidence(const DevGraph &d, int k, int rol
             H[0] += g00; H[1] += g01; H[2] -= t0; H[3] += g11; H[4] -= t1; H[5] += t2;
             b[0] += bw0; b[1] += bw1; b[2] -= a02 * We0 + a12 * We1 - We2;
             const bool both = !fi && !fj;
-            const int64_t E = d.Epp;
-            double *o = d.Hpp_off + k;
+            const int64_t E = hoff ? hoff_stride : (int64_t)d.Epp;
+            double *o = hoff ? hoff : d.Hpp_off + k;
             ST_O(o, both ? -g00 : 0.0);         ST_O(o + E, both ? -g01 : 0.0);     ST_O(o + 2 * E, both ? -g02 : 0.0);
             ST_O(o + 3 * E, both ? -g01 : 0.0); ST_O(o + 4 * E, both ? -g11 : 0.0); ST_O(o + 5 * E, both ? -g12 : 0.0);
             ST_O(o + 6 * E, both ? t0 : 0.0);   ST_O(o + 7 * E, both ? t1 : 0.0);   ST_O(o + 8 * E, both ? wa2 : 0.0);
@@ -659,7 +660,7 @@ void launch_linearize_gather(const DevGraph &d, hipStream_t st) {
 // iteration the front assembly sums the landmark slots itself and k_update totals chi2)
 void launch_linearize_finalize(const DevGraph &d, hipStream_t st) {
     if (d.n_wtiles > 0)
-        hipLaunchKernelGGL(k_linearize_finalize, dim3(max(1, (d.M + 255) / 256)), dim3(256), 0, st, d, d.n_wtiles);
+        hipLaunchKernelGGL(k_linearize_finalize, dim3(max(1, (d.M + 255) / 256)), dim3(256), 0, st, d, d.n_wtiles + (d.tN > 0 ? 1 : 0));     // (+ the tail's partial)
 }
 // start / stop (optional): HIP events attached to THIS dispatch (hipExtLaunchKernelGGL) — the kernel's own begin and end as the
 // command processor stamps them, what a kernel trace reports; an event recorded before / after the launch also holds the
@@ -675,7 +676,91 @@ void launch_linearize(const DevGraph &d, hipStream_t st, hipEvent_t start, hipEv
         default: hipExtLaunchKernelGGL(k_linearize_ell<8>, grid, block, 0, st, start, stop, 0, d); break;
     }
 }
+// ---- the tail of a grown plan (grow_plan: poses and edges appended since the plan was built; reference src/slam.cpp:433-459,
+// 537-550 add exactly these).  ONE wave, after the main pass: per tail pose, in pose order, its observation edges on the lanes
+// (same quad_pl as the main kernel), the pose-side sums by a fixed-order wave reduction, then its odometry edges on lane 0.  What
+// lands where: a tail pose's diagonal block and rhs, the H_pl / off-diagonal H_pp blocks of tail edges -> the tail arenas (the
+// assembly records of the grown fronts point there); an edge's share of an OLD vertex's diagonal block and rhs (a landmark's
+// first partial-sum slot, a pose's H_pp / b entries) is ADDED in place, behind the main kernel's stores.  All adds to one address
+// come from successive steps of this one wave, through L2 atomics, a fence between steps: the order is fixed, the result
+// reproducible.  grow_plan guarantees that a tail pose sees a landmark at most once (no two lanes of a step on one address).
+__global__ void __launch_bounds__(64) k_linearize_tail(DevGraph d) {
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 6 * d.tcapN; i += 64) d.t_Hpp_diag[i] = 0.0;
+    for (int i = lane; i < 3 * d.tcapN; i += 64) d.t_b_pose[i] = 0.0;
+    __threadfence();
+    double chi = 0.0;
+    const int64_t G = d.n_groups;
+    for (int t = 0; t < d.tN; ++t) {
+        const int p = d.N + t;
+        const double px = d.pose_est[3 * p], py = d.pose_est[3 * p + 1];
+        const double2 cs = reinterpret_cast<const double2 *>(d.pose_cs)[p];
+        double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+        for (int e0 = 0; e0 < d.tEpl; e0 += 64) { const int e = e0 + lane;
+            if (e < d.tEpl && d.t_pl[2 * e] == p) {
+                const int l = d.t_pl[2 * e + 1];
+                PlQuad q;
+                quad_pl(px, py, cs.x, cs.y, d.lm_est[2 * l], d.lm_est[2 * l + 1], d.t_pl_z[2 * e], d.t_pl_z[2 * e + 1],
+                        d.t_pl_w[3 * e], d.t_pl_w[3 * e + 1], d.t_pl_w[3 * e + 2], q);
+                chi += q.chi;
+                const bool fl = d.lm_fixed[l];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { H[k] += q.Hp[k]; d.t_Hpl[(int64_t)k * d.tcapEpl + e] = fl ? 0.0 : q.W6[k]; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) b[k] += q.bp[k];
+                if (!fl) { const int slot = d.lm_grp_start[l];        // the landmark's first partial-sum slot: the fronts sum the slots in order
+                    atomicAdd(d.lm_part + slot, q.Hl[0]); atomicAdd(d.lm_part + G + slot, q.Hl[1]); atomicAdd(d.lm_part + 2 * G + slot, q.Hl[2]);
+                    atomicAdd(d.lm_part + 3 * G + slot, q.bl[0]); atomicAdd(d.lm_part + 4 * G + slot, q.bl[1]); }
+            } }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) H[k] = wave_sum(H[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) b[k] = wave_sum(b[k]);
+        if (lane == 0) {
+            for (int kk = 0; kk < d.tEpp; ++kk) { const int i = d.t_pp_ij[2 * kk], j = d.t_pp_ij[2 * kk + 1];
+                if (max(i, j) != p) continue;                          // an odometry edge belongs to the step of its later end
+                const int64_t k = (int64_t)d.Epp + kk;
+                double xi[3], xj[3], z5[5], w[6];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { xi[c] = d.pose_est[3 * i + c]; xj[c] = d.pose_est[3 * j + c]; }
+#pragma unroll
+                for (int c = 0; c < 5; ++c) z5[c] = d.pp_zinv[5 * k + c];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) w[c] = d.pp_info[6 * k + c];
+                const double2 ci = reinterpret_cast<const double2 *>(d.pose_cs)[i];
+                const bool fi = d.pose_fixed[i], fj = d.pose_fixed[j];
+                double Hi[6] = {0, 0, 0, 0, 0, 0}, bi[3] = {0, 0, 0}, Hj[6] = {0, 0, 0, 0, 0, 0}, bj[3] = {0, 0, 0};
+                chi += pp_incidence<true>(d, (int)k, 0, xi, xj, ci.x, ci.y, z5, w, fi, fj, Hi, bi, d.t_Hpp_off + kk, d.tcapEpp);
+                pp_incidence<true>(d, (int)k, 1, xi, xj, ci.x, ci.y, z5, w, fi, fj, Hj, bj);
+                const int other = i == p ? j : i;
+                const double *Ho = i == p ? Hj : Hi, *bo = i == p ? bj : bi, *Hs = i == p ? Hi : Hj, *bs = i == p ? bi : bj;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) H[c] += Hs[c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) b[c] += bs[c];
+                if (!d.pose_fixed[other]) {                            // the older end's share, in place
+                    const bool tl = other >= d.N; const int64_t S = tl ? d.tcapN : d.N; const int o = tl ? other - d.N : other;
+                    double *Hd = tl ? d.t_Hpp_diag : d.Hpp_diag, *bp = tl ? d.t_b_pose : d.b_pose;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) atomicAdd(Hd + c * S + o, Ho[c]);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) atomicAdd(bp + c * S + o, bo[c]); }
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) atomicAdd(d.t_Hpp_diag + (int64_t)c * d.tcapN + t, H[c]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) atomicAdd(d.t_b_pose + (int64_t)c * d.tcapN + t, b[c]);
+        }
+        __threadfence();
+    }
+    chi = wave_sum(chi);
+    if (lane == 0) d.chi2_partial[d.n_wtiles] = chi;                 // one more partial for k_update's total
+}
+void launch_linearize_tail(const DevGraph &d, hipStream_t st) {
+    if (d.tN > 0) hipLaunchKernelGGL(k_linearize_tail, dim3(1), dim3(64), 0, st, d);
+}
 void launch_chi2_only(const DevGraph &d, hipStream_t st) {
+    if (d.tN > 0 && d.n_wtiles > 0) { launch_linearize(d, st); launch_linearize_tail(d, st); launch_linearize_finalize(d, st); return; }   // a grown plan: the full pass (the gather kernels do not know the tail)
     const int gp = (d.N + 255) / 256;
     if (gp > 0) hipLaunchKernelGGL(k_linearize_pose_gather<false>, dim3(gp), dim3(256), 0, st, d);
     hipLaunchKernelGGL(k_reduce_chi2, dim3(1), dim3(256), 0, st, d, gp);
@@ -1263,11 +1348,13 @@ __device__ __forceinline__ void asm3_load(const DevGraph &d, int kind_cnt, int s
 #pragma unroll
     for (int k = 0; k < 9; ++k) v[k] = 0.0;
     switch (kind) {
-        case 0: { const int64_t S = d.N;
+        case 0: { const bool tl = src >= d.N;                           // a tail pose (grow_plan): its blocks live in the tail arenas
+            const int64_t S = tl ? d.tcapN : d.N; const int i = tl ? src - d.N : src;
+            const double *Hd = tl ? d.t_Hpp_diag : d.Hpp_diag, *bp = tl ? d.t_b_pose : d.b_pose;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) v[k] = d.Hpp_diag[k * S + src];
+            for (int k = 0; k < 6; ++k) v[k] = Hd[k * S + i];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) v[6 + k] = d.b_pose[k * S + src]; } break;
+            for (int k = 0; k < 3; ++k) v[6 + k] = bp[k * S + i]; } break;
         case 1: {
             if (d.n_wtiles > 0) { const int cnt = kind_cnt >> 8; const int64_t G = d.n_groups;
                 for (int q0 = 0; q0 < cnt; q0 += 4) {                // four slots' loads in flight, added in slot order
@@ -1283,12 +1370,14 @@ __device__ __forceinline__ void asm3_load(const DevGraph &d, int kind_cnt, int s
             } else { const int64_t S = d.M;
                 v[0] = d.Hll_diag[src]; v[1] = d.Hll_diag[S + src]; v[2] = d.Hll_diag[2 * S + src]; v[3] = d.b_lm[src]; v[4] = d.b_lm[S + src]; }
         } break;
-        case 2: case 3: { const int64_t S = d.Epp;
+        case 2: case 3: { const bool tl = src >= d.Epp;
+            const int64_t S = tl ? d.tcapEpp : d.Epp; const double *H = tl ? d.t_Hpp_off + (src - d.Epp) : d.Hpp_off + src;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) v[k] = d.Hpp_off[k * S + src]; } break;
-        default: { const int64_t S = d.ell_len;
+            for (int k = 0; k < 9; ++k) v[k] = H[k * S]; } break;
+        default: { const bool tl = src >= d.ell_len;
+            const int64_t S = tl ? (int64_t)d.tcapEpl : d.ell_len; const double *H = tl ? d.t_Hpl + (src - d.ell_len) : d.Hpl + src;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) v[k] = d.Hpl[k * S + src]; } break;
+            for (int k = 0; k < 6; ++k) v[k] = H[k * S]; } break;
     }
 }
 // staging of a front's original entries before they go to the accumulators.  StageT<false>: the 64 x 64 tile image
@@ -2500,10 +2589,12 @@ __device__ __forceinline__ int32_t f3_pack(int i, bool col_ok) {
 __global__ void __launch_bounds__(256) k_build_f3(int nq, const int32_t *__restrict__ lf, const DevFront *__restrict__ fronts,
         const int32_t *__restrict__ children, const int32_t *__restrict__ child_map, const int32_t *__restrict__ u3_off,
         const int32_t *__restrict__ u3_size, const int32_t *__restrict__ bf /*[front][8]*/, const int32_t *__restrict__ xrow_off,
-        const int64_t *__restrict__ x_off /* nullable */, int32_t *__restrict__ f3_desc, int32_t *__restrict__ f3_x, int x_stride) {
+        const int64_t *__restrict__ x_off /* nullable */, int32_t *__restrict__ f3_desc, int32_t *__restrict__ f3_x, int x_stride,
+        const int32_t *__restrict__ list /* nullable: the level positions to (re)build */) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + wave;
-    if (q >= nq) return;
+    const int qi = blockIdx.x * 4 + wave;
+    if (qi >= nq) return;
+    const int q = list ? list[qi] : qi;
     const int32_t none = (int32_t)((uint32_t)((-30000) & 0xffff) | ((uint32_t)(-30000) << 16));
     const int s = lf[q];
     const DevFront F = fronts[s];
@@ -2555,8 +2646,23 @@ __global__ void __launch_bounds__(256) k_build_f3(int nq, const int32_t *__restr
 }
 void launch_build_f3(int nq, const int32_t *lf, const DevFront *fronts, const int32_t *children, const int32_t *child_map,
                      const int32_t *u3_off, const int32_t *u3_size, const int32_t *bf, const int32_t *xrow_off, const int64_t *x_off,
-                     int32_t *f3_desc, int32_t *f3_x, int x_stride, hipStream_t st) {
-    if (nq > 0) hipLaunchKernelGGL(k_build_f3, dim3((nq + 3) / 4), dim3(256), 0, st, nq, lf, fronts, children, child_map, u3_off, u3_size, bf, xrow_off, x_off, f3_desc, f3_x, x_stride);
+                     int32_t *f3_desc, int32_t *f3_x, int x_stride, hipStream_t st, const int32_t *list) {
+    if (nq > 0) hipLaunchKernelGGL(k_build_f3, dim3((nq + 3) / 4), dim3(256), 0, st, nq, lf, fronts, children, child_map, u3_off, u3_size, bf, xrow_off, x_off, f3_desc, f3_x, x_stride, list);
+}
+// growth: scattered rows of fronts / u3_off / u3_size / bf from one packed patch buffer (32 ints per front: front, DevFront as 20 ints,
+// u3_off, u3_size, bf[8], one spare)
+__global__ void __launch_bounds__(256) k_apply_front_patch(int n, const int32_t *__restrict__ patch, DevFront *fronts, int32_t *u3_off, int32_t *u3_size, int32_t *bf) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, i = t >> 5, c = t & 31;
+    if (i >= n) return;
+    static_assert(sizeof(DevFront) == 80, "DevFront travels as 20 ints");
+    const int32_t *r = patch + 32 * (int64_t)i; const int s = r[0]; const int32_t v = r[c];
+    if (c >= 1 && c <= 20) reinterpret_cast<int32_t *>(fronts + s)[c - 1] = v;
+    else if (c == 21) u3_off[s] = v;
+    else if (c == 22) u3_size[s] = v;
+    else if (c >= 23 && c <= 30) bf[8 * (int64_t)s + (c - 23)] = v;
+}
+void launch_apply_front_patch(int n, const int32_t *patch, DevFront *fronts, int32_t *u3_off, int32_t *u3_size, int32_t *bf, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_apply_front_patch, dim3((n * 32 + 255) / 256), dim3(256), 0, st, n, patch, fronts, u3_off, u3_size, bf);
 }
 // landmark-diagonal block records of the fused linearisation: {kind 1, landmark} -> {1 | #partial slots << 8, first slot}
 __global__ void __launch_bounds__(256) k_patch_asm3(int64_t n, int32_t *__restrict__ asm3, const int32_t *__restrict__ lm_grp_start) {
@@ -2574,10 +2680,11 @@ void launch_patch_asm3(int64_t n, int32_t *asm3, const int32_t *lm_grp_start, hi
 // record, a wave prefix sum places its 5 / 6 / 9 scalars.  (On the host this expansion was 33 of the 110 ms of the
 // structure phase at 100k poses, plus 67 MB over PCIe.)
 __global__ void __launch_bounds__(256) k_build_sc3(const int32_t *__restrict__ bf, const int32_t *__restrict__ asm3, int32_t *__restrict__ sc3,
-                                                   int32_t *__restrict__ lm3, int n_fronts, Sc3Args A) {
+                                                   int32_t *__restrict__ lm3, int n_fronts, Sc3Args A, const int32_t *__restrict__ list /* nullable */) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 4 + wave;
-    if (s >= n_fronts) return;
+    const int si = blockIdx.x * 4 + wave;
+    if (si >= n_fronts) return;
+    const int s = list ? list[si] : si;
     const int asm_off = bf[8 * s], n_uniq = bf[8 * s + 1], f = bf[8 * s + 2], sc_off = bf[8 * s + 3], sc_cnt = bf[8 * s + 4], lm_off = bf[8 * s + 5];
     int sbase = sc_off, lbase = lm_off;
     auto img = [](int r, int c) { const int I = r >> 4, J = c >> 4; return (((I * (I + 1)) >> 1) + J) * 256 + (r & 15) * 16 + (c & 15); };
@@ -2595,7 +2702,8 @@ __global__ void __launch_bounds__(256) k_build_sc3(const int32_t *__restrict__ b
         auto add = [&](int64_t src, int rr, int cc) { sc3[2 * (int64_t)q] = (int32_t)src; sc3[2 * (int64_t)q + 1] = img(rr, cc); ++q; };
         const int64_t src = r.y; const int r0 = r.z, c0 = r.w;
         if (on) switch (kind) {
-            case 0: { const int64_t H = A.off[0], B = A.off[1], N = A.N;
+            case 0: { const bool tl = src >= A.N;                          // sources beyond the base counts: the tail arenas (grow_plan)
+                const int64_t N = tl ? A.tcapN : A.N, H = tl ? A.toff[0] - A.N : A.off[0], B = tl ? A.toff[1] - A.N : A.off[1];
                 add(H + src, r0, c0); add(H + N + src, r0 + 1, c0); add(H + 2 * N + src, r0 + 2, c0);
                 add(H + 3 * N + src, r0 + 1, c0 + 1); add(H + 4 * N + src, r0 + 2, c0 + 1); add(H + 5 * N + src, r0 + 2, c0 + 2);
                 for (int k = 0; k < 3; ++k) add(B + k * N + src, f, c0 + k); } break;
@@ -2604,17 +2712,20 @@ __global__ void __launch_bounds__(256) k_build_sc3(const int32_t *__restrict__ b
                 else { const int64_t H = A.off[5], B = A.off[6], M = A.M;
                     add(H + src, r0, c0); add(H + M + src, r0 + 1, c0); add(H + 2 * M + src, r0 + 1, c0 + 1); add(B + src, f, c0); add(B + M + src, f, c0 + 1); }
                 break;
-            case 2: for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) add(A.off[2] + (3 * a + b) * (int64_t)A.Epp + src, r0 + a, c0 + b); break;
-            case 3: for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) add(A.off[2] + (3 * b + a) * (int64_t)A.Epp + src, r0 + a, c0 + b); break;
-            case 4: for (int a = 0; a < 3; ++a) for (int b = 0; b < 2; ++b) add(A.off[3] + (2 * a + b) * A.L + src, r0 + a, c0 + b); break;
-            default: for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b) add(A.off[3] + (2 * b + a) * A.L + src, r0 + a, c0 + b); break;
+            case 2: case 3: { const bool tl = src >= A.Epp;
+                const int64_t E = tl ? A.tcapEpp : A.Epp, H = tl ? A.toff[2] - A.Epp : A.off[2];
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) add(H + (kind == 2 ? 3 * a + b : 3 * b + a) * E + src, r0 + a, c0 + b); } break;
+            default: { const bool tl = src >= A.L;
+                const int64_t L = tl ? (int64_t)A.tcapEpl : A.L, H = tl ? A.toff[3] - A.L : A.off[3];
+                if (kind == 4) { for (int a = 0; a < 3; ++a) for (int b = 0; b < 2; ++b) add(H + (2 * a + b) * L + src, r0 + a, c0 + b); }
+                else { for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b) add(H + (2 * b + a) * L + src, r0 + a, c0 + b); } } break;
         }
         sbase += tot_s; lbase += tot_l;
     }
     for (int q = sbase + lane; q < sc_off + sc_cnt; q += 64) { sc3[2 * (int64_t)q] = 0; sc3[2 * (int64_t)q + 1] = 1; }      // padding: (value 0 -> a don't-care slot)
 }
-void launch_build_sc3(const int32_t *bf, const int32_t *asm3, int32_t *sc3, int32_t *lm3, int n_fronts, const Sc3Args &A, hipStream_t st) {
-    if (n_fronts > 0) hipLaunchKernelGGL(k_build_sc3, dim3((n_fronts + 3) / 4), dim3(256), 0, st, bf, asm3, sc3, lm3, n_fronts, A);
+void launch_build_sc3(const int32_t *bf, const int32_t *asm3, int32_t *sc3, int32_t *lm3, int n_fronts, const Sc3Args &A, hipStream_t st, const int32_t *list) {
+    if (n_fronts > 0) hipLaunchKernelGGL(k_build_sc3, dim3((n_fronts + 3) / 4), dim3(256), 0, st, bf, asm3, sc3, lm3, n_fronts, A, list);
 }
 
 // whole-tree launches of variant 3 (own fronts of a single-GPU graph): every level in one kernel each
@@ -2769,7 +2880,11 @@ __global__ void __launch_bounds__(256) k_pose_trig(int n, const double *__restri
     pose_cs[2 * t] = cs; pose_cs[2 * t + 1] = sn;
 }
 void launch_pose_trig(const DevGraph &d, hipStream_t st) {
-    if (d.N > 0) hipLaunchKernelGGL(k_pose_trig, dim3((d.N + 255) / 256), dim3(256), 0, st, d.N, d.pose_est, d.pose_cs);
+    const int n = d.N + d.tN;
+    if (n > 0) hipLaunchKernelGGL(k_pose_trig, dim3((n + 255) / 256), dim3(256), 0, st, n, d.pose_est, d.pose_cs);
+}
+void launch_pose_trig_range(const DevGraph &d, int first, int count, hipStream_t st) {
+    if (count > 0) hipLaunchKernelGGL(k_pose_trig, dim3((count + 255) / 256), dim3(256), 0, st, count, d.pose_est + 3 * (int64_t)first, d.pose_cs + 2 * (int64_t)first);
 }
 
 // ------------------------------------------------------------------ A9
@@ -2791,16 +2906,18 @@ __global__ void __launch_bounds__(256) k_update(DevGraph d) {
     // One thread per SCALAR of the estimates (3 N pose scalars, then 2 M landmark scalars): the estimate, the increment record and
     // the solution vector are read and written as fully coalesced 8-byte streams (a thread per vertex touched them with a 24-byte
     // stride: 1.0 TB/s at 1M poses); the lane that holds a pose's angle normalises it and refreshes the pose's cos / sin.
+    // (the scalars of a grown plan's tail poses follow the landmarks': pose scalar index ps = t - 2 M)
+    const int ps = t < 3 * d.N ? t : ((t >= 3 * d.N + 2 * d.M && t < 3 * (d.N + d.tN) + 2 * d.M) ? t - 2 * d.M : -1);
     if (stop) { }
-    else if (t < 3 * d.N) {
-        const int p = t / 3, c = t - 3 * p;
-        const int g = d.pose_known[p] ? d.pose_gidx[p] : -1;
+    else if (ps >= 0) {
+        const int p = ps / 3, c = ps - 3 * p;
+        const int g = (p >= d.N || d.pose_known[p]) ? d.pose_gidx[p] : -1;
         double dx = 0.0;
         if (g >= 0) { dx = d.xe[g + c];
-            double v = d.pose_est[t] + dx;
+            double v = d.pose_est[ps] + dx;
             if (c == 2) { v = normalize_theta(v); double sn, cs; sincos(v, &sn, &cs); reinterpret_cast<double2 *>(d.pose_cs)[p] = make_double2(cs, sn); }
-            d.pose_est[t] = v; }
-        d.dpose[t] = dx;
+            d.pose_est[ps] = v; }
+        d.dpose[ps] = dx;
     } else if (t < 3 * d.N + 2 * d.M) {
         const int u = t - 3 * d.N, l = u >> 1, c = u & 1;
         const int g = d.lm_known[l] ? d.lm_gidx[l] : -1;
@@ -2816,12 +2933,13 @@ __global__ void __launch_bounds__(256) k_update(DevGraph d) {
             // (sixteen loads in flight per thread, added in the same order as one at a time: a thread's chain of dependent
             // load -> add was the whole duration of this kernel — 80 us at 1M poses, 7 of its 10 us at 100k)
             double s = 0.0;
-            for (int k0 = threadIdx.x; k0 < d.n_wtiles; k0 += 256 * 16) {
+            const int nsum = d.n_wtiles + (d.tN > 0 ? 1 : 0);      // a grown plan's tail leaves one more partial (k_linearize_tail)
+            for (int k0 = threadIdx.x; k0 < nsum; k0 += 256 * 16) {
                 double v[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) { const int k = k0 + 256 * j; v[j] = k < d.n_wtiles ? d.chi2_partial[k] : 0.0; }
+                for (int j = 0; j < 16; ++j) { const int k = k0 + 256 * j; v[j] = k < nsum ? d.chi2_partial[k] : 0.0; }
 #pragma unroll
-                for (int j = 0; j < 16; ++j) if (k0 + 256 * j < d.n_wtiles) s += v[j]; }
+                for (int j = 0; j < 16; ++j) if (k0 + 256 * j < nsum) s += v[j]; }
             tot = block_sum(s, red);
             if (threadIdx.x == 0) d.chi2[0] = tot;
         } else if (threadIdx.x == 0) tot = d.chi2[0];              // gather kernels: k_reduce_chi2 totalled it already
@@ -2835,7 +2953,7 @@ __global__ void __launch_bounds__(256) k_update(DevGraph d) {
     }
 }
 void launch_update(const DevGraph &d, hipStream_t st) {
-    int n = 3 * d.N + 2 * d.M;
+    int n = 3 * (d.N + d.tN) + 2 * d.M;
     if (n > 0) hipLaunchKernelGGL(k_update, dim3((n + 255) / 256), dim3(256), 0, st, d);
 }
 

@@ -33,7 +33,7 @@ void HostGraph::clear() {
     pose_index.clear(); lm_index.clear();
     pp_i.clear(); pp_j.clear(); pp_z.clear(); pp_info.clear();
     pl_p.clear(); pl_l.clear(); pl_z.clear(); pl_info.clear();
-    ++structure_version; ++estimate_version;
+    ++structure_version; ++estimate_version; ++reshape_version;
 }
 
 namespace {
@@ -143,9 +143,10 @@ struct Builder {
         // and the bound becomes the 7-tile-row instance's 111 — otherwise such a range falls back to binary splits and
         // leaves level after level of ONE-pose separators (3 pivots each) with 60-100 boundary rows
         const int p_first = p;
-        int limit = 63;
+        const int wave_limit = 63 - std::max(0, std::min(opt.grow_headroom, 30));
+        int limit = wave_limit;
         for (;; --p) {
-            if (p <= 2) { if (limit == 63 && opt.big_cluster_front > 63) { limit = opt.big_cluster_front; p = p_first + 1; continue; } return false; }
+            if (p <= 2) { if (limit == wave_limit && opt.big_cluster_front > 63) { limit = opt.big_cluster_front; p = p_first + 1; continue; } return false; }
             sep_poses.clear(); cut.clear(); sep_cones.clear(); orphans.clear();
             // split poses: the unassigned ones at ranks (un * k) / p, k = 1 .. p - 1; part k = positions (cut[k], cut[k + 1])
             cut.push_back(a - 1);
@@ -583,9 +584,135 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         for (int q = 0; q < G; ++q) plan.grp_slot[q] = fill[plan.grp_lm[q]]++;
     }
 
+    plan.base_N = plan.planned_N = N; plan.base_Epp = plan.planned_Epp = Epp; plan.base_Epl = plan.planned_Epl = Epl;
+    plan.n_growths = 0; plan.reshape_version = g.reshape_version;
+    // room for grow_plan's re-written runs: without it the first growth step pays for reallocating (and copying) these arrays — 3 of
+    // its 4 ms at 100k poses
+    plan.bnd_rows.reserve(plan.bnd_rows.size() + 64 * 1024); plan.child_map.reserve(plan.child_map.size() + 64 * 1024);
+    plan.asm_recs.reserve(plan.asm_recs.size() + 96 * 1024);
+    plan.pose_gidx.reserve((size_t)N + TAIL_POSES); plan.pose_known.reserve((size_t)N + TAIL_POSES);
+    plan.pl_order.reserve((size_t)Epl + TAIL_PL); plan.ell_of_ins.reserve((size_t)Epl + TAIL_PL); plan.pl_rank.reserve((size_t)Epl + TAIL_PL);
+    plan.ell_ins.reserve((size_t)plan.ell_len + TAIL_PL); plan.pp_order.reserve((size_t)Epp + TAIL_PP); plan.pp_rank.reserve((size_t)Epp + TAIL_PP);
     plan.valid = true;
     GS_PT(7);
     plan.ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return true;
+}
+
+// ---- append-only growth -------------------------------------------------------------------------------------------------
+// New poses are eliminated LAST: extra pivots of the root front.  A neighbour v of a new pose P (the other end of one of P's
+// edges, free, older) is a pivot of some front s0; eliminating v makes P a neighbour of everything v touched later, i.e. P joins
+// the boundary of s0 and of every front on the way from s0 to the root — the exact fill of the enlarged matrix under the enlarged
+// order.  P's scalars get the largest elimination indices, so they are the LAST rows of every front they enter: no existing row of
+// any front moves, no existing child map entry changes; runs that grow (boundary rows, child map, assembly records of a front)
+// are re-written at the end of their arrays.  The block of an edge (v, P) lands in s0 (v is the earlier end), P's diagonal block in
+// the root.  Edge sources beyond the base counts name the tail arenas of the device: observation edge k -> virtual layout index
+// ell_len + (k - base_Epl), odometry edge k -> k, pose p -> p.
+bool grow_plan(const HostGraph &g, Plan &P, Growth &out, std::string &why) {
+    out = Growth();
+    auto no = [&](const char *m) { why = m; return false; };
+    if (!P.valid) return no("no plan");
+    if (P.world > 1) return no("sharded plan");
+    if (!P.lin_ell_ok || P.max_front > 63) return no("plan outside the wave-per-front form");
+    if (g.reshape_version != P.reshape_version) return no("a fixed flag or the landmark set changed");
+    const int N0 = P.planned_N, N1 = g.n_poses(), Epp0 = P.planned_Epp, Epp1 = g.n_pp(), Epl0 = P.planned_Epl, Epl1 = g.n_pl();
+    if (g.n_lms() != (int)P.lm_gidx.size()) return no("new landmark");
+    if (N1 < N0 || Epp1 < Epp0 || Epl1 < Epl0) return no("graph shrank");
+    if (N1 == N0 && Epp1 == Epp0 && Epl1 == Epl0) return no("nothing new");
+    if (N1 - P.base_N > TAIL_POSES || Epl1 - P.base_Epl > TAIL_PL || Epp1 - P.base_Epp > TAIL_PP) return no("tail capacity");
+    const int S = (int)P.fronts.size();
+    if (S == 0) return no("empty plan");
+    const int R = S - 1;
+    for (int s = 0; s < S; ++s) if ((P.fronts[s].parent < 0) != (s == R)) return no("forest: more than one root");
+    if (P.fronts[R].nbnd != 0) return no("root with a boundary");
+    // every new edge must have a NEW pose at the pose end (observation) / at one end (odometry): an old pose's observation edges
+    // sit in the linearisation layout, which does not grow
+    for (int k = Epl0; k < Epl1; ++k) if (g.pl_p[k] < N0) return no("new observation edge on an old pose");
+    for (int k = Epp0; k < Epp1; ++k) if (g.pp_i[k] < N0 && g.pp_j[k] < N0) return no("new odometry edge between old poses");
+    for (int p = N0; p < N1; ++p) if (g.pose_fixed[p]) return no("new pose is fixed");
+    // front of a scalar: fronts are in elimination order with contiguous pivots
+    std::vector<int32_t> piv0(S);
+    for (int s = 0; s < S; ++s) piv0[s] = P.fronts[s].piv0;
+    auto front_of = [&](int gi) { return (int)(std::upper_bound(piv0.begin(), piv0.end(), gi) - piv0.begin()) - 1; };
+    // edges of each new pose (insertion order)
+    struct Nb { int32_t gv, kind, src; };                    // neighbour's first scalar, record kind, record source
+    std::vector<std::vector<Nb>> nbs(N1 - N0);
+    std::vector<int32_t> gidx_new(N1 - N0);
+    for (int p = N0; p < N1; ++p) gidx_new[p - N0] = P.n_scalar + 3 * (p - N0);
+    auto pose_g = [&](int p) { return p < N0 ? P.pose_gidx[p] : gidx_new[p - N0]; };
+    for (int k = Epl0; k < Epl1; ++k) { const int p = g.pl_p[k], l = g.pl_l[k];
+        if (g.lm_fixed[l]) continue;                         // fixed landmark: the edge only feeds the pose's diagonal block
+        if (P.lm_gidx[l] < 0) return no("free landmark without a scalar");
+        if (P.lm_grp_start[l + 1] <= P.lm_grp_start[l]) return no("landmark without a partial-sum slot");
+        for (const Nb &o : nbs[p - N0]) if (o.kind == ASM_PL && o.gv == P.lm_gidx[l]) return no("a new pose observes a landmark twice");
+        nbs[p - N0].push_back({P.lm_gidx[l], ASM_PL, (int32_t)(P.ell_len + (k - P.base_Epl))}); }
+    for (int k = Epp0; k < Epp1; ++k) { const int i = g.pp_i[k], j = g.pp_j[k];
+        if (g.pose_fixed[i] || g.pose_fixed[j]) continue;    // (a fixed end: diagonal contribution only)
+        const int later = std::max(i, j), earlier = std::min(i, j);      // poses enter the order by index: the larger index is eliminated later
+        if (later < N0) continue;
+        const int ge = pose_g(earlier);
+        if (ge < 0) continue;
+        for (const Nb &o : nbs[later - N0]) if (o.kind != ASM_PL && o.gv == ge) return no("parallel odometry edges on a new pose");
+        nbs[later - N0].push_back({ge, later == j ? ASM_PP_T : ASM_PP, k}); }   // earlier end = i: F = Hpp_off^T (rows of j below i's columns)
+    // ---- size check before anything is written
+    { std::vector<int32_t> add(S, 0), stamp(S, -1);
+      for (int p = N0; p < N1; ++p) { add[R] += 3;
+          for (const Nb &o : nbs[p - N0]) { const int s0 = front_of(o.gv < P.n_scalar ? o.gv : P.fronts[R].piv0);
+              for (int s = s0; s != R; s = P.fronts[s].parent) { if (stamp[s] == p) break; stamp[s] = p; add[s] += 3; } } }
+      for (int s = 0; s < S; ++s) if (add[s] && P.fronts[s].npiv + P.fronts[s].nbnd + add[s] > 63) return no("a front would exceed 63 scalars"); }
+    // ---- apply
+    out.bnd_from = (int64_t)P.bnd_rows.size(); out.map_from = (int64_t)P.child_map.size(); out.asm_from = (int64_t)P.asm_recs.size();
+    out.first_pose = N0; out.first_pp = Epp0; out.first_pl = Epl0;
+    std::vector<uint8_t> touched(S, 0);
+    std::vector<int32_t> stamp(S, -1), path;
+    std::vector<std::vector<AsmRec>> newrec(S);
+    for (int p = N0; p < N1; ++p) {
+        Front &Rf = P.fronts[R];
+        const int gP = gidx_new[p - N0], rowR = Rf.npiv;
+        Rf.npiv += 3; touched[R] = 1;
+        P.pose_gidx.push_back(gP);
+        path.clear();
+        for (const Nb &o : nbs[p - N0]) { const int s0 = front_of(o.gv);
+            for (int s = s0; s != R; s = P.fronts[s].parent) { if (stamp[s] == p) break; stamp[s] = p; path.push_back(s); } }
+        std::sort(path.begin(), path.end());
+        for (int s : path) { P.fronts[s].nbnd += 3; touched[s] = 1; }
+        for (int s : path) { Front &F = P.fronts[s]; const int nb_old = F.nbnd - 3;
+            // boundary rows: the old run + P's scalars, at the end of the array
+            { const int64_t o = (int64_t)P.bnd_rows.size(); P.bnd_rows.resize((size_t)o + F.nbnd);
+              std::copy(P.bnd_rows.begin() + F.bnd_off, P.bnd_rows.begin() + F.bnd_off + nb_old, P.bnd_rows.begin() + o);
+              for (int t = 0; t < 3; ++t) P.bnd_rows[(size_t)o + nb_old + t] = gP + t;
+              F.bnd_off = o; }
+            // rows of the parent's front: P's are its last (the root: its newest pivots)
+            { const Front &Pa = P.fronts[F.parent]; const int prow = F.parent == R ? rowR : Pa.npiv + Pa.nbnd - 3;
+              const int64_t o = (int64_t)P.child_map.size(); P.child_map.resize((size_t)o + F.nbnd);
+              std::copy(P.child_map.begin() + F.map_off, P.child_map.begin() + F.map_off + nb_old, P.child_map.begin() + o);
+              for (int t = 0; t < 3; ++t) P.child_map[(size_t)o + nb_old + t] = prow + t;
+              F.map_off = o; } }
+        for (const Nb &o : nbs[p - N0]) { const int s0 = front_of(o.gv); const Front &F = P.fronts[s0];
+            const int r0 = s0 == R ? rowR : F.npiv + F.nbnd - 3;
+            newrec[s0].push_back({o.kind, o.src, r0, o.gv - F.piv0}); }
+        newrec[R].push_back({ASM_POSE_DIAG, p, rowR, rowR});
+    }
+    P.n_scalar += 3 * (N1 - N0);
+    for (int s = 0; s < S; ++s) { if (!touched[s]) continue;
+        Front &F = P.fronts[s]; out.fronts.push_back(s);
+        if (!newrec[s].empty()) {                                // unique records (the new ones have the largest rows), then the duplicates
+            const int nu = F.asm_cnt - F.asm_dup; const int64_t o = (int64_t)P.asm_recs.size();
+            P.asm_recs.resize((size_t)o + F.asm_cnt + newrec[s].size());
+            std::copy(P.asm_recs.begin() + F.asm_off, P.asm_recs.begin() + F.asm_off + nu, P.asm_recs.begin() + o);
+            std::copy(newrec[s].begin(), newrec[s].end(), P.asm_recs.begin() + o + nu);
+            std::copy(P.asm_recs.begin() + F.asm_off + nu, P.asm_recs.begin() + F.asm_off + F.asm_cnt, P.asm_recs.begin() + o + nu + (int64_t)newrec[s].size());
+            F.asm_off = (int32_t)o; F.asm_cnt += (int32_t)newrec[s].size(); }
+        F.L_off = P.l_doubles; F.U_off = P.u_doubles;
+        P.l_doubles += (int64_t)(F.npiv + F.nbnd + 1) * F.npiv; P.u_doubles += (int64_t)(F.nbnd + 1) * F.nbnd;
+        P.max_front = std::max(P.max_front, F.npiv + F.nbnd); }
+    for (int k = Epl0; k < Epl1; ++k) { const int32_t e = (int32_t)(P.ell_len + (k - P.base_Epl));
+        P.pl_order.push_back(k); P.ell_of_ins.push_back(e);
+        if ((int64_t)P.ell_ins.size() < (int64_t)e + 1) P.ell_ins.resize((size_t)e + 1, -1);
+        P.ell_ins[(size_t)e] = k; }
+    for (int k = Epp0; k < Epp1; ++k) P.pp_order.push_back(k);
+    P.pose_known.resize(N1, 1); P.pl_rank.resize(Epl1, 0); P.pp_rank.resize(Epp1, 0);
+    P.planned_N = N1; P.planned_Epp = Epp1; P.planned_Epl = Epl1; ++P.n_growths;
     return true;
 }
 
@@ -601,7 +728,7 @@ void export_plan(const Plan &p, std::vector<int32_t> &out) {
     int32_t hdr[16] = {0x47535031, p.n_scalar, (int32_t)p.fronts.size(), nlev, p.max_front,
                        (int32_t)p.pose_gidx.size(), (int32_t)p.lm_gidx.size(), (int32_t)p.pl_order.size(),
                        (int32_t)p.pp_order.size(), (int32_t)p.asm_recs.size(), (int32_t)p.bnd_rows.size(),
-                       (int32_t)p.child_map.size(), (int32_t)p.children.size(), (int32_t)p.ell_len, p.ell_T, p.ell_R};
+                       (int32_t)p.child_map.size(), (int32_t)p.children.size(), (int32_t)p.ell_ins.size() /* = ell_len; after grow_plan: + the tail's virtual indices */, p.ell_T, p.ell_R};
     out.insert(out.end(), hdr, hdr + 16);
     auto app = [&](const auto &v) { out.insert(out.end(), v.begin(), v.end()); };
     app(p.pose_gidx); app(p.lm_gidx); app(p.pl_order); app(p.pp_order); app(p.ell_ins);

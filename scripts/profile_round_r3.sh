@@ -16,6 +16,7 @@ step structure; GS_PLAN_TIMING=1 timeout -k 10 200 python scripts/iter_loop.py c
 step levels; GS_LIB=$B/var_ts/libgraphslam_hip.so timeout -k 10 200 python scripts/level_times.py cfg4 > $O/level_completion_times_cfg4.txt 2>&1
 GS_LIB=$B/var_ts/libgraphslam_hip.so timeout -k 10 300 python scripts/level_times.py cfg5 > $O/level_completion_times_cfg5.txt 2>&1
 GS_LIB=$B/var_ts/libgraphslam_hip.so timeout -k 10 300 python scripts/level_times.py cfg4 24 > $O/level_completion_times_cfg4_K24.txt 2>&1
+step call_latency; timeout -k 10 300 python scripts/call_latency.py > $O/call_latency_reference_sizes.txt 2>&1; cat $O/call_latency_reference_sizes.txt
 step wide_view; timeout -k 10 300 python scripts/wide_view.py cfg4 8 16 24 > $O/wide_view_tracks_cfg4.txt 2>&1; cat $O/wide_view_tracks_cfg4.txt
 step shard_footprint; timeout -k 10 600 python scripts/shard_footprint.py 8 cfg4 > $O/shard_footprint_8xcfg4.txt 2>&1; cat $O/shard_footprint_8xcfg4.txt
 step spreads; timeout -k 10 400 python scripts/parity_spread.py cfg4 r03 > $O/parity_spread_cfg4.log 2>&1; grep -h " vs \|b_pose" $O/parity_spread_cfg4.log | cut -c1-220

@@ -51,6 +51,36 @@ def make_oracle_graph(po, g):
     return og
 
 
+def split_for_growth(g, h):
+    """A bench graph cut into a BASE (everything but the last `h` poses and their edges) and the TAIL that an append-only growth
+    brings in (reference src/slam.cpp:433-459, 537-550: a pose vertex, its odometry edge, its observation edges).  Returns
+    (base, tail, full) where `full` holds the edges in the order a handle sees them: base edges, then tail edges.  Every cone must be
+    observed by a base pose (the last poses of the closed track look at cones the first ones mapped)."""
+    N = len(g["pose_est"]); Nb = N - h
+    kpp = (g["pp_i"] < Nb) & (g["pp_j"] < Nb); kpl = g["pl_p"] < Nb
+    assert set(np.unique(g["pl_l"][~kpl])) <= set(np.unique(g["pl_l"][kpl])), "a held-back pose is the first to see a cone"
+    pick = lambda m: dict(pp_i=g["pp_i"][m[0]], pp_j=g["pp_j"][m[0]], pp_z=g["pp_z"][m[0]], pp_info=g["pp_info"][m[0]],
+                          pl_p=g["pl_p"][m[1]], pl_l=g["pl_l"][m[1]], pl_z=g["pl_z"][m[1]], pl_info=g["pl_info"][m[1]])
+    base = dict(g); base.update(pick((kpp, kpl))); base["pose_est"] = g["pose_est"][:Nb].copy()
+    tail = pick((~kpp, ~kpl)); tail["pose_est"] = g["pose_est"][Nb:].copy(); tail["first_pose"] = Nb
+    full = dict(g)
+    for k in ("pp_i", "pp_j", "pp_z", "pp_info", "pl_p", "pl_l", "pl_z", "pl_info"):
+        full[k] = np.concatenate([base[k], tail[k]])
+    return base, tail, full
+
+
+def append_tail(G, tail, poses=None):
+    """adds the tail's poses [first_pose + a, first_pose + b) and the edges whose later pose lies in that range to a handle"""
+    f = tail["first_pose"]; a, b = poses if poses else (0, len(tail["pose_est"]))
+    G.add_poses(np.arange(f + a, f + b), tail["pose_est"][a:b])
+    later = np.maximum(tail["pp_i"], tail["pp_j"]); m = (later >= f + a) & (later < f + b)
+    if m.any():
+        G.add_odometry_edges(tail["pp_i"][m], tail["pp_j"][m], tail["pp_z"][m], tail["pp_info"][m])
+    m = (tail["pl_p"] >= f + a) & (tail["pl_p"] < f + b)
+    if m.any():
+        G.add_observation_edges(tail["pl_p"][m], tail["pl_l"][m], tail["pl_z"][m], tail["pl_info"][m])
+
+
 @pytest.fixture(scope="session")
 def bench_graphs(pkg, frontend):
     """Lazily built bench graphs keyed by (N, M); arrays from the ORACLE front end."""

@@ -13,7 +13,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import make_oracle_graph, random_graph
+from conftest import append_tail, make_oracle_graph, random_graph, split_for_growth
 
 pytestmark = pytest.mark.gpu
 
@@ -311,10 +311,16 @@ def test_front_flag_timeout_falls_back_to_level_launches_and_finishes(pkg, po, b
     assert rel(G.poses(), og.poses()) < 1e-9 and rel(G.landmarks(), og.landmarks()) < 1e-9
     done, st = G.optimize(2); og.optimize(2, ordering=1)       # later calls stay on one launch per level until the next plan
     assert done == 2 and st.fell_back == 1 and st.first_failure == 0 and rel(G.poses(), og.poses()) < 1e-9
-    G.add_pose(5000, g["pose_est"][-1] + [0.25, 0.0, 0.0])       # a structure change builds a new plan: whole-tree launches again
-    G.add_odometry_edge(len(g["pose_est"]) - 1, 5000, [0.25, 0.0, 0.0], 5 * np.eye(3))
+    n = len(g["pose_est"])
+    G.add_pose(5000, g["pose_est"][-1] + [0.25, 0.0, 0.0])       # one more pose: the plan GROWS (same launches, still one per level) ...
+    G.add_odometry_edge(n - 1, 5000, [0.25, 0.0, 0.0], 5 * np.eye(3))
+    og.add_poses(np.array([g["pose_est"][-1] + [0.25, 0.0, 0.0]])); og.add_odometry_edges(np.array([n - 1]), np.array([n]), np.array([[0.25, 0.0, 0.0]]), (5 * np.eye(3)).reshape(1, 9))
+    done, st = G.optimize(1); og.optimize(1, ordering=1)
+    assert done == 1 and G.plan_growths() == 1 and st.fell_back == 1 and st.first_failure == 0
+    assert rel(G.poses(), og.poses()) < 1e-9 and rel(G.landmarks(), og.landmarks()) < 1e-9
+    G.set_fixed_pose(5000, True)                                 # ... a change that needs a new plan: whole-tree launches again
     done, st = G.optimize(1)
-    assert done == 1 and st.fell_back == 0 and st.first_failure == 0
+    assert done == 1 and G.plan_growths() == 0 and st.fell_back == 0 and st.first_failure == 0
     G.close()
 
 
@@ -927,3 +933,55 @@ def test_wide_view_tracks_match_oracle(pkg, po, frontend, K, N, M):
     assert np.sqrt(((G.poses()[:, :2] - og.poses()[:, :2]) ** 2).sum(1).mean()) / rms < 1e-9      # north_star bar: 1e-6
     assert np.array_equal(G.poses()[:2], g["pose_est"][:2])
     G.close()
+
+
+# ---- append-only growth (reference src/slam.cpp:433-459, 537-550 add one pose vertex with its odometry and observation edges per
+# keyframe; g2o's initializeOptimization rebuilds everything, :480): the plan and the device tables absorb the new poses
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,M,h,steps", [(50, 30, 1, 1), (1000, 200, 3, 1), (1000, 200, 4, 2), (10000, 2000, 2, 1)])
+def test_appended_poses_are_absorbed_by_the_plan_and_give_the_full_builds_answer(pkg, po, bench_graphs, N, M, h, steps):
+    _, g = bench_graphs(N, M)
+    base, tail, full = split_for_growth(g, h)
+    og = make_oracle_graph(po, full); done_o, _, _ = og.optimize(10, ordering=1)
+    G = fresh(pkg, base); G.initialize_optimization(); ms_full = G.stats().ms_structure
+    per = h // steps
+    for k in range(steps):
+        append_tail(G, tail, (k * per, h if k == steps - 1 else (k + 1) * per))
+        G.initialize_optimization()
+        assert G.plan_growths() == k + 1, G.growth_refusal()
+    st0 = G.stats(); assert st0.n_growths == steps and st0.ms_structure < ms_full
+    done, st = G.optimize(10)
+    F = fresh(pkg, full); done_f, st_f = F.optimize(10); assert F.plan_growths() == 0
+    assert done == done_f == done_o == 10
+    rms = np.sqrt((og.poses()[:, :2] ** 2).sum(1).mean())
+    for A, B, tol in ((G, F, 1e-9), (G, og, 1e-6)):                 # grown plan vs full build; vs the oracle: the north_star bar
+        assert np.sqrt(((A.poses()[:, :2] - B.poses()[:, :2]) ** 2).sum(1).mean()) / rms < tol
+        assert np.sqrt(((A.landmarks() - B.landmarks()) ** 2).sum(1).mean()) / rms < tol
+        assert np.abs(A.poses()[:, 2] - B.poses()[:, 2]).max() < max(tol, 1e-9)
+    assert abs(st.chi2_initial - st_f.chi2_initial) <= 1e-9 * st_f.chi2_initial and abs(st.chi2_final - st_f.chi2_final) <= 1e-6 * max(st_f.chi2_final, 1e-12)
+    assert abs(G.chi2() - F.chi2()) <= 1e-6 * max(F.chi2(), 1e-12)
+    G.close(); F.close()
+
+
+@pytest.mark.gpu
+def test_growth_between_optimisations_keeps_the_estimates_in_hbm_and_falls_back_when_it_must(pkg, po, bench_graphs, monkeypatch):
+    """iterations on the base graph, THEN the new poses, then more iterations: the grown handle must continue from the iterate in HBM
+    exactly like a handle that is given the same state and rebuilds everything (GS_GROW=0); a change growth cannot absorb is
+    refused with a reason and rebuilt."""
+    _, g = bench_graphs(1000, 200)
+    base, tail, full = split_for_growth(g, 3)
+    G = fresh(pkg, base); G.optimize(2); append_tail(G, tail); done, _ = G.optimize(5)
+    assert G.plan_growths() == 1 and done == 5
+    monkeypatch.setenv("GS_GROW", "0")
+    R = fresh(pkg, base); R.optimize(2); append_tail(R, tail); done_r, _ = R.optimize(5)
+    assert R.plan_growths() == 0 and R.growth_refusal() == "GS_GROW=0" and done_r == 5
+    monkeypatch.delenv("GS_GROW")
+    rms = np.sqrt((R.poses()[:, :2] ** 2).sum(1).mean())
+    assert np.sqrt(((G.poses()[:, :2] - R.poses()[:, :2]) ** 2).sum(1).mean()) / rms < 1e-9
+    assert np.sqrt(((G.landmarks() - R.landmarks()) ** 2).sum(1).mean()) / rms < 1e-9
+    assert np.abs(G.poses()[:, 2] - R.poses()[:, 2]).max() < 1e-9
+    # not absorbable: a new landmark -> full structure phase, the handle keeps working
+    G.add_landmark(10 ** 6, [float(G.poses()[-1, 0]) + 1.0, float(G.poses()[-1, 1])]); G.add_observation_edge(len(G.poses()) - 1, 10 ** 6, [1.0, 0.0], [0.01, 0, 0, 0.01])
+    done, _ = G.optimize(2)
+    assert done == 2 and G.plan_growths() == 0 and "landmark" in G.growth_refusal()
+    G.close(); R.close()

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import make_oracle_graph, random_graph
+from conftest import append_tail, make_oracle_graph, random_graph, split_for_growth
 from plan_exec import Plan
 
 
@@ -148,3 +148,35 @@ def test_a_rank_plans_its_own_window_and_the_shared_top_only(pkg, bench_graphs):
         assert slots is None or sl == slots                                                                   # same shared fronts, same slots, on every rank
         slots = sl
     assert len(slots) >= world - 1
+
+
+@pytest.mark.parametrize("N,M,h,steps", [(50, 30, 1, 1), (1000, 200, 3, 1), (1000, 200, 4, 2)])
+def test_appended_poses_grow_the_plan_instead_of_rebuilding_it(pkg, po, bench_graphs, N, M, h, steps):
+    """Append-only growth (reference src/slam.cpp:433-459, 537-550; gs::grow_plan): the last h poses of the track arrive after the plan
+    was built, in `steps` batches.  The plan must absorb them (same fronts, same tree, only root-path fronts larger), stay a valid
+    multifrontal plan, and its numeric replay must reproduce the oracle's joint solve of the WHOLE graph."""
+    _, g = bench_graphs(N, M)
+    base, tail, full = split_for_growth(g, h)
+    G = host_graph(pkg, base)
+    info0 = G.plan_build_host(); P0 = Plan(G.plan_export())
+    assert G.plan_growths() == 0
+    per = h // steps
+    for k in range(steps):
+        append_tail(G, tail, (k * per, h if k == steps - 1 else (k + 1) * per))
+        info = G.plan_build_host()
+        assert G.plan_growths() == k + 1, G.growth_refusal()
+    P = Plan(G.plan_export()); P.check_invariants()
+    assert P.n_fronts == P0.n_fronts and np.array_equal(P.parent, P0.parent) and np.array_equal(P.level, P0.level)
+    assert info.n_scalar == info0.n_scalar + 3 * h and P.n_poses == N
+    changed = np.flatnonzero((P.npiv != P0.npiv) | (P.nbnd != P0.nbnd))
+    assert 0 < len(changed) <= 16 * P.n_levels and changed[-1] == P.n_fronts - 1            # a few root paths, the root among them
+    assert np.array_equal(P.pose_gidx[:N - h], P0.pose_gidx) and np.array_equal(P.lm_gidx, P0.lm_gidx)      # nothing older moved
+    blocks, (dp_o, dl_o) = oracle_increment(po, full)
+    dp, dl, ok = P.solve(blocks)
+    scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
+    assert ok and np.abs(dp - dp_o).max() / scale < 1e-8 and np.abs(dl - dl_o).max() / scale < 1e-8
+    # what growth cannot absorb is refused with a reason, and the full build takes over
+    G.add_landmark(10 ** 6, [0.0, 0.0]); G.add_observation_edge(N - 1, 10 ** 6, [1.0, 0.0], [0.01, 0, 0, 0.01])
+    G.plan_build_host()
+    assert G.plan_growths() == 0 and "landmark" in G.growth_refusal()
+    G.close()
