@@ -259,12 +259,14 @@ typedef struct gs_plan_info {
 } gs_plan_info;
 /* builds the plan on the host only (no HIP), usable without a device */
 int  gs_plan_build_host(gs_graph *g, gs_plan_info *info);
-/* Append-only growth (reference src/slam.cpp:433-459, 537-550 add one pose vertex, its odometry edge and its observation edges per
- * keyframe; g2o's initializeOptimization rebuilds everything, :480).  When the only changes since the last structure phase are new poses
- * with their edges (observation edges to EXISTING landmarks; at most 16 poses / 512 + 64 edges since the last full phase; every front stays
- * <= 63 scalars), gs_initialize_optimization / gs_optimize keep the plan: the new poses become pivots of the root front, the fronts between a
- * neighbour's front and the root gain them as boundary rows, and only those fronts' tables are rebuilt (csrc/gs_plan.cpp grow_plan,
- * csrc/gs_api.cpp upload_growth).  Anything else (new landmark, fixed flag, GS_GROW=0 in the environment) is a full structure phase.
+/* Append-only growth.  Per keyframe the reference adds one pose vertex with its odometry edge (src/slam.cpp:433-459), observation edges
+ * to cones of the map (:537-550) and the cones it is the first to see with their first observation (:525-535); g2o's
+ * initializeOptimization rebuilds everything at the next optimize() (:480).  Here, when the only changes since the last structure phase
+ * are of that kind — new poses, new landmarks, edges whose pose end is a new pose; at most 16 poses / 16 landmarks / 512 + 64 edges since
+ * the last full phase; every front stays <= 63 scalars — gs_initialize_optimization / gs_optimize keep the plan: the new vertices become
+ * pivots of the root front, the fronts between a neighbour's front and the root gain them as boundary rows, and only those fronts' tables
+ * are rebuilt (csrc/gs_plan.cpp grow_plan, csrc/gs_api.cpp upload_growth).  Anything else (a fixed flag, an edge between old vertices,
+ * GS_GROW=0 in the environment) is a full structure phase.
  * gs_plan_growths: steps absorbed by the current plan; gs_growth_refusal: why the last change was NOT absorbed ("" if it was). */
 int  gs_plan_growths(gs_graph *g);
 const char *gs_growth_refusal(gs_graph *g);

@@ -170,7 +170,7 @@ extern "C" int gs_add_landmark(gs_graph *g, int32_t id, const double est[2]) {
     int rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
     g->h.lm_index[id] = g->h.n_lms();
     g->h.lm_id.push_back(id); g->h.lm_est.insert(g->h.lm_est.end(), est, est + 2); g->h.lm_fixed.push_back(0);
-    ++g->h.structure_version; ++g->h.reshape_version;
+    ++g->h.structure_version;
     return GS_OK;
 }
 static bool sym_ok(const double *m, int n) {
@@ -268,7 +268,7 @@ extern "C" int gs_set_landmark_estimate(gs_graph *g, int32_t id, const double es
 static int pull_estimates_if_needed(gs_graph *g) {
     if (!g->dev_valid || !g->dev_estimates_newer) return GS_OK;
     int rc = ensure_device(g); if (rc != GS_OK) return rc;
-    const int N = g->d.N + g->d.tN, M = g->d.M;          // (tail poses of a grown plan follow the base ones in the same array)
+    const int N = g->d.N + g->d.tN, M = g->d.M + g->d.tM;          // (tail vertices of a grown plan follow the base ones in the same arrays)
     if (N > 0) HIP_TRY(hipMemcpyAsync(g->h.pose_est.data(), g->d.pose_est, (size_t)N * 3 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
     if (M > 0) HIP_TRY(hipMemcpyAsync(g->h.lm_est.data(), g->d.lm_est, (size_t)M * 2 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
@@ -381,11 +381,12 @@ static int upload_raw_begin(gs_graph *g, RawUpload &R) {
     int rc;
     // room for the tail of a grown plan (gs::grow_plan) behind the per-pose and per-odometry-edge arrays
     const size_t TP = TAIL_POSES, TPP = TAIL_PP;
-    if ((rc = dev_alloc(g, &d.pose_est, (N + TP) * 3)) != GS_OK || (rc = dev_alloc(g, &d.lm_est, M * 2)) != GS_OK ||
-        (rc = dev_alloc(g, &d.pose_fixed, N + TP)) != GS_OK || (rc = dev_alloc(g, &d.lm_fixed, M)) != GS_OK ||
+    const size_t TL = TAIL_LMS;
+    if ((rc = dev_alloc(g, &d.pose_est, (N + TP) * 3)) != GS_OK || (rc = dev_alloc(g, &d.lm_est, (M + TL) * 2)) != GS_OK ||
+        (rc = dev_alloc(g, &d.pose_fixed, N + TP)) != GS_OK || (rc = dev_alloc(g, &d.lm_fixed, M + TL)) != GS_OK ||
         (rc = dev_alloc(g, &d.pose_cs, (N + TP) * 2)) != GS_OK || (rc = dev_alloc(g, &d.pp_zinv, (Epp + TPP) * 5)) != GS_OK ||
         (rc = dev_alloc(g, &d.pp_info, (Epp + TPP) * 6)) != GS_OK) return rc;
-    HIP_TRY(hipMemsetAsync(d.pose_fixed + N, 0, TP, g->stream));
+    HIP_TRY(hipMemsetAsync(d.pose_fixed + N, 0, TP, g->stream)); HIP_TRY(hipMemsetAsync(d.lm_fixed + M, 0, TL, g->stream));
     // the observation edges as inserted travel now only on a single GPU; a pose-window shard uploads the ones it evaluates, in
     // device layout, once the plan says which they are (upload_graph)
     const bool raw_pl = g->world <= 1;
@@ -429,10 +430,11 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
         for (int p = 0; p < N; ++p) { cs[2 * (size_t)p] = std::cos(h.pose_est[3 * (size_t)p + 2]); cs[2 * (size_t)p + 1] = std::sin(h.pose_est[3 * (size_t)p + 2]); }
         HIP_TRY(hipMemcpyAsync(d.pose_cs, cs.data(), cs.size() * sizeof(double), hipMemcpyHostToDevice, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream)); }
-    g->room = gs_graph::GrowRoom(); d.tN = d.tEpp = d.tEpl = 0; d.tcapN = TAIL_POSES; d.tcapEpp = TAIL_PP; d.tcapEpl = TAIL_PL;
+    g->room = gs_graph::GrowRoom(); d.tN = d.tM = d.tEpp = d.tEpl = 0; d.tcapN = TAIL_POSES; d.tcapM = TAIL_LMS; d.tcapEpp = TAIL_PP; d.tcapEpl = TAIL_PL;
     if ((rc = dev_alloc(g, &d.pose_gidx, (size_t)N + TAIL_POSES)) != GS_OK) return rc;              // (room for a grown plan's tail poses)
     if (N > 0) HIP_TRY(hipMemcpyAsync(d.pose_gidx, P.pose_gidx.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
-    UP(lm_gidx, P.lm_gidx);
+    if ((rc = dev_alloc(g, &d.lm_gidx, (size_t)M + TAIL_LMS)) != GS_OK) return rc;
+    if (M > 0) HIP_TRY(hipMemcpyAsync(d.lm_gidx, P.lm_gidx.data(), (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
     d.ell_T = P.ell_T; d.ell_R = P.ell_R; d.ell_len = P.ell_len; d.ell_p0 = P.ell_p0; d.ell_np = P.ell_np;
     { const size_t L = (size_t)P.ell_len;
       if ((rc = dev_alloc(g, &d.ell_l, L)) != GS_OK || (rc = dev_alloc(g, &d.ell_z, 2 * L)) != GS_OK || (rc = dev_alloc(g, &d.ell_w, 3 * L)) != GS_OK) return rc;
@@ -467,18 +469,19 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
         d.wt_lo = P.wt_lo; d.wt_hi = P.wt_hi;                             // the wave tiles this shard has any edge in (gs_plan.cpp)
     } else if (P.world > 1) return fail(GS_ERR_INVALID, "pose-window shards need the fused linearisation layout (<= 32 observations per pose)");
     // block-sparse H and b live in ONE arena (the variant-3 front assembly addresses every scalar by its offset in it)
-    int64_t arena_off[12], arena_doubles = 0;
-    { // (the last four parts: the blocks of a grown plan's tail — diagonal blocks and rhs of tail poses, off-diagonal blocks of tail edges)
-      const int64_t sizes[11] = {(int64_t)N * 6, (int64_t)N * 3, (int64_t)Epp * 9, (int64_t)P.ell_len * 6, (int64_t)d.n_groups * 5, (int64_t)M * 3, (int64_t)M * 2,
-                                 (int64_t)TAIL_POSES * 6, (int64_t)TAIL_POSES * 3, (int64_t)TAIL_PP * 9, (int64_t)TAIL_PL * 6};
+    int64_t arena_off[14], arena_doubles = 0;
+    { // (the last six parts: the blocks of a grown plan's tail — diagonal blocks and rhs of tail poses / landmarks, off-diagonal blocks of tail edges)
+      const int64_t sizes[13] = {(int64_t)N * 6, (int64_t)N * 3, (int64_t)Epp * 9, (int64_t)P.ell_len * 6, (int64_t)d.n_groups * 5, (int64_t)M * 3, (int64_t)M * 2,
+                                 (int64_t)TAIL_POSES * 6, (int64_t)TAIL_POSES * 3, (int64_t)TAIL_PP * 9, (int64_t)TAIL_PL * 6, (int64_t)TAIL_LMS * 3, (int64_t)TAIL_LMS * 2};
       arena_off[0] = 0;
-      for (int k = 0; k < 11; ++k) arena_off[k + 1] = arena_off[k] + ((sizes[k] + 1) & ~(int64_t)1);       // 16-byte aligned parts
-      if (arena_off[11] >= ((int64_t)1 << 31)) return fail(GS_ERR_INVALID, "graph too large for 32-bit arena offsets");
-      arena_doubles = arena_off[11];
-      AL(H_arena, (size_t)arena_off[11] + 2);
+      for (int k = 0; k < 13; ++k) arena_off[k + 1] = arena_off[k] + ((sizes[k] + 1) & ~(int64_t)1);       // 16-byte aligned parts
+      if (arena_off[13] >= ((int64_t)1 << 31)) return fail(GS_ERR_INVALID, "graph too large for 32-bit arena offsets");
+      arena_doubles = arena_off[13];
+      AL(H_arena, (size_t)arena_off[13] + 2);
       // blocks of edges / tiles this rank never evaluates must read as zero
-      ZERO(H_arena, (size_t)arena_off[11] + 2);
+      ZERO(H_arena, (size_t)arena_off[13] + 2);
       d.t_Hpp_diag = d.H_arena + arena_off[7]; d.t_b_pose = d.H_arena + arena_off[8]; d.t_Hpp_off = d.H_arena + arena_off[9]; d.t_Hpl = d.H_arena + arena_off[10];
+      d.t_Hll_diag = d.H_arena + arena_off[11]; d.t_b_lm = d.H_arena + arena_off[12];
       AL(t_pp_ij, (size_t)TAIL_PP * 2); AL(t_pl, (size_t)TAIL_PL * 2); AL(t_pl_z, (size_t)TAIL_PL * 2); AL(t_pl_w, (size_t)TAIL_PL * 3);
       // (the fused linearisation kernel stores Hpp_diag's 6 planes and b_pose's 3 as 9 contiguous planes: 6N is even, no padding between)
       d.Hpp_diag = d.H_arena + arena_off[0]; d.b_pose = d.H_arena + arena_off[1]; d.Hpp_off = d.H_arena + arena_off[2];
@@ -495,7 +498,9 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
           o.bnd_off = F.bnd_off; o.map_off = F.map_off; o.L_off = F.L_off; o.U_off = F.U_off; }
       UP(fronts, df); d.n_fronts = (int32_t)df.size(); }
     // boundary rows, child maps and assembly records with room behind them: a growth step re-writes the runs of the fronts it changes there
-    constexpr size_t ROOM_ROWS = 64 * 1024, ROOM_RECS = 96 * 1024;
+    // (sized with the plan, within bounds: a lap-sized graph must not pay for a 100k-pose graph's room with extra device chunks)
+    auto room_of = [](size_t n, size_t lo, size_t hi) { return std::min(hi, std::max(lo, n / 2)); };
+    const size_t ROOM_ROWS = room_of(P.bnd_rows.size(), 8 * 1024, 64 * 1024), ROOM_RECS = room_of(P.asm_recs.size(), 12 * 1024, 96 * 1024);
     { auto up_room = [&](int32_t **dst, const int32_t *src, size_t n, size_t room) -> int {
           int r2 = dev_alloc(g, dst, n + room); if (r2 != GS_OK) return r2;
           if (n) { hipError_t e = hipMemcpyAsync(*dst, src, n * sizeof(int32_t), hipMemcpyHostToDevice, g->stream); if (e != hipSuccess) return fail(GS_ERR_HIP, hipGetErrorString(e)); }
@@ -545,7 +550,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
             for (size_t f0 = 0; f0 < P.fronts.size(); ++f0) { const int nb = P.fronts[f0].nbnd;
                 u3_off[f0] = (int32_t)tot; u3_size[f0] = (nb * (nb + 1)) / 2 + nb; tot += ((u3_size[f0] + 2 + 1) & ~1);
                 if (tot >= ((int64_t)1 << 31)) return fail(GS_ERR_INVALID, "update-matrix arena beyond 32-bit offsets"); }
-            constexpr int64_t ROOM_U = (int64_t)1 << 20;          // doubles: the update matrices of fronts a growth step enlarges move here
+            const int64_t ROOM_U = (int64_t)room_of((size_t)tot, (size_t)128 << 10, (size_t)1 << 20);      // doubles: the update matrices of fronts a growth step enlarges move here
             if (tot + ROOM_U >= ((int64_t)1 << 31)) return fail(GS_ERR_INVALID, "update-matrix arena beyond 32-bit offsets");
             AL(Uimg, (size_t)(tot + ROOM_U) + 2); ZERO(Uimg, (size_t)(tot + ROOM_U) + 2);
             g->room.used_U = tot; g->room.cap_U = tot + ROOM_U; }
@@ -571,13 +576,13 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
             parallel_chunks((int64_t)S, 2048, [&](int64_t b, int64_t e, int) {
                 for (int64_t sidx = b; sidx < e; ++sidx) { const Front &F = P.fronts[sidx]; int ns = 0, nl = 0;
                     for (int t = F.asm_off; t < F.asm_off + F.asm_cnt - F.asm_dup; ++t) { const int k = P.asm_recs[t].kind;
-                        if (k == 0) ns += 9; else if (k == 1) { if (fused) ++nl; else ns += 5; } else if (k <= 3) ns += 9; else ns += 6; }
+                        if (k == 0) ns += 9; else if (k == 1) { if (fused) ++nl; else ns += 5; } else if (k <= 3) ns += 9; else if (k == 6) ns += 5; else ns += 6; }
                     bf[8 * sidx + 4] = (ns + 63) & ~63; bf[8 * sidx + 6] = nl; } });
             int64_t so = 0, lo = 0;
             for (size_t sidx = 0; sidx < S; ++sidx) { const Front &F = P.fronts[sidx]; int32_t *r = &bf[8 * sidx];
                 if (so >= ((int64_t)1 << 31) - 64) return fail(GS_ERR_INVALID, "too many assembly scalars");
                 r[0] = F.asm_off; r[1] = F.asm_cnt - F.asm_dup; r[2] = F.npiv + F.nbnd; r[3] = (int32_t)so; r[5] = (int32_t)lo; so += r[4]; lo += r[6]; }
-            constexpr int64_t ROOM_SC = (int64_t)1 << 19;         // scalar records of the fronts a growth step rebuilds
+            const int64_t ROOM_SC = (int64_t)room_of((size_t)so, (size_t)64 << 10, (size_t)1 << 19);         // scalar records of the fronts a growth step rebuilds
             if (so + ROOM_SC >= ((int64_t)1 << 31) - 64) return fail(GS_ERR_INVALID, "too many assembly scalars");
             AL(sc3, 2 * (size_t)(so + ROOM_SC) + 2); AL(lm3, 4 * (size_t)lo + 4);
             g->room.used_sc = so; g->room.cap_sc = so + ROOM_SC;
@@ -585,8 +590,8 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
             g->d_bf = bf_dev; g->bf_host = bf;
             Sc3Args A; for (int k = 0; k < 8; ++k) A.off[k] = arena_off[k];
             A.L = P.ell_len; A.N = N; A.M = M; A.Epp = Epp; A.fused = fused ? 1 : 0;
-            for (int k = 0; k < 4; ++k) A.toff[k] = arena_off[7 + k];
-            A.tcapN = TAIL_POSES; A.tcapEpp = TAIL_PP; A.tcapEpl = TAIL_PL; A.pad = 0;
+            for (int k = 0; k < 6; ++k) A.toff[k] = arena_off[7 + k];
+            A.tcapN = TAIL_POSES; A.tcapEpp = TAIL_PP; A.tcapEpl = TAIL_PL; A.tcapM = TAIL_LMS;
             g->sc3_args = A;
             launch_build_sc3(bf_dev, d.asm3, d.sc3, d.lm3, (int)S, A, g->stream);
             GS_UT("sc3 build");
@@ -610,15 +615,15 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
     GS_UT("f3 x+desc upload");
     AL(dbg_ts, 64); ZERO(dbg_ts, 64);
     AL(done_ts, 2 * P.fronts.size() + 2); ZERO(done_ts, 2 * P.fronts.size() + 2);
-    { const int64_t room_L = g->room.ok ? ((int64_t)2 << 20) : 0;          // doubles: the L panels of fronts a growth step enlarges move here
+    { const int64_t room_L = g->room.ok ? (int64_t)room_of((size_t)P.l_doubles, (size_t)256 << 10, (size_t)2 << 20) : 0;          // doubles: the L panels of fronts a growth step enlarges move here
       AL(Lbuf, P.l_doubles + room_L); g->room.cap_L = P.l_doubles + room_L; }
     AL(Ubuf, (d.factor_variant == 0 || d.factor_variant == 1) ? P.u_doubles : 1);      // variants 2 and 3 keep their update matrices in Uimg
-    AL(xe, P.n_scalar + 3 * TAIL_POSES); g->room.cap_xe = P.n_scalar + 3 * TAIL_POSES;
-    AL(dpose, ((size_t)N + TAIL_POSES) * 3); AL(dlm, (size_t)M * 2); AL(fail, 4);
+    AL(xe, P.n_scalar + 3 * TAIL_POSES + 2 * TAIL_LMS); g->room.cap_xe = P.n_scalar + 3 * TAIL_POSES + 2 * TAIL_LMS;
+    AL(dpose, ((size_t)N + TAIL_POSES) * 3); AL(dlm, ((size_t)M + TAIL_LMS) * 2); AL(fail, 4);
     HIP_TRY(hipMemsetAsync(d.fail, 0, 4 * sizeof(int32_t), g->stream));
     HIP_TRY(hipMemsetAsync(d.chi2, 0, 80 * sizeof(double), g->stream));
     HIP_TRY(hipMemsetAsync(d.dpose, 0, ((size_t)N + TAIL_POSES) * 3 * sizeof(double), g->stream));
-    HIP_TRY(hipMemsetAsync(d.dlm, 0, std::max<size_t>((size_t)M * 2, 1) * sizeof(double), g->stream));
+    HIP_TRY(hipMemsetAsync(d.dlm, 0, ((size_t)M + TAIL_LMS) * 2 * sizeof(double), g->stream));
     // per-level launch parameters and the global workspace for fronts beyond the LDS limit
     const int nlev = (int)P.level_start.size() - 1;
     const int lim = factor_lds_limit_f();
@@ -670,7 +675,7 @@ static int upload_growth(gs_graph *g, const Growth &gr) {
         const int nb = F.nbnd; const int32_t usz = (nb * (nb + 1)) / 2 + nb;
         int ns = 0;
         for (int t = F.asm_off; t < F.asm_off + F.asm_cnt - F.asm_dup; ++t) { const int k = P.asm_recs[t].kind;
-            if (k == 0) ns += 9; else if (k == 1) { if (!fused) ns += 5; } else if (k <= 3) ns += 9; else ns += 6; }
+            if (k == 0) ns += 9; else if (k == 1) { if (!fused) ns += 5; } else if (k <= 3) ns += 9; else if (k == 6) ns += 5; else ns += 6; }
         const int32_t sc_cnt = (ns + 63) & ~63;
         if (used_U + usz + 4 > g->room.cap_U || used_sc + sc_cnt > g->room.cap_sc) return fail(GS_ERR_CAPACITY, "growth: room behind the update matrices / scalar records used up");
         DevFront o; o.npiv = F.npiv; o.nbnd = F.nbnd; o.piv0 = F.piv0; o.parent = F.parent; o.asm_off = F.asm_off; o.asm_cnt = F.asm_cnt;
@@ -694,6 +699,9 @@ static int upload_growth(gs_graph *g, const Growth &gr) {
     int rc;
     if ((rc = H2D(d.pose_est + 3 * (size_t)N0, &h.pose_est[3 * (size_t)N0], (size_t)(N1 - N0) * 3 * sizeof(double))) != GS_OK) return rc;
     if ((rc = H2D(d.pose_gidx + N0, &P.pose_gidx[N0], (size_t)(N1 - N0) * sizeof(int32_t))) != GS_OK) return rc;
+    { const int M0 = gr.first_lm, M1 = P.planned_M;                  // landmarks first seen by the new poses
+      if (M1 > M0) { if ((rc = H2D(d.lm_est + 2 * (size_t)M0, &h.lm_est[2 * (size_t)M0], (size_t)(M1 - M0) * 2 * sizeof(double))) != GS_OK) return rc;
+          if ((rc = H2D(d.lm_gidx + M0, &P.lm_gidx[M0], (size_t)(M1 - M0) * sizeof(int32_t))) != GS_OK) return rc; } }
     launch_pose_trig_range(d, N0, N1 - N0, g->stream);
     for (int k = E0; k < E1; ++k) { double inv[3]; se2_inverse_host(&h.pp_z[3 * (size_t)k], inv);
         double *o = &zinv[5 * (size_t)(k - E0)]; o[0] = inv[0]; o[1] = inv[1]; o[2] = inv[2]; o[3] = std::cos(inv[2]); o[4] = std::sin(inv[2]);
@@ -724,7 +732,7 @@ static int upload_growth(gs_graph *g, const Growth &gr) {
     // changed front too: its copy of the child's row table is rebuilt with it)
     launch_build_sc3(g->d_bf, d.asm3, d.sc3, d.lm3, nf, g->sc3_args, g->stream, g->d_list);
     launch_build_f3(nf, d.level_fronts, d.fronts, d.children, d.child_map, d.u3_off, d.u3_size, g->d_bf, g->d_xrow, nullptr, d.f3_desc, d.f3_x, d.f3x_stride, g->stream, g->d_list + 1024);
-    d.n_scalar = P.n_scalar; d.tN = N1 - P.base_N; d.tEpp = E1 - P.base_Epp; d.tEpl = K1 - P.base_Epl;
+    d.n_scalar = P.n_scalar; d.tN = N1 - P.base_N; d.tM = P.planned_M - P.base_M; d.tEpp = E1 - P.base_Epp; d.tEpl = K1 - P.base_Epl;
     HIP_TRY(hipStreamSynchronize(g->stream));                       // the staging vectors above go out of scope
     { hipError_t e = hipGetLastError(); if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("growth: ") + hipGetErrorString(e)); }
     // host mirrors and launch parameters
@@ -762,7 +770,7 @@ static int build_plan_host(gs_graph *g) {
     if (const char *e = std::getenv("GS_CLUSTER_WAYS")) o.cluster_ways = std::atoi(e);   // tuning override: 2 = binary dissection down to the leaves
     if (const char *e = std::getenv("GS_ELL_LANES")) o.ell_lanes = std::atoi(e);       // tuning knob: lanes per pose of the ELL layout
     if (const char *e = std::getenv("GS_BIG_CLUSTER")) o.big_cluster_front = std::atoi(e);   // tuning override: 0 = clusters only where they fit a wave
-    if (const char *e = std::getenv("GS_GROW_HEADROOM")) o.grow_headroom = std::atoi(e);   // tuning override: 0 = cluster fronts up to the full 63 scalars
+    if (const char *e = std::getenv("GS_GROW_HEADROOM")) { o.grow_headroom = std::atoi(e); o.grow_spine_headroom = std::min(o.grow_spine_headroom, 3 * o.grow_headroom); }   // tuning override: 0 = cluster fronts up to the full 63 scalars
     std::string err;
     if (!build_plan(g->h, o, g->plan, err)) { g->plan_version = ~0ull; return fail(GS_ERR_EMPTY, "plan: " + err); }
     g->plan_version = g->h.structure_version;
@@ -839,7 +847,7 @@ static int ensure_ready(gs_graph *g) {
     int rc = ensure_device(g); if (rc != GS_OK) return rc;
     if (!g->dev_valid || g->plan_version != g->h.structure_version) return gs_initialize_optimization(g);
     if (g->dev_estimate_version != g->h.estimate_version) {      // host-side setEstimate since the upload
-        const int N = g->d.N + g->d.tN, M = g->d.M;
+        const int N = g->d.N + g->d.tN, M = g->d.M + g->d.tM;
         if (N > 0) HIP_TRY(hipMemcpyAsync(g->d.pose_est, g->h.pose_est.data(), (size_t)N * 3 * sizeof(double), hipMemcpyHostToDevice, g->stream));
         if (M > 0) HIP_TRY(hipMemcpyAsync(g->d.lm_est, g->h.lm_est.data(), (size_t)M * 2 * sizeof(double), hipMemcpyHostToDevice, g->stream));
         launch_pose_trig(g->d, g->stream);
@@ -1188,7 +1196,7 @@ extern "C" int gs_export_delta(gs_graph *g, double *dpose, double *dlm) {
     if (!g->dev_valid) return fail(GS_ERR_NOT_INITIALIZED, "no iteration run yet");
     int rc = ensure_device(g); if (rc != GS_OK) return rc;
     if (dpose && g->d.N) HIP_TRY(hipMemcpyAsync(dpose, g->d.dpose, (size_t)(g->d.N + g->d.tN) * 3 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
-    if (dlm && g->d.M) HIP_TRY(hipMemcpyAsync(dlm, g->d.dlm, (size_t)g->d.M * 2 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    if (dlm && g->d.M) HIP_TRY(hipMemcpyAsync(dlm, g->d.dlm, (size_t)(g->d.M + g->d.tM) * 2 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     return GS_OK;
 }
@@ -1196,7 +1204,7 @@ extern "C" int gs_time_iterations(gs_graph *g, int32_t reps, gs_stats *s) {
     if (!g || !s || reps <= 0) return fail(GS_ERR_INVALID, "bad argument");
     if (g->world > 1) return fail(GS_ERR_INVALID, "sharded graph: time the two halves from the caller");
     int rc = ensure_ready(g); if (rc != GS_OK) return rc;
-    const int N = g->d.N + g->d.tN, M = g->d.M;
+    const int N = g->d.N + g->d.tN, M = g->d.M + g->d.tM;
     double *sp = nullptr, *sl = nullptr;                        // save estimates
     HIP_TRY(hipMalloc((void **)&sp, std::max<size_t>((size_t)N * 3, 1) * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&sl, std::max<size_t>((size_t)M * 2, 1) * sizeof(double)));

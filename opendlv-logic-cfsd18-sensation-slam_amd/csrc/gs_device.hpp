@@ -79,11 +79,12 @@ struct DevGraph {
     // BASE counts (they are the plane strides of the H blocks and the extent of the linearisation layout); a tail pose p >= N uses
     // slot p - N, a tail odometry edge k >= Epp slot k - Epp, a tail observation edge the virtual layout index ell_len + slot.
     // pose_est / pose_cs / pose_fixed / pose_gidx / dpose / pp_zinv / pp_info / xe are allocated with room for the tail.
-    int32_t tN = 0, tEpp = 0, tEpl = 0;                         // tail counts (0: no tail, nothing below is touched)
-    int32_t tcapN = 0, tcapEpp = 0, tcapEpl = 0;                // plane strides of the tail blocks
+    int32_t tN = 0, tM = 0, tEpp = 0, tEpl = 0;                 // tail counts (0: no tail, nothing below is touched); tail landmark l >= M: slot l - M
+    int32_t tcapN = 0, tcapM = 0, tcapEpp = 0, tcapEpl = 0;     // plane strides of the tail blocks
     int32_t *t_pp_ij = nullptr;                                 // [tcapEpp][2] endpoints of the tail odometry edges
     int32_t *t_pl = nullptr; double *t_pl_z = nullptr, *t_pl_w = nullptr;    // [tcapEpl][2] {pose, landmark}, [tcapEpl][2], [tcapEpl][3]
     double *t_Hpp_diag = nullptr, *t_b_pose = nullptr, *t_Hpp_off = nullptr, *t_Hpl = nullptr;   // [6][tcapN] [3][tcapN] [9][tcapEpp] [6][tcapEpl], inside H_arena
+    double *t_Hll_diag = nullptr, *t_b_lm = nullptr;            // [3][tcapM] [2][tcapM], inside H_arena (lm_est / lm_fixed / lm_gidx / dlm have room for tcapM more landmarks)
     // pose-window shards (world == 1: everything is "own", no exchange)
     int32_t rank = 0, wt_lo = 0, wt_hi = 0;                     // this shard sweeps wave tiles [wt_lo, wt_hi)
     uint8_t *pose_known = nullptr, *lm_known = nullptr;         // vertex estimates tracked by this rank
@@ -115,7 +116,7 @@ void launch_associate_grid(int n, const double *poses, const int32_t *pose_of_ob
                            double inv_cell, int nx, int ny, const int32_t *cell_start, const int32_t *cell_items, int32_t *out, hipStream_t st);
 // structure phase on the device: expand the block assembly records into scalar / landmark records (k_build_sc3)
 struct Sc3Args { int64_t off[8]; int64_t L; int32_t N, M, Epp, fused;
-                 int64_t toff[4]; int32_t tcapN, tcapEpp, tcapEpl, pad; };     // tail blocks (grow_plan): arena offsets of t_Hpp_diag, t_b_pose, t_Hpp_off, t_Hpl; plane strides
+                 int64_t toff[6]; int32_t tcapN, tcapEpp, tcapEpl, tcapM; };   // tail blocks (grow_plan): arena offsets of t_Hpp_diag, t_b_pose, t_Hpp_off, t_Hpl, t_Hll_diag, t_b_lm; plane strides
 // list != nullptr: only the fronts list[0 .. n_fronts) (growth)
 void launch_build_sc3(const int32_t *bf, const int32_t *asm3, int32_t *sc3, int32_t *lm3, int n_fronts, const Sc3Args &A, hipStream_t st, const int32_t *list = nullptr);
 void launch_linearize_tail(const DevGraph &d, hipStream_t st);  // the tail's edges: their blocks into the tail arenas, their shares of old vertices' diagonal blocks added in place

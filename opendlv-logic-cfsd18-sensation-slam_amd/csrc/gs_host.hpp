@@ -36,7 +36,7 @@ struct HostGraph {
     std::vector<int32_t> pp_i, pp_j; std::vector<double> pp_z /*[E*3]*/, pp_info /*[E*6] xx xy xt yy yt tt*/;
     std::vector<int32_t> pl_p, pl_l; std::vector<double> pl_z /*[E*2]*/, pl_info /*[E*3] xx xy yy*/;
     uint64_t structure_version = 0;     // bumped by every change that invalidates the plan
-    uint64_t reshape_version = 0;       // bumped by the changes a plan cannot absorb by growing: a fixed flag flipped, a landmark added, clear()
+    uint64_t reshape_version = 0;       // bumped by the changes a plan cannot absorb by growing: a fixed flag flipped, clear(), a new shard layout
     uint64_t estimate_version = 0;      // bumped by host-side estimate writes
 
     int n_poses() const { return (int)pose_id.size(); }
@@ -54,6 +54,7 @@ enum AsmKind : int32_t {
     ASM_PP_T = 3,        //                         F[r0+a][c0+b] = Hpp_off[b][a]   (j-vertex rows later)
     ASM_PL = 4,          // src = sorted pl edge  : F[r0+a][c0+b] = Hpl[a][b]  3x2  (pose rows later)
     ASM_PL_T = 5,        //                         F[r0+a][c0+b] = Hpl[b][a]  2x3  (landmark rows later)
+    ASM_LM_DIAG_TAIL = 6,// src = landmark index >= base_M (a landmark appended after the plan was built, grow_plan): like ASM_LM_DIAG, its block in the tail arena
 };
 struct AsmRec { int32_t kind, src, r0, c0; };
 
@@ -119,20 +120,20 @@ struct Plan {
     double ms_build = 0;
     // ---- append-only growth (grow_plan): what the LINEARISATION LAYOUT above covers are the base counts; poses / edges beyond them
     // form the tail (their blocks live in the tail arenas of the device, gs_device.hpp)
-    int32_t base_N = 0, base_Epp = 0, base_Epl = 0;      // counts build_plan saw
-    int32_t planned_N = 0, planned_Epp = 0, planned_Epl = 0;   // counts the plan covers now (base + tail)
+    int32_t base_N = 0, base_M = 0, base_Epp = 0, base_Epl = 0;      // counts build_plan saw
+    int32_t planned_N = 0, planned_M = 0, planned_Epp = 0, planned_Epl = 0;   // counts the plan covers now (base + tail)
     int32_t n_growths = 0;                               // grow_plan calls since build_plan
     uint64_t reshape_version = 0;                        // HostGraph::reshape_version the plan was built at
 };
 
 // Tail capacities (device arenas are sized for them at every full structure phase)
-constexpr int TAIL_POSES = 16, TAIL_PL = 512, TAIL_PP = 64;
+constexpr int TAIL_POSES = 16, TAIL_LMS = 16, TAIL_PL = 512, TAIL_PP = 64;
 
 // What one grow_plan call changed (the device patch works from this)
 struct Growth {
     std::vector<int32_t> fronts;            // fronts whose size, storage, records or maps changed (ascending = elimination order; the root last)
     int64_t bnd_from = 0, map_from = 0, asm_from = 0;     // Plan::bnd_rows / child_map / asm_recs entries from these on are new
-    int32_t first_pose = 0, first_pp = 0, first_pl = 0;   // the poses / edges this call took in: [first, planned)
+    int32_t first_pose = 0, first_lm = 0, first_pp = 0, first_pl = 0;   // the vertices / edges this call took in: [first, planned)
 };
 
 // Append-only growth of a built plan (reference src/slam.cpp:433-459, 537-550: one more pose vertex, its odometry edge, its
@@ -146,7 +147,8 @@ bool grow_plan(const HostGraph &g, Plan &plan, Growth &out, std::string &why_not
 struct PlanOptions { int leaf_poses = 8; int world = 1; int rank = 0; int ell_lanes = 0;
                      int cluster_ways = 0;         // fan-out of the multi-way split above the leaves (0 = default 8, <= 2 = binary all the way down)
                      int big_cluster_front = 111;      // second-pass bound of a cluster front when 63 scalars cannot be met (<= 63: off)
-                     int grow_headroom = 6; };         // scalars a cluster front stays below the 63 of a wave: room for the boundary rows of two appended poses (grow_plan)
+                     int grow_headroom = 6;            // scalars a cluster front stays below the 63 of a wave: room for the boundary rows of two appended poses (grow_plan)
+                     int grow_spine_headroom = 18; };  // the same for the cluster front that holds the LAST pose: appended keyframes continue the track there (six poses)
 
 constexpr int LIN_R = 4;               // observation slots per lane handled by the fused linearisation kernel
 

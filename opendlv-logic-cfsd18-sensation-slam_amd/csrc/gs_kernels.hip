@@ -688,6 +688,8 @@ __global__ void __launch_bounds__(64) k_linearize_tail(DevGraph d) {
     const int lane = threadIdx.x;
     for (int i = lane; i < 6 * d.tcapN; i += 64) d.t_Hpp_diag[i] = 0.0;
     for (int i = lane; i < 3 * d.tcapN; i += 64) d.t_b_pose[i] = 0.0;
+    for (int i = lane; i < 3 * d.tcapM; i += 64) d.t_Hll_diag[i] = 0.0;
+    for (int i = lane; i < 2 * d.tcapM; i += 64) d.t_b_lm[i] = 0.0;
     __threadfence();
     double chi = 0.0;
     const int64_t G = d.n_groups;
@@ -708,7 +710,11 @@ __global__ void __launch_bounds__(64) k_linearize_tail(DevGraph d) {
                 for (int k = 0; k < 6; ++k) { H[k] += q.Hp[k]; d.t_Hpl[(int64_t)k * d.tcapEpl + e] = fl ? 0.0 : q.W6[k]; }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) b[k] += q.bp[k];
-                if (!fl) { const int slot = d.lm_grp_start[l];        // the landmark's first partial-sum slot: the fronts sum the slots in order
+                if (fl) { }
+                else if (l >= d.M) { const int o = l - d.M; const int64_t S = d.tcapM;   // a tail landmark: all of its edges are tail edges, its block is summed here
+                    atomicAdd(d.t_Hll_diag + o, q.Hl[0]); atomicAdd(d.t_Hll_diag + S + o, q.Hl[1]); atomicAdd(d.t_Hll_diag + 2 * S + o, q.Hl[2]);
+                    atomicAdd(d.t_b_lm + o, q.bl[0]); atomicAdd(d.t_b_lm + S + o, q.bl[1]); }
+                else { const int slot = d.lm_grp_start[l];            // an old landmark's first partial-sum slot: the fronts sum the slots in order
                     atomicAdd(d.lm_part + slot, q.Hl[0]); atomicAdd(d.lm_part + G + slot, q.Hl[1]); atomicAdd(d.lm_part + 2 * G + slot, q.Hl[2]);
                     atomicAdd(d.lm_part + 3 * G + slot, q.bl[0]); atomicAdd(d.lm_part + 4 * G + slot, q.bl[1]); }
             } }
@@ -1370,6 +1376,8 @@ __device__ __forceinline__ void asm3_load(const DevGraph &d, int kind_cnt, int s
             } else { const int64_t S = d.M;
                 v[0] = d.Hll_diag[src]; v[1] = d.Hll_diag[S + src]; v[2] = d.Hll_diag[2 * S + src]; v[3] = d.b_lm[src]; v[4] = d.b_lm[S + src]; }
         } break;
+        case 6: { const int64_t S = d.tcapM; const int i = src - d.M;        // a landmark appended after the plan was built: summed by k_linearize_tail
+            v[0] = d.t_Hll_diag[i]; v[1] = d.t_Hll_diag[S + i]; v[2] = d.t_Hll_diag[2 * S + i]; v[3] = d.t_b_lm[i]; v[4] = d.t_b_lm[S + i]; } break;
         case 2: case 3: { const bool tl = src >= d.Epp;
             const int64_t S = tl ? d.tcapEpp : d.Epp; const double *H = tl ? d.t_Hpp_off + (src - d.Epp) : d.Hpp_off + src;
 #pragma unroll
@@ -1403,7 +1411,7 @@ __device__ __forceinline__ void asm3_put(const St &P, int kind_cnt, int r0, int 
             put(r0 + 1, c0 + 1, v[3]); put(r0 + 2, c0 + 1, v[4]); put(r0 + 2, c0 + 2, v[5]);
             put(f, c0, v[6]); put(f, c0 + 1, v[7]); put(f, c0 + 2, v[8]);
             break;
-        case 1:
+        case 1: case 6:
             put(r0, c0, v[0]); put(r0 + 1, c0, v[1]); put(r0 + 1, c0 + 1, v[2]); put(f, c0, v[3]); put(f, c0 + 1, v[4]);
             break;
         case 2: case 3:
@@ -2693,7 +2701,7 @@ __global__ void __launch_bounds__(256) k_build_sc3(const int32_t *__restrict__ b
         const int4 r = on ? reinterpret_cast<const int4 *>(asm3)[asm_off + t] : make_int4(-1, 0, 0, 0);
         const int kind = r.x & 0xff;
         const bool islm = on && kind == 1 && A.fused;
-        int nsc = !on ? 0 : (kind == 0 ? 9 : (kind == 1 ? (A.fused ? 0 : 5) : (kind <= 3 ? 9 : 6)));
+        int nsc = !on ? 0 : (kind == 0 ? 9 : (kind == 1 ? (A.fused ? 0 : 5) : (kind <= 3 ? 9 : (kind == 6 ? 5 : 6))));
         int ps = nsc, pl = islm ? 1 : 0;                                  // inclusive prefix sums over the lanes
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int a = __shfl_up(ps, o, WAVE), b = __shfl_up(pl, o, WAVE); if (lane >= o) { ps += a; pl += b; } }
@@ -2712,10 +2720,12 @@ __global__ void __launch_bounds__(256) k_build_sc3(const int32_t *__restrict__ b
                 else { const int64_t H = A.off[5], B = A.off[6], M = A.M;
                     add(H + src, r0, c0); add(H + M + src, r0 + 1, c0); add(H + 2 * M + src, r0 + 1, c0 + 1); add(B + src, f, c0); add(B + M + src, f, c0 + 1); }
                 break;
+            case 6: { const int64_t H = A.toff[4] - A.M, B = A.toff[5] - A.M, M = A.tcapM;   // tail landmark: diagonal block + rhs out of the tail arena
+                add(H + src, r0, c0); add(H + M + src, r0 + 1, c0); add(H + 2 * M + src, r0 + 1, c0 + 1); add(B + src, f, c0); add(B + M + src, f, c0 + 1); } break;
             case 2: case 3: { const bool tl = src >= A.Epp;
                 const int64_t E = tl ? A.tcapEpp : A.Epp, H = tl ? A.toff[2] - A.Epp : A.off[2];
                 for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) add(H + (kind == 2 ? 3 * a + b : 3 * b + a) * E + src, r0 + a, c0 + b); } break;
-            default: { const bool tl = src >= A.L;
+            default: { const bool tl = src >= A.L;                       // kinds 4, 5
                 const int64_t L = tl ? (int64_t)A.tcapEpl : A.L, H = tl ? A.toff[3] - A.L : A.off[3];
                 if (kind == 4) { for (int a = 0; a < 3; ++a) for (int b = 0; b < 2; ++b) add(H + (2 * a + b) * L + src, r0 + a, c0 + b); }
                 else { for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b) add(H + (2 * b + a) * L + src, r0 + a, c0 + b); } } break;
@@ -2918,9 +2928,9 @@ __global__ void __launch_bounds__(256) k_update(DevGraph d) {
             if (c == 2) { v = normalize_theta(v); double sn, cs; sincos(v, &sn, &cs); reinterpret_cast<double2 *>(d.pose_cs)[p] = make_double2(cs, sn); }
             d.pose_est[ps] = v; }
         d.dpose[ps] = dx;
-    } else if (t < 3 * d.N + 2 * d.M) {
-        const int u = t - 3 * d.N, l = u >> 1, c = u & 1;
-        const int g = d.lm_known[l] ? d.lm_gidx[l] : -1;
+    } else if (t < 3 * d.N + 2 * d.M || (t >= 3 * (d.N + d.tN) + 2 * d.M && t < 3 * (d.N + d.tN) + 2 * (d.M + d.tM))) {
+        const int u = t < 3 * d.N + 2 * d.M ? t - 3 * d.N : t - 3 * (d.N + d.tN), l = u >> 1, c = u & 1;     // (tail landmarks' scalars come last: u = 2 M + ...)
+        const int g = (l >= d.M || d.lm_known[l]) ? d.lm_gidx[l] : -1;
         double dx = 0.0;
         if (g >= 0) { dx = d.xe[g + c]; d.lm_est[u] += dx; }
         d.dlm[u] = dx;
@@ -2953,7 +2963,7 @@ __global__ void __launch_bounds__(256) k_update(DevGraph d) {
     }
 }
 void launch_update(const DevGraph &d, hipStream_t st) {
-    int n = 3 * (d.N + d.tN) + 2 * d.M;
+    int n = 3 * (d.N + d.tN) + 2 * (d.M + d.tM);
     if (n > 0) hipLaunchKernelGGL(k_update, dim3((n + 255) / 256), dim3(256), 0, st, d);
 }
 

@@ -143,10 +143,16 @@ struct Builder {
         // and the bound becomes the 7-tile-row instance's 111 — otherwise such a range falls back to binary splits and
         // leaves level after level of ONE-pose separators (3 pivots each) with 60-100 boundary rows
         const int p_first = p;
-        const int wave_limit = 63 - std::max(0, std::min(opt.grow_headroom, 30));
-        int limit = wave_limit;
+        // the bounds tried in turn: (the cluster that holds the LAST pose: room for six appended keyframes,) room for two (grow_plan: an
+        // appended pose becomes three boundary rows of the fronts between its neighbours and the root), then the workgroup-front bound
+        int limits[3], nlim = 0;
+        { const int room = std::max(0, std::min(opt.grow_headroom, 30)), spine = std::max(room, std::min(opt.grow_spine_headroom, 30));
+          if (b == nfp && spine > room) limits[nlim++] = 63 - spine;
+          limits[nlim++] = 63 - room;
+          if (opt.big_cluster_front > 63) limits[nlim++] = opt.big_cluster_front; }
+        int li = 0, limit = limits[0];
         for (;; --p) {
-            if (p <= 2) { if (limit == wave_limit && opt.big_cluster_front > 63) { limit = opt.big_cluster_front; p = p_first + 1; continue; } return false; }
+            if (p <= 2) { if (++li < nlim) { limit = limits[li]; p = p_first + 1; continue; } return false; }
             sep_poses.clear(); cut.clear(); sep_cones.clear(); orphans.clear();
             // split poses: the unassigned ones at ranks (un * k) / p, k = 1 .. p - 1; part k = positions (cut[k], cut[k + 1])
             cut.push_back(a - 1);
@@ -584,13 +590,14 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         for (int q = 0; q < G; ++q) plan.grp_slot[q] = fill[plan.grp_lm[q]]++;
     }
 
-    plan.base_N = plan.planned_N = N; plan.base_Epp = plan.planned_Epp = Epp; plan.base_Epl = plan.planned_Epl = Epl;
+    plan.base_N = plan.planned_N = N; plan.base_M = plan.planned_M = M; plan.base_Epp = plan.planned_Epp = Epp; plan.base_Epl = plan.planned_Epl = Epl;
     plan.n_growths = 0; plan.reshape_version = g.reshape_version;
     // room for grow_plan's re-written runs: without it the first growth step pays for reallocating (and copying) these arrays — 3 of
     // its 4 ms at 100k poses
     plan.bnd_rows.reserve(plan.bnd_rows.size() + 64 * 1024); plan.child_map.reserve(plan.child_map.size() + 64 * 1024);
     plan.asm_recs.reserve(plan.asm_recs.size() + 96 * 1024);
     plan.pose_gidx.reserve((size_t)N + TAIL_POSES); plan.pose_known.reserve((size_t)N + TAIL_POSES);
+    plan.lm_gidx.reserve((size_t)M + TAIL_LMS); plan.lm_known.reserve((size_t)M + TAIL_LMS);
     plan.pl_order.reserve((size_t)Epl + TAIL_PL); plan.ell_of_ins.reserve((size_t)Epl + TAIL_PL); plan.pl_rank.reserve((size_t)Epl + TAIL_PL);
     plan.ell_ins.reserve((size_t)plan.ell_len + TAIL_PL); plan.pp_order.reserve((size_t)Epp + TAIL_PP); plan.pp_rank.reserve((size_t)Epp + TAIL_PP);
     plan.valid = true;
@@ -600,7 +607,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
 }
 
 // ---- append-only growth -------------------------------------------------------------------------------------------------
-// New poses are eliminated LAST: extra pivots of the root front.  A neighbour v of a new pose P (the other end of one of P's
+// New poses (and new landmarks: they can only touch new poses) are eliminated LAST: extra pivots of the root front.  A neighbour v of a new pose P (the other end of one of P's
 // edges, free, older) is a pivot of some front s0; eliminating v makes P a neighbour of everything v touched later, i.e. P joins
 // the boundary of s0 and of every front on the way from s0 to the root — the exact fill of the enlarged matrix under the enlarged
 // order.  P's scalars get the largest elimination indices, so they are the LAST rows of every front they enter: no existing row of
@@ -614,12 +621,11 @@ bool grow_plan(const HostGraph &g, Plan &P, Growth &out, std::string &why) {
     if (!P.valid) return no("no plan");
     if (P.world > 1) return no("sharded plan");
     if (!P.lin_ell_ok || P.max_front > 63) return no("plan outside the wave-per-front form");
-    if (g.reshape_version != P.reshape_version) return no("a fixed flag or the landmark set changed");
-    const int N0 = P.planned_N, N1 = g.n_poses(), Epp0 = P.planned_Epp, Epp1 = g.n_pp(), Epl0 = P.planned_Epl, Epl1 = g.n_pl();
-    if (g.n_lms() != (int)P.lm_gidx.size()) return no("new landmark");
-    if (N1 < N0 || Epp1 < Epp0 || Epl1 < Epl0) return no("graph shrank");
-    if (N1 == N0 && Epp1 == Epp0 && Epl1 == Epl0) return no("nothing new");
-    if (N1 - P.base_N > TAIL_POSES || Epl1 - P.base_Epl > TAIL_PL || Epp1 - P.base_Epp > TAIL_PP) return no("tail capacity");
+    if (g.reshape_version != P.reshape_version) return no("a fixed flag changed (or the graph was cleared)");
+    const int N0 = P.planned_N, N1 = g.n_poses(), M0 = P.planned_M, M1 = g.n_lms(), Epp0 = P.planned_Epp, Epp1 = g.n_pp(), Epl0 = P.planned_Epl, Epl1 = g.n_pl();
+    if (N1 < N0 || M1 < M0 || Epp1 < Epp0 || Epl1 < Epl0) return no("graph shrank");
+    if (N1 == N0 && M1 == M0 && Epp1 == Epp0 && Epl1 == Epl0) return no("nothing new");
+    if (N1 - P.base_N > TAIL_POSES || M1 - P.base_M > TAIL_LMS || Epl1 - P.base_Epl > TAIL_PL || Epp1 - P.base_Epp > TAIL_PP) return no("tail capacity");
     const int S = (int)P.fronts.size();
     if (S == 0) return no("empty plan");
     const int R = S - 1;
@@ -630,70 +636,86 @@ bool grow_plan(const HostGraph &g, Plan &P, Growth &out, std::string &why) {
     for (int k = Epl0; k < Epl1; ++k) if (g.pl_p[k] < N0) return no("new observation edge on an old pose");
     for (int k = Epp0; k < Epp1; ++k) if (g.pp_i[k] < N0 && g.pp_j[k] < N0) return no("new odometry edge between old poses");
     for (int p = N0; p < N1; ++p) if (g.pose_fixed[p]) return no("new pose is fixed");
-    // front of a scalar: fronts are in elimination order with contiguous pivots
+    for (int l = M0; l < M1; ++l) if (g.lm_fixed[l]) return no("new landmark is fixed");
+    // front of a scalar: fronts are in elimination order with contiguous pivots (anything beyond the old scalars: the root)
     std::vector<int32_t> piv0(S);
     for (int s = 0; s < S; ++s) piv0[s] = P.fronts[s].piv0;
     auto front_of = [&](int gi) { return (int)(std::upper_bound(piv0.begin(), piv0.end(), gi) - piv0.begin()) - 1; };
-    // edges of each new pose (insertion order)
-    struct Nb { int32_t gv, kind, src; };                    // neighbour's first scalar, record kind, record source
-    std::vector<std::vector<Nb>> nbs(N1 - N0);
-    std::vector<int32_t> gidx_new(N1 - N0);
-    for (int p = N0; p < N1; ++p) gidx_new[p - N0] = P.n_scalar + 3 * (p - N0);
-    auto pose_g = [&](int p) { return p < N0 ? P.pose_gidx[p] : gidx_new[p - N0]; };
+    // the batch's vertices enter the order as: new poses (by index), then new landmarks (by index)
+    const int nP = N1 - N0, nL = M1 - M0, nV = nP + nL;
+    auto vdim = [&](int v) { return v < nP ? 3 : 2; };
+    std::vector<int32_t> gnew(nV);
+    { int sc = P.n_scalar; for (int v = 0; v < nV; ++v) { gnew[v] = sc; sc += vdim(v); } }
+    auto pose_g = [&](int p) { return p < N0 ? P.pose_gidx[p] : gnew[p - N0]; };
+    auto lm_g = [&](int l) { return l < M0 ? P.lm_gidx[l] : gnew[nP + (l - M0)]; };
+    // neighbours: for every new vertex the OLDER free end of each of its new edges (the block of an edge lands in the front of its
+    // earlier end, at the later end's rows)
+    struct Nb { int32_t gv, kind, src; };                    // earlier end's first scalar, record kind, record source
+    std::vector<std::vector<Nb>> nbs(nV);
+    std::vector<uint8_t> lm_seen(nL, 0);
     for (int k = Epl0; k < Epl1; ++k) { const int p = g.pl_p[k], l = g.pl_l[k];
         if (g.lm_fixed[l]) continue;                         // fixed landmark: the edge only feeds the pose's diagonal block
-        if (P.lm_gidx[l] < 0) return no("free landmark without a scalar");
-        if (P.lm_grp_start[l + 1] <= P.lm_grp_start[l]) return no("landmark without a partial-sum slot");
-        for (const Nb &o : nbs[p - N0]) if (o.kind == ASM_PL && o.gv == P.lm_gidx[l]) return no("a new pose observes a landmark twice");
-        nbs[p - N0].push_back({P.lm_gidx[l], ASM_PL, (int32_t)(P.ell_len + (k - P.base_Epl))}); }
+        const int gp = pose_g(p), gl = lm_g(l);
+        if (gl < 0) return no("free landmark without a scalar");
+        if (l < M0 && l < P.base_M && P.lm_grp_start[l + 1] <= P.lm_grp_start[l]) return no("landmark without a partial-sum slot");
+        if (l >= M0) lm_seen[l - M0] = 1;
+        const int src = (int32_t)(P.ell_len + (k - P.base_Epl));
+        if (gl < gp) { auto &v = nbs[p - N0];                // landmark earlier: rows of the pose below the landmark's columns
+            for (const Nb &o : v) if (o.kind == ASM_PL && o.gv == gl) return no("a new pose observes a landmark twice");
+            v.push_back({gl, ASM_PL, src}); }
+        else { auto &v = nbs[nP + (l - M0)];                 // (a new landmark seen by a pose of the same batch) pose earlier
+            for (const Nb &o : v) if (o.kind == ASM_PL_T && o.gv == gp) return no("a new pose observes a landmark twice");
+            v.push_back({gp, ASM_PL_T, src}); } }
+    for (int l = M0; l < M1; ++l) if (!lm_seen[l - M0]) return no("new landmark without an observation");
     for (int k = Epp0; k < Epp1; ++k) { const int i = g.pp_i[k], j = g.pp_j[k];
         if (g.pose_fixed[i] || g.pose_fixed[j]) continue;    // (a fixed end: diagonal contribution only)
         const int later = std::max(i, j), earlier = std::min(i, j);      // poses enter the order by index: the larger index is eliminated later
         if (later < N0) continue;
         const int ge = pose_g(earlier);
         if (ge < 0) continue;
-        for (const Nb &o : nbs[later - N0]) if (o.kind != ASM_PL && o.gv == ge) return no("parallel odometry edges on a new pose");
+        for (const Nb &o : nbs[later - N0]) if ((o.kind == ASM_PP || o.kind == ASM_PP_T) && o.gv == ge) return no("parallel odometry edges on a new pose");
         nbs[later - N0].push_back({ge, later == j ? ASM_PP_T : ASM_PP, k}); }   // earlier end = i: F = Hpp_off^T (rows of j below i's columns)
     // ---- size check before anything is written
     { std::vector<int32_t> add(S, 0), stamp(S, -1);
-      for (int p = N0; p < N1; ++p) { add[R] += 3;
-          for (const Nb &o : nbs[p - N0]) { const int s0 = front_of(o.gv < P.n_scalar ? o.gv : P.fronts[R].piv0);
-              for (int s = s0; s != R; s = P.fronts[s].parent) { if (stamp[s] == p) break; stamp[s] = p; add[s] += 3; } } }
+      for (int v = 0; v < nV; ++v) { add[R] += vdim(v);
+          for (const Nb &o : nbs[v]) { const int s0 = front_of(o.gv);
+              for (int s = s0; s != R; s = P.fronts[s].parent) { if (stamp[s] == v) break; stamp[s] = v; add[s] += vdim(v); } } }
       for (int s = 0; s < S; ++s) if (add[s] && P.fronts[s].npiv + P.fronts[s].nbnd + add[s] > 63) return no("a front would exceed 63 scalars"); }
     // ---- apply
     out.bnd_from = (int64_t)P.bnd_rows.size(); out.map_from = (int64_t)P.child_map.size(); out.asm_from = (int64_t)P.asm_recs.size();
-    out.first_pose = N0; out.first_pp = Epp0; out.first_pl = Epl0;
+    out.first_pose = N0; out.first_lm = M0; out.first_pp = Epp0; out.first_pl = Epl0;
     std::vector<uint8_t> touched(S, 0);
     std::vector<int32_t> stamp(S, -1), path;
     std::vector<std::vector<AsmRec>> newrec(S);
-    for (int p = N0; p < N1; ++p) {
+    for (int v = 0; v < nV; ++v) {
         Front &Rf = P.fronts[R];
-        const int gP = gidx_new[p - N0], rowR = Rf.npiv;
-        Rf.npiv += 3; touched[R] = 1;
-        P.pose_gidx.push_back(gP);
+        const int dv = vdim(v), gV = gnew[v], rowR = Rf.npiv;
+        Rf.npiv += dv; touched[R] = 1;
+        if (v < nP) P.pose_gidx.push_back(gV); else P.lm_gidx.push_back(gV);
         path.clear();
-        for (const Nb &o : nbs[p - N0]) { const int s0 = front_of(o.gv);
-            for (int s = s0; s != R; s = P.fronts[s].parent) { if (stamp[s] == p) break; stamp[s] = p; path.push_back(s); } }
+        for (const Nb &o : nbs[v]) { const int s0 = front_of(o.gv);
+            for (int s = s0; s != R; s = P.fronts[s].parent) { if (stamp[s] == v) break; stamp[s] = v; path.push_back(s); } }
         std::sort(path.begin(), path.end());
-        for (int s : path) { P.fronts[s].nbnd += 3; touched[s] = 1; }
-        for (int s : path) { Front &F = P.fronts[s]; const int nb_old = F.nbnd - 3;
-            // boundary rows: the old run + P's scalars, at the end of the array
+        for (int s : path) { P.fronts[s].nbnd += dv; touched[s] = 1; }
+        for (int s : path) { Front &F = P.fronts[s]; const int nb_old = F.nbnd - dv;
+            // boundary rows: the old run + the new vertex's scalars, at the end of the array
             { const int64_t o = (int64_t)P.bnd_rows.size(); P.bnd_rows.resize((size_t)o + F.nbnd);
               std::copy(P.bnd_rows.begin() + F.bnd_off, P.bnd_rows.begin() + F.bnd_off + nb_old, P.bnd_rows.begin() + o);
-              for (int t = 0; t < 3; ++t) P.bnd_rows[(size_t)o + nb_old + t] = gP + t;
+              for (int t = 0; t < dv; ++t) P.bnd_rows[(size_t)o + nb_old + t] = gV + t;
               F.bnd_off = o; }
-            // rows of the parent's front: P's are its last (the root: its newest pivots)
-            { const Front &Pa = P.fronts[F.parent]; const int prow = F.parent == R ? rowR : Pa.npiv + Pa.nbnd - 3;
+            // rows of the parent's front: the new vertex's are its last (the root: its newest pivots)
+            { const Front &Pa = P.fronts[F.parent]; const int prow = F.parent == R ? rowR : Pa.npiv + Pa.nbnd - dv;
               const int64_t o = (int64_t)P.child_map.size(); P.child_map.resize((size_t)o + F.nbnd);
               std::copy(P.child_map.begin() + F.map_off, P.child_map.begin() + F.map_off + nb_old, P.child_map.begin() + o);
-              for (int t = 0; t < 3; ++t) P.child_map[(size_t)o + nb_old + t] = prow + t;
+              for (int t = 0; t < dv; ++t) P.child_map[(size_t)o + nb_old + t] = prow + t;
               F.map_off = o; } }
-        for (const Nb &o : nbs[p - N0]) { const int s0 = front_of(o.gv); const Front &F = P.fronts[s0];
-            const int r0 = s0 == R ? rowR : F.npiv + F.nbnd - 3;
+        for (const Nb &o : nbs[v]) { const int s0 = front_of(o.gv); const Front &F = P.fronts[s0];
+            const int r0 = s0 == R ? rowR : F.npiv + F.nbnd - dv;
             newrec[s0].push_back({o.kind, o.src, r0, o.gv - F.piv0}); }
-        newrec[R].push_back({ASM_POSE_DIAG, p, rowR, rowR});
+        if (v < nP) newrec[R].push_back({ASM_POSE_DIAG, N0 + v, rowR, rowR});
+        else newrec[R].push_back({ASM_LM_DIAG_TAIL, M0 + (v - nP), rowR, rowR});
     }
-    P.n_scalar += 3 * (N1 - N0);
+    P.n_scalar = gnew.empty() ? P.n_scalar : gnew.back() + vdim(nV - 1);
     for (int s = 0; s < S; ++s) { if (!touched[s]) continue;
         Front &F = P.fronts[s]; out.fronts.push_back(s);
         if (!newrec[s].empty()) {                                // unique records (the new ones have the largest rows), then the duplicates
@@ -711,8 +733,8 @@ bool grow_plan(const HostGraph &g, Plan &P, Growth &out, std::string &why) {
         if ((int64_t)P.ell_ins.size() < (int64_t)e + 1) P.ell_ins.resize((size_t)e + 1, -1);
         P.ell_ins[(size_t)e] = k; }
     for (int k = Epp0; k < Epp1; ++k) P.pp_order.push_back(k);
-    P.pose_known.resize(N1, 1); P.pl_rank.resize(Epl1, 0); P.pp_rank.resize(Epp1, 0);
-    P.planned_N = N1; P.planned_Epp = Epp1; P.planned_Epl = Epl1; ++P.n_growths;
+    P.pose_known.resize(N1, 1); P.lm_known.resize(M1, 1); P.pl_rank.resize(Epl1, 0); P.pp_rank.resize(Epp1, 0);
+    P.planned_N = N1; P.planned_M = M1; P.planned_Epp = Epp1; P.planned_Epl = Epl1; ++P.n_growths;
     return true;
 }
 

@@ -6,5 +6,6 @@ timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; 
 timeout -k 10 300 python scripts/growth_time.py cfg4 1 1 2>&1 | tee $O/growth_time.txt
 timeout -k 10 300 python scripts/growth_time.py cfg4 4 4 2>&1 | tee -a $O/growth_time.txt
 timeout -k 10 300 python scripts/growth_time.py cfg3 2 2 2>&1 | tee -a $O/growth_time.txt
+timeout -k 10 300 python scripts/growth_time.py cfg4 5 5 60007 2>&1 | tee -a $O/growth_time.txt
 timeout -k 10 600 python scripts/growth_time.py cfg5 1 1 2>&1 | tee -a $O/growth_time.txt
 timeout -k 10 300 python scripts/iter_time.py cfg4 | tee $O/iter_cfg4.txt

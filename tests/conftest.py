@@ -51,34 +51,49 @@ def make_oracle_graph(po, g):
     return og
 
 
-def split_for_growth(g, h):
-    """A bench graph cut into a BASE (everything but the last `h` poses and their edges) and the TAIL that an append-only growth
-    brings in (reference src/slam.cpp:433-459, 537-550: a pose vertex, its odometry edge, its observation edges).  Returns
-    (base, tail, full) where `full` holds the edges in the order a handle sees them: base edges, then tail edges.  Every cone must be
-    observed by a base pose (the last poses of the closed track look at cones the first ones mapped)."""
-    N = len(g["pose_est"]); Nb = N - h
-    kpp = (g["pp_i"] < Nb) & (g["pp_j"] < Nb); kpl = g["pl_p"] < Nb
-    assert set(np.unique(g["pl_l"][~kpl])) <= set(np.unique(g["pl_l"][kpl])), "a held-back pose is the first to see a cone"
+def split_for_growth(g, h, keep=None):
+    """A bench graph cut into a BASE (everything but the last `h` poses, their edges and the cones only they see) and the TAIL that an
+    append-only growth brings in (reference src/slam.cpp:433-459, 525-550: a pose vertex, its odometry edge, its observation edges,
+    cones it is the first to see).  keep: use only the first `keep` poses of the lap — an open stretch whose last poses discover
+    cones; the whole closed lap's last poses only re-observe cones the first ones mapped.  Returns (base, tail, full) where `full`
+    holds the edges in the order a handle sees them: base edges, then tail edges.  Landmarks are numbered by first observation
+    (track.bench_graph), so the cones of the base are a prefix of the landmark array."""
+    N = len(g["pose_est"]) if keep is None else int(keep); Nb = N - h
+    in_pp = (g["pp_i"] < N) & (g["pp_j"] < N); in_pl = g["pl_p"] < N
+    M = int(g["pl_l"][in_pl].max()) + 1
+    assert len(np.unique(g["pl_l"][in_pl])) == M, "the cones of the first poses are not a prefix of the landmark array"
+    kpp = in_pp & (g["pp_i"] < Nb) & (g["pp_j"] < Nb); kpl = in_pl & (g["pl_p"] < Nb)
+    Mb = int(g["pl_l"][kpl].max()) + 1
+    assert len(np.unique(g["pl_l"][kpl])) == Mb
     pick = lambda m: dict(pp_i=g["pp_i"][m[0]], pp_j=g["pp_j"][m[0]], pp_z=g["pp_z"][m[0]], pp_info=g["pp_info"][m[0]],
                           pl_p=g["pl_p"][m[1]], pl_l=g["pl_l"][m[1]], pl_z=g["pl_z"][m[1]], pl_info=g["pl_info"][m[1]])
-    base = dict(g); base.update(pick((kpp, kpl))); base["pose_est"] = g["pose_est"][:Nb].copy()
-    tail = pick((~kpp, ~kpl)); tail["pose_est"] = g["pose_est"][Nb:].copy(); tail["first_pose"] = Nb
-    full = dict(g)
+    base = dict(g); base.update(pick((kpp, kpl))); base["pose_est"] = g["pose_est"][:Nb].copy(); base["lm_est"] = g["lm_est"][:Mb].copy()
+    tail = pick((in_pp & ~kpp, in_pl & ~kpl)); tail["pose_est"] = g["pose_est"][Nb:N].copy(); tail["first_pose"] = Nb
+    tail["lm_est"] = g["lm_est"][Mb:M].copy(); tail["first_lm"] = Mb
+    # a new cone arrives with the first pose that sees it
+    tail["lm_first_pose"] = np.array([tail["pl_p"][tail["pl_l"] == l].min() for l in range(Mb, M)], dtype=np.int64)
+    full = dict(g); full["pose_est"] = g["pose_est"][:N].copy(); full["lm_est"] = g["lm_est"][:M].copy()
     for k in ("pp_i", "pp_j", "pp_z", "pp_info", "pl_p", "pl_l", "pl_z", "pl_info"):
         full[k] = np.concatenate([base[k], tail[k]])
     return base, tail, full
 
 
 def append_tail(G, tail, poses=None):
-    """adds the tail's poses [first_pose + a, first_pose + b) and the edges whose later pose lies in that range to a handle"""
+    """adds the tail's poses [first_pose + a, first_pose + b), the cones they are the first to see, and the edges whose later pose lies in
+    that range to a handle — in the order the reference inserts them: vertices, then edges"""
     f = tail["first_pose"]; a, b = poses if poses else (0, len(tail["pose_est"]))
     G.add_poses(np.arange(f + a, f + b), tail["pose_est"][a:b])
+    newl = np.flatnonzero((tail["lm_first_pose"] >= f + a) & (tail["lm_first_pose"] < f + b))
+    if len(newl):
+        assert np.array_equal(newl, np.arange(newl[0], newl[0] + len(newl)))     # discovered in index order
+        G.add_landmarks(tail["first_lm"] + newl, tail["lm_est"][newl])
     later = np.maximum(tail["pp_i"], tail["pp_j"]); m = (later >= f + a) & (later < f + b)
     if m.any():
         G.add_odometry_edges(tail["pp_i"][m], tail["pp_j"][m], tail["pp_z"][m], tail["pp_info"][m])
     m = (tail["pl_p"] >= f + a) & (tail["pl_p"] < f + b)
     if m.any():
         G.add_observation_edges(tail["pl_p"][m], tail["pl_l"][m], tail["pl_z"][m], tail["pl_info"][m])
+    return len(newl)
 
 
 @pytest.fixture(scope="session")

@@ -107,7 +107,7 @@ class Plan:
                 for c in range(3):
                     F[r0 + c:r0 + 3, c0 + c] += H[c:, c]
                 F[f, c0:c0 + 3] += blocks["b_pose"][src]
-            elif kind == 1:
+            elif kind in (1, 6):                # 6: a landmark appended after the plan was built (grow_plan), same block
                 H = blocks["Hll_diag"][src].reshape(2, 2)
                 for c in range(2):
                     F[r0 + c:r0 + 2, c0 + c] += H[c:, c]

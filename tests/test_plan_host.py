@@ -150,33 +150,40 @@ def test_a_rank_plans_its_own_window_and_the_shared_top_only(pkg, bench_graphs):
     assert len(slots) >= world - 1
 
 
-@pytest.mark.parametrize("N,M,h,steps", [(50, 30, 1, 1), (1000, 200, 3, 1), (1000, 200, 4, 2)])
-def test_appended_poses_grow_the_plan_instead_of_rebuilding_it(pkg, po, bench_graphs, N, M, h, steps):
-    """Append-only growth (reference src/slam.cpp:433-459, 537-550; gs::grow_plan): the last h poses of the track arrive after the plan
-    was built, in `steps` batches.  The plan must absorb them (same fronts, same tree, only root-path fronts larger), stay a valid
-    multifrontal plan, and its numeric replay must reproduce the oracle's joint solve of the WHOLE graph."""
+@pytest.mark.parametrize("N,M,h,steps,keep", [(50, 30, 1, 1, None), (1000, 200, 3, 1, None), (1000, 200, 4, 2, None), (1000, 200, 6, 3, 600), (10000, 2000, 4, 2, 4007)])
+def test_appended_poses_grow_the_plan_instead_of_rebuilding_it(pkg, po, bench_graphs, N, M, h, steps, keep):
+    """Append-only growth (reference src/slam.cpp:433-459, 525-550; gs::grow_plan): the last h poses of the track — with `keep`, of an
+    open stretch of it, where they are the first to see some cones — arrive after the plan was built, in `steps` batches.  The plan
+    must absorb them (same fronts, same tree, only root-path fronts larger), stay a valid multifrontal plan, and its numeric replay
+    must reproduce the oracle's joint solve of the WHOLE graph."""
     _, g = bench_graphs(N, M)
-    base, tail, full = split_for_growth(g, h)
+    base, tail, full = split_for_growth(g, h, keep)
+    Nf, Mf = len(full["pose_est"]), len(full["lm_est"])
     G = host_graph(pkg, base)
     info0 = G.plan_build_host(); P0 = Plan(G.plan_export())
     assert G.plan_growths() == 0
-    per = h // steps
+    per = h // steps; new_lms = 0
     for k in range(steps):
-        append_tail(G, tail, (k * per, h if k == steps - 1 else (k + 1) * per))
+        new_lms += append_tail(G, tail, (k * per, h if k == steps - 1 else (k + 1) * per))
         info = G.plan_build_host()
         assert G.plan_growths() == k + 1, G.growth_refusal()
+    assert new_lms == Mf - len(base["lm_est"]) and (keep is None or new_lms > 0)
     P = Plan(G.plan_export()); P.check_invariants()
     assert P.n_fronts == P0.n_fronts and np.array_equal(P.parent, P0.parent) and np.array_equal(P.level, P0.level)
-    assert info.n_scalar == info0.n_scalar + 3 * h and P.n_poses == N
+    assert info.n_scalar == info0.n_scalar + 3 * h + 2 * new_lms and P.n_poses == Nf and P.n_lms == Mf
     changed = np.flatnonzero((P.npiv != P0.npiv) | (P.nbnd != P0.nbnd))
     assert 0 < len(changed) <= 16 * P.n_levels and changed[-1] == P.n_fronts - 1            # a few root paths, the root among them
-    assert np.array_equal(P.pose_gidx[:N - h], P0.pose_gidx) and np.array_equal(P.lm_gidx, P0.lm_gidx)      # nothing older moved
+    assert np.array_equal(P.pose_gidx[:Nf - h], P0.pose_gidx) and np.array_equal(P.lm_gidx[:Mf - new_lms], P0.lm_gidx)      # nothing older moved
     blocks, (dp_o, dl_o) = oracle_increment(po, full)
     dp, dl, ok = P.solve(blocks)
     scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
-    assert ok and np.abs(dp - dp_o).max() / scale < 1e-8 and np.abs(dl - dl_o).max() / scale < 1e-8
+    tol = 1e-8 if keep is None else 1e-5          # (an open stretch anchored at one end is worse conditioned than the closed lap: 1e-6 at 4 000 poses, for a full build's replay as well)
+    assert ok and np.abs(dp - dp_o).max() / scale < tol and np.abs(dl - dl_o).max() / scale < tol
+    if keep is not None:                          # ... so there the grown plan is also held against the replay of a FULL build of the same graph
+        Ff = host_graph(pkg, full); Ff.plan_build_host(); dpf, dlf, okf = Plan(Ff.plan_export()).solve(blocks); Ff.close()
+        assert okf and np.abs(dp - dpf).max() / scale < tol and np.abs(dl - dlf).max() / scale < tol
     # what growth cannot absorb is refused with a reason, and the full build takes over
-    G.add_landmark(10 ** 6, [0.0, 0.0]); G.add_observation_edge(N - 1, 10 ** 6, [1.0, 0.0], [0.01, 0, 0, 0.01])
+    G.set_fixed_pose(Nf - 1, True)
     G.plan_build_host()
-    assert G.plan_growths() == 0 and "landmark" in G.growth_refusal()
+    assert G.plan_growths() == 0 and "fixed" in G.growth_refusal()
     G.close()
