@@ -382,6 +382,22 @@ def main():
         rb = {"cfg4": dict(algorithmic_bytes=alg_bytes, ms_per_launch=out["roofline"]["ms_per_launch"], achieved=out["roofline"]["achieved"],
                            frac=out["roofline"]["frac"], ms_per_launch_back_to_back=lin_ms, frac_back_to_back=achieved / HBM_PEAK_GBS,
                            iteration_ms=ms_per_step, iterations_per_s=value)}
+        # one more keyframe on the timed handle (reference src/slam.cpp:433-459, 537-550: a pose vertex, its odometry edge, observation
+        # edges to the cones the last pose sees): the structure phase the next optimize() needs — the plan grows, nothing is rebuilt
+        try:
+            p_last = G.poses()[-1]; step = np.array([0.25, 0.0, 0.0]); c, s_ = np.cos(p_last[2]), np.sin(p_last[2])
+            p_new = np.array([p_last[0] + c * step[0], p_last[1] + s_ * step[0], p_last[2]])
+            seen = g["pl_l"][g["pl_p"] == N - 1]; L_xy = G.landmarks()[seen]
+            z = np.stack([c * (L_xy[:, 0] - p_new[0]) + s_ * (L_xy[:, 1] - p_new[1]), -s_ * (L_xy[:, 0] - p_new[0]) + c * (L_xy[:, 1] - p_new[1])], axis=1)
+            G.add_pose(N, p_new); G.add_odometry_edge(N - 1, N, step, np.asarray(g["pp_info"][0]).reshape(3, 3))
+            G.add_observation_edges(np.full(len(seen), N), seen, z, np.tile(np.asarray(g["pl_info"][0]).reshape(1, 4), (len(seen), 1)))
+            t0 = time.perf_counter(); G.initialize_optimization(); grow_ms = 1e3 * (time.perf_counter() - t0)
+            grown = G.plan_growths(); it_g = G.time_iterations(10)
+            out["growth"] = dict(what="one more pose + its odometry edge + %d observation edges on the timed handle, then gs_initialize_optimization" % len(seen),
+                                 ms_structure_after_one_more_keyframe=grow_ms, plan_growths=int(grown), refusal=G.growth_refusal(),
+                                 ms_structure_full=plan.ms_structure, iteration_ms_after=it_g.ms_total, iteration_ms_before=phases.ms_total)
+        except Exception as e:                                  # an extra: never costs the bench line
+            out["growth"] = dict(error=str(e))
         G.close(); G = None                                     # cfg5 wants the HBM to itself
         for name in ("cfg3", "cfg5"):
             rb[name] = linearize_roofline_of(pkg, name, local)

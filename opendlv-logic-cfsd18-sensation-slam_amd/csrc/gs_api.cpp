@@ -35,10 +35,16 @@ static int usable_devices() {
 }
 
 // Device memory of a plan comes out of a few large chunks (8 MB, then doubling): the ~70 arrays of one structure phase
-// cost 7 hipMalloc calls instead of 70 (each is 50-100 us of the structure phase), and dev_free_all returns them together.
+// cost a dozen hipMalloc calls instead of 70 (each is 50-100 us of the structure phase), and dev_free_all returns them together.
+// Arrays of 32 MB and more get an allocation of their own.
 template <class T> static int dev_alloc(gs_graph *g, T **ptr, size_t count) {
     *ptr = nullptr;
     const size_t bytes = (std::max<size_t>(count, 1) * sizeof(T) + 255) & ~(size_t)255;
+    if (bytes >= ((size_t)32 << 20)) {                                // a big array: its own allocation, exactly its size (a chunk rounded up to a
+        void *p = nullptr;                                            // power of two for it, or the abandoned rest of the current chunk, were 270 MB of
+        HIP_TRY(hipMalloc(&p, bytes));                                // an 800 MB footprint at 100k poses)
+        g->allocs.push_back(p); g->pool_total += bytes; *ptr = (T *)p;
+        return GS_OK; }
     if (g->pool_off + bytes > g->pool_size) {
         size_t want = std::max<size_t>(g->pool_next, (size_t)8 << 20);
         while (want < bytes) want <<= 1;

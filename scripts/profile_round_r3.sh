@@ -17,6 +17,7 @@ step levels; GS_LIB=$B/var_ts/libgraphslam_hip.so timeout -k 10 200 python scrip
 GS_LIB=$B/var_ts/libgraphslam_hip.so timeout -k 10 300 python scripts/level_times.py cfg5 > $O/level_completion_times_cfg5.txt 2>&1
 GS_LIB=$B/var_ts/libgraphslam_hip.so timeout -k 10 300 python scripts/level_times.py cfg4 24 > $O/level_completion_times_cfg4_K24.txt 2>&1
 step call_latency; timeout -k 10 300 python scripts/call_latency.py > $O/call_latency_reference_sizes.txt 2>&1; cat $O/call_latency_reference_sizes.txt
+step growth; for a in "cfg4 1 1" "cfg4 4 4" "cfg3 2 2" "cfg5 1 1"; do timeout -k 10 600 python scripts/growth_time.py $a; done > $O/growth_step.txt 2>&1; cat $O/growth_step.txt
 step wide_view; timeout -k 10 300 python scripts/wide_view.py cfg4 8 16 24 > $O/wide_view_tracks_cfg4.txt 2>&1; cat $O/wide_view_tracks_cfg4.txt
 step shard_footprint; timeout -k 10 600 python scripts/shard_footprint.py 8 cfg4 > $O/shard_footprint_8xcfg4.txt 2>&1; cat $O/shard_footprint_8xcfg4.txt
 step spreads; timeout -k 10 400 python scripts/parity_spread.py cfg4 r03 > $O/parity_spread_cfg4.log 2>&1; grep -h " vs \|b_pose" $O/parity_spread_cfg4.log | cut -c1-220
@@ -32,6 +33,7 @@ step rocprof; cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu --no-extra-configs > $GRAFT_REPO_ROOT/$O/rocprof_bench.log 2>&1; echo "rocprof exit=$?"
 cd $GRAFT_REPO_ROOT
 f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/bench_cfg4_kernel_stats.csv && head -14 "$f"
+f=$(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python scripts/lin_duration_check.py "$f" | tee $O/linearize_duration_trace.txt
 find gpurun_out/prof_$TAG -name "*kernel_trace.csv" -size +20M -delete
 step done
 for c in cfg3 cfg4 cfg5; do python - <<PY
