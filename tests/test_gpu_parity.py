@@ -987,3 +987,52 @@ def test_growth_between_optimisations_keeps_the_estimates_in_hbm_and_falls_back_
     done, _ = G.optimize(2)
     assert done == 2 and G.plan_growths() == 0 and "old pose" in G.growth_refusal()
     G.close(); R.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_growth_of_irregular_graphs_takes_one_step_like_the_oracle(pkg, po, seed):
+    """The device side of tests/test_plan_host.py::test_growth_of_irregular_graphs_replays_like_a_full_build: random graphs grown by two
+    keyframes that bring an odometry edge to an arbitrary old pose (the new pose at either end), one between the two new poses,
+    observations of old cones, a cone seen first by the first new pose and again by the second, an observation of a fixed cone.
+    One Gauss-Newton step of the grown handle = the oracle's joint solve of the whole graph (1e-9), also when the handle was NOT
+    able to grow (then it rebuilt)."""
+    rng = np.random.default_rng(100 + seed)
+    g = random_graph(seed, n_poses=30 + 3 * seed, n_lms=20 + seed, extra_pp=4, obs_per_pose=3, dup_edges=1)
+    N, M = len(g["pose_est"]), len(g["lm_est"])
+    G = fresh(pkg, g); G.initialize_optimization()
+    spd = lambda n: (lambda A: (A @ A.T + n * np.eye(n)))(rng.normal(size=(n, n)))
+    full = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in g.items()}
+    def add(kind, a, b, z, info):
+        if kind == "pp":
+            G.add_odometry_edge(a, b, z, info)
+            full["pp_i"] = np.append(full["pp_i"], np.int32(a)); full["pp_j"] = np.append(full["pp_j"], np.int32(b))
+            full["pp_z"] = np.vstack([full["pp_z"], z]); full["pp_info"] = np.vstack([full["pp_info"], info.reshape(1, 9)])
+        else:
+            G.add_observation_edge(a, b, z, info)
+            full["pl_p"] = np.append(full["pl_p"], np.int32(a)); full["pl_l"] = np.append(full["pl_l"], np.int32(b))
+            full["pl_z"] = np.vstack([full["pl_z"], z]); full["pl_info"] = np.vstack([full["pl_info"], info.reshape(1, 4)])
+    grown = 0
+    for batch in range(2):
+        p = N + batch; est = g["pose_est"][-1] + rng.normal(0.5, 0.2, 3) * [1 + batch, 0.3, 0.05]
+        G.add_pose(p, est); full["pose_est"] = np.vstack([full["pose_est"], est])
+        if batch == 0:
+            G.add_landmark(M, [3.0, 4.0]); full["lm_est"] = np.vstack([full["lm_est"], [3.0, 4.0]])
+            add("pp", int(rng.integers(2, N)), p, rng.normal(0, 0.5, 3), spd(3))
+        else:
+            add("pp", p - 1, p, rng.normal(0, 0.5, 3), spd(3))
+            add("pp", p, int(rng.integers(2, N)), rng.normal(0, 0.5, 3), spd(3))
+        for l in rng.choice(np.arange(2, M), 2, replace=False):
+            add("pl", p, int(l), rng.normal(0, 3, 2), spd(2))
+        add("pl", p, M, rng.normal(0, 3, 2), spd(2))
+        add("pl", p, int(g["fixed_landmarks"][0]), rng.normal(0, 3, 2), spd(2))
+        G.initialize_optimization(); grown += G.plan_growths() > 0
+    og = make_oracle_graph(po, full); chi_o = og.chi2(); og.build_system(); og.apply_update(og.solve_ldlt(0)); dp_o, dl_o = og.delta()
+    assert abs(G.chi2() - chi_o) <= 1e-10 * chi_o
+    done, st = G.optimize(1)
+    assert done == 1
+    dp, dl = G.export_delta()
+    scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
+    assert np.abs(dp - dp_o).max() / scale < 1e-9 and np.abs(dl - dl_o).max() / scale < 1e-9, (grown, G.growth_refusal())
+    assert rel(G.poses(), og.poses()) < 1e-9 and rel(G.landmarks(), og.landmarks()) < 1e-9
+    G.close()

@@ -187,3 +187,53 @@ def test_appended_poses_grow_the_plan_instead_of_rebuilding_it(pkg, po, bench_gr
     G.plan_build_host()
     assert G.plan_growths() == 0 and "fixed" in G.growth_refusal()
     G.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_growth_of_irregular_graphs_replays_like_a_full_build(pkg, po, seed):
+    """Random graphs (loop-closure style odometry edges, anisotropic information, duplicate edges) grown by two keyframes that bring
+    everything a keyframe can: an odometry edge to an arbitrary old pose, one between the two new poses, observations of old cones,
+    a cone seen first by the first new pose and again by the second, an observation of a FIXED cone.  The grown plan must stay valid
+    and replay to the oracle's joint solve — or refuse with a reason (a small random graph's fronts can be full), never be wrong."""
+    rng = np.random.default_rng(100 + seed)
+    g = random_graph(seed, n_poses=30 + 3 * seed, n_lms=20 + seed, extra_pp=4, obs_per_pose=3, dup_edges=1)
+    N, M = len(g["pose_est"]), len(g["lm_est"])
+    G = host_graph(pkg, g); G.plan_build_host(); P0 = Plan(G.plan_export())
+    spd = lambda n: (lambda A: (A @ A.T + n * np.eye(n)))(rng.normal(size=(n, n)))
+    full = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in g.items()}
+    def add(kind, a, b, z, info):
+        if kind == "pp":
+            G.add_odometry_edge(a, b, z, info)
+            full["pp_i"] = np.append(full["pp_i"], np.int32(a)); full["pp_j"] = np.append(full["pp_j"], np.int32(b))
+            full["pp_z"] = np.vstack([full["pp_z"], z]); full["pp_info"] = np.vstack([full["pp_info"], info.reshape(1, 9)])
+        else:
+            G.add_observation_edge(a, b, z, info)
+            full["pl_p"] = np.append(full["pl_p"], np.int32(a)); full["pl_l"] = np.append(full["pl_l"], np.int32(b))
+            full["pl_z"] = np.vstack([full["pl_z"], z]); full["pl_info"] = np.vstack([full["pl_info"], info.reshape(1, 4)])
+    steps = 0; rebuilt = False
+    for batch in range(2):
+        p = N + batch; est = g["pose_est"][-1] + rng.normal(0.5, 0.2, 3) * [1 + batch, 0.3, 0.05]
+        G.add_pose(p, est); full["pose_est"] = np.vstack([full["pose_est"], est])
+        if batch == 0:
+            G.add_landmark(M, [3.0, 4.0]); full["lm_est"] = np.vstack([full["lm_est"], [3.0, 4.0]])
+            add("pp", int(rng.integers(2, N)), p, rng.normal(0, 0.5, 3), spd(3))            # from an arbitrary old pose
+        else:
+            add("pp", p - 1, p, rng.normal(0, 0.5, 3), spd(3))                               # between the two new poses
+            add("pp", p, int(rng.integers(2, N)), rng.normal(0, 0.5, 3), spd(3))             # new pose as the i end, old pose as j
+        for l in rng.choice(np.arange(2, M), 2, replace=False):
+            add("pl", p, int(l), rng.normal(0, 3, 2), spd(2))
+        add("pl", p, M, rng.normal(0, 3, 2), spd(2))                                          # the new cone (first seen in batch 0)
+        add("pl", p, int(g["fixed_landmarks"][0]), rng.normal(0, 3, 2), spd(2))             # a fixed cone: feeds the pose's block only
+        G.plan_build_host()
+        if G.plan_growths() != steps + 1:
+            assert G.growth_refusal() in ("a front would exceed 63 scalars", "plan outside the wave-per-front form"), G.growth_refusal()
+            rebuilt = True; break
+        steps += 1
+    P = Plan(G.plan_export()); P.check_invariants()
+    if steps and not rebuilt:
+        assert P.n_fronts == P0.n_fronts and np.array_equal(P.parent, P0.parent)
+    blocks, (dp_o, dl_o) = oracle_increment(po, full)
+    dp, dl, ok = P.solve(blocks)
+    scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
+    assert ok and np.abs(dp - dp_o).max() / scale < 1e-8 and np.abs(dl - dl_o).max() / scale < 1e-8
+    G.close()
