@@ -436,7 +436,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
         for (int p = 0; p < N; ++p) { cs[2 * (size_t)p] = std::cos(h.pose_est[3 * (size_t)p + 2]); cs[2 * (size_t)p + 1] = std::sin(h.pose_est[3 * (size_t)p + 2]); }
         HIP_TRY(hipMemcpyAsync(d.pose_cs, cs.data(), cs.size() * sizeof(double), hipMemcpyHostToDevice, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream)); }
-    g->room = gs_graph::GrowRoom(); d.tN = d.tM = d.tEpp = d.tEpl = 0; d.tcapN = TAIL_POSES; d.tcapM = TAIL_LMS; d.tcapEpp = TAIL_PP; d.tcapEpl = TAIL_PL;
+    g->room = gs_graph::GrowRoom(); d.tN = d.tM = d.tEpp = d.tEpl = d.tLt = 0; d.tcapN = TAIL_POSES; d.tcapM = TAIL_LMS; d.tcapEpp = TAIL_PP; d.tcapEpl = TAIL_PL;
     if ((rc = dev_alloc(g, &d.pose_gidx, (size_t)N + TAIL_POSES)) != GS_OK) return rc;              // (room for a grown plan's tail poses)
     if (N > 0) HIP_TRY(hipMemcpyAsync(d.pose_gidx, P.pose_gidx.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
     if ((rc = dev_alloc(g, &d.lm_gidx, (size_t)M + TAIL_LMS)) != GS_OK) return rc;
@@ -489,6 +489,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
       d.t_Hpp_diag = d.H_arena + arena_off[7]; d.t_b_pose = d.H_arena + arena_off[8]; d.t_Hpp_off = d.H_arena + arena_off[9]; d.t_Hpl = d.H_arena + arena_off[10];
       d.t_Hll_diag = d.H_arena + arena_off[11]; d.t_b_lm = d.H_arena + arena_off[12];
       AL(t_pp_ij, (size_t)TAIL_PP * 2); AL(t_pl, (size_t)TAIL_PL * 2); AL(t_pl_z, (size_t)TAIL_PL * 2); AL(t_pl_w, (size_t)TAIL_PL * 3);
+      AL(t_pose_start, (size_t)TAIL_POSES + 1); AL(t_pose_edges, (size_t)TAIL_PL); AL(t_lt_id, (size_t)TAIL_PL); AL(t_lt_start, (size_t)TAIL_PL + 1); AL(t_lt_edges, (size_t)TAIL_PL);
       // (the fused linearisation kernel stores Hpp_diag's 6 planes and b_pose's 3 as 9 contiguous planes: 6N is even, no padding between)
       d.Hpp_diag = d.H_arena + arena_off[0]; d.b_pose = d.H_arena + arena_off[1]; d.Hpp_off = d.H_arena + arena_off[2];
       d.Hpl = d.H_arena + arena_off[3]; d.lm_part = d.H_arena + arena_off[4]; d.Hll_diag = d.H_arena + arena_off[5]; d.b_lm = d.H_arena + arena_off[6]; }
@@ -722,6 +723,24 @@ static int upload_growth(gs_graph *g, const Growth &gr) {
       if ((rc = H2D(d.t_pl + 2 * s0, plpl.data(), plpl.size() * sizeof(int32_t))) != GS_OK) return rc;
       if ((rc = H2D(d.t_pl_z + 2 * s0, plz.data(), plz.size() * sizeof(double))) != GS_OK) return rc;
       if ((rc = H2D(d.t_pl_w + 3 * s0, plw.data(), plw.size() * sizeof(double))) != GS_OK) return rc; }
+    // the tail's edges grouped by pose and by touched landmark (edge order inside a group: the order of the sums in k_linearize_tail);
+    // the whole tail, not only this step's part
+    std::vector<int32_t> tps, tpe, ltid, lts, lte;
+    { const int tN = N1 - P.base_N, tE = K1 - P.base_Epl;
+      tps.assign((size_t)tN + 1, 0); tpe.resize((size_t)tE);
+      for (int e = 0; e < tE; ++e) tps[(size_t)(h.pl_p[P.base_Epl + e] - P.base_N) + 1]++;
+      for (int t = 0; t < tN; ++t) tps[(size_t)t + 1] += tps[(size_t)t];
+      { std::vector<int32_t> fill(tps.begin(), tps.end() - 1); for (int e = 0; e < tE; ++e) tpe[(size_t)fill[(size_t)(h.pl_p[P.base_Epl + e] - P.base_N)]++] = e; }
+      std::vector<std::pair<int32_t, int32_t>> le; le.reserve((size_t)tE);        // (landmark, edge), fixed cones left out: nothing is summed for them
+      for (int e = 0; e < tE; ++e) { const int l = h.pl_l[P.base_Epl + e]; if (!h.lm_fixed[l]) le.emplace_back(l, e); }
+      std::sort(le.begin(), le.end());
+      lts.push_back(0);
+      for (size_t q = 0; q < le.size(); ++q) { if (q == 0 || le[q].first != le[q - 1].first) { if (q) lts.push_back((int32_t)q); ltid.push_back(le[q].first); } lte.push_back(le[q].second); }
+      if (!le.empty()) lts.push_back((int32_t)le.size());
+      d.tLt = (int32_t)ltid.size();
+      if ((rc = H2D(d.t_pose_start, tps.data(), tps.size() * sizeof(int32_t))) != GS_OK || (rc = H2D(d.t_pose_edges, tpe.data(), tpe.size() * sizeof(int32_t))) != GS_OK ||
+          (rc = H2D(d.t_lt_id, ltid.data(), ltid.size() * sizeof(int32_t))) != GS_OK || (rc = H2D(d.t_lt_start, lts.data(), lts.size() * sizeof(int32_t))) != GS_OK ||
+          (rc = H2D(d.t_lt_edges, lte.data(), lte.size() * sizeof(int32_t))) != GS_OK) return rc; }
     // the re-written runs
     if ((rc = H2D(d.bnd_rows + gr.bnd_from, &P.bnd_rows[(size_t)gr.bnd_from], (P.bnd_rows.size() - (size_t)gr.bnd_from) * sizeof(int32_t))) != GS_OK) return rc;
     if ((rc = H2D(d.child_map + gr.map_from, &P.child_map[(size_t)gr.map_from], (P.child_map.size() - (size_t)gr.map_from) * sizeof(int32_t))) != GS_OK) return rc;

@@ -83,6 +83,9 @@ struct DevGraph {
     int32_t tcapN = 0, tcapM = 0, tcapEpp = 0, tcapEpl = 0;     // plane strides of the tail blocks
     int32_t *t_pp_ij = nullptr;                                 // [tcapEpp][2] endpoints of the tail odometry edges
     int32_t *t_pl = nullptr; double *t_pl_z = nullptr, *t_pl_w = nullptr;    // [tcapEpl][2] {pose, landmark}, [tcapEpl][2], [tcapEpl][3]
+    int32_t tLt = 0;                                            // landmarks the tail's observation edges touch
+    int32_t *t_pose_start = nullptr, *t_pose_edges = nullptr;   // [tcapN+1], [tcapEpl]: tail pose -> its tail observation edges, edge order
+    int32_t *t_lt_id = nullptr, *t_lt_start = nullptr, *t_lt_edges = nullptr;   // [tcapEpl], [tcapEpl+1], [tcapEpl]: touched landmark -> its tail edges, edge order
     double *t_Hpp_diag = nullptr, *t_b_pose = nullptr, *t_Hpp_off = nullptr, *t_Hpl = nullptr;   // [6][tcapN] [3][tcapN] [9][tcapEpp] [6][tcapEpl], inside H_arena
     double *t_Hll_diag = nullptr, *t_b_lm = nullptr;            // [3][tcapM] [2][tcapM], inside H_arena (lm_est / lm_fixed / lm_gidx / dlm have room for tcapM more landmarks)
     // pose-window shards (world == 1: everything is "own", no exchange)

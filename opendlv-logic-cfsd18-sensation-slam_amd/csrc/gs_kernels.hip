@@ -676,94 +676,99 @@ void launch_linearize(const DevGraph &d, hipStream_t st, hipEvent_t start, hipEv
         default: hipExtLaunchKernelGGL(k_linearize_ell<8>, grid, block, 0, st, start, stop, 0, d); break;
     }
 }
-// ---- the tail of a grown plan (grow_plan: poses and edges appended since the plan was built; reference src/slam.cpp:433-459,
-// 537-550 add exactly these).  ONE wave, after the main pass: per tail pose, in pose order, its observation edges on the lanes
-// (same quad_pl as the main kernel), the pose-side sums by a fixed-order wave reduction, then its odometry edges on lane 0.  What
-// lands where: a tail pose's diagonal block and rhs, the H_pl / off-diagonal H_pp blocks of tail edges -> the tail arenas (the
-// assembly records of the grown fronts point there); an edge's share of an OLD vertex's diagonal block and rhs (a landmark's
-// first partial-sum slot, a pose's H_pp / b entries) is ADDED in place, behind the main kernel's stores.  All adds to one address
-// come from successive steps of this one wave, through L2 atomics, a fence between steps: the order is fixed, the result
-// reproducible.  grow_plan guarantees that a tail pose sees a landmark at most once (no two lanes of a step on one address).
-__global__ void __launch_bounds__(64) k_linearize_tail(DevGraph d) {
-    const int lane = threadIdx.x;
-    for (int i = lane; i < 6 * d.tcapN; i += 64) d.t_Hpp_diag[i] = 0.0;
-    for (int i = lane; i < 3 * d.tcapN; i += 64) d.t_b_pose[i] = 0.0;
-    for (int i = lane; i < 3 * d.tcapM; i += 64) d.t_Hll_diag[i] = 0.0;
-    for (int i = lane; i < 2 * d.tcapM; i += 64) d.t_b_lm[i] = 0.0;
-    __threadfence();
-    double chi = 0.0;
-    const int64_t G = d.n_groups;
-    for (int t = 0; t < d.tN; ++t) {
-        const int p = d.N + t;
-        const double px = d.pose_est[3 * p], py = d.pose_est[3 * p + 1];
+// ---- the tail of a grown plan (grow_plan: poses, cones and edges appended since the plan was built; reference src/slam.cpp:433-459,
+// 525-550 add exactly these).  ONE workgroup, behind the main pass; no atomics, every sum in a fixed order:
+//   1. a thread per tail observation edge: the same quad_pl as the main kernel; H_pl block to the tail arena, the pose-side and the
+//      landmark-side shares to LDS;
+//   2. a thread per tail pose sums its edges' pose-side shares in edge order (t_pose_start / t_pose_edges); a thread per landmark
+//      the tail touches sums its edges' landmark-side shares in edge order (t_lt_*) and ADDS the sum to the landmark's first
+//      partial-sum slot (an old cone: the fronts sum a cone's slots in order) or stores it in the tail arena (a tail cone: all of
+//      its edges are tail edges) — one writer per address;
+//   3. thread 0 walks the tail odometry edges in order: the new pose's share into the LDS accumulators, the older end's share into
+//      its accumulator (a tail pose) or, read-modify-write, into the old pose's H_pp / b entries; off-diagonal blocks to the tail arena;
+//   4. the tail poses' diagonal blocks and rhs out; chi2 of the tail (edges in order) as one more partial for k_update.
+__global__ void __launch_bounds__(256) k_linearize_tail(DevGraph d) {
+    constexpr int EC = 512, PC = 16;                                 // == gs::TAIL_PL, gs::TAIL_POSES (launch_linearize_tail checks)
+    __shared__ double s_p[9][EC], s_l[5][EC], s_chi[EC], s_acc[PC][9];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < d.tEpl; e += 256) {
+        const int p = d.t_pl[2 * e], l = d.t_pl[2 * e + 1];
         const double2 cs = reinterpret_cast<const double2 *>(d.pose_cs)[p];
-        double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-        for (int e0 = 0; e0 < d.tEpl; e0 += 64) { const int e = e0 + lane;
-            if (e < d.tEpl && d.t_pl[2 * e] == p) {
-                const int l = d.t_pl[2 * e + 1];
-                PlQuad q;
-                quad_pl(px, py, cs.x, cs.y, d.lm_est[2 * l], d.lm_est[2 * l + 1], d.t_pl_z[2 * e], d.t_pl_z[2 * e + 1],
-                        d.t_pl_w[3 * e], d.t_pl_w[3 * e + 1], d.t_pl_w[3 * e + 2], q);
-                chi += q.chi;
-                const bool fl = d.lm_fixed[l];
+        PlQuad q;
+        quad_pl(d.pose_est[3 * p], d.pose_est[3 * p + 1], cs.x, cs.y, d.lm_est[2 * l], d.lm_est[2 * l + 1], d.t_pl_z[2 * e], d.t_pl_z[2 * e + 1],
+                d.t_pl_w[3 * e], d.t_pl_w[3 * e + 1], d.t_pl_w[3 * e + 2], q);
+        const bool fl = d.lm_fixed[l];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) { H[k] += q.Hp[k]; d.t_Hpl[(int64_t)k * d.tcapEpl + e] = fl ? 0.0 : q.W6[k]; }
+        for (int k = 0; k < 6; ++k) { s_p[k][e] = q.Hp[k]; d.t_Hpl[(int64_t)k * d.tcapEpl + e] = fl ? 0.0 : q.W6[k]; }
 #pragma unroll
-                for (int k = 0; k < 3; ++k) b[k] += q.bp[k];
-                if (fl) { }
-                else if (l >= d.M) { const int o = l - d.M; const int64_t S = d.tcapM;   // a tail landmark: all of its edges are tail edges, its block is summed here
-                    atomicAdd(d.t_Hll_diag + o, q.Hl[0]); atomicAdd(d.t_Hll_diag + S + o, q.Hl[1]); atomicAdd(d.t_Hll_diag + 2 * S + o, q.Hl[2]);
-                    atomicAdd(d.t_b_lm + o, q.bl[0]); atomicAdd(d.t_b_lm + S + o, q.bl[1]); }
-                else { const int slot = d.lm_grp_start[l];            // an old landmark's first partial-sum slot: the fronts sum the slots in order
-                    atomicAdd(d.lm_part + slot, q.Hl[0]); atomicAdd(d.lm_part + G + slot, q.Hl[1]); atomicAdd(d.lm_part + 2 * G + slot, q.Hl[2]);
-                    atomicAdd(d.lm_part + 3 * G + slot, q.bl[0]); atomicAdd(d.lm_part + 4 * G + slot, q.bl[1]); }
-            } }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) H[k] = wave_sum(H[k]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) b[k] = wave_sum(b[k]);
-        if (lane == 0) {
-            for (int kk = 0; kk < d.tEpp; ++kk) { const int i = d.t_pp_ij[2 * kk], j = d.t_pp_ij[2 * kk + 1];
-                if (max(i, j) != p) continue;                          // an odometry edge belongs to the step of its later end
-                const int64_t k = (int64_t)d.Epp + kk;
-                double xi[3], xj[3], z5[5], w[6];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { xi[c] = d.pose_est[3 * i + c]; xj[c] = d.pose_est[3 * j + c]; }
-#pragma unroll
-                for (int c = 0; c < 5; ++c) z5[c] = d.pp_zinv[5 * k + c];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) w[c] = d.pp_info[6 * k + c];
-                const double2 ci = reinterpret_cast<const double2 *>(d.pose_cs)[i];
-                const bool fi = d.pose_fixed[i], fj = d.pose_fixed[j];
-                double Hi[6] = {0, 0, 0, 0, 0, 0}, bi[3] = {0, 0, 0}, Hj[6] = {0, 0, 0, 0, 0, 0}, bj[3] = {0, 0, 0};
-                chi += pp_incidence<true>(d, (int)k, 0, xi, xj, ci.x, ci.y, z5, w, fi, fj, Hi, bi, d.t_Hpp_off + kk, d.tcapEpp);
-                pp_incidence<true>(d, (int)k, 1, xi, xj, ci.x, ci.y, z5, w, fi, fj, Hj, bj);
-                const int other = i == p ? j : i;
-                const double *Ho = i == p ? Hj : Hi, *bo = i == p ? bj : bi, *Hs = i == p ? Hi : Hj, *bs = i == p ? bi : bj;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) H[c] += Hs[c];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) b[c] += bs[c];
-                if (!d.pose_fixed[other]) {                            // the older end's share, in place
-                    const bool tl = other >= d.N; const int64_t S = tl ? d.tcapN : d.N; const int o = tl ? other - d.N : other;
-                    double *Hd = tl ? d.t_Hpp_diag : d.Hpp_diag, *bp = tl ? d.t_b_pose : d.b_pose;
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) atomicAdd(Hd + c * S + o, Ho[c]);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) atomicAdd(bp + c * S + o, bo[c]); }
-            }
-#pragma unroll
-            for (int c = 0; c < 6; ++c) atomicAdd(d.t_Hpp_diag + (int64_t)c * d.tcapN + t, H[c]);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) atomicAdd(d.t_b_pose + (int64_t)c * d.tcapN + t, b[c]);
-        }
-        __threadfence();
+        for (int k = 0; k < 3; ++k) { s_p[6 + k][e] = q.bp[k]; s_l[k][e] = q.Hl[k]; }
+        s_l[3][e] = q.bl[0]; s_l[4][e] = q.bl[1]; s_chi[e] = q.chi;   // (a tail pose is free: the edge counts)
     }
-    chi = wave_sum(chi);
-    if (lane == 0) d.chi2_partial[d.n_wtiles] = chi;                 // one more partial for k_update's total
+    __syncthreads();
+    if (tid < d.tN) {                                                // pose side
+        double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = d.t_pose_start[tid]; q < d.t_pose_start[tid + 1]; ++q) { const int e = d.t_pose_edges[q];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) a[k] += s_p[k][e]; }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_acc[tid][k] = a[k];
+    }
+    for (int j = tid - 64; j >= 0 && j < d.tLt; j += 192) {          // landmark side (threads 64 ..)
+        const int l = d.t_lt_id[j];
+        double a[5] = {0, 0, 0, 0, 0};
+        for (int q = d.t_lt_start[j]; q < d.t_lt_start[j + 1]; ++q) { const int e = d.t_lt_edges[q];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) a[k] += s_l[k][e]; }
+        if (l >= d.M) { const int o = l - d.M; const int64_t S = d.tcapM;
+            d.t_Hll_diag[o] = a[0]; d.t_Hll_diag[S + o] = a[1]; d.t_Hll_diag[2 * S + o] = a[2]; d.t_b_lm[o] = a[3]; d.t_b_lm[S + o] = a[4]; }
+        else { const int64_t G = d.n_groups; const int slot = d.lm_grp_start[l];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) d.lm_part[k * G + slot] += a[k]; }
+    }
+    __syncthreads();
+    double chi = 0.0;
+    if (tid == 0) {
+        for (int kk = 0; kk < d.tEpp; ++kk) { const int i = d.t_pp_ij[2 * kk], j = d.t_pp_ij[2 * kk + 1];
+            const int64_t k = (int64_t)d.Epp + kk;
+            double xi[3], xj[3], z5[5], w[6];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { xi[c] = d.pose_est[3 * i + c]; xj[c] = d.pose_est[3 * j + c]; }
+#pragma unroll
+            for (int c = 0; c < 5; ++c) z5[c] = d.pp_zinv[5 * k + c];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) w[c] = d.pp_info[6 * k + c];
+            const double2 ci = reinterpret_cast<const double2 *>(d.pose_cs)[i];
+            const bool fi = d.pose_fixed[i], fj = d.pose_fixed[j];
+            double Hi[6] = {0, 0, 0, 0, 0, 0}, bi[3] = {0, 0, 0}, Hj[6] = {0, 0, 0, 0, 0, 0}, bj[3] = {0, 0, 0};
+            chi += pp_incidence<true>(d, (int)k, 0, xi, xj, ci.x, ci.y, z5, w, fi, fj, Hi, bi, d.t_Hpp_off + kk, d.tcapEpp);
+            pp_incidence<true>(d, (int)k, 1, xi, xj, ci.x, ci.y, z5, w, fi, fj, Hj, bj);
+            auto share = [&](int v, const double *H, const double *b) {   // endpoint v's share of the edge
+                if (d.pose_fixed[v]) return;
+                if (v >= d.N) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) s_acc[v - d.N][c] += H[c];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) s_acc[v - d.N][6 + c] += b[c]; }
+                else { const int64_t S = d.N;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) d.Hpp_diag[c * S + v] += H[c];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) d.b_pose[c * S + v] += b[c]; } };
+            share(i, Hi, bi); share(j, Hj, bj);
+        }
+        for (int e = 0; e < d.tEpl; ++e) chi += s_chi[e];
+        d.chi2_partial[d.n_wtiles] = chi;                            // one more partial for k_update's total
+    }
+    __syncthreads();
+    if (tid < d.tN) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) d.t_Hpp_diag[(int64_t)c * d.tcapN + tid] = s_acc[tid][c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d.t_b_pose[(int64_t)c * d.tcapN + tid] = s_acc[tid][6 + c];
+    }
 }
 void launch_linearize_tail(const DevGraph &d, hipStream_t st) {
-    if (d.tN > 0) hipLaunchKernelGGL(k_linearize_tail, dim3(1), dim3(64), 0, st, d);
+    if (d.tN > 0 && d.tcapEpl <= 512 && d.tcapN <= 16) hipLaunchKernelGGL(k_linearize_tail, dim3(1), dim3(256), 0, st, d);
 }
 void launch_chi2_only(const DevGraph &d, hipStream_t st) {
     if (d.tN > 0 && d.n_wtiles > 0) { launch_linearize(d, st); launch_linearize_tail(d, st); launch_linearize_finalize(d, st); return; }   // a grown plan: the full pass (the gather kernels do not know the tail)
