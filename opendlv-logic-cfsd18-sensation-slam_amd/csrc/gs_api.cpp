@@ -1092,9 +1092,10 @@ static int optimize_impl(gs_graph *g, int32_t iterations, double rel_tol, gs_sta
     while (enq < iterations) {
         const int upto = std::min(iterations, enq == 0 ? 1 : enq + (until ? 4 : 8));
         for (int it = enq; it < upto; ++it) {
+            g->d.hist_slot = it < nh ? it : -1;                      // k_update files the chi2 of this iteration's linearisation point itself
             enqueue_iteration(g, false);
-            if (it < nh) hipMemcpyAsync(g->d.chi2 + 1 + it, g->d.chi2, sizeof(double), hipMemcpyDeviceToDevice, g->stream);
         }
+        g->d.hist_slot = -1;
         enq = upto;
         HIP_TRY(hipMemcpyAsync(ff, g->d.fail, sizeof(ff), hipMemcpyDeviceToHost, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
@@ -1114,10 +1115,15 @@ static int optimize_impl(gs_graph *g, int32_t iterations, double rel_tol, gs_sta
     hipEventRecord(g->ev[6], g->stream);
     double hist[80];
     HIP_TRY(hipMemcpyAsync(hist, g->d.chi2, sizeof(hist), hipMemcpyDeviceToHost, g->stream));
+    // the estimates come back with the same wait (on failure: the last good iterate, what g2o's vertices hold)
+    const bool pull = g->dev_valid && g->dev_estimates_newer;
+    if (pull) { const size_t Np = (size_t)(g->d.N + g->d.tN), Mp = (size_t)(g->d.M + g->d.tM);
+        if (Np) HIP_TRY(hipMemcpyAsync(g->h.pose_est.data(), g->d.pose_est, Np * 3 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+        if (Mp) HIP_TRY(hipMemcpyAsync(g->h.lm_est.data(), g->d.lm_est, Mp * 2 * sizeof(double), hipMemcpyDeviceToHost, g->stream)); }
     HIP_TRY(hipStreamSynchronize(g->stream));
+    if (pull) g->dev_estimates_newer = false;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("iteration: ") + hipGetErrorString(e));
-    rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;   // on failure: the last good iterate (what g2o's vertices hold)
     float ms = 0; hipEventElapsedTime(&ms, g->ev[5], g->ev[6]);
     if (g->cfg.verbose) for (int it = 0; it < nshow; ++it)  // g2o prints the chi2 AFTER the update of iteration it
         std::fprintf(stderr, "iteration= %d\t chi2= %.6f\t edges= %d\t schur= 0\n", it, it + 1 < applied ? hist[2 + it] : hist[1 + nh], g->h.n_pp() + g->h.n_pl());

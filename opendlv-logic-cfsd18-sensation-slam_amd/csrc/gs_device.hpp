@@ -61,6 +61,7 @@ struct DevGraph {
                                                                 // front's flag, 3 another rank reported a failure; [1] updates applied since the last reset
     int32_t iter = 0, inject_iter = 0, inject_code = 0;         // iteration counter of this handle; gs_debug_fail_at_iteration (fault injection)
     int64_t xfail_off = -1;                                     // pose-window shards: offset of the failure slot in the exchange buffer (-1: none)
+    int32_t hist_slot = -1;                                     // gs_optimize: k_update also stores the chi2 total of this iteration's linearisation point in chi2[1 + hist_slot] (< 0: no)
     double conv_tol = -1.0;                                     // gs_optimize_until: relative chi2 change that stops the iterations (< 0: no stop rule); fail[2] = the iteration (iter) in which the rule fired, 0 = not yet; chi2[70] = previous chi2
     double *front_ws = nullptr; int64_t front_ws_stride = 0;    // global workspace for fronts too big for LDS
     long long *done_ts = nullptr;                               // [2][n_fronts] F3_DONE_TS tuning builds: 100 MHz completion time of every front (factor, backsolve)

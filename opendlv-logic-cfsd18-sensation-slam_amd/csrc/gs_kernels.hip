@@ -2958,6 +2958,7 @@ __global__ void __launch_bounds__(256) k_update(DevGraph d) {
             tot = block_sum(s, red);
             if (threadIdx.x == 0) d.chi2[0] = tot;
         } else if (threadIdx.x == 0) tot = d.chi2[0];              // gather kernels: k_reduce_chi2 totalled it already
+        if (threadIdx.x == 0 && d.hist_slot >= 0) d.chi2[1 + d.hist_slot] = tot;   // gs_optimize's chi2 history (a copy kernel per iteration before)
         // stop rule of gs_optimize_until: this iteration's update has been applied; if the chi2 of its linearisation point
         // is within conv_tol (relative) of the previous one, no later update is applied
         if (threadIdx.x == 0 && d.conv_tol >= 0.0 && !stop) {
