@@ -1084,13 +1084,14 @@ static int optimize_impl(gs_graph *g, int32_t iterations, double rel_tol, gs_sta
     // Stop rule (gs_optimize_until): k_update compares the chi2 of consecutive linearisation points on the device and
     // raises fail[2]; later updates are skipped like after a failure.  The host enqueues chunks of 4 iterations and
     // looks at the flags in between, so at most 3 enqueued iterations run as no-ops after convergence.
-    // Chunks: the FIRST iteration on its own, then groups of 8 (stop rule: 4).  A whole-tree launch whose flag hand-off fails
+    // Chunks: the FIRST iteration on its own, then groups of 8 — a remainder of up to 12 in one — (stop rule: 4).  A whole-tree launch whose flag hand-off fails
     // (its pollers are bounded and leave at once when any front has reported a failure, so such a launch drains in one poll
     // budget, ~30 ms) would otherwise have every remaining iteration queued up behind it, each paying the same again: with
     // chunks a timeout costs one chunk before the per-level fallback takes over.  One host round trip per chunk.
     int applied = 0, enq = 0, first_failure = 0; int32_t ff[4] = {0, 0, 0, 0}; bool fell_back = false;
     while (enq < iterations) {
-        const int upto = std::min(iterations, enq == 0 ? 1 : enq + (until ? 4 : 8));
+        // (a remainder of up to 12 goes out as one chunk: the reference's optimize(10) is 1 + 9, two host round trips instead of three)
+        const int upto = std::min(iterations, enq == 0 ? 1 : (until ? enq + 4 : (iterations - enq <= 12 ? iterations : enq + 8)));
         for (int it = enq; it < upto; ++it) {
             g->d.hist_slot = it < nh ? it : -1;                      // k_update files the chi2 of this iteration's linearisation point itself
             enqueue_iteration(g, false);
