@@ -37,22 +37,34 @@ static int usable_devices() {
 // Device memory of a plan comes out of a few large chunks (8 MB, then doubling): the ~70 arrays of one structure phase
 // cost a dozen hipMalloc calls instead of 70 (each is 50-100 us of the structure phase), and dev_free_all returns them together.
 // Arrays of 32 MB and more get an allocation of their own.
+// GS_POOL_POISON=1 (tests): every chunk is filled with 0xFF bytes (NaN doubles, negative indices) when it is allocated and whenever a plan
+// releases it — an array that is read before this code writes it cannot pass for zero-initialised
+static bool pool_poison() { static const bool on = [] { const char *e = std::getenv("GS_POOL_POISON"); return e && std::atoi(e) != 0; }(); return on; }
 template <class T> static int dev_alloc(gs_graph *g, T **ptr, size_t count) {
     *ptr = nullptr;
     const size_t bytes = (std::max<size_t>(count, 1) * sizeof(T) + 255) & ~(size_t)255;
     if (bytes >= ((size_t)32 << 20)) {                                // a big array: its own allocation, exactly its size (a chunk rounded up to a
-        void *p = nullptr;                                            // power of two for it, or the abandoned rest of the current chunk, were 270 MB of
-        HIP_TRY(hipMalloc(&p, bytes));                                // an 800 MB footprint at 100k poses)
-        g->allocs.push_back(p); g->pool_total += bytes; *ptr = (T *)p;
+        int best = -1;                                                // power of two for it, or the abandoned rest of the current chunk, were 270 MB of
+        for (size_t i = 0; i < g->allocs.size(); ++i) { const auto &c = g->allocs[i];      // an 800 MB footprint at 100k poses); one kept from the last plan
+            if (c.big && !c.in_use && c.size >= bytes && c.size <= bytes + bytes / 4 && (best < 0 || c.size < g->allocs[best].size)) best = (int)i; }   // serves if it fits within 25 %
+        if (best < 0) { void *p = nullptr;
+            HIP_TRY(hipMalloc(&p, bytes));
+            if (pool_poison()) HIP_TRY(hipMemsetAsync(p, 0xFF, bytes, g->stream));
+            gs_graph::DevChunk c; c.p = p; c.size = bytes; c.big = true; g->allocs.push_back(c); best = (int)g->allocs.size() - 1; }
+        g->allocs[best].in_use = true; g->pool_total += g->allocs[best].size; *ptr = (T *)g->allocs[best].p;
         return GS_OK; }
     if (g->pool_off + bytes > g->pool_size) {
         size_t want = std::max<size_t>(g->pool_next, (size_t)8 << 20);
         while (want < bytes) want <<= 1;
-        void *p = nullptr;
-        HIP_TRY(hipMalloc(&p, want));
-        g->allocs.push_back(p); g->pool_total += want;
-        g->pool_base = (char *)p; g->pool_size = want; g->pool_off = 0;
-        g->pool_next = std::min<size_t>(want << 1, (size_t)128 << 20);      // chunks of at most 128 MB (a larger single array gets its own): little slack in the footprint
+        int pick = -1;
+        for (size_t i = 0; i < g->allocs.size() && pick < 0; ++i) { const auto &c = g->allocs[i]; if (!c.big && !c.in_use && c.size >= want) pick = (int)i; }   // a chunk of the last plan
+        if (pick < 0) { void *p = nullptr;
+            HIP_TRY(hipMalloc(&p, want));
+            if (pool_poison()) HIP_TRY(hipMemsetAsync(p, 0xFF, want, g->stream));
+            gs_graph::DevChunk c; c.p = p; c.size = want; g->allocs.push_back(c); pick = (int)g->allocs.size() - 1; }
+        auto &c = g->allocs[pick]; c.in_use = true; g->pool_total += c.size;
+        g->pool_base = (char *)c.p; g->pool_size = c.size; g->pool_off = 0;
+        g->pool_next = std::min<size_t>(std::max(want, c.size) << 1, (size_t)128 << 20);      // chunks of at most 128 MB: little slack in the footprint
     }
     *ptr = (T *)(g->pool_base + g->pool_off);
     g->pool_off += bytes;
@@ -64,13 +76,21 @@ template <class T, class A> static int dev_upload(gs_graph *g, T **ptr, const st
     if (!v.empty()) HIP_TRY(hipMemcpyAsync(*ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, g->stream));
     return GS_OK;
 }
-static void dev_free_all(gs_graph *g) {
-    for (void *p : g->allocs) hipFree(p);
-    g->allocs.clear();
+// the device side of a plan goes away; keep = the memory stays with the handle for the next plan
+static void dev_release(gs_graph *g, bool keep) {
+    if (!keep) { for (auto &c : g->allocs) hipFree(c.p); g->allocs.clear(); }
+    else for (auto &c : g->allocs) { c.in_use = false; if (pool_poison() && g->stream) hipMemsetAsync(c.p, 0xFF, c.size, g->stream); }
     g->pool_base = nullptr; g->pool_size = g->pool_off = 0; g->pool_next = 0; g->pool_total = 0;
     g->d = DevGraph();
     g->dev_valid = false;
     g->room = gs_graph::GrowRoom(); g->d_bf = g->d_xrow = g->d_patch = g->d_list = nullptr;
+}
+static void dev_free_all(gs_graph *g) { dev_release(g, false); }
+// after a structure phase: what the new plan did not take again goes back to the device
+static void dev_trim(gs_graph *g) {
+    size_t w = 0;
+    for (size_t i = 0; i < g->allocs.size(); ++i) { if (g->allocs[i].in_use) g->allocs[w++] = g->allocs[i]; else hipFree(g->allocs[i].p); }
+    g->allocs.resize(w);
 }
 
 static int ensure_device(gs_graph *g) {
@@ -856,7 +876,7 @@ extern "C" int gs_initialize_optimization(gs_graph *g) {
             g->no_growth_reason = g_last_error;                     // (the plan object is rebuilt from scratch below)
         } else g->no_growth_reason = why;
     }
-    dev_free_all(g);
+    dev_release(g, true);                                            // the handle keeps its device memory for the new plan
     RawUpload raw;
     rc = upload_raw_begin(g, raw); if (rc != GS_OK) { if (raw.th.joinable()) raw.th.join(); dev_free_all(g); return rc; }
     rc = build_plan_host(g);                                        // the host threads build the plan while the raw arrays travel
@@ -864,6 +884,7 @@ extern "C" int gs_initialize_optimization(gs_graph *g) {
     if (rc == GS_OK && raw.rc != GS_OK) rc = fail(raw.rc, raw.err);
     if (rc != GS_OK) { dev_free_all(g); return rc; }
     rc = upload_graph(g, raw); if (rc != GS_OK) { dev_free_all(g); return rc; }
+    dev_trim(g);
     g->ms_structure = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return GS_OK;
 }

@@ -21,8 +21,12 @@ struct gs_graph {
     gs::Plan plan;
     uint64_t plan_version = ~0ull;          // h.structure_version the plan was built for
     gs::DevGraph d;
-    std::vector<void *> allocs;             // every device allocation of this handle (chunks the plan's arrays are carved from)
-    char *pool_base = nullptr; size_t pool_size = 0, pool_off = 0, pool_next = 0, pool_total = 0;
+    // device memory of this handle: chunks the plan's small arrays are carved from, and one allocation per big array.  They SURVIVE a
+    // structure phase (dev_release keeps them: on some boxes hipFree + hipMalloc of a plan's memory costs more than building the plan);
+    // what the next plan does not take again is returned afterwards (dev_trim).
+    struct DevChunk { void *p = nullptr; size_t size = 0; bool big = false, in_use = false; };
+    std::vector<DevChunk> allocs;
+    char *pool_base = nullptr; size_t pool_size = 0, pool_off = 0, pool_next = 0, pool_total = 0;     // pool_total: bytes of the chunks in use
     bool dev_valid = false;                 // device mirrors the host graph + plan
     bool dev_estimates_newer = false;       // estimates in HBM are ahead of the host copy
     uint64_t dev_estimate_version = 0;
