@@ -131,6 +131,12 @@ int  gs_destroy(gs_graph *g);
 int  gs_clear(gs_graph *g);                           /* drop all vertices and edges */
 /* use an externally owned hipStream_t (e.g. torch's current stream); NULL = own stream */
 int  gs_set_stream(gs_graph *g, void *hip_stream);
+/* Device memory for the first structure phase, taken (and touched) now — e.g. at start-up, where the reference constructs its
+ * optimizer (src/slam.cpp:36-65) — instead of inside the first gs_optimize: chunks of 8, 16, 32 ... MB until `bytes` are held.  A handle
+ * keeps its device memory across structure phases anyway (a re-plan allocates nothing); this only moves the FIRST allocations out of
+ * the first optimize(): 0.05 ms for a lap-sized graph, up to ~12 ms at 10k poses on machines where fresh allocations are slow.
+ * gs_slam_create reserves 24 MB (a lap-sized graph needs 3-8 MB). */
+int  gs_reserve_device(gs_graph *g, int64_t bytes);
 
 /* ---- graph construction (A2) --------------------------------------------
  * gs_add_pose             <- new VertexSE2; setId; setEstimate; addVertex        (src/slam.cpp:434-438)

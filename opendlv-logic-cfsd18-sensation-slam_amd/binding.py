@@ -145,6 +145,7 @@ def lib():
     L.gs_time_iterations.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
     L.gs_plan_build_host.argtypes = [vp, C.POINTER(PlanInfo)]
     L.gs_plan_export.argtypes = [vp, _ip, C.POINTER(C.c_int64)]
+    L.gs_reserve_device.argtypes = [vp, C.c_int64]
     L.gs_plan_growths.argtypes = [vp]; L.gs_growth_refusal.argtypes = [vp]; L.gs_growth_refusal.restype = C.c_char_p
     L.gs_polar_to_xy_batch.argtypes = [vp, C.c_int32, _dp, _dp, _dp, _dp]
     L.gs_cone_to_global_batch.argtypes = [vp, C.c_int32, _dp, C.c_int32, _ip, _dp, _dp]
@@ -396,6 +397,10 @@ class Graph:
     # ---- host-only plan (no device work)
     def plan_build_host(self):
         info = PlanInfo(); self._check(self.L.gs_plan_build_host(self.h, C.byref(info))); return info
+
+    def reserve_device(self, nbytes):
+        """takes device memory for the first structure phase now (start-up) instead of inside the first optimize()"""
+        self._check(self.L.gs_reserve_device(self.h, int(nbytes)))
 
     def plan_growths(self):
         """append-only growth steps the current plan has absorbed (0: the plan is a full build)"""

@@ -44,6 +44,7 @@ extern "C" int gs_slam_create(const gs_config *cfg, gs_slam **out) {
     gs_graph *g = nullptr;
     int rc = gs_create(cfg, &g);
     if (rc != GS_OK) return rc;
+    if (!g->host_only) gs_reserve_device(g, (int64_t)24 << 20);      // the first optimizeGraph() of a lap-sized graph finds its device memory in place
     gs_slam *s = new gs_slam();
     s->g = g; s->cfg = g->cfg;
     *out = s;
