@@ -1036,3 +1036,26 @@ def test_growth_of_irregular_graphs_takes_one_step_like_the_oracle(pkg, po, seed
     assert np.abs(dp - dp_o).max() / scale < 1e-9 and np.abs(dl - dl_o).max() / scale < 1e-9, (grown, G.growth_refusal())
     assert rel(G.poses(), og.poses()) < 1e-9 and rel(G.landmarks(), og.landmarks()) < 1e-9
     G.close()
+
+
+@pytest.mark.gpu
+def test_repeated_structure_phases_reuse_the_handles_device_memory(pkg, bench_graphs, monkeypatch):
+    """A handle keeps its device memory across structure phases (a re-plan takes the chunks of the last plan again): twelve forced full
+    phases on a growing graph must neither grow the footprint beyond the graph's own growth nor change the answer of a fresh handle."""
+    monkeypatch.setenv("GS_GROW", "0")
+    _, g = bench_graphs(1000, 200)
+    base, tail, full = split_for_growth(g, 12)
+    G = fresh(pkg, base); G.reserve_device(16 << 20); G.optimize(1)
+    sizes = [G.stats().device_bytes]
+    for k in range(12):
+        append_tail(G, tail, (k, k + 1)); done, st = G.optimize(1)
+        assert done == 1 and G.plan_growths() == 0
+        sizes.append(st.device_bytes)
+    assert max(sizes) <= 1.25 * min(sizes) + (8 << 20), sizes
+    monkeypatch.delenv("GS_GROW")
+    F = fresh(pkg, base); F.optimize(1)
+    for k in range(12):
+        append_tail(F, tail, (k, k + 1)); F.optimize(1)
+    assert F.plan_growths() > 0                                      # the same stream, absorbed by the plan where it fits
+    assert rel(G.poses(), F.poses()) < 1e-9 and rel(G.landmarks(), F.landmarks()) < 1e-9
+    G.close(); F.close()
