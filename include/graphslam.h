@@ -269,7 +269,8 @@ int  gs_plan_build_host(gs_graph *g, gs_plan_info *info);
  * to cones of the map (:537-550) and the cones it is the first to see with their first observation (:525-535); g2o's
  * initializeOptimization rebuilds everything at the next optimize() (:480).  Here, when the only changes since the last structure phase
  * are of that kind — new poses, new landmarks, edges whose pose end is a new pose; at most 16 poses / 16 landmarks / 512 + 64 edges since
- * the last full phase; every front stays <= 63 scalars — gs_initialize_optimization / gs_optimize keep the plan: the new vertices become
+ * the last full phase; every front stays within its form (63 scalars, or 159 in a plan with workgroup fronts) — gs_initialize_optimization /
+ * gs_optimize keep the plan: the new vertices become
  * pivots of the root front, the fronts between a neighbour's front and the root gain them as boundary rows, and only those fronts' tables
  * are rebuilt (csrc/gs_plan.cpp grow_plan, csrc/gs_api.cpp upload_growth).  Anything else (a fixed flag, an edge between old vertices,
  * GS_GROW=0 in the environment) is a full structure phase.

@@ -596,7 +596,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
             for (size_t f0 = 0; f0 < P.fronts.size(); ++f0) { const int nb = P.fronts[f0].nbnd;
                 u3_off[f0] = (int32_t)tot; u3_size[f0] = (nb * (nb + 1)) / 2 + nb; tot += ((u3_size[f0] + 2 + 1) & ~1);
                 if (tot >= ((int64_t)1 << 31)) return fail(GS_ERR_INVALID, "update-matrix arena beyond 32-bit offsets"); }
-            const int64_t ROOM_U = (int64_t)room_of((size_t)tot, (size_t)128 << 10, (size_t)1 << 20);      // doubles: the update matrices of fronts a growth step enlarges move here
+            const int64_t ROOM_U = (int64_t)room_of((size_t)tot, (size_t)128 << 10, (size_t)(P.max_front > 63 ? 4 : 1) << 20);      // doubles: the update matrices of fronts a growth step enlarges move here
             if (tot + ROOM_U >= ((int64_t)1 << 31)) return fail(GS_ERR_INVALID, "update-matrix arena beyond 32-bit offsets");
             AL(Uimg, (size_t)(tot + ROOM_U) + 2); ZERO(Uimg, (size_t)(tot + ROOM_U) + 2);
             g->room.used_U = tot; g->room.cap_U = tot + ROOM_U; }
@@ -628,7 +628,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
             for (size_t sidx = 0; sidx < S; ++sidx) { const Front &F = P.fronts[sidx]; int32_t *r = &bf[8 * sidx];
                 if (so >= ((int64_t)1 << 31) - 64) return fail(GS_ERR_INVALID, "too many assembly scalars");
                 r[0] = F.asm_off; r[1] = F.asm_cnt - F.asm_dup; r[2] = F.npiv + F.nbnd; r[3] = (int32_t)so; r[5] = (int32_t)lo; so += r[4]; lo += r[6]; }
-            const int64_t ROOM_SC = (int64_t)room_of((size_t)so, (size_t)64 << 10, (size_t)1 << 19);         // scalar records of the fronts a growth step rebuilds
+            const int64_t ROOM_SC = (int64_t)room_of((size_t)so, (size_t)64 << 10, (size_t)(P.max_front > 63 ? 4 : 1) << 19);         // scalar records of the fronts a growth step rebuilds
             if (so + ROOM_SC >= ((int64_t)1 << 31) - 64) return fail(GS_ERR_INVALID, "too many assembly scalars");
             AL(sc3, 2 * (size_t)(so + ROOM_SC) + 2); AL(lm3, 4 * (size_t)lo + 4);
             g->room.used_sc = so; g->room.cap_sc = so + ROOM_SC;
@@ -654,14 +654,14 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
             AL(f3_desc, lf.size() * (size_t)F3W); AL(f3_x, (size_t)xrow[lf.size()] + 168);
             launch_build_f3((int)lf.size(), d.level_fronts, d.fronts, d.children, d.child_map, d.u3_off, d.u3_size, bf_dev, xrow_dev,
                             P.world > 1 ? d.x_off : nullptr, d.f3_desc, d.f3_x, d.f3x_stride, g->stream);
-            // a growth step needs all of the above: variant 3, one GPU, every front on a wave, the fused linearisation layout
-            g->room.ok = P.world == 1 && P.max_front <= 63 && fused;
+            // a growth step needs all of the above: variant 3, one GPU, the fused linearisation layout
+            g->room.ok = P.world == 1 && fused;
             GS_UT("f3 tables"); }
       } }
     GS_UT("f3 x+desc upload");
     AL(dbg_ts, 64); ZERO(dbg_ts, 64);
     AL(done_ts, 2 * P.fronts.size() + 2); ZERO(done_ts, 2 * P.fronts.size() + 2);
-    { const int64_t room_L = g->room.ok ? (int64_t)room_of((size_t)P.l_doubles, (size_t)256 << 10, (size_t)2 << 20) : 0;          // doubles: the L panels of fronts a growth step enlarges move here
+    { const int64_t room_L = g->room.ok ? (int64_t)room_of((size_t)P.l_doubles, (size_t)256 << 10, (size_t)(P.max_front > 63 ? 8 : 2) << 20) : 0;          // doubles: the L panels of fronts a growth step enlarges move here
       AL(Lbuf, P.l_doubles + room_L); g->room.cap_L = P.l_doubles + room_L; }
     AL(Ubuf, (d.factor_variant == 0 || d.factor_variant == 1) ? P.u_doubles : 1);      // variants 2 and 3 keep their update matrices in Uimg
     AL(xe, P.n_scalar + 3 * TAIL_POSES + 2 * TAIL_LMS); g->room.cap_xe = P.n_scalar + 3 * TAIL_POSES + 2 * TAIL_LMS;
@@ -808,6 +808,7 @@ static int upload_growth(gs_graph *g, const Growth &gr) {
           for (int q = ls.start[l]; q < ls.start[l + 1]; ++q) { const Front &F = P.fronts[P.level_fronts_owned[q]];
               ls.max_f[l] = std::max(ls.max_f[l], F.npiv + F.nbnd); ls.max_npiv[l] = std::max(ls.max_npiv[l], F.npiv); ls.max_nbnd[l] = std::max(ls.max_nbnd[l], F.nbnd); } } }
     g->leaf_n = -1; g->block_n = -1;                                // the leaf instance and its LDS slot are chosen again from the grown fronts
+    g->wg_f.clear(); g->wg_b.clear(); g->d_wg_f = g->d_wg_b = nullptr;   // ... and so are the workgroup tables of a plan with workgroup fronts (a grown front may change its size class)
     g->dev_estimate_version = h.estimate_version;
     return GS_OK;
 }

@@ -123,6 +123,7 @@ struct Plan {
     int32_t base_N = 0, base_M = 0, base_Epp = 0, base_Epl = 0;      // counts build_plan saw
     int32_t planned_N = 0, planned_M = 0, planned_Epp = 0, planned_Epl = 0;   // counts the plan covers now (base + tail)
     int32_t n_growths = 0;                               // grow_plan calls since build_plan
+    int32_t front_limit = 63;                            // what a front may grow to: 63 (every front a wave: the plan was built without workgroup fronts) or 159 (it holds some: table-driven launches, 160-entry row tables)
     uint64_t reshape_version = 0;                        // HostGraph::reshape_version the plan was built at
 };
 

@@ -596,7 +596,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     }
 
     plan.base_N = plan.planned_N = N; plan.base_M = plan.planned_M = M; plan.base_Epp = plan.planned_Epp = Epp; plan.base_Epl = plan.planned_Epl = Epl;
-    plan.n_growths = 0; plan.reshape_version = g.reshape_version;
+    plan.n_growths = 0; plan.reshape_version = g.reshape_version; plan.front_limit = plan.max_front > 63 ? 159 : 63;
     // room for grow_plan's re-written runs: without it the first growth step pays for reallocating (and copying) these arrays — 3 of
     // its 4 ms at 100k poses
     plan.bnd_rows.reserve(plan.bnd_rows.size() + 64 * 1024); plan.child_map.reserve(plan.child_map.size() + 64 * 1024);
@@ -625,7 +625,7 @@ bool grow_plan(const HostGraph &g, Plan &P, Growth &out, std::string &why) {
     auto no = [&](const char *m) { why = m; return false; };
     if (!P.valid) return no("no plan");
     if (P.world > 1) return no("sharded plan");
-    if (!P.lin_ell_ok || P.max_front > 63) return no("plan outside the wave-per-front form");
+    if (!P.lin_ell_ok || P.max_front > 159) return no("plan outside the matrix-core forms");
     if (g.reshape_version != P.reshape_version) return no("a fixed flag changed (or the graph was cleared)");
     const int N0 = P.planned_N, N1 = g.n_poses(), M0 = P.planned_M, M1 = g.n_lms(), Epp0 = P.planned_Epp, Epp1 = g.n_pp(), Epl0 = P.planned_Epl, Epl1 = g.n_pl();
     if (N1 < N0 || M1 < M0 || Epp1 < Epp0 || Epl1 < Epl0) return no("graph shrank");
@@ -685,7 +685,7 @@ bool grow_plan(const HostGraph &g, Plan &P, Growth &out, std::string &why) {
       for (int v = 0; v < nV; ++v) { add[R] += vdim(v);
           for (const Nb &o : nbs[v]) { const int s0 = front_of(o.gv);
               for (int s = s0; s != R; s = P.fronts[s].parent) { if (stamp[s] == v) break; stamp[s] = v; add[s] += vdim(v); } } }
-      for (int s = 0; s < S; ++s) if (add[s] && P.fronts[s].npiv + P.fronts[s].nbnd + add[s] > 63) return no("a front would exceed 63 scalars"); }
+      for (int s = 0; s < S; ++s) if (add[s] && P.fronts[s].npiv + P.fronts[s].nbnd + add[s] > P.front_limit) return no(P.front_limit == 63 ? "a front would exceed 63 scalars" : "a front would exceed 159 scalars"); }
     // ---- apply
     out.bnd_from = (int64_t)P.bnd_rows.size(); out.map_from = (int64_t)P.child_map.size(); out.asm_from = (int64_t)P.asm_recs.size();
     out.first_pose = N0; out.first_lm = M0; out.first_pp = Epp0; out.first_pl = Epl0;

@@ -966,6 +966,30 @@ def test_appended_poses_are_absorbed_by_the_plan_and_give_the_full_builds_answer
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,M,K,h", [(1000, 200, 16, 3), (1000, 200, 24, 2), (10000, 2000, 16, 4)])
+def test_plans_with_workgroup_fronts_grow_as_well(pkg, po, N, M, K, h, frontend):
+    """Frames with 16 / 24 cones in view (what the reference's coneMappingThreshold lets a frame hold): the plan holds fronts of 64-159
+    scalars and table-driven launches; appended keyframes are absorbed there too (a grown front may change its size class: the
+    workgroup tables are rebuilt), same answer as a fresh full build and as the oracle."""
+    t = pkg.track.generate(N, M, K); g = pkg.track.bench_graph(t, frontend)
+    base, tail, full = split_for_growth(g, h)
+    og = make_oracle_graph(po, full); done_o, _, _ = og.optimize(10, ordering=1)
+    G = fresh(pkg, base); G.initialize_optimization(); st0 = G.stats()
+    assert st0.max_front > 63 and st0.factor_variant == 3 and st0.n_big_fronts > 0
+    for k in range(h):
+        append_tail(G, tail, (k, k + 1)); G.initialize_optimization()
+        assert G.plan_growths() == k + 1, G.growth_refusal()
+    done, st = G.optimize(10)
+    F = fresh(pkg, full); done_f, _ = F.optimize(10)
+    assert done == done_f == done_o == 10 and st.fell_back == 0 and st.factor_variant == 3
+    rms = np.sqrt((og.poses()[:, :2] ** 2).sum(1).mean())
+    for A, B, tol in ((G, F, 1e-9), (G, og, 1e-6)):
+        assert np.sqrt(((A.poses()[:, :2] - B.poses()[:, :2]) ** 2).sum(1).mean()) / rms < tol
+        assert np.sqrt(((A.landmarks() - B.landmarks()) ** 2).sum(1).mean()) / rms < tol
+    G.close(); F.close()
+
+
+@pytest.mark.gpu
 def test_growth_between_optimisations_keeps_the_estimates_in_hbm_and_falls_back_when_it_must(pkg, po, bench_graphs, monkeypatch):
     """iterations on the base graph, THEN the new poses, then more iterations: the grown handle must continue from the iterate in HBM
     exactly like a handle that is given the same state and rebuilds everything (GS_GROW=0); a change growth cannot absorb is

@@ -226,12 +226,34 @@ def test_growth_of_irregular_graphs_replays_like_a_full_build(pkg, po, seed):
         add("pl", p, int(g["fixed_landmarks"][0]), rng.normal(0, 3, 2), spd(2))             # a fixed cone: feeds the pose's block only
         G.plan_build_host()
         if G.plan_growths() != steps + 1:
-            assert G.growth_refusal() in ("a front would exceed 63 scalars", "plan outside the wave-per-front form"), G.growth_refusal()
+            assert G.growth_refusal() in ("a front would exceed 63 scalars", "a front would exceed 159 scalars", "plan outside the matrix-core forms", "forest: more than one root"), G.growth_refusal()
             rebuilt = True; break
         steps += 1
     P = Plan(G.plan_export()); P.check_invariants()
     if steps and not rebuilt:
         assert P.n_fronts == P0.n_fronts and np.array_equal(P.parent, P0.parent)
+    blocks, (dp_o, dl_o) = oracle_increment(po, full)
+    dp, dl, ok = P.solve(blocks)
+    scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
+    assert ok and np.abs(dp - dp_o).max() / scale < 1e-8 and np.abs(dl - dl_o).max() / scale < 1e-8
+    G.close()
+
+
+@pytest.mark.parametrize("N,M,K,h", [(1000, 200, 16, 3), (1000, 200, 24, 2), (240, 200, None, 3)])
+def test_plans_with_workgroup_fronts_grow_up_to_159_scalars(pkg, po, frontend, N, M, K, h):
+    """Wide views (16 / 24 cones per frame) and the lap-sized graph of the reference's own scale (240 poses / 200 cones: fronts up to 109):
+    their plans hold fronts of 64-159 scalars; appended keyframes are absorbed up to 159 per front, and the grown plan replays to the
+    oracle's joint solve."""
+    t = pkg.track.generate(N, M, K) if K else pkg.track.generate(N, M)
+    g = pkg.track.bench_graph(t, frontend)
+    base, tail, full = split_for_growth(g, h)
+    G = host_graph(pkg, base); i0 = G.plan_build_host()
+    assert i0.max_front > 63
+    for k in range(h):
+        append_tail(G, tail, (k, k + 1)); i = G.plan_build_host()
+        assert G.plan_growths() == k + 1, G.growth_refusal()
+    assert 63 < i.max_front <= 159
+    P = Plan(G.plan_export()); P.check_invariants()
     blocks, (dp_o, dl_o) = oracle_increment(po, full)
     dp, dl, ok = P.solve(blocks)
     scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
