@@ -273,7 +273,7 @@ int  gs_plan_build_host(gs_graph *g, gs_plan_info *info);
  * gs_optimize keep the plan: the new vertices become
  * pivots of the root front, the fronts between a neighbour's front and the root gain them as boundary rows, and only those fronts' tables
  * are rebuilt (csrc/gs_plan.cpp grow_plan, csrc/gs_api.cpp upload_growth).  Anything else (a fixed flag, an edge between old vertices,
- * GS_GROW=0 in the environment) is a full structure phase.
+ * a graph below 128 poses — GS_GROW_MIN_POSES —, where there is nothing to gain, GS_GROW=0 in the environment) is a full structure phase.
  * gs_plan_growths: steps absorbed by the current plan; gs_growth_refusal: why the last change was NOT absorbed ("" if it was). */
 int  gs_plan_growths(gs_graph *g);
 const char *gs_growth_refusal(gs_graph *g);

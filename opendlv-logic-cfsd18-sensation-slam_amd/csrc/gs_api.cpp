@@ -886,7 +886,11 @@ extern "C" int gs_initialize_optimization(gs_graph *g) {
     if (g->dev_valid && g->plan.valid && g->plan_version != ~0ull && g->plan_version != g->h.structure_version) {
         bool on = true; if (const char *e = std::getenv("GS_GROW")) on = std::atoi(e) != 0;
         Growth gr; std::string why;
+        // below ~a hundred poses the full phase costs 0.25 ms, the tail kernel of ten iterations 0.08: nothing to gain (a lap, 200 poses
+        // mapped: 1.03 ms per optimize(10) grown against 1.16 rebuilt, scripts/keyframe_stream.py)
+        int min_poses = 128; if (const char *e = std::getenv("GS_GROW_MIN_POSES")) min_poses = std::atoi(e);
         if (!on) g->no_growth_reason = "GS_GROW=0";
+        else if (g->plan.base_N < min_poses) g->no_growth_reason = "graph below the size at which growing pays (GS_GROW_MIN_POSES)";
         else if (!g->room.ok) g->no_growth_reason = "plan uploaded without room to grow";
         else if (grow_plan(g->h, g->plan, gr, why)) {
             rc = upload_growth(g, gr);

@@ -123,6 +123,7 @@ struct Plan {
     int32_t base_N = 0, base_M = 0, base_Epp = 0, base_Epl = 0;      // counts build_plan saw
     int32_t planned_N = 0, planned_M = 0, planned_Epp = 0, planned_Epl = 0;   // counts the plan covers now (base + tail)
     int32_t n_growths = 0;                               // grow_plan calls since build_plan
+    int32_t root_f0 = 0;                                 // size of the root front as build_plan left it
     int32_t front_limit = 63;                            // what a front may grow to: 63 (every front a wave: the plan was built without workgroup fronts) or 159 (it holds some: table-driven launches, 160-entry row tables)
     uint64_t reshape_version = 0;                        // HostGraph::reshape_version the plan was built at
 };
@@ -147,7 +148,8 @@ bool grow_plan(const HostGraph &g, Plan &plan, Growth &out, std::string &why_not
 
 struct PlanOptions { int leaf_poses = 8; int world = 1; int rank = 0; int ell_lanes = 0;
                      int cluster_ways = 0;         // fan-out of the multi-way split above the leaves (0 = default 8, <= 2 = binary all the way down)
-                     int big_cluster_front = 111;      // second-pass bound of a cluster front when 63 scalars cannot be met (<= 63: off)
+                     int big_cluster_front = -1;       // second-pass bound of a cluster front when 63 scalars cannot be met (0 .. 63: off); -1 = by the view: 111 with more than 10
+                                                       // cones per frame, off below (there binary splits of wave fronts beat a workgroup front: lap-sized graphs 1.1 vs 1.9-2.6 ms per optimize(10))
                      int grow_headroom = 6;            // scalars a cluster front stays below the 63 of a wave: room for the boundary rows of two appended poses (grow_plan)
                      int grow_spine_headroom = 18; };  // the same for the cluster front that holds the LAST pose: appended keyframes continue the track there (six poses)
 

@@ -293,7 +293,8 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     // room to grow (grow_plan) only where fronts fit a wave anyway: with more than ~10 cones in view the cluster fronts are workgroup
     // fronts, such a plan cannot grow, and keeping them below 57 would only cost fronts (K = 16: 26 571 instead of 21 026, -5 % it/s)
     { int kmax0 = 0; for (int p = 0; p < N; ++p) kmax0 = std::max(kmax0, plan.pl_start[p + 1] - plan.pl_start[p]);
-      if (kmax0 > 10) B.opt.grow_headroom = B.opt.grow_spine_headroom = 0; }
+      if (kmax0 > 10) B.opt.grow_headroom = B.opt.grow_spine_headroom = 0;
+      if (B.opt.big_cluster_front < 0) B.opt.big_cluster_front = kmax0 > 10 ? 111 : 0; }
     // ---- elimination order by nested dissection ----
     B.build_adjacency(plan, lm_k);
     GS_PT(21);
@@ -597,6 +598,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
 
     plan.base_N = plan.planned_N = N; plan.base_M = plan.planned_M = M; plan.base_Epp = plan.planned_Epp = Epp; plan.base_Epl = plan.planned_Epl = Epl;
     plan.n_growths = 0; plan.reshape_version = g.reshape_version; plan.front_limit = plan.max_front > 63 ? 159 : 63;
+    plan.root_f0 = plan.fronts.empty() ? 0 : plan.fronts.back().npiv + plan.fronts.back().nbnd;
     // room for grow_plan's re-written runs: without it the first growth step pays for reallocating (and copying) these arrays — 3 of
     // its 4 ms at 100k poses
     plan.bnd_rows.reserve(plan.bnd_rows.size() + 64 * 1024); plan.child_map.reserve(plan.child_map.size() + 64 * 1024);
@@ -685,7 +687,13 @@ bool grow_plan(const HostGraph &g, Plan &P, Growth &out, std::string &why) {
       for (int v = 0; v < nV; ++v) { add[R] += vdim(v);
           for (const Nb &o : nbs[v]) { const int s0 = front_of(o.gv);
               for (int s = s0; s != R; s = P.fronts[s].parent) { if (stamp[s] == v) break; stamp[s] = v; add[s] += vdim(v); } } }
-      for (int s = 0; s < S; ++s) if (add[s] && P.fronts[s].npiv + P.fronts[s].nbnd + add[s] > P.front_limit) return no(P.front_limit == 63 ? "a front would exceed 63 scalars" : "a front would exceed 159 scalars"); }
+      // in a plan that holds workgroup fronts a front may grow to 159 scalars (a wave front of the path may become a workgroup front).
+      // The ROOT, which every new vertex enters, at most 24 scalars beyond what the full phase gave it: grown without bound it costs
+      // every iteration more than the structure phases it saves (lap-sized graphs: 2.5 -> 4.0 ms per optimize(10) over 16 keyframes,
+      // scripts/keyframe_stream.py)
+      for (int s = 0; s < S; ++s) { if (!add[s]) continue;
+          const int f0 = P.fronts[s].npiv + P.fronts[s].nbnd, lim = s == R ? std::min(P.front_limit, std::max(63, P.root_f0 + 24)) : P.front_limit;
+          if (f0 + add[s] > lim) return no(lim == 63 ? "a front would exceed 63 scalars" : "a front would exceed 159 scalars"); } }
     // ---- apply
     out.bnd_from = (int64_t)P.bnd_rows.size(); out.map_from = (int64_t)P.child_map.size(); out.asm_from = (int64_t)P.asm_recs.size();
     out.first_pose = N0; out.first_lm = M0; out.first_pp = Epp0; out.first_pl = Epl0;

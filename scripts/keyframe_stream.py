@@ -2,14 +2,14 @@
 (a pose, its odometry edge, its observation edges, the cones it is the first to see — reference src/slam.cpp:433-459, 525-550) and the whole graph is
 optimised again (the call the reference has commented out at :594 / :620-621).  Per keyframe: wall time of gs_optimize(10) — structure phase or growth
 step, 10 iterations, estimates back.  Run once as it is and once with GS_GROW=0; the estimates of the two runs must agree.
-usage: keyframe_stream.py [cfg3] [keep=6000] [keyframes=24]"""
+usage: keyframe_stream.py [cfg3 | N:M] [keep=6000] [keyframes=24]"""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import append_tail, split_for_growth
 pkg = importlib.import_module("opendlv-logic-cfsd18-sensation-slam_amd")
-name = sys.argv[1] if len(sys.argv) > 1 else "cfg3"; N, M = pkg.track.CONFIGS[name]
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg3"; N, M = pkg.track.CONFIGS[name] if name in pkg.track.CONFIGS else tuple(int(v) for v in name.split(":"))
 keep = int(sys.argv[2]) if len(sys.argv) > 2 else int(0.6 * N); K = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 t = pkg.track.generate(N, M); fe = pkg.Graph(); g = pkg.track.bench_graph(t, fe)
 base, tail, full = split_for_growth(g, K, keep + K)

@@ -5,6 +5,16 @@ import sys
 import numpy as np
 import pytest
 
+
+@pytest.fixture(autouse=True, scope="session")
+def _grow_plans_of_every_size():
+    """the tests grow plans of every size (the product's default leaves graphs below 128 poses to the full phase: GS_GROW_MIN_POSES)"""
+    had = os.environ.get("GS_GROW_MIN_POSES")
+    os.environ.setdefault("GS_GROW_MIN_POSES", "0")
+    yield
+    if had is None:
+        os.environ.pop("GS_GROW_MIN_POSES", None)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

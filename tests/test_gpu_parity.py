@@ -1011,6 +1011,13 @@ def test_growth_between_optimisations_keeps_the_estimates_in_hbm_and_falls_back_
     done, _ = G.optimize(2)
     assert done == 2 and G.plan_growths() == 0 and "old pose" in G.growth_refusal()
     G.close(); R.close()
+    # the product's default leaves small graphs to the full phase (the tests run with GS_GROW_MIN_POSES=0)
+    monkeypatch.setenv("GS_GROW_MIN_POSES", "128")
+    _, gs = bench_graphs(50, 30)
+    b2, t2, _ = split_for_growth(gs, 1)
+    S = fresh(pkg, b2); S.optimize(1); append_tail(S, t2); done, _ = S.optimize(1)
+    assert done == 1 and S.plan_growths() == 0 and "GS_GROW_MIN_POSES" in S.growth_refusal()
+    S.close()
 
 
 @pytest.mark.gpu
