@@ -1090,3 +1090,24 @@ def test_repeated_structure_phases_reuse_the_handles_device_memory(pkg, bench_gr
     assert F.plan_growths() > 0                                      # the same stream, absorbed by the plan where it fits
     assert rel(G.poses(), F.poses()) < 1e-9 and rel(G.landmarks(), F.landmarks()) < 1e-9
     G.close(); F.close()
+
+
+@pytest.mark.gpu
+def test_a_failed_solve_on_a_grown_plan_keeps_the_last_good_iterate_of_the_tail_too(pkg, po, bench_graphs):
+    """g2o's rule (optimize() leaves its loop at the first failed solve, the vertices keep the previous iterate; call site reference
+    src/slam.cpp:481) on a handle whose plan has grown: the poses and cones of the tail are gated by the same flag, and the stop rule of
+    gs_optimize_until sees the chi2 of the tail's edges."""
+    _, g = bench_graphs(1000, 200)
+    base, tail, full = split_for_growth(g, 6, 600)
+    og = make_oracle_graph(po, full); og.optimize(2, ordering=1)
+    G = fresh(pkg, base); G.initialize_optimization(); new_lms = append_tail(G, tail); G.initialize_optimization()
+    assert G.plan_growths() == 1 and new_lms > 0
+    G.debug_fail_at_iteration(3, 1)
+    done, st = G.optimize(5)
+    assert done == 0 and st.numeric_failure == 1 and st.iterations == 2
+    assert rel(G.poses(), og.poses()) < 1e-9 and rel(G.landmarks(), og.landmarks()) < 1e-9
+    done, st = G.optimize_until(30, 1e-6); chi = og.optimize_until(30, 1e-6, ordering=1)
+    assert done == chi[0] and not chi[2] and G.plan_growths() == 1
+    assert rel(G.poses(), og.poses()) < 1e-7 and rel(G.landmarks(), og.landmarks()) < 1e-7
+    assert abs(G.chi2() - og.chi2()) <= 1e-6 * og.chi2()
+    G.close()
