@@ -80,7 +80,11 @@ typedef struct gs_config {
     int32_t optimize_iterations;    /* 10    (src/slam.cpp:481)                             */
     int32_t reference_quirks;       /* 1: keep SURVEY §8-B quirks 1-2 (duplicate first edge,
                                        re-optimise per remaining observation)              */
-    int32_t reserved1;
+    int32_t optimize_every_keyframe; /* 0 (the reference): the graph is optimised once, at loop closure.  1: gs_slam_perform also runs
+                                        optimizeGraph + updateMap at the end of every keyframe that did not run it already — the calls
+                                        the reference carries commented out (src/slam.cpp:403, 594, 620-621).  One more keyframe does
+                                        not rebuild the structure here (append-only growth), so the call costs about a millisecond at
+                                        lap size; in localizer mode the published pose is then the optimised one. */
 } gs_config;
 
 /* per-call statistics of gs_optimize / gs_iterate (all times from HIP events on

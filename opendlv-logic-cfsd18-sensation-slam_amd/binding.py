@@ -37,7 +37,7 @@ class Config(C.Structure):
                 ("same_cone_threshold", C.c_double), ("cone_mapping_threshold", C.c_double),
                 ("lidar_to_cog", C.c_double), ("loop_closing_radius", C.c_double),
                 ("loop_closing_min_index", C.c_int32), ("optimize_iterations", C.c_int32),
-                ("reference_quirks", C.c_int32), ("reserved1", C.c_int32)]
+                ("reference_quirks", C.c_int32), ("optimize_every_keyframe", C.c_int32)]
 
 
 class Stats(C.Structure):

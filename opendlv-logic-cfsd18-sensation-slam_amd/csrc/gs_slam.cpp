@@ -222,6 +222,14 @@ extern "C" int gs_slam_perform(gs_slam *s, const double odometry[3], const doubl
     if (elapsed > 0 && elapsed < 1) pose[2] = pose[2] - (double)s->yaw_rate * elapsed;
     s->poses.push_back({pose[0], pose[1], pose[2]});
     int rc;
+    const auto optimised_before = s->optimise_calls;
+    // cfg.optimize_every_keyframe (not the reference's behaviour: its calls at :403, :594, :620-621 are commented out): optimizeGraph +
+    // updateMap at the end of a keyframe that did not run them itself, once the gauge vertices and something to solve for exist
+    auto keyframe_optimise = [&]() -> int {
+        if (!s->cfg.optimize_every_keyframe || s->optimise_calls != optimised_before || s->pose_id - 1000 < 3 || s->map.size() < 3) return GS_OK;
+        int r = optimize_and_update_map(s); if (r < 0) return r;
+        if (s->loop_closing_complete) return gs_get_pose(s->g, s->pose_id - 1, s->send_pose);      // updatePoseFromGraph again: the optimised pose goes out
+        return GS_OK; };
     // ---- addPoseToGraph + addOdometryMeasurement (:433-459)
     if ((rc = gs_add_pose(s->g, s->pose_id, pose)) != GS_OK) return rc;
     if (s->pose_id > 1000) {
@@ -250,7 +258,7 @@ extern "C" int gs_slam_perform(gs_slam *s, const double odometry[3], const doubl
         if ((rc = frame_frontend(s, pose, cones, k, true, fx)) != GS_OK) return rc;
         if ((rc = localizer(s, cones, k, fx)) != GS_OK) return rc;
     }
-    return GS_OK;
+    return keyframe_optimise();
 }
 
 // ------------------------------------------------------------------ f-2: frame collector and output encoders

@@ -15,10 +15,11 @@ from oracle import pyoracle as po
 
 
 class RefSlam:
-    def __init__(self, same_cone_threshold=1.2, cone_mapping_threshold=67.0, quirks=False, iterations=10):
+    def __init__(self, same_cone_threshold=1.2, cone_mapping_threshold=67.0, quirks=False, iterations=10, optimize_every_keyframe=False):
         self.g = po.OracleGraph(); self.fe = po.OracleFrontend()
         self.thr = same_cone_threshold; self.map_thr = cone_mapping_threshold
         self.quirks = quirks; self.iterations = iterations
+        self.optimize_every_keyframe = optimize_every_keyframe     # NOT the reference: its optimizeGraph() calls at :403, :594, :620-621 are commented out
         self.map = []                      # [x, y, type, id]
         self.n_poses = 0
         self.loop_closing = False; self.loop_closing_complete = False
@@ -99,10 +100,15 @@ class RefSlam:
         self._add_pose_to_graph(pose)                                     # :325
         if len(cones) == 0:                                               # never happens in the reference (:245)
             return
+        before = self.optimise_calls
         if not self.loop_closing_complete:                                # :329-331
             self._add_cones_to_map(cones, pose)
         if self.loop_closing_complete and len(cones) > 1:                 # :332-334 — a second, independent if
             self._localizer(pose, cones)
+        if self.optimize_every_keyframe and self.optimise_calls == before and self.n_poses >= 3 and len(self.map) >= 3:
+            self._optimise()                                              # the commented-out calls, once per keyframe
+            if self.loop_closing_complete:
+                self.send_pose = self.g.poses()[self.n_poses - 1].copy()
 
     # addPoseToGraph + addOdometryMeasurement, :433-459
     def _add_pose_to_graph(self, pose):

@@ -1111,3 +1111,30 @@ def test_a_failed_solve_on_a_grown_plan_keeps_the_last_good_iterate_of_the_tail_
     assert rel(G.poses(), og.poses()) < 1e-7 and rel(G.landmarks(), og.landmarks()) < 1e-7
     assert abs(G.chi2() - og.chi2()) <= 1e-6 * og.chi2()
     G.close()
+
+
+@pytest.mark.gpu
+def test_slam_mirror_with_an_optimisation_per_keyframe_follows_its_restatement(pkg):
+    """cfg.optimize_every_keyframe = 1 (NOT the reference's behaviour: optimizeGraph + updateMap at the end of every keyframe, the calls
+    the reference carries commented out at src/slam.cpp:403, 594, 620-621): csrc/gs_slam.cpp against tests/ref_slam.py with the same switch,
+    frame by frame through mapping, loop closure and localizer frames.  The structure phase of most keyframes is a growth step."""
+    from ref_slam import RefSlam
+    N, M = 160, 70
+    t = pkg.track.generate(N, M)
+    S = pkg.Slam(same_cone_threshold=1.2, cone_mapping_threshold=67.0, reference_quirks=0, optimize_every_keyframe=1)
+    R = RefSlam(same_cone_threshold=1.2, cone_mapping_threshold=67.0, quirks=False, optimize_every_keyframe=True)
+    frames = list(range(N)) + list(range(8))
+    grown = 0
+    for n, k in enumerate(frames):
+        S.perform_slam(t["odom_poses"][k], t["obs"][k]); R.perform(t["odom_poses"][k], t["obs"][k])
+        assert S.map_size == len(R.map), (n, S.map_size, len(R.map))
+        assert S.loop_closed == R.loop_closing_complete and S.current_cone_index == R.current_cone_index, n
+        assert S.graph.n_pl == R.g.n_pl and S.graph.n_pp == R.g.n_pp, n
+        assert np.abs(S.send_pose() - R.send_pose).max() < 1e-6, n
+        grown += S.graph.plan_growths() > 0
+    assert R.optimise_calls >= len(frames) - 4 and S.loop_closed
+    assert grown > len(frames) // 2                                  # most keyframes entered the plan without a structure phase
+    xy, ty = S.map()
+    Rm = np.array([[c[0], c[1]] for c in R.map])
+    assert np.abs(xy - Rm).max() < 1e-6 and np.abs(S.graph.poses() - R.g.poses()).max() < 1e-6
+    S.close()
