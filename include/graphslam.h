@@ -61,12 +61,10 @@ typedef struct gs_config {
                                    (reference: setVerbose(true), src/slam.cpp:63)          */
     int32_t leaf_poses;         /* nested-dissection leaf size in poses; 0 = default        */
     int32_t factor_variant;     /* front factorisation kernel: 0 = default (3 when every front has <= 159
-                                   scalars, else 4); 3 = LDL^T on the fp64 matrix cores
-                                   (v_mfma_f64_16x16x4_f64), chosen PER FRONT: a wave for a front of <= 63
-                                   scalars, a workgroup for one of 64 .. 159; update matrices moved in
-                                   storage order; 2 = wave-per-front Cholesky on the matrix cores; 1 =
-                                   wave-per-front VALU (both: every front <= 63 scalars, else 4);
-                                   4 = block-per-front VALU, any front size                        */
+                                   scalars and the H arena fits 32-bit byte offsets, else 4); 3 = LDL^T on the fp64
+                                   matrix cores (v_mfma_f64_16x16x4_f64), chosen PER FRONT: a wave for a front of <= 63
+                                   scalars, a workgroup for one of 64 .. 159; update matrices moved in storage order;
+                                   4 = block-per-front VALU Cholesky, any front size                 */
     int32_t linearize_gather;   /* 1: force the general gather kernels instead of the fused tiled
                                    linearisation kernel (both are HIP; for tests and A/B timing)   */
     /* Slam-level constants, defaults are the reference's hard-coded values */
@@ -80,11 +78,14 @@ typedef struct gs_config {
     int32_t optimize_iterations;    /* 10    (src/slam.cpp:481)                             */
     int32_t reference_quirks;       /* 1: keep SURVEY §8-B quirks 1-2 (duplicate first edge,
                                        re-optimise per remaining observation)              */
-    int32_t optimize_every_keyframe; /* 0 (the reference): the graph is optimised once, at loop closure.  1: gs_slam_perform also runs
-                                        optimizeGraph + updateMap at the end of every keyframe that did not run it already — the calls
-                                        the reference carries commented out (src/slam.cpp:403, 594, 620-621).  One more keyframe does
-                                        not rebuild the structure here (append-only growth), so the call costs about a millisecond at
-                                        lap size; in localizer mode the published pose is then the optimised one. */
+    int32_t optimize_every_keyframe; /* 0 (the reference): the graph is optimised once, at loop closure.  1 (NOT the reference's behaviour):
+                                        gs_slam_perform also runs optimizeGraph + updateMap at the end of every keyframe that did not run
+                                        them already.  The reference carries optimizeGraph() calls commented out at src/slam.cpp:594 and
+                                        :620-621 (with updateMap) and at :403 (localizer: optimizeGraph ONLY, no updateMap); with this flag
+                                        localizer-mode keyframes also run updateMap — the map and the resident association map are
+                                        rewritten after loop closure, which restoring the reference's comments would not do.  One more
+                                        keyframe does not rebuild the structure here (append-only growth), so the call costs about a
+                                        millisecond at lap size; in localizer mode the published pose is then the optimised one. */
 } gs_config;
 
 /* per-call statistics of gs_optimize / gs_iterate (all times from HIP events on
@@ -195,7 +196,7 @@ int  gs_get_landmarks(gs_graph *g, int32_t capacity, int32_t *out_ids, double *o
  *      The default solver is an LDL^T like the Eigen 3.3.4 SimplicialLDLT behind g2o's
  *      LinearSolverEigen and fails like it on a pivot d == 0 only
  *      (thirdparty/Eigen/src/SparseCholesky/SimplicialCholesky_impl.h:172-176), plus on NaN;
- *      the Cholesky fallback kernels (factor_variant 1, 2, 4) fail on d <= 0 like SimplicialLLT.
+ *      the Cholesky fallback kernel (factor_variant 4) fails on d <= 0 like SimplicialLLT.
  * gs_iterate                 one Gauss-Newton iteration, asynchronous on the handle's stream
  *      (the bench's "step"); estimates stay in HBM until gs_sync_estimates / gs_optimize.
  *      A failed iteration applies no update either; gs_stream_synchronize / gs_sync_estimates
@@ -216,7 +217,7 @@ int  gs_stream_synchronize(gs_graph *g);
 int  gs_chi2(gs_graph *g, double *out_chi2);
 int  gs_get_stats(gs_graph *g, gs_stats *stats);      /* plan statistics after initialize */
 
-/* ---- measurement / parity hooks ------------------------------------------
+/* ---- measurement / parity hooks (tuning, fault injection and timestamps: include/graphslam_debug.h) ----------
  * gs_linearize: one A5+A6+A7 pass (the roofline kernel) on the stream, nothing else.
  * gs_time_linearize: `reps` back-to-back passes bracketed by HIP events on the handle's
  *      stream; returns the mean milliseconds per pass in *out_ms_per_pass.
@@ -230,22 +231,6 @@ int  gs_get_stats(gs_graph *g, gs_stats *stats);      /* plan statistics after i
  *      (zeros for fixed vertices): dpose [N*3], dlm [M*2]. */
 int  gs_linearize(gs_graph *g);
 int  gs_time_linearize(gs_graph *g, int32_t reps, double *out_ms_per_pass);
-
-/* Tuning aid: with GS_DBG = 8 | (count << 8) in the environment, the factor / backsolve kernels of the level that
- * holds `count` fronts record 100 MHz timestamps at their phase boundaries for that level's first front
- * (factor: slots 0.., backsolve: slots 32..).  Copies the 64 slots out.  No reference counterpart. */
-int gs_debug_timestamps(gs_graph *g, int64_t *out64);
-/* Tuning aid (F3_DONE_TS builds of the library only, zeros otherwise): 100 MHz completion time of every front in the
- * last factor launch ([0, n)) and the last backward-solve launch ([n, 2n)); returns n.  No reference counterpart. */
-int gs_debug_front_times(gs_graph *g, int64_t *out, int64_t capacity);
-/* Fault injection (tests of the failure semantics; the reference has none): the k-th iteration enqueued after
- * this call reports `code` (1 = zero pivot, 2 = front-flag timeout) from its first front; k = 0 disarms. */
-int gs_debug_fail_at_iteration(gs_graph *g, int32_t k, int32_t code);
-/* The factor-kernel variant a plan with the given largest front and H-arena size (doubles) is given for a requested variant
- * (gs_config.factor_variant; 0 = default): 3 = matrix-core LDL^T fronts with 32-bit byte offsets into the arena (fronts <= 63
- * scalars, arena < 2^29 doubles), 4 = block-per-front kernel with 64-bit addressing (anything else).  Pure function; what
- * gs_initialize_optimization applies.  No reference counterpart. */
-int gs_debug_select_factor_variant(int32_t requested, int32_t max_front, int64_t arena_doubles);
 
 int64_t gs_linearize_bytes(gs_graph *g);
 int  gs_export_system(gs_graph *g, double *Hpp_diag, double *Hll_diag, double *Hpp_off,
@@ -277,7 +262,7 @@ int  gs_plan_build_host(gs_graph *g, gs_plan_info *info);
  * gs_optimize keep the plan: the new vertices become
  * pivots of the root front, the fronts between a neighbour's front and the root gain them as boundary rows, and only those fronts' tables
  * are rebuilt (csrc/gs_plan.cpp grow_plan, csrc/gs_api.cpp upload_growth).  Anything else (a fixed flag, an edge between old vertices,
- * a graph below 128 poses — GS_GROW_MIN_POSES —, where there is nothing to gain, GS_GROW=0 in the environment) is a full structure phase.
+ * a graph below 128 poses, where there is nothing to gain; switches: gs_debug_options.grow / grow_min_poses, graphslam_debug.h) is a full structure phase.
  * gs_plan_growths: steps absorbed by the current plan; gs_growth_refusal: why the last change was NOT absorbed ("" if it was). */
 int  gs_plan_growths(gs_graph *g);
 const char *gs_growth_refusal(gs_graph *g);

@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("GS_LIB", os.path.join(CSRC, "libgraphslam_hip.so"))    # GS_LIB: A/B builds of the same library (tuning)
 HEADER = os.path.join(os.path.dirname(HERE), "include", "graphslam.h")
+DEBUG_HEADER = os.path.join(os.path.dirname(HERE), "include", "graphslam_debug.h")     # tuning / fault injection / timestamps: not the drop-in boundary
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -63,17 +64,32 @@ class ShellMsg(C.Structure):
                 ("object_id", C.c_uint32), ("reserved", C.c_uint32), ("v", C.c_double * 3)]
 
 
+class DebugOptions(C.Structure):
+    """gs_debug_options (include/graphslam_debug.h): every tuning switch of a handle."""
+    _fields_ = [("struct_size", C.c_int32)] + [(k, C.c_int32) for k in (
+        "tree", "block_fronts", "leaf_kernel", "leaf_min", "bs_wide", "leaf_nt3", "f3_lds_kb", "small_tree",
+        "leaf_poses", "cluster_ways", "ell_lanes", "big_cluster", "grow_headroom", "factor_variant",
+        "grow", "grow_min_poses", "assoc_grid", "force_shared_top", "host_trig", "pool_poison", "plan_timing", "dbg")] + [("reserved", C.c_int32 * 8)]
+
+
+# switches applied to every handle this process creates through the binding (tests: conftest sets grow_min_poses = 0)
+DEFAULT_DEBUG = {}
+
+
 class PlanInfo(C.Structure):
     _fields_ = [("n_scalar", C.c_int32), ("n_fronts", C.c_int32), ("n_levels", C.c_int32),
                 ("max_front", C.c_int32), ("l_doubles", C.c_int64), ("u_doubles", C.c_int64),
                 ("n_asm_blocks", C.c_int64), ("n_child_map", C.c_int64)]
 
 
-def declared_symbols():
-    """Every function name include/graphslam.h declares."""
-    txt = open(HEADER).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", txt)))
+def declared_symbols(debug=True):
+    """Every function name include/graphslam.h (and, debug=True, include/graphslam_debug.h) declares."""
+    names = set()
+    for h in (HEADER, DEBUG_HEADER) if debug else (HEADER,):
+        txt = open(h).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
 
 
 def build(force=False):
@@ -137,6 +153,9 @@ def lib():
     L.gs_optimize_until.argtypes = [vp, C.c_int32, C.c_double, C.POINTER(Stats)]
     L.gs_debug_fail_at_iteration.argtypes = [vp, C.c_int32, C.c_int32]
     L.gs_debug_select_factor_variant.argtypes = [C.c_int32, C.c_int32, C.c_int64]
+    L.gs_debug_options_default.argtypes = [C.POINTER(DebugOptions)]
+    L.gs_debug_get_options.argtypes = [vp, C.POINTER(DebugOptions)]
+    L.gs_debug_set_options.argtypes = [vp, C.POINTER(DebugOptions)]
     L.gs_chi2.argtypes = [vp, _dp]
     L.gs_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.gs_time_linearize.argtypes = [vp, C.c_int32, _dp]
@@ -224,7 +243,7 @@ def device_count():
 class Graph:
     """Mirror of the calls Slam makes on g2o::SparseOptimizer (reference src/slam.cpp:53-65,433-484,525-550)."""
 
-    def __init__(self, cfg=None, _handle=None, **kw):
+    def __init__(self, cfg=None, _handle=None, debug=None, **kw):
         self.L = lib()
         self._owned = _handle is None
         if _handle is not None:
@@ -235,6 +254,21 @@ class Graph:
         h = C.c_void_p()
         self._check(self.L.gs_create(C.byref(cfg), C.byref(h)))
         self.h = h
+        if DEFAULT_DEBUG or debug:
+            self.set_debug(**dict(DEFAULT_DEBUG, **(debug or {})))
+
+    # ---- tuning switches (include/graphslam_debug.h)
+    def debug_options(self):
+        o = DebugOptions(); self._check(self.L.gs_debug_get_options(self.h, C.byref(o))); return o
+
+    def set_debug(self, **kw):
+        """gs_debug_set_options: change the named switches of this handle, keep the others."""
+        o = self.debug_options()
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise AttributeError("gs_debug_options has no field %r" % k)
+            setattr(o, k, int(v))
+        self._check(self.L.gs_debug_set_options(self.h, C.byref(o)))
 
     def _check(self, rc):
         if rc < 0:
@@ -502,7 +536,7 @@ class Graph:
 class Slam:
     """Mirror of the graph side of class Slam (reference src/slam.cpp:298-338 performSLAM and what it calls)."""
 
-    def __init__(self, cfg=None, _handle=None, **kw):
+    def __init__(self, cfg=None, _handle=None, debug=None, **kw):
         self.L = lib()
         self._owned = _handle is None
         if _handle is not None:
@@ -516,6 +550,8 @@ class Slam:
                 raise GsError(rc, (self.L.gs_last_error() or b"").decode())
             self.h = h
         self.graph = Graph(_handle=self.L.gs_slam_graph(self.h))
+        if _handle is None and (DEFAULT_DEBUG or debug):
+            self.graph.set_debug(**dict(DEFAULT_DEBUG, **(debug or {})))
 
     def _check(self, rc):
         if rc < 0:

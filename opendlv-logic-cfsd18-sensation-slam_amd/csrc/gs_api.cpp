@@ -2,6 +2,7 @@
 // Host side of the drop-in boundary: everything Slam calls on g2o::SparseOptimizer
 // (reference src/slam.cpp:53-65, 433-484, 525-550, 713-732) lands here.
 #include "../../include/graphslam.h"
+#include "../../include/graphslam_debug.h"
 #include "gs_device.hpp"
 #include "gs_host.hpp"
 #include "gs_internal.hpp"
@@ -37,9 +38,9 @@ static int usable_devices() {
 // Device memory of a plan comes out of a few large chunks (8 MB, then doubling): the ~70 arrays of one structure phase
 // cost a dozen hipMalloc calls instead of 70 (each is 50-100 us of the structure phase), and dev_free_all returns them together.
 // Arrays of 32 MB and more get an allocation of their own.
-// GS_POOL_POISON=1 (tests): every chunk is filled with 0xFF bytes (NaN doubles, negative indices) when it is allocated and whenever a plan
+// gs_debug_options.pool_poison (tests): every chunk is filled with 0xFF bytes (NaN doubles, negative indices) when it is allocated and whenever a plan
 // releases it — an array that is read before this code writes it cannot pass for zero-initialised
-static bool pool_poison() { static const bool on = [] { const char *e = std::getenv("GS_POOL_POISON"); return e && std::atoi(e) != 0; }(); return on; }
+static bool pool_poison(const gs_graph *g) { return g->opt.pool_poison > 0; }
 template <class T> static int dev_alloc(gs_graph *g, T **ptr, size_t count) {
     *ptr = nullptr;
     const size_t bytes = (std::max<size_t>(count, 1) * sizeof(T) + 255) & ~(size_t)255;
@@ -49,7 +50,7 @@ template <class T> static int dev_alloc(gs_graph *g, T **ptr, size_t count) {
             if (c.big && !c.in_use && c.size >= bytes && c.size <= bytes + bytes / 4 && (best < 0 || c.size < g->allocs[best].size)) best = (int)i; }   // serves if it fits within 25 %
         if (best < 0) { void *p = nullptr;
             HIP_TRY(hipMalloc(&p, bytes));
-            if (pool_poison()) HIP_TRY(hipMemsetAsync(p, 0xFF, bytes, g->stream));
+            if (pool_poison(g)) HIP_TRY(hipMemsetAsync(p, 0xFF, bytes, g->stream));
             gs_graph::DevChunk c; c.p = p; c.size = bytes; c.big = true; g->allocs.push_back(c); best = (int)g->allocs.size() - 1; }
         g->allocs[best].in_use = true; g->pool_total += g->allocs[best].size; *ptr = (T *)g->allocs[best].p;
         return GS_OK; }
@@ -60,7 +61,7 @@ template <class T> static int dev_alloc(gs_graph *g, T **ptr, size_t count) {
         for (size_t i = 0; i < g->allocs.size() && pick < 0; ++i) { const auto &c = g->allocs[i]; if (!c.big && !c.in_use && c.size >= want) pick = (int)i; }   // a chunk of the last plan
         if (pick < 0) { void *p = nullptr;
             HIP_TRY(hipMalloc(&p, want));
-            if (pool_poison()) HIP_TRY(hipMemsetAsync(p, 0xFF, want, g->stream));
+            if (pool_poison(g)) HIP_TRY(hipMemsetAsync(p, 0xFF, want, g->stream));
             gs_graph::DevChunk c; c.p = p; c.size = want; g->allocs.push_back(c); pick = (int)g->allocs.size() - 1; }
         auto &c = g->allocs[pick]; c.in_use = true; g->pool_total += c.size;
         g->pool_base = (char *)c.p; g->pool_size = c.size; g->pool_off = 0;
@@ -79,7 +80,7 @@ template <class T, class A> static int dev_upload(gs_graph *g, T **ptr, const st
 // the device side of a plan goes away; keep = the memory stays with the handle for the next plan
 static void dev_release(gs_graph *g, bool keep) {
     if (!keep) { for (auto &c : g->allocs) hipFree(c.p); g->allocs.clear(); }
-    else for (auto &c : g->allocs) { c.in_use = false; if (pool_poison() && g->stream) hipMemsetAsync(c.p, 0xFF, c.size, g->stream); }
+    else for (auto &c : g->allocs) { c.in_use = false; if (pool_poison(g) && g->stream) hipMemsetAsync(c.p, 0xFF, c.size, g->stream); }
     g->pool_base = nullptr; g->pool_size = g->pool_off = 0; g->pool_next = 0; g->pool_total = 0;
     g->d = DevGraph();
     g->dev_valid = false;
@@ -124,6 +125,52 @@ extern "C" int gs_config_default(gs_config *c) {
     return GS_OK;
 }
 
+
+// ------------------------------------------------------------------ tuning switches (include/graphslam_debug.h)
+extern "C" int gs_debug_options_default(gs_debug_options *o) {
+    if (!o) return fail(GS_ERR_INVALID, "null options");
+    std::memset(o, 0, sizeof(*o));
+    o->struct_size = (int32_t)sizeof(*o);
+    o->tree = 1; o->block_fronts = 512; o->leaf_kernel = -1; o->leaf_min = 2048; o->bs_wide = 2048; o->leaf_nt3 = 1; o->f3_lds_kb = 0; o->small_tree = 512;
+    o->leaf_poses = 0; o->cluster_ways = 0; o->ell_lanes = 0; o->big_cluster = -1; o->grow_headroom = -1; o->factor_variant = 0;
+    o->grow = 1; o->grow_min_poses = 128;
+    o->assoc_grid = -1;
+    o->force_shared_top = 0;
+    o->host_trig = 0; o->pool_poison = 0; o->plan_timing = 0; o->dbg = 0;
+    return GS_OK;
+}
+// The ONE place the environment is read: once per gs_create (graphslam_debug.h names the variable of every field).
+static void options_from_environment(gs_debug_options &o) {
+    gs_debug_options_default(&o);
+    auto env = [](const char *name, int32_t &field) { if (const char *e = std::getenv(name)) field = (int32_t)std::atoi(e); };
+    env("GS_TREE", o.tree); env("GS_BLOCK_FRONTS", o.block_fronts); env("GS_LEAF_KERNEL", o.leaf_kernel); env("GS_LEAF_MIN", o.leaf_min);
+    env("GS_BS_WIDE", o.bs_wide); env("GS_LEAF_NT3", o.leaf_nt3); env("GS_F3_LDS_KB", o.f3_lds_kb); env("GS_SMALL_TREE", o.small_tree);
+    env("GS_LEAF_POSES", o.leaf_poses); env("GS_CLUSTER_WAYS", o.cluster_ways); env("GS_ELL_LANES", o.ell_lanes); env("GS_BIG_CLUSTER", o.big_cluster);
+    env("GS_GROW_HEADROOM", o.grow_headroom); env("GS_FACTOR_VARIANT", o.factor_variant);
+    env("GS_GROW", o.grow); env("GS_GROW_MIN_POSES", o.grow_min_poses); env("GS_ASSOC_GRID", o.assoc_grid); env("GS_FORCE_SHARED_TOP", o.force_shared_top);
+    env("GS_HOST_TRIG", o.host_trig); env("GS_POOL_POISON", o.pool_poison); env("GS_DBG", o.dbg);
+    if (std::getenv("GS_PLAN_TIMING")) o.plan_timing = 1;
+}
+extern "C" int gs_debug_get_options(gs_graph *g, gs_debug_options *o) {
+    if (!g || !o) return fail(GS_ERR_INVALID, "null argument");
+    *o = g->opt; return GS_OK;
+}
+extern "C" int gs_debug_set_options(gs_graph *g, const gs_debug_options *o) {
+    if (!g || !o) return fail(GS_ERR_INVALID, "null argument");
+    gs_debug_options n; gs_debug_options_default(&n);
+    std::memcpy(&n, o, std::min<size_t>(sizeof(n), (size_t)std::max(o->struct_size, 0))); n.struct_size = (int32_t)sizeof(n);
+    const gs_debug_options &c = g->opt;
+    // a "plan" field changed: the next structure phase is a full one (a grown plan keeps the launch shapes it was built with)
+    const bool plan_changed = n.tree != c.tree || n.block_fronts != c.block_fronts || n.leaf_kernel != c.leaf_kernel || n.leaf_min != c.leaf_min ||
+        n.bs_wide != c.bs_wide || n.leaf_nt3 != c.leaf_nt3 || n.f3_lds_kb != c.f3_lds_kb || n.small_tree != c.small_tree || n.leaf_poses != c.leaf_poses ||
+        n.cluster_ways != c.cluster_ways || n.ell_lanes != c.ell_lanes || n.big_cluster != c.big_cluster || n.grow_headroom != c.grow_headroom ||
+        n.factor_variant != c.factor_variant || n.force_shared_top != c.force_shared_top || n.host_trig != c.host_trig || n.pool_poison != c.pool_poison ||
+        n.dbg != c.dbg;
+    g->opt = n;
+    if (plan_changed) { ++g->h.structure_version; ++g->h.reshape_version; }
+    return GS_OK;
+}
+
 extern "C" int gs_create(const gs_config *cfg, gs_graph **out) {
     if (!out) return fail(GS_ERR_INVALID, "null out");
     *out = nullptr;
@@ -131,7 +178,7 @@ extern "C" int gs_create(const gs_config *cfg, gs_graph **out) {
     gs_config_default(&c);
     if (cfg) { size_t n = std::min<size_t>(sizeof(c), (size_t)std::max(cfg->struct_size, 0)); std::memcpy(&c, cfg, n); c.struct_size = (int32_t)sizeof(c); }
     if (c.device == -2) {   // host-only handle: graph container + plan inspection, never any arithmetic
-        gs_graph *g = new gs_graph(); g->cfg = c; g->device = -2; g->host_only = true; *out = g; return GS_OK; }
+        gs_graph *g = new gs_graph(); g->cfg = c; g->device = -2; g->host_only = true; options_from_environment(g->opt); *out = g; return GS_OK; }
     int ndev = usable_devices();
     if (ndev <= 0) return fail(GS_ERR_NO_DEVICE, "no HIP device: this back-end has no CPU fallback");
     int dev = c.device;
@@ -143,6 +190,7 @@ extern "C" int gs_create(const gs_config *cfg, gs_graph **out) {
         return fail(GS_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     gs_graph *g = new gs_graph();
     g->cfg = c; g->device = dev; g->force_gather = c.linearize_gather != 0; g->default_factor_variant = c.factor_variant;
+    options_from_environment(g->opt);
     HIP_TRY(hipSetDevice(dev));
     if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) { delete g; return fail(GS_ERR_HIP, "hipStreamCreate failed"); }
     g->own_stream = true;
@@ -458,7 +506,7 @@ static int upload_raw_begin(gs_graph *g, RawUpload &R) {
 
 static int upload_graph(gs_graph *g, RawUpload &raw) {
     const HostGraph &h = g->h; const Plan &P = g->plan; DevGraph &d = g->d;
-    const bool ut_on = std::getenv("GS_PLAN_TIMING") != nullptr; auto ut_prev = std::chrono::steady_clock::now();
+    const bool ut_on = g->opt.plan_timing > 0; auto ut_prev = std::chrono::steady_clock::now();
 #define GS_UT(name) do { if (ut_on) { auto n_ = std::chrono::steady_clock::now(); std::fprintf(stderr, "upload %-18s %.2f ms\n", (name), std::chrono::duration<double, std::milli>(n_ - ut_prev).count()); ut_prev = n_; } } while (0)
     const int N = h.n_poses(), M = h.n_lms(), Epp = h.n_pp(), Epl = h.n_pl();
     d.N = N; d.M = M; d.Epp = Epp; d.Epl = Epl; d.n_scalar = P.n_scalar;
@@ -467,10 +515,10 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
 #define UP(dst, vec) if ((rc = dev_upload(g, &d.dst, vec)) != GS_OK) return rc
     // estimates, fixed flags, odometry edges and the insertion-order observation arrays are in HBM already (RawUpload)
     launch_pose_trig(d, g->stream);
-    // GS_HOST_TRIG=1 (an experiment, scripts/parity_spread.py): the cos / sin of the INITIAL pose angles from the host's libm
+    // gs_debug_options.host_trig (an experiment, scripts/parity_spread.py): the cos / sin of the INITIAL pose angles from the host's libm
     // instead of the device's — what the CPU oracle linearises with — to tell how much of the first increment's distance
     // to the CPU paths is the last bit of two transcendental functions
-    if (const char *e = std::getenv("GS_HOST_TRIG")) if (std::atoi(e) != 0 && N > 0) {
+    if (g->opt.host_trig > 0 && N > 0) {
         std::vector<double> cs(2 * (size_t)N);
         for (int p = 0; p < N; ++p) { cs[2 * (size_t)p] = std::cos(h.pose_est[3 * (size_t)p + 2]); cs[2 * (size_t)p + 1] = std::sin(h.pose_est[3 * (size_t)p + 2]); }
         HIP_TRY(hipMemcpyAsync(d.pose_cs, cs.data(), cs.size() * sizeof(double), hipMemcpyHostToDevice, g->stream));
@@ -573,18 +621,17 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
       if (!P.asm_recs.empty()) HIP_TRY(hipMemcpyAsync(d.asm_recs, P.asm_recs.data(), P.asm_recs.size() * sizeof(AsmRec), hipMemcpyHostToDevice, g->stream));
       g->room.cap_asm = (int64_t)(P.asm_recs.size() + ROOM_RECS); }
     GS_UT("plan arrays");
-    // factor kernel variant (gs_config.factor_variant, GS_FACTOR_VARIANT overrides): 0 = default = 3 when every front
-    // fits 63 scalars, else 4.  3 = wave-per-front LDL^T on the fp64 matrix cores, latency-shaped; 2 = wave-per-front
-    // Cholesky on the matrix cores (first version); 1 = wave-per-front VALU; 4 = block-per-front VALU (any front size).
+    // factor kernel variant (gs_config.factor_variant; gs_debug_options.factor_variant overrides): 0 = default = 3 when every
+    // front fits 159 scalars, else 4.  3 = LDL^T on the fp64 matrix cores, a wave or a workgroup per front; 4 = block-per-front
+    // VALU Cholesky (any front size).
     { int v = g->default_factor_variant;
-      if (const char *e = std::getenv("GS_FACTOR_VARIANT")) v = std::atoi(e);
+      if (g->opt.factor_variant > 0) v = g->opt.factor_variant;
       v = gs_debug_select_factor_variant(v, P.max_front, arena_doubles);
       if (v == 3 && P.max_front > 63 && P.world > 1) v = 4;           // the workgroup-per-front form has no shard modes (contribution / shared top) yet
       if (v == 4) v = 0;                                              // device-side code for the block-per-front kernel
       g->wg_f.clear(); g->wg_b.clear(); g->d_wg_f = g->d_wg_b = nullptr;
       d.factor_variant = v;
-      if (const char *e = std::getenv("GS_DBG")) d.dbg = std::atoi(e);
-      if (v == 2) { AL(Uimg, (size_t)P.fronts.size() * 2568); ZERO(Uimg, (size_t)P.fronts.size() * 2568); }   // 2560-double tile images
+      d.dbg = g->opt.dbg; d.leaf_nt3 = g->opt.leaf_nt3 != 0 ? 1 : 0; d.f3_lds_kb = std::max(g->opt.f3_lds_kb, 0);
       if (v == 3) {
           std::vector<int32_t> lf = P.level_fronts_owned;
           lf.insert(lf.end(), P.level_fronts_shared.begin(), P.level_fronts_shared.end());
@@ -603,8 +650,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
           UP(u3_off, u3_off); UP(u3_size, u3_size);
           g->u3_off_host = u3_off; g->u3_size_host = u3_size;
           AL(done_f, P.fronts.size()); ZERO(done_f, P.fronts.size());
-          d.epoch = 0; d.tree = 1; g->fell_back = false;              // whole-tree launches for this rank's own subtrees (GS_TREE=0: one launch per level)
-          if (const char *e = std::getenv("GS_TREE")) d.tree = std::atoi(e) != 0 ? 1 : 0;
+          d.epoch = 0; d.tree = g->opt.tree != 0 ? 1 : 0; g->fell_back = false;   // whole-tree launches for this rank's own subtrees (gs_debug_options.tree = 0: one launch per level)
           // ---- everything below is expanded ON THE DEVICE from the compact plan arrays
           const bool fused = P.lin_ell_ok && d.n_wtiles > 0;
           // block assembly records: the plan's, as they are (AsmRec = 4 ints); landmark-diagonal records of the fused
@@ -663,7 +709,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
     AL(done_ts, 2 * P.fronts.size() + 2); ZERO(done_ts, 2 * P.fronts.size() + 2);
     { const int64_t room_L = g->room.ok ? (int64_t)room_of((size_t)P.l_doubles, (size_t)256 << 10, (size_t)(P.max_front > 63 ? 8 : 2) << 20) : 0;          // doubles: the L panels of fronts a growth step enlarges move here
       AL(Lbuf, P.l_doubles + room_L); g->room.cap_L = P.l_doubles + room_L; }
-    AL(Ubuf, (d.factor_variant == 0 || d.factor_variant == 1) ? P.u_doubles : 1);      // variants 2 and 3 keep their update matrices in Uimg
+    AL(Ubuf, d.factor_variant == 0 ? P.u_doubles : 1);              // variant 3 keeps its update matrices in Uimg
     AL(xe, P.n_scalar + 3 * TAIL_POSES + 2 * TAIL_LMS); g->room.cap_xe = P.n_scalar + 3 * TAIL_POSES + 2 * TAIL_LMS;
     AL(dpose, ((size_t)N + TAIL_POSES) * 3); AL(dlm, ((size_t)M + TAIL_LMS) * 2); AL(fail, 4);
     HIP_TRY(hipMemsetAsync(d.fail, 0, 4 * sizeof(int32_t), g->stream));
@@ -748,7 +794,12 @@ static int upload_growth(gs_graph *g, const Growth &gr) {
     { const int M0 = gr.first_lm, M1 = P.planned_M;                  // landmarks first seen by the new poses
       if (M1 > M0) { if ((rc = H2D(d.lm_est + 2 * (size_t)M0, &h.lm_est[2 * (size_t)M0], (size_t)(M1 - M0) * 2 * sizeof(double))) != GS_OK) return rc;
           if ((rc = H2D(d.lm_gidx + M0, &P.lm_gidx[M0], (size_t)(M1 - M0) * sizeof(int32_t))) != GS_OK) return rc; } }
-    launch_pose_trig_range(d, N0, N1 - N0, g->stream);
+    if (g->dev_estimate_version != h.estimate_version) {          // a host-side setEstimate on an OLDER vertex since the last upload (g2o: setEstimate, then
+        const int M1 = P.planned_M;                                 // optimize() uses the new value): the whole estimate arrays go up again, not only the tail's
+        if ((rc = H2D(d.pose_est, h.pose_est.data(), (size_t)N1 * 3 * sizeof(double))) != GS_OK) return rc;
+        if ((rc = H2D(d.lm_est, h.lm_est.data(), (size_t)M1 * 2 * sizeof(double))) != GS_OK) return rc;
+        launch_pose_trig_range(d, 0, N1, g->stream);
+    } else launch_pose_trig_range(d, N0, N1 - N0, g->stream);
     for (int k = E0; k < E1; ++k) { double inv[3]; se2_inverse_host(&h.pp_z[3 * (size_t)k], inv);
         double *o = &zinv[5 * (size_t)(k - E0)]; o[0] = inv[0]; o[1] = inv[1]; o[2] = inv[2]; o[3] = std::cos(inv[2]); o[4] = std::sin(inv[2]);
         ppij[2 * (size_t)(k - E0)] = h.pp_i[k]; ppij[2 * (size_t)(k - E0) + 1] = h.pp_j[k]; }
@@ -813,17 +864,16 @@ static int upload_growth(gs_graph *g, const Growth &gr) {
     return GS_OK;
 }
 
-// The factor kernel a plan gets (gs_config.factor_variant, GS_FACTOR_VARIANT overrides): 0 = default = 3.
-//   3 = wave-per-front LDL^T on the fp64 matrix cores, latency-shaped; 2 = wave-per-front Cholesky on the matrix cores (first
-//   version); 1 = wave-per-front VALU; 4 = block-per-front VALU (any front size, 64-bit addressing throughout).
-// Variants 1-2 hold a front in 64 lanes; variant 3 gives a front of up to 63 scalars a wave and one of 64 .. 159 a workgroup,
-// chosen per front; variant 3 additionally names every scalar of the linearised system by a 32-bit BYTE
-// offset into H_arena ((uint32_t)record * 8 in the front kernels): beyond 2^29 doubles (4 GiB) those would wrap and assemble the
-// wrong entries silently, so such a graph gets variant 4.
+// The factor kernel a plan gets (gs_config.factor_variant; gs_debug_options.factor_variant overrides): 0 = default = 3.
+//   3 = LDL^T on the fp64 matrix cores, latency-shaped: a front of up to 63 scalars a wave, one of 64 .. 159 a workgroup, chosen per
+//   front; 4 = block-per-front VALU Cholesky (any front size, 64-bit addressing throughout).  (Rounds 1-3 also kept a wave-per-front
+//   VALU kernel and a first matrix-core Cholesky as variants 1 and 2; nothing but tests ran them: removed in round 4, requests for
+//   them get variant 3.)
+// Variant 3 names every scalar of the linearised system by a 32-bit BYTE offset into H_arena ((uint32_t)record * 8 in the front
+// kernels): beyond 2^29 doubles (4 GiB) those would wrap and assemble the wrong entries silently, so such a graph gets variant 4.
 extern "C" int gs_debug_select_factor_variant(int32_t requested, int32_t max_front, int64_t arena_doubles) {
     int v = requested;
-    if (v <= 0 || v > 4) v = 3;
-    if ((v == 1 || v == 2) && max_front > 63) v = 4;                // the first-generation wave-per-front kernels hold a front in 64 lanes
+    if (v != 4) v = 3;
     if (v == 3 && max_front > 159) v = 4;                           // variant 3: a wave up to 63 scalars, a workgroup up to 159 (ten tile rows)
     if (v == 3 && arena_doubles >= ((int64_t)1 << 29)) v = 4;
     return v;
@@ -831,11 +881,13 @@ extern "C" int gs_debug_select_factor_variant(int32_t requested, int32_t max_fro
 
 static int build_plan_host(gs_graph *g) {
     PlanOptions o; o.leaf_poses = g->cfg.leaf_poses; o.world = g->world; o.rank = g->rank;
-    if (const char *e = std::getenv("GS_LEAF_POSES")) o.leaf_poses = std::atoi(e);       // tuning override
-    if (const char *e = std::getenv("GS_CLUSTER_WAYS")) o.cluster_ways = std::atoi(e);   // tuning override: 2 = binary dissection down to the leaves
-    if (const char *e = std::getenv("GS_ELL_LANES")) o.ell_lanes = std::atoi(e);       // tuning knob: lanes per pose of the ELL layout
-    if (const char *e = std::getenv("GS_BIG_CLUSTER")) o.big_cluster_front = std::atoi(e);   // tuning override: 0 = clusters only where they fit a wave
-    if (const char *e = std::getenv("GS_GROW_HEADROOM")) { o.grow_headroom = std::atoi(e); o.grow_spine_headroom = std::min(o.grow_spine_headroom, 3 * o.grow_headroom); }   // tuning override: 0 = cluster fronts up to the full 63 scalars
+    const gs_debug_options &t = g->opt;                             // tuning overrides (graphslam_debug.h)
+    if (t.leaf_poses > 0) o.leaf_poses = t.leaf_poses;
+    if (t.cluster_ways > 0) o.cluster_ways = t.cluster_ways;             // 2 = binary dissection down to the leaves
+    if (t.ell_lanes > 0) o.ell_lanes = t.ell_lanes;                      // lanes per pose of the ELL layout
+    if (t.big_cluster >= 0) o.big_cluster_front = t.big_cluster;         // 0 = clusters only where they fit a wave
+    if (t.grow_headroom >= 0) { o.grow_headroom = t.grow_headroom; o.grow_spine_headroom = std::min(o.grow_spine_headroom, 3 * o.grow_headroom); }   // 0 = cluster fronts up to the full 63 scalars
+    o.timing = t.plan_timing > 0;
     std::string err;
     if (!build_plan(g->h, o, g->plan, err)) { g->plan_version = ~0ull; return fail(GS_ERR_EMPTY, "plan: " + err); }
     g->plan_version = g->h.structure_version;
@@ -849,10 +901,10 @@ extern "C" int gs_plan_build_host(gs_graph *g, gs_plan_info *info) {
     // inspected and replayed without a GPU; GS_GROW=0 or any other change: full build
     bool grown = false;
     if (g->host_only && g->plan.valid && g->plan_version != ~0ull && g->plan_version != g->h.structure_version) {
-        bool on = true; if (const char *e = std::getenv("GS_GROW")) on = std::atoi(e) != 0;
+        const bool on = g->opt.grow != 0;
         Growth gr; std::string why;
         if (on && grow_plan(g->h, g->plan, gr, why)) { grown = true; g->plan_version = g->h.structure_version; g->no_growth_reason.clear(); }
-        else g->no_growth_reason = on ? why : "GS_GROW=0";
+        else g->no_growth_reason = on ? why : "growth switched off (gs_debug_options.grow = 0 / GS_GROW=0)";
     }
     if (!grown) { rc = build_plan_host(g); if (rc != GS_OK) return rc; }
     if (info) { const Plan &P = g->plan; info->n_scalar = P.n_scalar; info->n_fronts = (int32_t)P.fronts.size();
@@ -884,12 +936,12 @@ extern "C" int gs_initialize_optimization(gs_graph *g) {
     // upload_growth); anything else — or GS_GROW=0 — rebuilds
     g->no_growth_reason.clear();
     if (g->dev_valid && g->plan.valid && g->plan_version != ~0ull && g->plan_version != g->h.structure_version) {
-        bool on = true; if (const char *e = std::getenv("GS_GROW")) on = std::atoi(e) != 0;
+        const bool on = g->opt.grow != 0;
         Growth gr; std::string why;
         // below ~a hundred poses the full phase costs 0.25 ms, the tail kernel of ten iterations 0.08: nothing to gain (a lap, 200 poses
         // mapped: 1.03 ms per optimize(10) grown against 1.16 rebuilt, scripts/keyframe_stream.py)
-        int min_poses = 128; if (const char *e = std::getenv("GS_GROW_MIN_POSES")) min_poses = std::atoi(e);
-        if (!on) g->no_growth_reason = "GS_GROW=0";
+        const int min_poses = g->opt.grow_min_poses;
+        if (!on) g->no_growth_reason = "growth switched off (gs_debug_options.grow = 0 / GS_GROW=0)";
         else if (g->plan.base_N < min_poses) g->no_growth_reason = "graph below the size at which growing pays (GS_GROW_MIN_POSES)";
         else if (!g->room.ok) g->no_growth_reason = "plan uploaded without room to grow";
         else if (grow_plan(g->h, g->plan, gr, why)) {
@@ -1002,13 +1054,12 @@ static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int
             F_leaf_all = n_leaf;                                        // GS_LEAF_KERNEL=2: leaf launches whatever their number
             // few leaves (all resident at once anyway: <= GS_LEAF_MIN, default 2048): no separate leaf launches, the whole-tree
             // launches take level 0 as well — two kernel boundaries less per iteration (cfg1-cfg3: 6-11 % of it)
-            { int lmin = 2048; if (const char *e = std::getenv("GS_LEAF_MIN")) lmin = std::atoi(e);
-              if (n_leaf <= lmin) n_leaf = 0; }
-            if (const char *e = std::getenv("GS_LEAF_KERNEL")) { if (std::atoi(e) == 0) n_leaf = 0; else if (std::atoi(e) == 2) n_leaf = F_leaf_all; }
+            if (n_leaf <= g->opt.leaf_min) n_leaf = 0;
+            if (g->opt.leaf_kernel == 0) n_leaf = 0; else if (g->opt.leaf_kernel == 2) n_leaf = F_leaf_all;
             g->leaf_n = n_leaf; g->leaf_slot = slot; }
         // the upper levels — few fronts, all of them in the dependent chain — get four waves per front: whole levels from the
         // top down while a level has at most GS_BLOCK_FRONTS (512) fronts (those workgroups are all resident at once)
-        if (g->block_n < 0) { int thr = 512; if (const char *e = std::getenv("GS_BLOCK_FRONTS")) thr = std::atoi(e);
+        if (g->block_n < 0) { const int thr = g->opt.block_fronts;
             int nb = 0;
             for (int l = nlev - 1; l >= (g->leaf_n > 0 ? 1 : 0); --l) { const int nl = ls.start[l + 1] - ls.start[l];
                 if (nl > thr) break;
@@ -1032,7 +1083,7 @@ static void enqueue_backsolve_levels(gs_graph *g, const gs_graph::LevelSet &ls, 
         // of the upper levels (2.2 us per level), wrong for the wide levels at the bottom, which are bound by resident
         // waves x bytes: levels of more than GS_BS_WIDE (2048) fronts run one light launch each, like the leaves
         // (measured per-level completion times: scripts/level_times.py).
-        int wide = 2048; if (const char *e = std::getenv("GS_BS_WIDE")) wide = std::atoi(e);
+        const int wide = g->opt.bs_wide;
         int l0 = 0;
         if (g->leaf_n != 0) while (l0 + 1 < nlev && ls.start[l0 + 1] - ls.start[l0] > wide) ++l0;
         if (l0 == 0 && nlev > 1 && g->leaf_n != 0) l0 = 1;
@@ -1410,7 +1461,7 @@ extern "C" int gs_associate_batch(gs_graph *g, int32_t n, const double *poses, i
     // within the threshold sits in the 3 x 3 cells around the query); the brute-force kernel stays for small maps,
     // non-positive thresholds and degenerate extents.  GS_ASSOC_GRID=0/1 forces either (A/B, tests).
     bool grid = n_map >= 2048 && thr > 0.0;
-    if (const char *e = std::getenv("GS_ASSOC_GRID")) grid = std::atoi(e) != 0 && n_map > 0 && thr > 0.0;
+    if (g->opt.assoc_grid >= 0) grid = g->opt.assoc_grid != 0 && n_map > 0 && thr > 0.0;
     double minx = 0, miny = 0, maxx = 0, maxy = 0;
     if (grid) { minx = maxx = map_xy[0]; miny = maxy = map_xy[1];
         for (int j = 0; j < n_map; ++j) { const double x = map_xy[2 * (size_t)j], y = map_xy[2 * (size_t)j + 1];

@@ -66,9 +66,10 @@ struct DevGraph {
     double *front_ws = nullptr; int64_t front_ws_stride = 0;    // global workspace for fronts too big for LDS
     long long *done_ts = nullptr;                               // [2][n_fronts] F3_DONE_TS tuning builds: 100 MHz completion time of every front (factor, backsolve)
     long long *dbg_ts = nullptr;                                // [64] phase timestamps (100 MHz) of one front, GS_DBG = 8 | level_count << 8
-    int32_t dbg = 0;                                            // GS_DBG ablation bits (timing experiments only)
-    int32_t factor_variant = 0;                                 // 0 block-per-front VALU, 1 wave-per-front VALU, 2 wave-per-front MFMA, 3 MFMA LDL^T gather (default)
-    double *Uimg = nullptr;                                     // variant 2: update matrices as 16x16 tile images; variant 3: packed lower triangles (u3_off, u3_size)
+    int32_t dbg = 0;                                            // gs_debug_options.dbg: in-kernel timestamp probes (timing experiments only)
+    int32_t leaf_nt3 = 1, f3_lds_kb = 0;                        // gs_debug_options: three-tile-row leaf instance; LDS per workgroup of the per-level factor launches
+    int32_t factor_variant = 0;                                 // 0 block-per-front VALU Cholesky (the C-ABI's variant 4), 3 matrix-core LDL^T fronts (default)
+    double *Uimg = nullptr;                                     // variant 3: update matrices as packed lower triangles (u3_off, u3_size)
     // variant 3 (latency-shaped MFMA/LDL^T kernels): flat per-level descriptors, value-ready assembly records,
     // per-front inverse row maps into the parent (formats: gs_kernels.hip, "variant 3")
     int32_t *f3_x = nullptr;                                    // row tables + headers of the children of a front (f3x_stride ints per child)

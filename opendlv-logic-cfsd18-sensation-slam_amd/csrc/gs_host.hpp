@@ -151,7 +151,8 @@ struct PlanOptions { int leaf_poses = 8; int world = 1; int rank = 0; int ell_la
                      int big_cluster_front = -1;       // second-pass bound of a cluster front when 63 scalars cannot be met (0 .. 63: off); -1 = by the view: 111 with more than 10
                                                        // cones per frame, off below (there binary splits of wave fronts beat a workgroup front: lap-sized graphs 1.1 vs 1.9-2.6 ms per optimize(10))
                      int grow_headroom = 6;            // scalars a cluster front stays below the 63 of a wave: room for the boundary rows of two appended poses (grow_plan)
-                     int grow_spine_headroom = 18; };  // the same for the cluster front that holds the LAST pose: appended keyframes continue the track there (six poses)
+                     int grow_spine_headroom = 18;     // the same for the cluster front that holds the LAST pose: appended keyframes continue the track there (six poses)
+                     bool timing = false; };           // per-phase wall times on stderr (gs_debug_options.plan_timing)  // the same for the cluster front that holds the LAST pose: appended keyframes continue the track there (six poses)
 
 constexpr int LIN_R = 4;               // observation slots per lane handled by the fused linearisation kernel
 

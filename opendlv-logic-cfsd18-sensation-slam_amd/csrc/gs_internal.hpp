@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/graphslam.h"
+#include "../../include/graphslam_debug.h"
 #include "gs_device.hpp"
 #include "gs_host.hpp"
 
@@ -15,6 +16,7 @@ struct gs_graph {
     struct LevelSet { std::vector<int32_t> start; std::vector<int> max_f, max_npiv, max_nbnd; };
 
     gs_config cfg{};
+    gs_debug_options opt{};                 // every tuning switch (graphslam_debug.h): filled once at gs_create, replaced by gs_debug_set_options
     int device = 0;
     bool host_only = false;                 // cfg.device == -2: no HIP calls, no arithmetic
     gs::HostGraph h;

@@ -929,350 +929,17 @@ int factor_lds_limit_f() {
     return f;
 }
 
-// ---- one WAVE per front (fronts of <= 63 scalars, i.e. every front of a cone track): no block barrier at all.
-// The lower triangle of the (f+1) x f front (rows c..f of column c; row f = rhs) is packed in LDS, half the
-// footprint of the square layout, so twice as many fronts are resident per CU; lane r owns row r; the pivot
-// column is broadcast lane -> wave with readlane instead of LDS; four fronts per 256-thread workgroup.
-struct PackedFront {
-    double *F; int f;
-    __device__ __forceinline__ int col(int c) const { return c * (f + 1) - ((c * (c - 1)) >> 1); }   // start of column c
-    __device__ __forceinline__ double &at(int r, int c) const { return F[col(c) + (r - c)]; }        // r >= c
-};
-__device__ __forceinline__ int packed_front_doubles(int f) { return ((f * (f + 1)) >> 1) + f; }
-
 // tile-image layout of a 64 x 64 front: the 10 lower 16 x 16 tiles, tile (I, J) at index I(I+1)/2 + J, row-major
-// inside a tile.  It is both the LDS staging layout of the MFMA factor kernel and the HBM layout of its update
-// matrices: lane l of register q of tile t holds (row 16I + (l >> 4) + 4q, col 16J + (l & 15)), the C/D layout of
-// v_mfma_f64_16x16x4_f64, so a whole tile register moves as one 512-byte coalesced access.
+// inside a tile.  It is the LDS staging layout of the matrix-core front kernels: lane l of register q of tile t holds
+// (row 16I + (l >> 4) + 4q, col 16J + (l & 15)), the C/D layout of v_mfma_f64_16x16x4_f64.
 static constexpr int MF_IMG = 2560;
 __device__ __forceinline__ int mf_tile(int I, int J) { return ((I * (I + 1)) >> 1) + J; }
-struct StageFront {
-    double *F; int f;
-    __device__ __forceinline__ double &at(int r, int c) const { return F[mf_tile(r >> 4, c >> 4) * 256 + (r & 15) * 16 + (c & 15)]; }   // r >= c
-};
-
-// One assembly record into a front image.  ADD = false: the destination is known to be untouched (the image was
-// zeroed and every unique record owns its block), so the values are plain stores and all loads of the record are
-// issued before the first store (no read-modify-write chain on LDS).  ADD = true: duplicate (parallel) edges.
-template <bool ADD, class Acc>
-__device__ __forceinline__ void apply_asm_packed(const DevGraph &d, const int32_t *rec, const Acc &P) {
-    const int kind = rec[0], src = rec[1], r0 = rec[2], c0 = rec[3], f = P.f;
-    auto put = [&](int r, int c, double v) { if (ADD) P.at(r, c) += v; else P.at(r, c) = v; };
-    switch (kind) {
-        case 0: {
-            const double *H = d.Hpp_diag + src; const int64_t S = d.N;
-            double h[6], b[3];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) h[k] = H[k * S];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) b[k] = d.b_pose[k * S + src];
-            put(r0, c0, h[0]); put(r0 + 1, c0, h[1]); put(r0 + 2, c0, h[2]);
-            put(r0 + 1, c0 + 1, h[3]); put(r0 + 2, c0 + 1, h[4]); put(r0 + 2, c0 + 2, h[5]);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) put(f, c0 + c, b[c]);
-        } break;
-        case 1: {
-            double a[5] = {0, 0, 0, 0, 0};
-            if (d.n_wtiles > 0) {
-                for (int q = d.lm_grp_start[src]; q < d.lm_grp_start[src + 1]; ++q) {
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) a[k] += d.lm_part[(int64_t)k * d.n_groups + q]; }
-            } else { const int64_t S = d.M;
-                a[0] = d.Hll_diag[src]; a[1] = d.Hll_diag[S + src]; a[2] = d.Hll_diag[2 * S + src]; a[3] = d.b_lm[src]; a[4] = d.b_lm[S + src]; }
-            put(r0, c0, a[0]); put(r0 + 1, c0, a[1]); put(r0 + 1, c0 + 1, a[2]);
-            put(f, c0, a[3]); put(f, c0 + 1, a[4]);
-        } break;
-        case 2: case 3: {
-            const double *H = d.Hpp_off + src; const int64_t S = d.Epp;
-            double h[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) h[k] = H[k * S];
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) put(r0 + a, c0 + b, (kind == 2) ? h[3 * a + b] : h[3 * b + a]);
-        } break;
-        case 4: {
-            const double *H = d.Hpl + src; const int64_t S = d.ell_len;
-            double h[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) h[k] = H[k * S];
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) put(r0 + a, c0 + b, h[2 * a + b]);
-        } break;
-        default: {
-            const double *H = d.Hpl + src; const int64_t S = d.ell_len;
-            double h[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) h[k] = H[k * S];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) put(r0 + a, c0 + b, h[2 * b + a]);
-        } break;
-    }
-}
 
 __device__ __forceinline__ double lane_bcast(double v, int src_lane) {      // src_lane is wave-uniform
     int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
     return __hiloint2double(hi, lo);
 }
-
-__device__ __forceinline__ int lane_bcast_i(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
-
-__global__ void __launch_bounds__(256) k_factor_wave(DevGraph d, int level_off, int count, int mode, int slot_doubles) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    // the wave id is wave-uniform: say so (readfirstlane), otherwise everything derived from it (front id, f, loop
-    // bounds, readlane sources) is treated as divergent and every readlane becomes a waterfall loop
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int fi = blockIdx.x * 4 + wave;
-    if (fi >= count) return;                                        // whole wave leaves; no block barrier below
-    const int s = d.level_fronts[level_off + fi];
-    const DevFront fr = d.fronts[s];
-    const int npiv = fr.npiv, nbnd = fr.nbnd, f = npiv + nbnd;
-    PackedFront P{smem + (int64_t)wave * slot_doubles, f};
-    const int tot = packed_front_doubles(f);
-    if (mode == FRONT_TOP) {
-        const double *X = d.exchange + d.x_off[s];                   // slot layout: (f+1) x f column-major, ld = f+1
-        for (int c = 0; c < f; ++c) if (lane >= c && lane <= f) P.at(lane, c) = X[c * (f + 1) + lane];
-    } else {
-        for (int idx = lane; idx < tot; idx += 64) P.F[idx] = 0.0;
-        wave_lds_sync();
-        const int nuniq = fr.asm_cnt - fr.asm_dup;
-        for (int t = lane; t < nuniq; t += 64) apply_asm_packed<false>(d, d.asm_recs + 4 * (int64_t)(fr.asm_off + t), P);
-        wave_lds_sync();
-        if (fr.asm_dup > 0) { if (lane == 0) for (int t = nuniq; t < fr.asm_cnt; ++t) apply_asm_packed<true>(d, d.asm_recs + 4 * (int64_t)(fr.asm_off + t), P);
-            wave_lds_sync(); }
-    }
-    wave_lds_sync();
-    for (int ci = 0; ci < fr.child_cnt; ++ci) {
-        const int c = d.children[fr.child_off + ci];
-        const DevFront ch = d.fronts[c];
-        if (mode == FRONT_CONTRIB && ch.owner != d.rank) continue;
-        if (mode == FRONT_TOP && ch.owner >= 0) continue;
-        const int nb = ch.nbnd, ldu = nb + 1;
-        const double *U = d.Ubuf + ch.U_off;
-        const int32_t *map = d.child_map + ch.map_off;
-        // lane = row of the child's update matrix (nb + 1 <= 64 rows); column by column, coalesced
-        const int pr = (lane < nb) ? map[lane] : f;
-        for (int col0 = 0; col0 < nb; col0 += 8) {                   // batches of 8 columns: loads first, then LDS updates
-            double u[8]; int a[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const int col = col0 + j; const bool on = col < nb && lane >= col && lane <= nb;
-                u[j] = on ? U[col * ldu + lane] : 0.0;
-                a[j] = on ? P.col(lane_bcast_i(pr, col)) + (pr - lane_bcast_i(pr, col)) : -1; }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (a[j] >= 0) u[j] += P.F[a[j]];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (a[j] >= 0) P.F[a[j]] = u[j];
-        }
-        wave_lds_sync();
-    }
-    if (mode == FRONT_CONTRIB) {
-        double *X = d.exchange + d.x_off[s];
-        for (int c = 0; c < f; ++c) if (lane <= f) X[c * (f + 1) + lane] = (lane >= c) ? P.at(lane, c) : 0.0;
-        if (fi == 0 && lane == 0) contrib_publish_fail(d);
-        return;
-    }
-    // right-looking partial Cholesky, lane r = row r
-    double *L = d.Lbuf + fr.L_off; const int ldl = f + 1;
-    for (int k = 0; k < npiv; ++k) {
-        double piv = P.at(k, k);                                      // same address in every lane: LDS broadcast
-        if (!(piv > 0.0)) { if (lane == 0) atomicMax(d.fail, 1); piv = 1.0; }
-        const double dd = sqrt(piv), inv = 1.0 / dd;
-        double Lr = 0.0;
-        if (lane > k && lane <= f) Lr = P.at(lane, k) * inv;
-        if (lane == k) Lr = dd;
-        if (lane <= f) L[k * ldl + lane] = (lane >= k) ? Lr : 0.0;    // column k of the L panel, coalesced
-        // trailing update F[r][c] -= L[r] L[c] in register batches of 8 columns: 8 independent LDS reads in
-        // flight, then the FMAs, then 8 writes (a read-modify-write per column would serialise on LDS latency)
-        for (int c0 = k + 1; c0 < f; c0 += 8) {
-            double v[8]; int a[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const int c = c0 + j; a[j] = (c < f && lane >= c && lane <= f) ? P.col(c) + (lane - c) : -1;
-                v[j] = (a[j] >= 0) ? P.F[a[j]] : 0.0; }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const int c = min(c0 + j, f - 1); v[j] -= Lr * lane_bcast(Lr, c); }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (a[j] >= 0) P.F[a[j]] = v[j];
-        }
-        wave_lds_sync();
-    }
-    double *U = d.Ubuf + fr.U_off; const int ldu = nbnd + 1;
-    for (int c = 0; c < nbnd; ++c) if (lane <= nbnd) U[c * ldu + lane] = (lane >= c) ? P.at(npiv + lane, npiv + c) : 0.0;
-}
-
-// ---- MFMA variant: one wave per front (f <= 63), the dense pose/landmark Schur complement on the matrix cores.
-// The 64 x 64 front lives in registers as 10 lower 16 x 16 fp64 tiles (the MFMA accumulators).  Pivots go in
-// panels of 4 columns: the panel is spilled to a 64 x 4 LDS buffer, factorised with lane r = row r (pivot
-// broadcast by readlane), its columns stream out as the L panel (coalesced), and the trailing update of every
-// remaining tile is ONE v_mfma_f64_16x16x4_f64:  T(I,J) -= L_I (16x4) * L_J^T (4x16).  The rhs is row f of the
-// front, so the forward solve rides along.  Update matrices are written as tile images (512-byte stores).
 typedef double v4d __attribute__((ext_vector_type(4)));
-
-// a child's Schur complement is stored as tile images: element (row, col) of the CHILD front, cp <= col <= row <= cf
-__device__ __forceinline__ void mf_child_load(const double *U, bool use, int cp, int cf, int lane, double (&u)[10][4]) {
-    const int lc = lane & 15, lr = lane >> 4;
-#pragma unroll
-    for (int I = 0; I < 4; ++I)
-#pragma unroll
-        for (int J = 0; J <= I; ++J) { const int t = mf_tile(I, J);
-            const bool tile_on = use && !(16 * I + 15 < cp || 16 * J + 15 < cp);          // uniform
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const int row = 16 * I + lr + 4 * q, col = 16 * J + lc;
-                const bool on = tile_on && col >= cp && row >= col && row <= cf && col < cf;
-                u[t][q] = on ? U[(t * 4 + q) * 64 + lane] : 0.0; } }
-}
-__device__ __forceinline__ void mf_child_addr(const int32_t *map, bool use, int cp, int cf, int lane, int (&a)[10][4]) {
-    const int lc = lane & 15, lr = lane >> 4;
-#pragma unroll
-    for (int I = 0; I < 4; ++I)
-#pragma unroll
-        for (int J = 0; J <= I; ++J) { const int t = mf_tile(I, J);
-            const bool tile_on = use && !(16 * I + 15 < cp || 16 * J + 15 < cp);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const int row = 16 * I + lr + 4 * q, col = 16 * J + lc;
-                const bool on = tile_on && col >= cp && row >= col && row <= cf && col < cf;
-                if (on) { const int pr = map[row - cp], pc = map[col - cp];          // entry nb of the map = the parent's rhs row
-                    a[t][q] = mf_tile(pr >> 4, pc >> 4) * 256 + (pr & 15) * 16 + (pc & 15); } else a[t][q] = -1; } }
-}
-__device__ __forceinline__ void mf_child_apply(double *F, double (&u)[10][4], const int (&a)[10][4]) {
-#pragma unroll
-    for (int t = 0; t < 10; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) if (a[t][q] >= 0) u[t][q] += F[a[t][q]];
-#pragma unroll
-    for (int t = 0; t < 10; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) if (a[t][q] >= 0) F[a[t][q]] = u[t][q];
-}
-
-template <int B>      // panel B: pivots 4B .. 4B+3, which live in tile column J0 = B / 4
-__device__ __forceinline__ bool mf_panel_step(const DevGraph &d, v4d (&acc)[10], double *Pn, double *L, int npiv, int f, int lane) {
-    constexpr int k0 = 4 * B, J0 = B / 4, jc = (B % 4) * 4;
-    if (k0 >= npiv) return false;                                   // uniform
-    const int lc = lane & 15, lr = lane >> 4;
-    // 1. spill the panel's four columns (rows of tiles J0..3) to LDS, row-major 64 x 4
-    if (lc >= jc && lc < jc + 4) {
-#pragma unroll
-        for (int I = J0; I < 4; ++I)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Pn[(16 * I + lr + 4 * q) * 4 + (lc - jc)] = acc[mf_tile(I, J0)][q];
-    }
-    wave_lds_sync();
-    // 2. factorise the panel, lane r = row r
-    double p[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) p[j] = Pn[lane * 4 + j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = k0 + j;
-        if (col < npiv) {                                           // uniform
-            double piv = lane_bcast(p[j], col);
-            if (!(piv > 0.0)) { if (lane == 0) atomicMax(d.fail, 1); piv = 1.0; }
-            const double s = sqrt(piv), inv = 1.0 / s;
-            p[j] = (lane > col) ? p[j] * inv : (lane == col ? s : 0.0);
-#pragma unroll
-            for (int j2 = j + 1; j2 < 4; ++j2) { const double l2 = lane_bcast(p[j], k0 + j2); p[j2] -= p[j] * l2; }
-            if (lane <= f) L[(int64_t)col * (f + 1) + lane] = p[j];   // column `col` of the L panel (rows < col are 0)
-        } else p[j] = 0.0;                                          // not a pivot: contributes nothing to the update
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) Pn[lane * 4 + j] = p[j];
-    wave_lds_sync();
-    // 3. trailing update on the matrix cores
-    double a[4];
-#pragma unroll
-    for (int I = J0; I < 4; ++I) a[I] = Pn[(16 * I + lc) * 4 + lr];  // A[i = lane & 15][k = lane >> 4] = L[16 I + i][k]
-#pragma unroll
-    for (int I = J0; I < 4; ++I)
-#pragma unroll
-        for (int J = J0; J <= I; ++J)
-            acc[mf_tile(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[I], a[J], acc[mf_tile(I, J)], 0, 0, 0);
-    wave_lds_sync();
-    return true;
-}
-
-__global__ void __launch_bounds__(256, 2) k_factor_mfma(DevGraph d, int level_off, int count, int mode) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int fi = blockIdx.x * 4 + wave;
-    if (fi >= count) return;                                        // whole wave leaves; no block barrier below
-    const int s = d.level_fronts[level_off + fi];
-    const DevFront fr = d.fronts[s];
-    const int npiv = fr.npiv, nbnd = fr.nbnd, f = npiv + nbnd;
-    int32_t (*s_map)[64] = reinterpret_cast<int32_t (*)[64]>(smem + 4 * MF_IMG);   // one row map per wave, after the four tile images
-    StageFront P{smem + (int64_t)wave * MF_IMG, f};
-    const int lc = lane & 15, lr = lane >> 4;
-    // ---- assemble into the LDS tile image
-    for (int idx = lane; idx < MF_IMG; idx += 64) P.F[idx] = 0.0;
-    wave_lds_sync();
-    if (mode == FRONT_TOP) {
-        const double *X = d.exchange + d.x_off[s];                   // slot layout: (f+1) x f column-major, ld = f+1
-        for (int c = 0; c < f; ++c) if (lane >= c && lane <= f) P.at(lane, c) = X[c * (f + 1) + lane];
-    } else {
-        const int nuniq = (d.dbg & 4) ? 0 : fr.asm_cnt - fr.asm_dup;
-        for (int t = lane; t < nuniq; t += 64) apply_asm_packed<false>(d, d.asm_recs + 4 * (int64_t)(fr.asm_off + t), P);
-        wave_lds_sync();
-        if (fr.asm_dup > 0) { if (lane == 0) for (int t = nuniq; t < fr.asm_cnt; ++t) apply_asm_packed<true>(d, d.asm_recs + 4 * (int64_t)(fr.asm_off + t), P);
-            wave_lds_sync(); }
-    }
-    wave_lds_sync();
-    // ---- children: one descriptor record per (parent, child) — no fronts[c] lookup —, the row map staged into LDS
-    // with one coalesced load, all tile loads of the child issued before the LDS updates; children are added in list
-    // order (fixed summation order)
-    const int nchild = (d.dbg & 2) ? 0 : fr.child_cnt;
-    for (int ci = 0; ci < nchild; ++ci) {
-        const int4 dc = reinterpret_cast<const int4 *>(d.child_desc)[fr.child_off + ci];    // {front, npiv | nbnd << 16, owner, map offset}
-        if (mode == FRONT_CONTRIB && dc.z != d.rank) continue;
-        if (mode == FRONT_TOP && dc.z >= 0) continue;
-        const int cp = dc.y & 0xffff, nb = dc.y >> 16;
-        s_map[wave][lane] = (lane < nb) ? d.child_map[dc.w + lane] : f;
-        double u[10][4]; int a[10][4];
-        mf_child_load(d.Uimg + (int64_t)dc.x * MF_IMG, true, cp, cp + nb, lane, u);
-        wave_lds_sync();
-        mf_child_addr(s_map[wave], true, cp, cp + nb, lane, a);
-        mf_child_apply(P.F, u, a);
-        wave_lds_sync();
-    }
-    if (mode == FRONT_CONTRIB) {
-        double *X = d.exchange + d.x_off[s];
-        for (int c = 0; c < f; ++c) if (lane <= f) X[c * (f + 1) + lane] = (lane >= c) ? P.at(lane, c) : 0.0;
-        if (fi == 0 && lane == 0) contrib_publish_fail(d);
-        return;
-    }
-    // ---- tiles -> accumulators
-    v4d acc[10];
-#pragma unroll
-    for (int t = 0; t < 10; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[t][q] = P.F[t * 256 + (lr + 4 * q) * 16 + lc];
-    wave_lds_sync();
-    // ---- panels of 4 pivots; the LDS image is free now, its first 256 doubles serve as the panel buffer
-    double *Pn = P.F;
-    double *L = d.Lbuf + fr.L_off;
-    bool go = !(d.dbg & 1);
-    go = go && mf_panel_step<0>(d, acc, Pn, L, npiv, f, lane);   go = go && mf_panel_step<1>(d, acc, Pn, L, npiv, f, lane);
-    go = go && mf_panel_step<2>(d, acc, Pn, L, npiv, f, lane);   go = go && mf_panel_step<3>(d, acc, Pn, L, npiv, f, lane);
-    go = go && mf_panel_step<4>(d, acc, Pn, L, npiv, f, lane);   go = go && mf_panel_step<5>(d, acc, Pn, L, npiv, f, lane);
-    go = go && mf_panel_step<6>(d, acc, Pn, L, npiv, f, lane);   go = go && mf_panel_step<7>(d, acc, Pn, L, npiv, f, lane);
-    go = go && mf_panel_step<8>(d, acc, Pn, L, npiv, f, lane);   go = go && mf_panel_step<9>(d, acc, Pn, L, npiv, f, lane);
-    go = go && mf_panel_step<10>(d, acc, Pn, L, npiv, f, lane);  go = go && mf_panel_step<11>(d, acc, Pn, L, npiv, f, lane);
-    go = go && mf_panel_step<12>(d, acc, Pn, L, npiv, f, lane);  go = go && mf_panel_step<13>(d, acc, Pn, L, npiv, f, lane);
-    go = go && mf_panel_step<14>(d, acc, Pn, L, npiv, f, lane);  go = go && mf_panel_step<15>(d, acc, Pn, L, npiv, f, lane);
-    // ---- Schur complement out as tile images (only tiles that hold entries with col >= npiv)
-    double *U = d.Uimg + (int64_t)s * MF_IMG;
-#pragma unroll
-    for (int I = 0; I < 4; ++I)
-#pragma unroll
-        for (int J = 0; J <= I; ++J) {
-            if (16 * I + 15 < npiv || 16 * J + 15 < npiv) continue;   // uniform
-#pragma unroll
-            for (int q = 0; q < 4; ++q) U[(mf_tile(I, J) * 4 + q) * 64 + lane] = acc[mf_tile(I, J)][q];
-        }
-}
 
 // F3_NT: bit 0 = the L panels (written once by the factor kernel, read once by the backward solve) move with
 // non-temporal stores / loads, so that 2 x 141 MB per iteration do not sweep the caches the update matrices and the
@@ -1281,7 +948,10 @@ __global__ void __launch_bounds__(256, 2) k_factor_mfma(DevGraph d, int level_of
 #ifndef F3_NT
 #define F3_NT 1
 #endif
-#if F3_NT & 1
+#if F3_NT & 8      // bit 3 (experiment): the L panels written THROUGH the XCD's L2 (sc1) — nothing of them stays dirty until the end-of-kernel write-back
+#define F3_ST_L(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define F3_LD_L(ptr) __builtin_nontemporal_load(ptr)
+#elif F3_NT & 1
 #define F3_ST_L(ptr, v) __builtin_nontemporal_store((v), (ptr))
 #define F3_LD_L(ptr) __builtin_nontemporal_load(ptr)
 #else
@@ -2108,7 +1778,10 @@ __device__ __forceinline__ void f3_wave_front(const DevGraph &d, int pos, int mo
                     if (16 * J + 15 < npiv) continue;                // uniform
                     int off = ro + co[J];
                     if (I == J) off = (lr + 4 * q < lc) ? -1 : off;
-                    if (TREE && !LEAF) st_off_wt(U, min((uint32_t)off, dump), (double)acc[mf_tile(I, J)][q]);      // consumed inside this launch: write through
+#ifndef F3_LEAF_UWT
+#define F3_LEAF_UWT 0
+#endif
+                    if ((TREE && !LEAF) || F3_LEAF_UWT) st_off_wt(U, min((uint32_t)off, dump), (double)acc[mf_tile(I, J)][q]);      // consumed inside this launch: write through
                     else st_off(U, min((uint32_t)off, dump), (double)acc[mf_tile(I, J)][q]);                        // consumed by a later launch
                 }
             }
@@ -2749,7 +2422,7 @@ void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int leaf_m
     allow_max_lds((const void *)k_factor3<true, false>); allow_max_lds((const void *)k_factor3<true, true>); allow_max_lds((const void *)k_factor3<true, true, 3>);
     // level 0 (no children) through the high-occupancy leaf instance (three tile rows when every leaf has <= 47 scalars),
     // everything above in one launch whose fronts wait on flags
-    static int nt3 = -1; if (nt3 < 0) { nt3 = 1; if (const char *e = getenv("GS_LEAF_NT3")) nt3 = atoi(e) != 0; }
+    const int nt3 = d.leaf_nt3;                                      // gs_debug_options.leaf_nt3
     if (n_leaf > 0 && leaf_max_f <= 47 && nt3) hipLaunchKernelGGL((k_factor3<true, true, 3>), dim3((n_leaf + 3) / 4), dim3(256), (size_t)leaf_slot * 4 * sizeof(double), st, d, 0, n_leaf, FRONT_OWN, leaf_slot, 0);
     else if (n_leaf > 0) hipLaunchKernelGGL((k_factor3<true, true>), dim3((n_leaf + 3) / 4), dim3(256), (size_t)leaf_slot * 4 * sizeof(double), st, d, 0, n_leaf, FRONT_OWN, leaf_slot, 0);
     // the last n_block level positions (whole upper levels) get a workgroup each, the others a wave each
@@ -2775,20 +2448,8 @@ void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f,
     if (count <= 0) return;
     if (max_f <= 63 && d.factor_variant == 3) {
         allow_max_lds((const void *)k_factor3<false, false>);
-        static size_t lds3 = 0;                                      // GS_F3_LDS_KB: occupancy experiments (more LDS per block = fewer resident blocks)
-        if (lds3 == 0) { lds3 = (size_t)MF_IMG * 4 * sizeof(double); if (const char *e = getenv("GS_F3_LDS_KB")) lds3 = std::max(lds3, (size_t)atoi(e) * 1024); }
+        const size_t lds3 = std::max((size_t)MF_IMG * 4 * sizeof(double), (size_t)d.f3_lds_kb * 1024);   // gs_debug_options.f3_lds_kb: occupancy experiments (more LDS per block = fewer resident blocks)
         hipLaunchKernelGGL((k_factor3<false, false>), dim3((count + 3) / 4), dim3(256), lds3, st, d, level_off, count, mode, 0, count);
-        return;
-    }
-    if (max_f <= 63 && d.factor_variant == 2) {
-        allow_max_lds((const void *)k_factor_mfma);
-        hipLaunchKernelGGL(k_factor_mfma, dim3((count + 3) / 4), dim3(256), (size_t)MF_IMG * 4 * sizeof(double) + 8 * 64 * sizeof(int32_t), st, d, level_off, count, mode);
-        return;
-    }
-    if (max_f <= 63 && d.factor_variant == 1) {   // VALU wave-per-front variant: measured SLOWER than the block kernel, kept for A/B only
-        const int slot = ((max_f * (max_f + 1)) / 2 + max_f + 1) & ~1;                // doubles per wave, 16-B aligned
-        allow_max_lds((const void *)k_factor_wave);
-        hipLaunchKernelGGL(k_factor_wave, dim3((count + 3) / 4), dim3(256), (size_t)slot * 4 * sizeof(double), st, d, level_off, count, mode, slot);
         return;
     }
     int64_t bytes = (int64_t)((max_f + 1) | 1) * max_f * 8;

@@ -248,7 +248,7 @@ struct Builder {
 
 bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::string &err) {
     auto t0 = std::chrono::steady_clock::now();
-    const bool pt_on = std::getenv("GS_PLAN_TIMING") != nullptr; auto pt_prev = t0;      // GS_PLAN_TIMING: phase times on stderr
+    const bool pt_on = opt_in.timing; auto pt_prev = t0;              // gs_debug_options.plan_timing: phase times on stderr
 #define GS_PT(i) do { if (pt_on) { auto n_ = std::chrono::steady_clock::now(); std::fprintf(stderr, "plan phase %d: %.2f ms\n", (i), std::chrono::duration<double, std::milli>(n_ - pt_prev).count()); pt_prev = n_; } } while (0)
     plan = Plan();
     PlanOptions opt = opt_in;

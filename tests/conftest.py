@@ -6,15 +6,6 @@ import numpy as np
 import pytest
 
 
-@pytest.fixture(autouse=True, scope="session")
-def _grow_plans_of_every_size():
-    """the tests grow plans of every size (the product's default leaves graphs below 128 poses to the full phase: GS_GROW_MIN_POSES)"""
-    had = os.environ.get("GS_GROW_MIN_POSES")
-    os.environ.setdefault("GS_GROW_MIN_POSES", "0")
-    yield
-    if had is None:
-        os.environ.pop("GS_GROW_MIN_POSES", None)
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
@@ -29,10 +20,13 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def pkg():
-    """The product package; builds the native libraries if they are missing."""
+    """The product package; builds the native libraries if they are missing.
+    The tests grow plans of every size: every handle they create gets gs_debug_options.grow_min_poses = 0 through the API (the
+    product's default leaves graphs below 128 poses to the full phase; test_the_shipped_growth_gate_... runs that default)."""
     m = importlib.import_module(PKG_NAME)
     if not os.path.exists(m.binding.LIB_PATH) or not os.path.exists(m.track.LIB):
         m.build()
+    m.binding.DEFAULT_DEBUG["grow_min_poses"] = 0
     return m
 
 

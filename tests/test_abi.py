@@ -125,7 +125,45 @@ def test_arena_beyond_32_bit_byte_offsets_leaves_the_matrix_core_fronts(pkg):
     assert sel(0, 57, (1 << 29) - 1) == 3
     assert sel(0, 57, 1 << 29) == 4                         # the guard fires at 2^29 doubles, not at 2^31
     assert sel(3, 57, (1 << 30)) == 4
-    assert sel(2, 57, (1 << 30)) == 2                       # 64-bit addressing in the other kernels
-    assert sel(1, 64, 1000) == 4 and sel(4, 30, 1000) == 4 and sel(7, 30, 1000) == 3
+    assert sel(4, 57, (1 << 30)) == 4                       # 64-bit addressing in the block-per-front kernel
+    assert sel(4, 30, 1000) == 4 and sel(7, 30, 1000) == 3
+    assert sel(1, 30, 1000) == 3 and sel(2, 30, 1000) == 3  # the first-generation kernels (variants 1, 2) are gone: such a request runs the default
     # fronts beyond a wave: variant 3 gives them a workgroup up to 159 scalars (ten tile rows), chosen per front; beyond that variant 4
-    assert sel(0, 64, 1000) == 3 and sel(0, 153, 1000) == 3 and sel(0, 159, 1000) == 3 and sel(0, 160, 1000) == 4 and sel(2, 100, 1000) == 4
+    assert sel(0, 64, 1000) == 3 and sel(0, 153, 1000) == 3 and sel(0, 159, 1000) == 3 and sel(0, 160, 1000) == 4 and sel(2, 100, 1000) == 3
+
+
+def test_tuning_switches_live_in_one_struct_outside_the_public_header(pkg, monkeypatch):
+    """include/graphslam.h is the drop-in boundary: no gs_debug_* entry point, no environment variable.  The tuning switches are
+    ONE struct (include/graphslam_debug.h), filled once from the environment at gs_create and replaced through the API."""
+    import re
+    pub = re.sub(r"/\*.*?\*/", "", open(pkg.binding.HEADER).read(), flags=re.S)
+    assert "gs_debug" not in pub and "getenv" not in pub
+    dbg = set(pkg.binding.declared_symbols()) - set(pkg.binding.declared_symbols(debug=False))
+    assert {"gs_debug_options_default", "gs_debug_get_options", "gs_debug_set_options", "gs_debug_fail_at_iteration",
+            "gs_debug_select_factor_variant", "gs_debug_timestamps", "gs_debug_front_times"} <= dbg
+    d = pkg.binding.DebugOptions(); assert pkg.binding.lib().gs_debug_options_default(d) == 0
+    assert d.struct_size == C.sizeof(pkg.binding.DebugOptions)
+    assert (d.tree, d.block_fronts, d.leaf_min, d.grow, d.grow_min_poses, d.assoc_grid, d.force_shared_top) == (1, 512, 2048, 1, 128, -1, 0)
+    monkeypatch.setenv("GS_TREE", "0"); monkeypatch.setenv("GS_GROW_MIN_POSES", "7")
+    G = pkg.Graph(device=-2, debug={})                         # the environment is read ONCE, at gs_create ...
+    o = G.debug_options(); assert o.tree == 0 and o.grow_min_poses == (0 if pkg.binding.DEFAULT_DEBUG.get("grow_min_poses") == 0 else 7)
+    monkeypatch.setenv("GS_TREE", "1")
+    assert G.debug_options().tree == 0                         # ... and never again
+    G.set_debug(tree=1, cluster_ways=2); o = G.debug_options()
+    assert o.tree == 1 and o.cluster_ways == 2 and o.block_fronts == 512
+    with pytest.raises(AttributeError):
+        G.set_debug(no_such_switch=1)
+    G.close()
+    # the only getenv calls left in the product: the one function that fills the struct, and GS_THREADS
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "opendlv-logic-cfsd18-sensation-slam_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".cpp", ".hpp", ".hip", ".c")):
+            txt = open(os.path.join(csrc, f)).read()
+            if f == "gs_api.cpp":
+                body = txt[txt.index("static void options_from_environment"):]; body = body[:body.index("\n}\n")]
+                assert txt.count("getenv") == body.count("getenv"), "a getenv outside options_from_environment in gs_api.cpp"
+            elif f == "gs_parallel.hpp":
+                assert txt.count("getenv") == 1 and "GS_THREADS" in txt
+            else:
+                assert "getenv" not in txt, f

@@ -94,7 +94,7 @@ def test_association_first_match_wins_over_nearest(G, frontend):
 
 
 @pytest.mark.parametrize("N,M", [(1000, 200), (10000, 2000)])
-def test_association_grid_equals_brute_force_equals_oracle(G, frontend, bench_graphs, monkeypatch, N, M):
+def test_association_grid_equals_brute_force_equals_oracle(G, frontend, bench_graphs, N, M):
     """A1 at scale goes through a uniform grid over the map (k_associate_grid, O(n)); small maps through the LDS-tiled
     brute-force scan (k_associate, O(n * n_map)).  Same pair test => the same indices, bit for bit, and both equal the
     oracle's insertion-order scan (reference src/slam.cpp:570-607).  Decoys: wrong-colour cones on top of real ones,
@@ -110,9 +110,9 @@ def test_association_grid_equals_brute_force_equals_oracle(G, frontend, bench_gr
     obs[11, 2] = 5e3                                       # a cone "seen" 5 km away: outside the grid
     outs = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("GS_ASSOC_GRID", mode)
+        G.set_debug(assoc_grid=int(mode))
         outs[mode] = G.associate(t["truth_poses"], po_, obs, map_xy, map_type, 1.2)
-    monkeypatch.delenv("GS_ASSOC_GRID")
+    G.set_debug(assoc_grid=-1)
     auto = G.associate(t["truth_poses"], po_, obs, map_xy, map_type, 1.2)
     ref = frontend.associate(t["truth_poses"], po_, obs, map_xy, map_type, 1.2)
     assert np.array_equal(outs["0"], ref) and np.array_equal(outs["1"], ref) and np.array_equal(auto, ref)
@@ -411,11 +411,11 @@ def test_leaf_size_does_not_change_the_answer(pkg, bench_graphs):
 
 
 # ---------------------------------------------------------------- A8: every front-factorisation kernel variant
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [3, 4])
 def test_factor_kernel_variants_match_oracle(pkg, po, bench_graphs, variant):
-    """4 = block-per-front VALU (any front size), 1 = wave-per-front VALU, 2 = wave-per-front Cholesky on the fp64 matrix
-    cores (v_mfma_f64_16x16x4_f64, update matrices as 16x16 tile images), 3 = the default: latency-shaped matrix-core
-    kernels (LDL^T panels, update matrices moved in storage order, flat descriptors).  Same plan, same answer."""
+    """4 = block-per-front VALU Cholesky (any front size: the fallback for fronts beyond 159 scalars), 3 = the default:
+    latency-shaped matrix-core kernels (LDL^T panels on v_mfma_f64_16x16x4_f64, update matrices moved in storage order, flat
+    descriptors).  Same plan, same answer.  (Variants 1 and 2 of rounds 1-3 are gone: a request for them runs 3.)"""
     for N, M in ((1000, 200), (10000, 2000)):
         _, g = bench_graphs(N, M)
         og = make_oracle_graph(po, g); og.optimize(4, ordering=1)
@@ -431,21 +431,20 @@ def test_factor_kernel_variants_match_oracle(pkg, po, bench_graphs, variant):
     G.close()
 
 
-@pytest.mark.parametrize("env", [{"GS_TREE": "0"}, {"GS_LEAF_KERNEL": "0"}, {"GS_TREE": "0", "GS_FACTOR_VARIANT": "3"},
-                                 {"GS_BLOCK_FRONTS": "0"}, {"GS_BLOCK_FRONTS": "16"}, {"GS_LEAF_KERNEL": "2"},
-                                 {"GS_LEAF_KERNEL": "2", "GS_BLOCK_FRONTS": "0"}])
-def test_solver_launch_modes_give_the_same_answer(pkg, po, bench_graphs, monkeypatch, env):
+@pytest.mark.parametrize("env", [dict(tree=0), dict(leaf_kernel=0), dict(tree=0, factor_variant=3),
+                                 dict(block_fronts=0), dict(block_fronts=16), dict(leaf_kernel=2),
+                                 dict(leaf_kernel=2, block_fronts=0), dict(small_tree=0), dict(small_tree=1 << 20)])
+def test_solver_launch_modes_give_the_same_answer(pkg, po, bench_graphs, env):
     """The default solver runs one flagged launch for all levels above the leaves plus leaf-instance launches; the
-    same kernels also run one launch per level (GS_TREE=0, what the shared top of a sharded graph uses) and without
-    the leaf instances (GS_LEAF_KERNEL=0; the default below 2 049 leaves, 2 forces them).  The upper levels of the whole-tree launch give a front four waves instead of
-    one (levels of at most GS_BLOCK_FRONTS fronts; at this size the default puts every level above the leaves there, 0
-    none, 16 the top five).  Every mode must agree with the oracle and, bit for bit, with the default."""
+    same kernels also run one launch per level (gs_debug_options.tree = 0, what the shared top of a sharded graph uses) and without
+    the leaf instances (leaf_kernel = 0; the default below 2 049 leaves, 2 forces them).  The upper levels of the whole-tree launch give a front four waves instead of
+    one (levels of at most block_fronts fronts; at this size the default puts every level above the leaves there, 0
+    none, 16 the top five).  small_tree: the whole optimize() call as one persistent launch (off / forced at this size).
+    Every mode must agree with the oracle and, bit for bit, with the default."""
     _, g = bench_graphs(10000, 2000)
     og = make_oracle_graph(po, g); og.optimize(4, ordering=1)
     A = fresh(pkg, g); A.optimize(4)
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    B = fresh(pkg, g); done, st = B.optimize(4)
+    B = fresh(pkg, g, debug=env); done, st = B.optimize(4)
     assert done == 4 and st.numeric_failure == 0
     assert rel(B.poses(), og.poses()) < 1e-9 and rel(B.landmarks(), og.landmarks()) < 1e-9
     assert np.array_equal(A.poses(), B.poses()) and np.array_equal(A.landmarks(), B.landmarks())     # same arithmetic, same order
@@ -473,7 +472,7 @@ def test_irregular_graphs_one_step_matches_oracle(pkg, po, shape):
 @pytest.mark.parametrize("seed,shape", [(506, dict(n_poses=120, n_lms=18, obs_per_pose=3, extra_pp=6, dup_edges=1)),
                                         (500, dict(n_poses=120, n_lms=18, obs_per_pose=2, extra_pp=6, dup_edges=1)),
                                         (500, dict(n_poses=60, n_lms=18, obs_per_pose=3, extra_pp=6, dup_edges=1))])
-def test_fat_update_matrices_on_the_matrix_core_kernels(pkg, po, monkeypatch, seed, shape):
+def test_fat_update_matrices_on_the_matrix_core_kernels(pkg, po, seed, shape):
     """Fronts of at most 63 scalars whose children hand up update matrices of 46-52 boundary rows (1100-1430 doubles) and
     that have up to 7 children: beyond the 896 / 1024 elements a lane / thread of the wave-per-front / four-wave kernels
     keeps in registers, so the tail loops of the by-source scatter and of the Schur complement store run.  One Gauss-Newton
@@ -482,15 +481,11 @@ def test_fat_update_matrices_on_the_matrix_core_kernels(pkg, po, monkeypatch, se
     og = make_oracle_graph(po, g); og.build_system(); og.apply_update(og.solve_ldlt(0)); dp_o, dl_o = og.delta()
     scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
     outs = []
-    for env in ({}, {"GS_BLOCK_FRONTS": "0"}, {"GS_TREE": "0"}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        G = fresh(pkg, g); done, st = G.optimize(1); dp, dl = G.export_delta()
+    for env in ({}, dict(block_fronts=0), dict(tree=0), dict(small_tree=0)):
+        G = fresh(pkg, g, debug=env); done, st = G.optimize(1); dp, dl = G.export_delta()
         assert st.max_front <= 63 and done == 1 and st.numeric_failure == 0, (env, st.max_front)
         assert np.abs(dp - dp_o).max() / scale < 1e-9 and np.abs(dl - dl_o).max() / scale < 1e-9, env
         outs.append((dp.copy(), dl.copy())); G.close()
-        for k in env:
-            monkeypatch.delenv(k)
     for dp, dl in outs[1:]:
         assert np.array_equal(dp, outs[0][0]) and np.array_equal(dl, outs[0][1])
 
@@ -689,36 +684,100 @@ def test_normal_equation_residual_helper_agrees_with_the_oracle(pkg, po, bench_g
 
 
 def test_cfg5_single_handle_properties_and_eight_pose_windows(pkg, po, frontend):
-    """BASELINE config 5, "1M poses / 50k cones sharded by pose window across 8 GPUs".
-    (a) ONE handle against the CPU paths after the reference's 10 iterations (src/slam.cpp:481): the oracle with its own LDL^T
-    and the oracle with the reference's vendored Eigen SimplicialLDLT + AMD (oracle/_ref) run the same 10 iterations (~25 s
-    each); all pairwise pose RMSEs are printed and written to gpurun_out/cfg5_parity.json.  A 250 km lap is ill-conditioned
-    enough that two CPU paths that differ in elimination order only do not agree to 1e-6 themselves, so the bound for
-    GPU-vs-oracle is: <= 1e-6 (the north_star bar) OR <= K_SPREAD x the CPU-vs-CPU spread, K_SPREAD stated below.
-    Size-independent properties beside it: the increment of an iteration solves the exported normal equations (residual
-    1e-9 of |b|), chi2 decreases to a fixed point, the gauge stays put.
-    (b) The same graph split over 8 rank handles that share this one GPU — the exchange buffers summed in-process exactly
-    where the 8-GPU run all-reduces them over RCCL: the merged increment of the first iteration solves THE SAME normal
-    equations to 1e-9, and after 10 iterations the merged estimates are as close to the single handle's as the CPU paths
-    are to each other (same K_SPREAD) and have the single handle's chi2."""
+    """BASELINE config 5, "1M poses / 50k cones sharded by pose window across 8 GPUs" — statements that can fail.
+
+    A 250 km lap of relative measurements has cond(H) ~ 1e15: the FORWARD error of the reference's 10 undamped iterations
+    (src/slam.cpp:481) is undetermined there — two CPU solves of the same system end 10-75 track radii apart (diagnostic (d)
+    below prints every pair, it asserts nothing).  What IS determined, and is asserted against the ORACLE's arithmetic:
+    (a) the linearised system: the GPU's H blocks equal the oracle's (orc_linearize_blocks: g2o's linearizeOplus +
+        constructQuadraticForm restated) to the 1e-11 the smaller configurations use, b to max(1e-11 max|b|, 8 eps R w) — at the
+        initial point and at the GPU's own iterate after 9 iterations (the oracle is handed the GPU's estimates);
+    (b) the solve, as a BACKWARD error in the oracle's system: max|H_o dx_gpu - b_o| <= 1e-9 max|b_o| + the rounding floor of b (8 eps R w:
+        what b is determined to at coordinates of size R, see (a)) for the increment of the single handle at both iterates (iterations
+        1 and 10; at iteration 10 the gradient has vanished, max|b| ~ 1e-6, and the floor is the bar);
+    (c) the same two statements for the graph split over 8 rank handles that share this one GPU — the exchange buffers summed
+        in-process exactly where the 8-GPU run all-reduces them over RCCL: merged increment of iteration 1 against the oracle's
+        system at the initial point, merged increment of iteration 10 against the oracle's system at the windows' own merged
+        iterate after 9 iterations, whose blocks (a rank linearises its own edges only) are not exported, so the system there is
+        the oracle's alone;
+    plus size-independent properties: chi2 decreases to a fixed point, the gauge stays put, a rank holds ~1/8 of the plan.
+    Record: gpurun_out/cfg5_parity.json (committed as profiles/r04_cfg5_parity_test_record.json)."""
     import json
-    K_SPREAD = 10.0
+    BLOCKS = ("Hpp_diag", "Hll_diag", "Hpp_off", "Hpl", "b_pose", "b_lm")
     N, M = pkg.track.CONFIGS["cfg5"]
     t = pkg.track.generate(N, M)
     g = pkg.track.bench_graph(t, frontend)
     Mg = len(g["lm_est"])
+    og = make_oracle_graph(po, g)
+    rec = dict(config="cfg5: 1M poses / 50k cones", iterations=10, blocks_vs_oracle={}, backward_error_in_oracle_system={})
+
+    EPS = np.finfo(np.float64).eps
+    W_MAX = float(max(np.abs(g["pp_info"]).max(), np.abs(g["pl_info"]).max()))
+    B_ULPS = 8.0
+    failures = []                                                # every statement is evaluated and recorded; the asserts come at the end
+
+    def check(ok, what):
+        if not ok:
+            failures.append(what); print("cfg5 FAILED:", what)
+
+    def system_vs_oracle(G, tag):
+        """(a): H, b of the handle's linearisation against the oracle's at the estimates the oracle currently holds.
+        H blocks: max |diff| <= 1e-11 max |block array| (their entries are O(1) products of rotations, information and lever arms).
+        b: a residual is a difference of products c * x of coordinate size R (g2o's operation order), so two correct
+        evaluations — the device's cos / sin are not libm's to the last bit — differ by multiples of eps * R * w (w = largest
+        information entry) in b whatever the size of b itself: max |diff| <= max(1e-11 max|b|, B_ULPS * eps * R * w), R = the
+        largest pose / cone coordinate at this iterate.  B_ULPS = 8: measured 2.1-2.4 at cfg5 (initial point and after 9 iterations)."""
+        G.linearize(); got = G.export_system(); ref = og.linearize_blocks()
+        R = float(max(np.abs(og.poses()[:, :2]).max(), np.abs(og.landmarks()).max()))
+        d = {}
+        for k in BLOCKS:
+            mx = float(np.abs(ref[k]).max()); ad = float(np.abs(got[k] - ref[k]).max())
+            d[k] = dict(max_abs_diff=ad, max_abs=mx, rel=ad / max(mx, 1e-300), in_units_of_eps_R_w=ad / (EPS * R * W_MAX))
+            tol = 1e-11 * mx if k.startswith("H") else max(1e-11 * mx, B_ULPS * EPS * R * W_MAX)
+            check(ad <= tol, "%s: %s differs from the oracle's by %.3g (max %.3g, bound %.3g)" % (tag, k, ad, mx, tol))
+        rec["blocks_vs_oracle"][tag] = dict(blocks=d, largest_coordinate_R=R, largest_information_entry_w=W_MAX)
+        print("cfg5 %s (R = %.3g m): GPU vs oracle max|diff| / max|.|: %s; b in units of eps R w: b_pose %.2f, b_lm %.2f"
+              % (tag, R, ", ".join("%s %.2g" % (k, v["rel"]) for k, v in d.items()), d["b_pose"]["in_units_of_eps_R_w"], d["b_lm"]["in_units_of_eps_R_w"]))
+        c_g, c_o = G.chi2(), og.chi2()
+        check(abs(c_g - c_o) <= 1e-10 * c_o, "%s: chi2 %.17g vs the oracle's %.17g" % (tag, c_g, c_o))
+        return got, ref
+
+    def backward_error(tag, ref, dp, dl):
+        """(b): the GPU increment in the ORACLE's system.  Statement: max|H_o dx - b_o| <= 1e-9 max|b_o| + B_ULPS eps R w.  The second
+        term is the rounding floor of b itself established in (a): at a converged iterate (iteration 10: max|b| ~ 1e-6, the gradient
+        has vanished) b IS rounding noise of that size and no solver can be asked for a residual below what the right-hand side is
+        determined to; at the initial point (max|b| ~ 1) the first term is the bar."""
+        r = float(normal_equation_residual(g, ref, dp, dl))
+        bmax = float(max(np.abs(ref["b_pose"]).max(), np.abs(ref["b_lm"]).max()))
+        R = float(max(np.abs(og.poses()[:, :2]).max(), np.abs(og.landmarks()).max()))
+        floor = B_ULPS * EPS * R * W_MAX
+        rec["backward_error_in_oracle_system"][tag] = dict(max_abs_residual=r * bmax, max_b=bmax, residual_over_max_b=r, rounding_floor_of_b=floor,
+                                                          bound=1e-9 * bmax + floor, max_dx=float(max(np.abs(dp).max(), np.abs(dl).max())))
+        print("cfg5 %s: max|H_o dx_gpu - b_o| = %.3g (bound %.3g = 1e-9 x max|b_o| %.3g + rounding floor of b %.3g); max |dx| %.3g m"
+              % (tag, r * bmax, 1e-9 * bmax + floor, bmax, floor, max(np.abs(dp).max(), np.abs(dl).max())))
+        check(r * bmax <= 1e-9 * bmax + floor, "%s: backward error %.3g > %.3g" % (tag, r * bmax, 1e-9 * bmax + floor))
+        return r
+
+    # ---- single handle
     G = fresh(pkg, g)
-    G.linearize(); sysm = G.export_system()                      # H, b at the initial estimates
+    sys0, ref0 = system_vs_oracle(G, "initial point")
     done, st = G.optimize(1)
     assert done == 1 and st.numeric_failure == 0
     st_single = G.stats()
     dp, dl = G.export_delta()
-    r_single = normal_equation_residual(g, sysm, dp, dl)
-    assert r_single < 1e-9, r_single
-    done, st = G.optimize(9)                                     # the reference's 10 iterations in total
-    assert done == 9 and st.numeric_failure == 0 and st.chi2_final < st.chi2_initial
+    r_self = normal_equation_residual(g, sys0, dp, dl); del sys0
+    assert r_self < 1e-9, r_self                                 # ... and it solves the system the GPU itself exported
+    backward_error("single handle, iteration 1", ref0, dp, dl)
+    done, st = G.optimize(8)
+    assert done == 8 and st.numeric_failure == 0 and st.chi2_final < st.chi2_initial
+    P9, L9 = G.poses(), G.landmarks()
+    og.set_poses(P9); og.set_landmarks(L9)                       # the oracle at the GPU's iterate after 9 iterations
+    _, ref9 = system_vs_oracle(G, "GPU iterate after 9 iterations")
+    done, st = G.optimize(1)                                     # the reference's 10th iteration
+    assert done == 1 and st.numeric_failure == 0
+    dp10, dl10 = G.export_delta()
+    backward_error("single handle, iteration 10", ref9, dp10, dl10); del ref9
     P1, L1 = G.poses(), G.landmarks()
-    dp10 = np.abs(G.export_delta()[0]).max()
     c1 = G.chi2(); G.optimize(1); c2 = G.chi2()
     assert abs(c2 - c1) <= 1e-9 * c1                             # chi2 has reached its fixed point
     assert np.array_equal(G.poses()[:2], g["pose_est"][:2]) and np.array_equal(G.landmarks()[:2], g["lm_est"][:2])
@@ -726,31 +785,7 @@ def test_cfg5_single_handle_properties_and_eight_pose_windows(pkg, po, frontend)
     rms = np.sqrt((P1[:, :2] ** 2).sum(1).mean())
     def rmse(A, B): return float(np.sqrt(((A - B) ** 2).sum(1).mean()) / rms)
     def wrap(a): return (a + np.pi) % (2 * np.pi) - np.pi
-    # ---- (a) the CPU paths, 10 iterations each
-    est = {"gpu": (P1, L1)}
-    og = make_oracle_graph(po, g); d_o, _, _ = og.optimize(10, ordering=1); assert d_o == 10
-    est["oracle_ldlt_track_order"] = (og.poses(), og.landmarks()); del og
-    # the same CPU arithmetic in the GPU plan's nested-dissection order: what is left between it and the GPU is arithmetic, not ordering
-    from plan_exec import Plan
-    Hh = pkg.Graph(device=-2); Hh.load_bench_graph(g); Hh.plan_build_host(); PL = Plan(Hh.plan_export()); Hh.close()
-    og = make_oracle_graph(po, g); og.set_elimination_order_like(PL.pose_gidx, PL.lm_gidx); del PL
-    d_n, _, _ = og.optimize(10, ordering=2); assert d_n == 10
-    est["oracle_ldlt_gpu_plan_order"] = (og.poses(), og.landmarks()); del og
-    if po.ref_eigen() is not None:
-        og = make_oracle_graph(po, g); d_e, _, _ = og.optimize(10, ordering=1, solver=po.EigenSolver(0)); assert d_e == 10
-        est["eigen_simplicial_ldlt_amd"] = (og.poses(), og.landmarks()); del og
-    keys = list(est); pairs = {}
-    for i in range(len(keys)):
-        for j in range(i + 1, len(keys)):
-            A, B = est[keys[i]], est[keys[j]]
-            pairs[keys[i] + " vs " + keys[j]] = dict(pose_rmse_rel=rmse(A[0][:, :2], B[0][:, :2]), landmark_rmse_rel=rmse(A[1], B[1]),
-                                                      heading_max_abs=float(np.abs(wrap(A[0][:, 2] - B[0][:, 2])).max()))
-    for k, v in pairs.items():
-        print("cfg5 after 10 iterations: %-56s pose RMSE rel %.3g, landmark RMSE rel %.3g, heading max %.3g" % (k, v["pose_rmse_rel"], v["landmark_rmse_rel"], v["heading_max_abs"]))
-    gpu_worst = max(v["pose_rmse_rel"] for k, v in pairs.items() if k.startswith("gpu vs"))
-    cpu_spread = max([v["pose_rmse_rel"] for k, v in pairs.items() if not k.startswith("gpu vs")] or [0.0])
-    same_order = pairs["gpu vs oracle_ldlt_gpu_plan_order"]["pose_rmse_rel"]
-    # ---- (b) 8 pose windows on this one GPU
+    # ---- (c) 8 pose windows on this one GPU
     world = 8
     ranks = []
     for r in range(world):
@@ -764,6 +799,7 @@ def test_cfg5_single_handle_properties_and_eight_pose_windows(pkg, po, frontend)
     sr = ranks[world // 2].stats()
     print("cfg5 as 8 pose windows: rank structure %.0f ms (plan %.0f), %.0f MB of HBM, %d own + %d shared fronts; single handle: %.0f ms (plan %.0f), %.0f MB, %d fronts"
           % (sr.ms_structure, sr.ms_plan_host, sr.device_bytes / 1e6, sr.n_own_fronts, sr.n_shared_fronts, st_single.ms_structure, st_single.ms_plan_host, st_single.device_bytes / 1e6, st_single.n_fronts))
+    rec["rank_structure_ms"] = sr.ms_structure; rec["single_structure_ms"] = st_single.ms_structure
     def merged(fn, width_p, width_l):
         A = np.zeros((N, width_p)); B = np.zeros((Mg, width_l)); cp = np.zeros(N); cl = np.zeros(Mg); shared = np.ones(N, dtype=bool)
         for H in ranks:
@@ -773,43 +809,58 @@ def test_cfg5_single_handle_properties_and_eight_pose_windows(pkg, po, frontend)
         assert np.all(cp == 1) and np.all(cl == 1) and 0 < shared.sum() < 200      # every vertex has one primary rank; few are shared
         return A, B
     for it in range(10):
+        if it == 9:                                              # the oracle's system at the windows' own iterate after 9 iterations
+            for H in ranks:
+                H.sync_estimates()
+            Pw9, Lw9 = merged(lambda H: (H.poses(), H.landmarks()), 3, 2)
+            og.set_poses(Pw9); og.set_landmarks(Lw9); refw9 = og.linearize_blocks()
         for H in ranks:
             H.dist_iterate_local()
         total = sum(H.dist_read_exchange() for H in ranks)
         for H in ranks:
             H.dist_write_exchange(total); H.dist_iterate_finish()
-        if it == 0:
+        if it in (0, 9):
             for H in ranks:
                 H.synchronize()
             dps, dls = merged(lambda H: H.export_delta(), 3, 2)
-            r_shard = normal_equation_residual(g, sysm, dps, dls)
-            assert r_shard < 1e-9, r_shard
+            backward_error("8 pose windows merged, iteration %d" % (it + 1), ref0 if it == 0 else refw9, dps, dls)
+    del ref0, refw9
     for H in ranks:
         H.sync_estimates()
     P, L = merged(lambda H: (H.poses(), H.landmarks()), 3, 2)
     for H in ranks:
         H.close()
     e_sh = (rmse(P[:, :2], P1[:, :2]), rmse(L, L1), float(np.abs(wrap(P[:, 2] - P1[:, 2])).max()))
-    pairs["gpu 8 pose windows vs gpu"] = dict(pose_rmse_rel=e_sh[0], landmark_rmse_rel=e_sh[1], heading_max_abs=e_sh[2])
-    print("cfg5: normal-equation residual of the first increment: single handle %.3g, 8 pose windows %.3g; last increment of the single handle "
-          "%.3g m; 8 pose windows vs the single handle after 10 iterations: pose/landmark RMSE rel %.3g %.3g, heading max %.3g"
-          % ((r_single, r_shard, dp10) + e_sh))
-    rec = dict(config="cfg5: 1M poses / 50k cones", iterations=10, pairs=pairs, gpu_vs_cpu_worst_pose_rmse_rel=gpu_worst,
-               cpu_vs_cpu_spread_pose_rmse_rel=cpu_spread, gpu_vs_oracle_in_the_same_elimination_order_pose_rmse_rel=same_order, k_spread=K_SPREAD, normal_equation_residual_single=r_single, normal_equation_residual_8_windows=r_shard)
+    # chi2 of the merged estimates (evaluated by one fresh handle over ALL edges) equals the single handle's
+    def chi2_of(Pe, Le):
+        Hh = fresh(pkg, dict(g, pose_est=Pe, lm_est=Le)); c = Hh.chi2(); Hh.close(); return c
+    ca, cb = chi2_of(P, L), chi2_of(P1, L1)
+    assert abs(ca - cb) <= 1e-7 * cb
+    # ---- (d) DIAGNOSTIC, asserts nothing: the forward spread after 10 iterations, GPU and CPU paths pairwise
+    est = {"gpu": (P1, L1), "gpu 8 pose windows": (P, L)}
+    og.set_poses(g["pose_est"]); og.set_landmarks(g["lm_est"])
+    d_o, _, _ = og.optimize(10, ordering=1); assert d_o == 10
+    est["oracle_ldlt_track_order"] = (og.poses(), og.landmarks()); del og
+    if po.ref_eigen() is not None:
+        og = make_oracle_graph(po, g); d_e, _, _ = og.optimize(10, ordering=1, solver=po.EigenSolver(0)); assert d_e == 10
+        est["eigen_simplicial_ldlt_amd"] = (og.poses(), og.landmarks()); del og
+    keys = list(est); pairs = {}
+    for i in range(len(keys)):
+        for j in range(i + 1, len(keys)):
+            A, B = est[keys[i]], est[keys[j]]
+            pairs[keys[i] + " vs " + keys[j]] = dict(pose_rmse_rel=rmse(A[0][:, :2], B[0][:, :2]), landmark_rmse_rel=rmse(A[1], B[1]),
+                                                      heading_max_abs=float(np.abs(wrap(A[0][:, 2] - B[0][:, 2])).max()))
+    for k, v in pairs.items():
+        print("cfg5 after 10 iterations (diagnostic): %-56s pose RMSE rel %.3g, landmark RMSE rel %.3g, heading max %.3g" % (k, v["pose_rmse_rel"], v["landmark_rmse_rel"], v["heading_max_abs"]))
+    rec["forward_spread_after_10_iterations_diagnostic_only"] = pairs
+    rec["failed_statements"] = failures
     try:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
         json.dump(rec, open(os.path.join(root, "gpurun_out", "cfg5_parity.json"), "w"), indent=1)
     except OSError:
         pass
-    bound = max(1e-6, K_SPREAD * cpu_spread)
-    assert gpu_worst <= bound, (gpu_worst, cpu_spread)
-    assert e_sh[0] <= bound and e_sh[1] <= bound, (e_sh, cpu_spread)
-    # chi2 of the merged estimates (evaluated by one fresh handle over ALL edges) equals the single handle's
-    def chi2_of(Pe, Le):
-        Hh = fresh(pkg, dict(g, pose_est=Pe, lm_est=Le)); c = Hh.chi2(); Hh.close(); return c
-    ca, cb = chi2_of(P, L), chi2_of(P1, L1)
-    assert abs(ca - cb) <= 1e-7 * cb
+    assert not failures, failures
 
 
 # ---------------------------------------------------------------- the multi-GPU launch path: RCCL, torch side stream, device exchange buffer
@@ -891,7 +942,7 @@ def test_frame_collector_and_cone_encoders_match_reference_logic(pkg, quirks):
 @pytest.mark.parametrize("seed,shape", [(22, dict(n_poses=200, n_lms=45, obs_per_pose=4, extra_pp=0)), (23, dict(n_poses=90, n_lms=60, obs_per_pose=8, extra_pp=2)),
                                         (24, dict(n_poses=300, n_lms=70, obs_per_pose=3, extra_pp=3)), (7, dict()),
                                         (25, dict(n_poses=260, n_lms=50, obs_per_pose=4, extra_pp=5, dup_edges=12))])
-def test_fronts_beyond_a_wave_run_on_the_matrix_cores_and_match_the_oracle(pkg, po, monkeypatch, seed, shape):
+def test_fronts_beyond_a_wave_run_on_the_matrix_cores_and_match_the_oracle(pkg, po, seed, shape):
     """Irregular graphs whose separators exceed 63 scalars (up to ~150): the plan keeps variant 3, a big front gets a workgroup
     (7 or 10 tile rows), small fronts of the same tree still run a wave each.  One step and five iterations against the
     oracle, whole-tree launch and one launch per level (bitwise equal), and a flag timeout injected into a big plan."""
@@ -904,10 +955,9 @@ def test_fronts_beyond_a_wave_run_on_the_matrix_cores_and_match_the_oracle(pkg, 
     og.optimize(4, ordering=0); done, st = G.optimize(4)
     assert done == 4 and rel(G.poses(), og.poses()) < 1e-8 and rel(G.landmarks(), og.landmarks()) < 1e-8
     P1, L1 = G.poses(), G.landmarks(); G.close()
-    monkeypatch.setenv("GS_TREE", "0")
-    H = fresh(pkg, g); done, st = H.optimize(5)
+    H = fresh(pkg, g, debug=dict(tree=0)); done, st = H.optimize(5)
     assert done == 5 and st.factor_variant == 3 and np.array_equal(H.poses(), P1) and np.array_equal(H.landmarks(), L1)     # same arithmetic, same order
-    H.close(); monkeypatch.delenv("GS_TREE")
+    H.close()
     F = fresh(pkg, g); F.initialize_optimization(); F.debug_fail_at_iteration(2, 2)
     done, st = F.optimize(5)
     assert done == 5 and st.fell_back == 1 and st.first_failure == 2 and np.array_equal(F.poses(), P1)
@@ -990,18 +1040,16 @@ def test_plans_with_workgroup_fronts_grow_as_well(pkg, po, N, M, K, h, frontend)
 
 
 @pytest.mark.gpu
-def test_growth_between_optimisations_keeps_the_estimates_in_hbm_and_falls_back_when_it_must(pkg, po, bench_graphs, monkeypatch):
+def test_growth_between_optimisations_keeps_the_estimates_in_hbm_and_falls_back_when_it_must(pkg, po, bench_graphs):
     """iterations on the base graph, THEN the new poses, then more iterations: the grown handle must continue from the iterate in HBM
-    exactly like a handle that is given the same state and rebuilds everything (GS_GROW=0); a change growth cannot absorb is
+    exactly like a handle that is given the same state and rebuilds everything (gs_debug_options.grow = 0); a change growth cannot absorb is
     refused with a reason and rebuilt."""
     _, g = bench_graphs(1000, 200)
     base, tail, full = split_for_growth(g, 3)
     G = fresh(pkg, base); G.optimize(2); append_tail(G, tail); done, _ = G.optimize(5)
     assert G.plan_growths() == 1 and done == 5
-    monkeypatch.setenv("GS_GROW", "0")
-    R = fresh(pkg, base); R.optimize(2); append_tail(R, tail); done_r, _ = R.optimize(5)
-    assert R.plan_growths() == 0 and R.growth_refusal() == "GS_GROW=0" and done_r == 5
-    monkeypatch.delenv("GS_GROW")
+    R = fresh(pkg, base, debug=dict(grow=0)); R.optimize(2); append_tail(R, tail); done_r, _ = R.optimize(5)
+    assert R.plan_growths() == 0 and "growth switched off" in R.growth_refusal() and done_r == 5
     rms = np.sqrt((R.poses()[:, :2] ** 2).sum(1).mean())
     assert np.sqrt(((G.poses()[:, :2] - R.poses()[:, :2]) ** 2).sum(1).mean()) / rms < 1e-9
     assert np.sqrt(((G.landmarks() - R.landmarks()) ** 2).sum(1).mean()) / rms < 1e-9
@@ -1011,11 +1059,10 @@ def test_growth_between_optimisations_keeps_the_estimates_in_hbm_and_falls_back_
     done, _ = G.optimize(2)
     assert done == 2 and G.plan_growths() == 0 and "old pose" in G.growth_refusal()
     G.close(); R.close()
-    # the product's default leaves small graphs to the full phase (the tests run with GS_GROW_MIN_POSES=0)
-    monkeypatch.setenv("GS_GROW_MIN_POSES", "128")
+    # the product's default leaves small graphs to the full phase (the tests run with grow_min_poses = 0: conftest)
     _, gs = bench_graphs(50, 30)
     b2, t2, _ = split_for_growth(gs, 1)
-    S = fresh(pkg, b2); S.optimize(1); append_tail(S, t2); done, _ = S.optimize(1)
+    S = fresh(pkg, b2, debug=dict(grow_min_poses=128)); S.optimize(1); append_tail(S, t2); done, _ = S.optimize(1)
     assert done == 1 and S.plan_growths() == 0 and "GS_GROW_MIN_POSES" in S.growth_refusal()
     S.close()
 
@@ -1070,20 +1117,64 @@ def test_growth_of_irregular_graphs_takes_one_step_like_the_oracle(pkg, po, seed
 
 
 @pytest.mark.gpu
-def test_repeated_structure_phases_reuse_the_handles_device_memory(pkg, bench_graphs, monkeypatch):
+def test_set_estimate_on_an_old_vertex_survives_a_growth_step(pkg, bench_graphs):
+    """g2o: setEstimate on any vertex, then optimize() linearises at the new value.  Sequence that used to lose it (round 3's advisor): optimize,
+    gs_set_pose_estimate / gs_set_landmark_estimate on OLD vertices, append a keyframe (absorbed by the plan: only the new vertices'
+    estimates used to travel), optimize.  Checked against a fresh handle that is given the same state and builds from scratch."""
+    _, g = bench_graphs(1000, 200)
+    base, tail, full = split_for_growth(g, 2)
+    G = fresh(pkg, base); done, _ = G.optimize(3); assert done == 3
+    P, L = G.poses(), G.landmarks()
+    newp = P[400] + [0.30, -0.20, 0.02]; newl = L[77] + [0.25, 0.15]
+    G.set_pose_estimate(400, newp); G.set_landmark_estimate(77, newl)
+    nl = append_tail(G, tail)
+    done, _ = G.optimize(1); assert done == 1
+    assert G.plan_growths() > 0, G.growth_refusal()
+    st = dict(full); st["pose_est"] = np.vstack([P, tail["pose_est"]]); st["pose_est"][400] = newp
+    st["lm_est"] = np.vstack([L, tail["lm_est"][:nl]]) if nl else L.copy(); st["lm_est"][77] = newl
+    F = fresh(pkg, st); done, _ = F.optimize(1); assert done == 1 and F.plan_growths() == 0
+    assert rel(G.poses(), F.poses()) < 1e-9 and rel(G.landmarks(), F.landmarks()) < 1e-9
+    # and the set value was really used: without it the iterate differs by far more than the tolerance
+    W = fresh(pkg, dict(st, pose_est=np.vstack([P, tail["pose_est"]]))); W.optimize(1)
+    assert rel(W.poses(), F.poses()) > 1e-7
+    G.close(); F.close(); W.close()
+
+
+@pytest.mark.gpu
+def test_the_shipped_growth_gate_hands_over_from_full_phases_to_growth(pkg):
+    """The suite runs with grow_min_poses = 0 (conftest); the SHIPPED default rebuilds below 128 poses and grows above.  A lap streamed
+    through gs_slam_perform with optimize_every_keyframe across that size: refusals name the gate while the plan is small, growth steps
+    appear afterwards, and the map equals the one of a run that rebuilds on every keyframe (grow = 0)."""
+    t = pkg.track.generate(400, 120)
+    dflt = pkg.binding.DebugOptions(); pkg.binding.lib().gs_debug_options_default(dflt)
+    assert dflt.grow == 1 and dflt.grow_min_poses == 128
+    def run(grow):
+        S = pkg.Slam(same_cone_threshold=1.2, cone_mapping_threshold=50.0, optimize_every_keyframe=1, debug=dict(grow=int(grow), grow_min_poses=dflt.grow_min_poses))
+        seen_gate = seen_growth = 0
+        for k in range(180):
+            S.perform_slam(t["odom_poses"][k], t["obs"][k])
+            seen_gate += "GS_GROW_MIN_POSES" in S.graph.growth_refusal(); seen_growth += S.graph.plan_growths() > 0
+        m = S.map(); S.close()
+        return m, seen_gate, seen_growth
+    (xy_g, ty_g), gate, growth = run(True)
+    (xy_r, ty_r), _, _ = run(False)
+    assert np.array_equal(ty_g, ty_r) and rel(xy_g, xy_r) < 1e-8
+    assert gate > 0 and growth > 0, (gate, growth)               # full phases while the plan is small, growth steps once it is not
+
+
+@pytest.mark.gpu
+def test_repeated_structure_phases_reuse_the_handles_device_memory(pkg, bench_graphs):
     """A handle keeps its device memory across structure phases (a re-plan takes the chunks of the last plan again): twelve forced full
     phases on a growing graph must neither grow the footprint beyond the graph's own growth nor change the answer of a fresh handle."""
-    monkeypatch.setenv("GS_GROW", "0")
     _, g = bench_graphs(1000, 200)
     base, tail, full = split_for_growth(g, 12)
-    G = fresh(pkg, base); G.reserve_device(16 << 20); G.optimize(1)
+    G = fresh(pkg, base, debug=dict(grow=0)); G.reserve_device(16 << 20); G.optimize(1)
     sizes = [G.stats().device_bytes]
     for k in range(12):
         append_tail(G, tail, (k, k + 1)); done, st = G.optimize(1)
         assert done == 1 and G.plan_growths() == 0
         sizes.append(st.device_bytes)
     assert max(sizes) <= 1.25 * min(sizes) + (8 << 20), sizes
-    monkeypatch.delenv("GS_GROW")
     F = fresh(pkg, base); F.optimize(1)
     for k in range(12):
         append_tail(F, tail, (k, k + 1)); F.optimize(1)
