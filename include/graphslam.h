@@ -122,7 +122,7 @@ typedef struct gs_stats {
     double  ms_linearize_kernel; /* gs_time_iterations: the A5-A7 kernel's own begin -> end per launch, from events attached to its dispatch (ms_linearize
                                     is event to event on the stream: it also holds the hand-over from the previous kernel) */
     int32_t n_growths;          /* append-only growth steps the current plan has absorbed since the last full structure phase (0: none) */
-    int32_t reserved2;
+    int32_t n_subtrees;         /* level-1 fronts that run with the leaves below them in ONE workgroup (k_factor3_sub; known after the first iteration of a plan) */
 } gs_stats;
 
 int  gs_version(void);                               /* major*100+minor */
@@ -289,6 +289,13 @@ int  gs_associate_batch(gs_graph *g, int32_t n, const double *poses_xytheta, int
                         int32_t n_map, const double *map_xy, const int32_t *map_type,
                         double threshold, double type_tol, int32_t *out_index);
 
+/* gs_associate_resident: the same association with EVERYTHING resident — the map of gs_map_append (below; its uniform grid is built on
+ *      the device, once per map change), poses, observations and the result in DEVICE memory — asynchronous on the handle's stream:
+ *      nothing crosses PCIe, nothing waits (gs_stream_synchronize when the caller needs the indices).  The batched form of the loop
+ *      that SURVEY 8(a) calls the dominant front-end cost at scale (src/slam.cpp:570-607). */
+int  gs_associate_resident(gs_graph *g, int32_t n, const double *dev_poses_xytheta, int32_t n_poses, const int32_t *dev_pose_of_obs,
+                           const double *dev_obs_4xn, double threshold, double type_tol, int32_t *dev_out_index);
+
 /* ---- the per-keyframe front end: A0 + A1 fused, against a map that stays resident in HBM -------------------------
  * gs_map_clear / gs_map_append / gs_map_set_xy / gs_map_size: the device mirror of Slam::m_map (src/slam.hpp: std::vector<Cone>):
  *      cones are appended in map order (index = Cone id, src/slam.cpp:556,610) and their positions rewritten after
@@ -314,6 +321,21 @@ int64_t gs_dist_exchange_doubles(gs_graph *g);         /* length of the exchange
 int  gs_dist_set_exchange_buffer(gs_graph *g, void *device_ptr);   /* NULL: the library allocates its own   */
 int  gs_dist_iterate_local(gs_graph *g);               /* linearise own edges + own subtrees + contribution  */
 int  gs_dist_iterate_finish(gs_graph *g);              /* after the all-reduce: shared top, solve, update    */
+/* The all-reduce INSIDE the library (the host side stays C++: the microservice needs no Python and no torch): RCCL is resolved at run
+ * time (the copy the process has loaded already, else librccl.so), never linked.
+ * gs_dist_unique_id        ncclGetUniqueId: 128 bytes, made by one rank and handed to the others by whatever channel the ranks share
+ *                          (the microservices share an OD4 session: reference src/opendlv-logic-cfsd18-sensation-slam.cpp:62).
+ * gs_dist_comm_init        ncclCommInitRank on the handle's device (collective: every rank calls it); the handle owns the communicator.
+ * gs_dist_set_communicator adopt a caller-owned ncclComm_t instead.
+ * gs_dist_iterate          one sharded Gauss-Newton iteration, all enqueued from C++ on the handle's stream: local half ->
+ *                          ncclAllReduce(sum, fp64) of the exchange buffer (the shared rows of Omega / xi) -> shared top, solve, update.
+ * gs_dist_optimize         Slam's optimize(10) (src/slam.cpp:481) on a sharded graph: `iterations` x gs_dist_iterate, g2o's failure rule
+ *                          across ranks; returns the updates applied (0: a factorisation failed on some rank). */
+int  gs_dist_unique_id(void *out_128_bytes);
+int  gs_dist_comm_init(gs_graph *g, const void *unique_id_128_bytes, int32_t rank, int32_t world_size);
+int  gs_dist_set_communicator(gs_graph *g, void *nccl_comm);
+int  gs_dist_iterate(gs_graph *g);
+int  gs_dist_optimize(gs_graph *g, int32_t iterations, gs_stats *stats /* may be NULL */);
 /* host copies of the exchange buffer (tests; all-reduce over a CPU backend when ranks share one GPU) */
 int  gs_dist_read_exchange(gs_graph *g, double *host_out);
 int  gs_dist_write_exchange(gs_graph *g, const double *host_in);

@@ -28,6 +28,8 @@ extern "C" {
  *     bs_wide         GS_BS_WIDE       plan  backward solve: levels wider than this get a light launch of their own (default 2048)
  *     leaf_nt3        GS_LEAF_NT3      plan  1 three-tile-row leaf instance when every leaf has <= 47 scalars (default), 0 off
  *     f3_lds_kb       GS_F3_LDS_KB     plan  occupancy experiments: LDS per workgroup of the per-level factor launches, KB (0 = need)
+ *     subtree         GS_SUBTREE       plan  1 (default): a level-1 front and the leaves below it run in ONE workgroup (k_factor3_sub: the leaves'
+ *                                      update matrices stay in LDS); 0: leaf launch + flagged launch from level 1 up, as in rounds 1-3
  *     small_tree      GS_SMALL_TREE    plan  fronts up to which a whole optimize() call runs as ONE persistent launch (default 512; 0 off)
  *   plan shape — changes the elimination order, hence the last bits of the result (all are exact factorisations)
  *     leaf_poses      GS_LEAF_POSES    plan  nested-dissection leaf size in poses (0 = gs_config.leaf_poses / default 8)
@@ -59,7 +61,8 @@ typedef struct gs_debug_options {
     int32_t assoc_grid;
     int32_t force_shared_top;
     int32_t host_trig, pool_poison, plan_timing, dbg;
-    int32_t reserved[8];
+    int32_t subtree;
+    int32_t reserved[7];
 } gs_debug_options;
 
 int gs_debug_options_default(gs_debug_options *o);                     /* the library's defaults (the environment is NOT consulted) */
@@ -75,6 +78,10 @@ int gs_debug_front_times(gs_graph *g, int64_t *out, int64_t capacity);
 /* Fault injection (tests of the failure semantics; the reference has none): the k-th iteration enqueued after
  * this call reports `code` (1 = zero pivot, 2 = front-flag timeout) from its first front; k = 0 disarms. */
 int gs_debug_fail_at_iteration(gs_graph *g, int32_t k, int32_t code);
+/* Measurement hook of the batched association (bench.py's `association` entry): `reps` launches of gs_associate_resident, each with a HIP
+ * start / stop event pair attached to the query kernel's dispatch (its own begin -> end, on the handle's stream); mean ms per launch. */
+int gs_debug_time_associate_resident(gs_graph *g, int32_t n, const double *dev_poses_xytheta, int32_t n_poses, const int32_t *dev_pose_of_obs,
+                                     const double *dev_obs_4xn, double threshold, double type_tol, int32_t *dev_out_index, int32_t reps, double *out_ms);
 /* The factor-kernel variant a plan with the given largest front and H-arena size (doubles) is given for a requested variant
  * (gs_config.factor_variant; 0 = default): 3 = matrix-core LDL^T fronts with 32-bit byte offsets into the arena (a wave per front of
  * <= 63 scalars, a workgroup per front of 64 .. 159; arena < 2^29 doubles), 4 = block-per-front kernel with 64-bit addressing

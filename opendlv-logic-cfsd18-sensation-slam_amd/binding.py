@@ -12,7 +12,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.environ.get("GS_LIB", os.path.join(CSRC, "libgraphslam_hip.so"))    # GS_LIB: A/B builds of the same library (tuning)
+LIB_PATH = os.environ.get("GS_LIB") or os.path.join(CSRC, "libgraphslam_hip.so")    # GS_LIB: A/B builds of the same library (tuning)
 HEADER = os.path.join(os.path.dirname(HERE), "include", "graphslam.h")
 DEBUG_HEADER = os.path.join(os.path.dirname(HERE), "include", "graphslam_debug.h")     # tuning / fault injection / timestamps: not the drop-in boundary
 
@@ -53,7 +53,7 @@ class Stats(C.Structure):
                 ("factor_flops", C.c_int64), ("factor_bytes", C.c_int64), ("ms_event_overhead", C.c_double),
                 ("fell_back", C.c_int32), ("first_failure", C.c_int32), ("factor_variant", C.c_int32), ("n_big_fronts", C.c_int32),
                 ("device_bytes", C.c_int64), ("n_own_fronts", C.c_int32), ("n_shared_fronts", C.c_int32), ("ms_plan_host", C.c_double),
-                ("ms_linearize_kernel", C.c_double), ("n_growths", C.c_int32), ("reserved2", C.c_int32)]
+                ("ms_linearize_kernel", C.c_double), ("n_growths", C.c_int32), ("n_subtrees", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -69,7 +69,7 @@ class DebugOptions(C.Structure):
     _fields_ = [("struct_size", C.c_int32)] + [(k, C.c_int32) for k in (
         "tree", "block_fronts", "leaf_kernel", "leaf_min", "bs_wide", "leaf_nt3", "f3_lds_kb", "small_tree",
         "leaf_poses", "cluster_ways", "ell_lanes", "big_cluster", "grow_headroom", "factor_variant",
-        "grow", "grow_min_poses", "assoc_grid", "force_shared_top", "host_trig", "pool_poison", "plan_timing", "dbg")] + [("reserved", C.c_int32 * 8)]
+        "grow", "grow_min_poses", "assoc_grid", "force_shared_top", "host_trig", "pool_poison", "plan_timing", "dbg", "subtree")] + [("reserved", C.c_int32 * 7)]
 
 
 # switches applied to every handle this process creates through the binding (tests: conftest sets grow_min_poses = 0)
@@ -170,10 +170,17 @@ def lib():
     L.gs_cone_to_global_batch.argtypes = [vp, C.c_int32, _dp, C.c_int32, _ip, _dp, _dp]
     L.gs_associate_batch.argtypes = [vp, C.c_int32, _dp, C.c_int32, _ip, _dp, C.c_int32, _dp, _ip,
                                      C.c_double, C.c_double, _ip]
+    L.gs_associate_resident.argtypes = [vp, C.c_int32, vp, C.c_int32, vp, vp, C.c_double, C.c_double, vp]
+    L.gs_debug_time_associate_resident.argtypes = [vp, C.c_int32, vp, C.c_int32, vp, vp, C.c_double, C.c_double, vp, C.c_int32, _dp]
     L.gs_map_clear.argtypes = [vp]; L.gs_map_size.argtypes = [vp]
     L.gs_map_append.argtypes = [vp, C.c_int32, _dp, _ip]
     L.gs_map_set_xy.argtypes = [vp, C.c_int32, C.c_int32, _dp]
     L.gs_frame_frontend.argtypes = [vp, _dp, _dp, C.c_int32, C.c_double, C.c_double, C.c_int32, _dp, _dp, _ip]
+    L.gs_dist_unique_id.argtypes = [C.c_char_p]
+    L.gs_dist_comm_init.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32]
+    L.gs_dist_set_communicator.argtypes = [vp, vp]
+    L.gs_dist_iterate.argtypes = [vp]
+    L.gs_dist_optimize.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
     L.gs_dist_read_exchange.argtypes = [vp, _dp]
     L.gs_dist_write_exchange.argtypes = [vp, _dp]
     u8 = C.POINTER(C.c_uint8)
@@ -234,6 +241,63 @@ def default_config(**kw):
     for k, v in kw.items():
         setattr(cfg, k, v)
     return cfg
+
+
+_hip = None
+
+
+def hip_runtime():
+    """libamdhip64 (the runtime the library itself uses), for callers that keep their OWN buffers in device memory (gs_associate_resident,
+    gs_dist_set_exchange_buffer): tests and bench.py — a C++ consumer calls hipMalloc / hipMemcpy itself."""
+    global _hip
+    if _hip is None:
+        lib()                                               # the library has loaded the runtime already
+        H = C.CDLL("libamdhip64.so")
+        H.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]; H.hipFree.argtypes = [C.c_void_p]
+        H.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip = H
+    return _hip
+
+
+class DeviceArray:
+    """A caller-owned array in device memory (hipMalloc + hipMemcpy), e.g. the observations of gs_associate_resident."""
+
+    def __init__(self, host=None, nbytes=None):
+        H = hip_runtime()
+        self.host = None if host is None else np.ascontiguousarray(host)
+        self.nbytes = int(nbytes if nbytes is not None else self.host.nbytes)
+        p = C.c_void_p()
+        if H.hipMalloc(C.byref(p), max(self.nbytes, 8)) != 0:
+            raise RuntimeError("hipMalloc failed")
+        self.ptr = p
+        if self.host is not None and self.nbytes:
+            if H.hipMemcpy(self.ptr, self.host.ctypes.data_as(C.c_void_p), self.nbytes, 1) != 0:
+                raise RuntimeError("hipMemcpy (host to device) failed")
+
+    def to_host(self, dtype, count):
+        out = np.zeros(count, dtype=dtype)
+        if hip_runtime().hipMemcpy(out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes, 2) != 0:
+            raise RuntimeError("hipMemcpy (device to host) failed")
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            hip_runtime().hipFree(self.ptr); self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def dist_unique_id():
+    """ncclGetUniqueId through the library (128 bytes): made by one rank, handed to the others by whatever channel they share."""
+    buf = C.create_string_buffer(128)
+    rc = lib().gs_dist_unique_id(buf)
+    if rc < 0:
+        raise GsError(rc, (lib().gs_last_error() or b"").decode())
+    return buf.raw
 
 
 def device_count():
@@ -469,6 +533,16 @@ class Graph:
         return out
 
     # ---- per-keyframe front end against the resident map
+    def associate_resident(self, d_poses, n_poses, d_pose_of_obs, d_obs, n, thr, d_out, type_tol=1e-4):
+        """gs_associate_resident: the resident map (map_append), everything else DeviceArray; asynchronous (synchronize() before reading d_out)."""
+        self._check(self.L.gs_associate_resident(self.h, int(n), d_poses.ptr, int(n_poses), d_pose_of_obs.ptr, d_obs.ptr, float(thr), float(type_tol), d_out.ptr))
+
+    def time_associate_resident(self, d_poses, n_poses, d_pose_of_obs, d_obs, n, thr, d_out, reps, type_tol=1e-4):
+        ms = C.c_double()
+        self._check(self.L.gs_debug_time_associate_resident(self.h, int(n), d_poses.ptr, int(n_poses), d_pose_of_obs.ptr, d_obs.ptr, float(thr), float(type_tol), d_out.ptr,
+                                                             int(reps), C.byref(ms)))
+        return ms.value
+
     def map_clear(self): self._check(self.L.gs_map_clear(self.h))
     def map_size(self): return self._check(self.L.gs_map_size(self.h))
 
@@ -494,6 +568,22 @@ class Graph:
 
     def dist_set_exchange_buffer(self, device_ptr):
         self._check(self.L.gs_dist_set_exchange_buffer(self.h, C.c_void_p(device_ptr)))
+
+    def dist_comm_init(self, unique_id, rank, world):
+        """ncclCommInitRank inside the library (collective: every rank calls it with the id rank 0 made, dist_unique_id())."""
+        self._check(self.L.gs_dist_comm_init(self.h, bytes(unique_id), int(rank), int(world)))
+
+    def dist_set_communicator(self, comm_ptr):
+        self._check(self.L.gs_dist_set_communicator(self.h, C.c_void_p(comm_ptr)))
+
+    def dist_iterate(self):
+        """one sharded iteration, all from C++: local half -> ncclAllReduce of the exchange buffer -> finish"""
+        return self._check(self.L.gs_dist_iterate(self.h))
+
+    def dist_optimize(self, iterations=10):
+        st = Stats(); st.struct_size = C.sizeof(Stats)
+        done = self._check(self.L.gs_dist_optimize(self.h, int(iterations), C.byref(st)))
+        return done, st
 
     def dist_iterate_local(self):
         self._check(self.L.gs_dist_iterate_local(self.h))

@@ -8,6 +8,9 @@
 #include "gs_internal.hpp"
 #include "gs_parallel.hpp"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types and prototypes only: the library is resolved at run time (rccl_api), never linked
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -29,6 +32,7 @@ int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
 
 // ------------------------------------------------------------------ helpers
 void gs_frontend_release(gs_graph *g);       // front-end buffers of the handle (defined with the front end below)
+void gs_dist_comm_release(gs_graph *g);      // the handle's own RCCL communicator (defined with the multi-GPU entry points)
 static int usable_devices() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -131,6 +135,7 @@ extern "C" int gs_debug_options_default(gs_debug_options *o) {
     if (!o) return fail(GS_ERR_INVALID, "null options");
     std::memset(o, 0, sizeof(*o));
     o->struct_size = (int32_t)sizeof(*o);
+    o->subtree = 0;
     o->tree = 1; o->block_fronts = 512; o->leaf_kernel = -1; o->leaf_min = 2048; o->bs_wide = 2048; o->leaf_nt3 = 1; o->f3_lds_kb = 0; o->small_tree = 512;
     o->leaf_poses = 0; o->cluster_ways = 0; o->ell_lanes = 0; o->big_cluster = -1; o->grow_headroom = -1; o->factor_variant = 0;
     o->grow = 1; o->grow_min_poses = 128;
@@ -144,7 +149,7 @@ static void options_from_environment(gs_debug_options &o) {
     gs_debug_options_default(&o);
     auto env = [](const char *name, int32_t &field) { if (const char *e = std::getenv(name)) field = (int32_t)std::atoi(e); };
     env("GS_TREE", o.tree); env("GS_BLOCK_FRONTS", o.block_fronts); env("GS_LEAF_KERNEL", o.leaf_kernel); env("GS_LEAF_MIN", o.leaf_min);
-    env("GS_BS_WIDE", o.bs_wide); env("GS_LEAF_NT3", o.leaf_nt3); env("GS_F3_LDS_KB", o.f3_lds_kb); env("GS_SMALL_TREE", o.small_tree);
+    env("GS_SUBTREE", o.subtree); env("GS_BS_WIDE", o.bs_wide); env("GS_LEAF_NT3", o.leaf_nt3); env("GS_F3_LDS_KB", o.f3_lds_kb); env("GS_SMALL_TREE", o.small_tree);
     env("GS_LEAF_POSES", o.leaf_poses); env("GS_CLUSTER_WAYS", o.cluster_ways); env("GS_ELL_LANES", o.ell_lanes); env("GS_BIG_CLUSTER", o.big_cluster);
     env("GS_GROW_HEADROOM", o.grow_headroom); env("GS_FACTOR_VARIANT", o.factor_variant);
     env("GS_GROW", o.grow); env("GS_GROW_MIN_POSES", o.grow_min_poses); env("GS_ASSOC_GRID", o.assoc_grid); env("GS_FORCE_SHARED_TOP", o.force_shared_top);
@@ -162,7 +167,7 @@ extern "C" int gs_debug_set_options(gs_graph *g, const gs_debug_options *o) {
     const gs_debug_options &c = g->opt;
     // a "plan" field changed: the next structure phase is a full one (a grown plan keeps the launch shapes it was built with)
     const bool plan_changed = n.tree != c.tree || n.block_fronts != c.block_fronts || n.leaf_kernel != c.leaf_kernel || n.leaf_min != c.leaf_min ||
-        n.bs_wide != c.bs_wide || n.leaf_nt3 != c.leaf_nt3 || n.f3_lds_kb != c.f3_lds_kb || n.small_tree != c.small_tree || n.leaf_poses != c.leaf_poses ||
+        n.bs_wide != c.bs_wide || n.subtree != c.subtree || n.leaf_nt3 != c.leaf_nt3 || n.f3_lds_kb != c.f3_lds_kb || n.small_tree != c.small_tree || n.leaf_poses != c.leaf_poses ||
         n.cluster_ways != c.cluster_ways || n.ell_lanes != c.ell_lanes || n.big_cluster != c.big_cluster || n.grow_headroom != c.grow_headroom ||
         n.factor_variant != c.factor_variant || n.force_shared_top != c.force_shared_top || n.host_trig != c.host_trig || n.pool_poison != c.pool_poison ||
         n.dbg != c.dbg;
@@ -205,6 +210,7 @@ extern "C" int gs_destroy(gs_graph *g) {
     hipSetDevice(g->device);
     hipStreamSynchronize(g->stream);
     dev_free_all(g);
+    gs_dist_comm_release(g);
     gs_frontend_release(g);
     for (auto &e : g->ev) hipEventDestroy(e);
     if (g->own_stream) hipStreamDestroy(g->stream);
@@ -548,8 +554,10 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
           HIP_TRY(hipMemcpyAsync(d.ell_w, raw.ell_w.data(), 3 * L * sizeof(double), hipMemcpyHostToDevice, g->stream)); } }
     GS_UT("estimates+edges");
     UP(lm_start, P.lm_start); UP(lm_edges, P.lm_edges); UP(ppadj_start, P.ppadj_start);
-    { std::vector<int32_t> inc = P.ppinc;                                 // incidences of edges another rank evaluates: edge = -1
-      if (P.world > 1) for (size_t q = 0; q * 4 < inc.size(); ++q) if (P.pp_rank[inc[4 * q]] != P.rank) inc[4 * q] = -1;
+    { const size_t Q = P.ppinc.size() / 4;                                // device records are 8 bytes: {edge, other endpoint | role << 31}; the pose that
+      std::vector<int32_t> inc(2 * Q);                                    // holds the record is known to the kernel; an edge another rank evaluates: edge = -1
+      for (size_t q = 0; q < Q; ++q) { const int32_t k = P.ppinc[4 * q], role = P.ppinc[4 * q + 1], other = role ? P.ppinc[4 * q + 2] : P.ppinc[4 * q + 3];
+          inc[2 * q] = (P.world > 1 && P.pp_rank[k] != P.rank) ? -1 : k; inc[2 * q + 1] = (int32_t)((uint32_t)other | ((uint32_t)role << 31)); }
       UP(ppinc, inc); }
 #define AL(dst, cnt) if ((rc = dev_alloc(g, &d.dst, (size_t)(cnt))) != GS_OK) return rc
 #define ZERO(dst, cnt) HIP_TRY(hipMemsetAsync(d.dst, 0, std::max<size_t>((size_t)(cnt), 1) * sizeof(*d.dst), g->stream))
@@ -557,17 +565,22 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
     // the fused kernel addresses the ELL planes with 32-bit byte offsets: 8 B * ell_len must stay below 4 GiB
     if (P.lin_ell_ok && !g->force_gather && P.ell_len < ((int64_t)1 << 29)) {
         d.n_wtiles = P.n_wtiles; d.n_groups = (int32_t)P.grp_lm.size();
-        UP(wt_desc, P.wt_desc); UP(grp_pos_start, P.grp_pos_start); UP(grp_slot, P.grp_slot); UP(lm_grp_start, P.lm_grp_start);
+        UP(wt_desc, P.wt_desc); UP(lm_grp_start, P.lm_grp_start);
+        { const size_t Gn = P.grp_slot.size(); std::vector<int32_t> gt(2 * Gn + 2, 0);   // per group {first | end << 16 of its tile-local positions, partial-sum slot}
+          for (int w = P.wt_lo; w < P.wt_hi; ++w) { const int ga = P.wt_desc[4 * (size_t)w], gn = P.wt_desc[4 * (size_t)w + 1], pos_off = P.wt_desc[4 * (size_t)w + 2];
+              for (int q = ga; q < ga + gn; ++q) { gt[2 * (size_t)q] = (P.grp_pos_start[q] - pos_off) | ((P.grp_pos_start[q + 1] - pos_off) << 16); gt[2 * (size_t)q + 1] = P.grp_slot[q]; } }
+          UP(grp_tab, gt); }
         UP(ell_dst, P.ell_dst);
         d.wt_lo = P.wt_lo; d.wt_hi = P.wt_hi;                             // the wave tiles this shard has any edge in (gs_plan.cpp)
     } else if (P.world > 1) return fail(GS_ERR_INVALID, "pose-window shards need the fused linearisation layout (<= 32 observations per pose)");
     // block-sparse H and b live in ONE arena (the variant-3 front assembly addresses every scalar by its offset in it)
     int64_t arena_off[14], arena_doubles = 0;
     { // (the last six parts: the blocks of a grown plan's tail — diagonal blocks and rhs of tail poses / landmarks, off-diagonal blocks of tail edges)
-      const int64_t sizes[13] = {(int64_t)N * 6, (int64_t)N * 3, (int64_t)Epp * 9, (int64_t)P.ell_len * 6, (int64_t)d.n_groups * 5, (int64_t)M * 3, (int64_t)M * 2,
+      const int64_t sizes[13] = {(int64_t)N * 6, (int64_t)N * 3, (int64_t)Epp * 9, (int64_t)P.ell_len * 6, (int64_t)d.n_groups * 8, (int64_t)M * 3, (int64_t)M * 2,
                                  (int64_t)TAIL_POSES * 6, (int64_t)TAIL_POSES * 3, (int64_t)TAIL_PP * 9, (int64_t)TAIL_PL * 6, (int64_t)TAIL_LMS * 3, (int64_t)TAIL_LMS * 2};
       arena_off[0] = 0;
-      for (int k = 0; k < 13; ++k) arena_off[k + 1] = arena_off[k] + ((sizes[k] + 1) & ~(int64_t)1);       // 16-byte aligned parts
+      for (int k = 0; k < 13; ++k) { arena_off[k + 1] = arena_off[k] + ((sizes[k] + 1) & ~(int64_t)1);       // 16-byte aligned parts
+          if (k + 1 == 4) arena_off[4] = (arena_off[4] + 7) & ~(int64_t)7; }                                   // (the partial-sum records: one 64-byte line each)
       if (arena_off[13] >= ((int64_t)1 << 31)) return fail(GS_ERR_INVALID, "graph too large for 32-bit arena offsets");
       arena_doubles = arena_off[13];
       AL(H_arena, (size_t)arena_off[13] + 2);
@@ -612,7 +625,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
       lf.insert(lf.end(), P.level_fronts_shared.begin(), P.level_fronts_shared.end());
       UP(level_fronts, lf); }
     d.xfail_off = -1; d.iter = 0; d.inject_iter = 0; d.inject_code = 0;
-    if (P.world > 1) { UP(x_off, P.x_off);
+    if (P.dist) { UP(x_off, P.x_off);
         d.xfail_off = P.exchange_doubles - 2;                             // the ranks' failure flags ride at the tail of the exchange buffer
         if (!g->exchange_external) { AL(exchange, P.exchange_doubles); ZERO(exchange, P.exchange_doubles); }
         else d.exchange = g->exchange; }
@@ -627,7 +640,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
     { int v = g->default_factor_variant;
       if (g->opt.factor_variant > 0) v = g->opt.factor_variant;
       v = gs_debug_select_factor_variant(v, P.max_front, arena_doubles);
-      if (v == 3 && P.max_front > 63 && P.world > 1) v = 4;           // the workgroup-per-front form has no shard modes (contribution / shared top) yet
+      if (v == 3 && P.max_front > 63 && P.dist) v = 4;                // the workgroup-per-front form has no shard modes (contribution / shared top) yet
       if (v == 4) v = 0;                                              // device-side code for the block-per-front kernel
       g->wg_f.clear(); g->wg_b.clear(); g->d_wg_f = g->d_wg_b = nullptr;
       d.factor_variant = v;
@@ -696,12 +709,13 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
             g->d_xrow = xrow_dev;
             g->pos_of_front.assign(P.fronts.size(), -1);
             for (size_t q = 0; q < lf.size(); ++q) g->pos_of_front[lf[q]] = (int32_t)q;
+            if ((rc = dev_upload(g, &g->d_posof, g->pos_of_front)) != GS_OK) return rc;      // front -> level position: into the children's headers (k_factor3_sub finds a leaf's descriptor through it)
             if ((rc = dev_alloc(g, &g->d_patch, (size_t)1024 * 32)) != GS_OK || (rc = dev_alloc(g, &g->d_list, (size_t)2048)) != GS_OK) return rc;
             AL(f3_desc, lf.size() * (size_t)F3W); AL(f3_x, (size_t)xrow[lf.size()] + 168);
             launch_build_f3((int)lf.size(), d.level_fronts, d.fronts, d.children, d.child_map, d.u3_off, d.u3_size, bf_dev, xrow_dev,
-                            P.world > 1 ? d.x_off : nullptr, d.f3_desc, d.f3_x, d.f3x_stride, g->stream);
+                            P.dist ? d.x_off : nullptr, d.f3_desc, d.f3_x, d.f3x_stride, g->stream, nullptr, g->d_posof);
             // a growth step needs all of the above: variant 3, one GPU, the fused linearisation layout
-            g->room.ok = P.world == 1 && fused;
+            g->room.ok = !P.dist && fused;
             GS_UT("f3 tables"); }
       } }
     GS_UT("f3 x+desc upload");
@@ -846,7 +860,7 @@ static int upload_growth(gs_graph *g, const Growth &gr) {
     // device-side expansion for those fronts: scalar records, then descriptors + children tables (a changed front's parent is a
     // changed front too: its copy of the child's row table is rebuilt with it)
     launch_build_sc3(g->d_bf, d.asm3, d.sc3, d.lm3, nf, g->sc3_args, g->stream, g->d_list);
-    launch_build_f3(nf, d.level_fronts, d.fronts, d.children, d.child_map, d.u3_off, d.u3_size, g->d_bf, g->d_xrow, nullptr, d.f3_desc, d.f3_x, d.f3x_stride, g->stream, g->d_list + 1024);
+    launch_build_f3(nf, d.level_fronts, d.fronts, d.children, d.child_map, d.u3_off, d.u3_size, g->d_bf, g->d_xrow, nullptr, d.f3_desc, d.f3_x, d.f3x_stride, g->stream, g->d_list + 1024, g->d_posof);
     d.n_scalar = P.n_scalar; d.tN = N1 - P.base_N; d.tM = P.planned_M - P.base_M; d.tEpp = E1 - P.base_Epp; d.tEpl = K1 - P.base_Epl;
     HIP_TRY(hipStreamSynchronize(g->stream));                       // the staging vectors above go out of scope
     { hipError_t e = hipGetLastError(); if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("growth: ") + hipGetErrorString(e)); }
@@ -888,6 +902,7 @@ static int build_plan_host(gs_graph *g) {
     if (t.big_cluster >= 0) o.big_cluster_front = t.big_cluster;         // 0 = clusters only where they fit a wave
     if (t.grow_headroom >= 0) { o.grow_headroom = t.grow_headroom; o.grow_spine_headroom = std::min(o.grow_spine_headroom, 3 * o.grow_headroom); }   // 0 = cluster fronts up to the full 63 scalars
     o.timing = t.plan_timing > 0;
+    o.force_shared_top = g->world <= 1 ? std::max(t.force_shared_top, 0) : 0;
     std::string err;
     if (!build_plan(g->h, o, g->plan, err)) { g->plan_version = ~0ull; return fail(GS_ERR_EMPTY, "plan: " + err); }
     g->plan_version = g->h.structure_version;
@@ -1029,7 +1044,7 @@ template <class Launch> static void for_each_run(const std::vector<gs_graph::WgS
 }
 static void enqueue_factor_big(gs_graph *g, const gs_graph::LevelSet &ls, bool tree) {
     if (!g->d_wg_f && build_big_tables(g, ls) != GS_OK) return;     // (an allocation failure surfaces as a launch error on the next call)
-    if (g->leaf_n > 0) launch_factor_tree(g->d, g->leaf_n, g->leaf_slot, g->leaf_max_f, g->leaf_n, 0, g->stream);       // the leaf instance alone
+    if (g->leaf_n > 0) launch_factor_tree(g->d, g->leaf_n, g->leaf_slot, g->leaf_max_f, g->leaf_n, 0, 0, 0, g->stream);       // the leaf instance alone
     // "no flags to wait for at level 1" holds only if EVERY leaf went through the leaf launch (big leaves share the table launch with their parents)
     const int leaf_pre = (g->leaf_n > 0 && g->leaf_n == ls.start[1]) ? 1 : 0;
     for_each_run(g->seg_f, tree, [&](int first, int n, size_t lds, int cls) { launch_factor_tab(g->d, g->d_wg_f + first, n, leaf_pre, lds, cls, g->stream); });
@@ -1056,17 +1071,32 @@ static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int
             // launches take level 0 as well — two kernel boundaries less per iteration (cfg1-cfg3: 6-11 % of it)
             if (n_leaf <= g->opt.leaf_min) n_leaf = 0;
             if (g->opt.leaf_kernel == 0) n_leaf = 0; else if (g->opt.leaf_kernel == 2) n_leaf = F_leaf_all;
-            g->leaf_n = n_leaf; g->leaf_slot = slot; }
+            g->leaf_n = n_leaf; g->leaf_slot = slot;
+            // the bottom subtrees (k_factor3_sub): every level-1 front of this rank with the leaves below it in one workgroup — their update
+            // matrices never leave the chip.  Taken when the leaf instance is in use, the plan put the leaves under
+            // level-1 fronts behind the others (gs_plan.cpp) and the workgroup's LDS fits; the leaf launch then covers positions [0, sub_free).
+            g->sub_n = 0; g->sub_first = 0; g->sub_free = n_leaf;
+            if (g->opt.subtree != 0 && n_leaf > 0 && n_leaf == ls.start[1] && g->plan.max_front <= 63 && nlev >= 2 &&
+                factor_sub_lds_bytes(slot) <= (size_t)160 * 1024) {
+                const Plan &P = g->plan; const auto &lfo = P.level_fronts_owned;
+                auto under = [&](int s) { const int pa = P.fronts[s].parent; return pa >= 0 && P.fronts[pa].level == 1 && g->pos_of_front[pa] >= ls.start[1] && g->pos_of_front[pa] < ls.start[2]; };
+                int nfree = 0; while (nfree < n_leaf && !under(lfo[nfree])) ++nfree;
+                bool ok = true; int64_t kids = 0;
+                for (int q = nfree; q < n_leaf && ok; ++q) ok = under(lfo[q]);
+                for (int q = ls.start[1]; q < ls.start[2] && ok; ++q) { const Front &F = P.fronts[lfo[q]]; kids += F.child_cnt;
+                    for (int c = 0; c < F.child_cnt && ok; ++c) { const int cp = g->pos_of_front[P.children[F.child_off + c]]; ok = cp >= nfree && cp < n_leaf; } }
+                if (ok && kids == n_leaf - nfree && ls.start[2] > ls.start[1]) { g->sub_first = ls.start[1]; g->sub_n = ls.start[2] - ls.start[1]; g->sub_free = nfree; } } }
         // the upper levels — few fronts, all of them in the dependent chain — get four waves per front: whole levels from the
         // top down while a level has at most GS_BLOCK_FRONTS (512) fronts (those workgroups are all resident at once)
         if (g->block_n < 0) { const int thr = g->opt.block_fronts;
             int nb = 0;
-            for (int l = nlev - 1; l >= (g->leaf_n > 0 ? 1 : 0); --l) { const int nl = ls.start[l + 1] - ls.start[l];
+            const int lowest = g->sub_n > 0 ? 2 : (g->leaf_n > 0 ? 1 : 0);      // the first level of the flagged launch
+            for (int l = nlev - 1; l >= lowest; --l) { const int nl = ls.start[l + 1] - ls.start[l];
                 if (nl > thr) break;
                 nb += nl; }
-            g->block_n = std::min(nb, ls.start[nlev] - std::max(g->leaf_n, 0)); }
+            g->block_n = std::min(nb, ls.start[nlev] - (g->sub_n > 0 ? g->sub_first + g->sub_n : std::max(g->leaf_n, 0))); }
         if (g->plan.max_front > 63) { enqueue_factor_big(g, ls, true); return; }
-        launch_factor_tree(g->d, g->leaf_n, g->leaf_slot, g->leaf_max_f, ls.start[nlev], g->block_n, g->stream); return; }
+        launch_factor_tree(g->d, g->sub_n > 0 ? g->sub_free : g->leaf_n, g->leaf_slot, g->leaf_max_f, ls.start[nlev], g->block_n, g->sub_first, g->sub_n, g->stream); return; }
     if (g->d.factor_variant == 3 && !g->d.tree && mode == 0 && base == 0 && nlev > 0 && g->plan.max_front > 63) { ++g->d.epoch; enqueue_factor_big(g, ls, false); return; }
     if (g->d.factor_variant == 3 && g->d.tree && mode == 2 && nlev > 0 && ls.start[nlev] > 0) {     // the shared top of a sharded graph, one flagged launch
         launch_factor_tree_top(g->d, base, ls.start[nlev], g->stream); return; }
@@ -1126,7 +1156,7 @@ static void enqueue_iteration(gs_graph *g, bool timed) { enqueue_local(g, timed)
 extern "C" int gs_iterate(gs_graph *g) {
     if (!g) return fail(GS_ERR_INVALID, "null graph");
     if (!g->dev_valid || g->plan_version != g->h.structure_version) return fail(GS_ERR_NOT_INITIALIZED, "call gs_initialize_optimization first");
-    if (g->plan.world > 1) return fail(GS_ERR_INVALID, "sharded graph: use gs_dist_iterate_local / all-reduce / gs_dist_iterate_finish");
+    if (g->plan.dist) return fail(GS_ERR_INVALID, "sharded graph: use gs_dist_iterate (RCCL inside the library) or gs_dist_iterate_local / all-reduce / gs_dist_iterate_finish");
     int rc = ensure_device(g); if (rc != GS_OK) return rc;
     enqueue_iteration(g, false);
     hipError_t e = hipGetLastError();
@@ -1148,6 +1178,7 @@ static void fill_plan_stats(gs_graph *g, gs_stats *s) {
     for (const Front &F : P.fronts) s->n_big_fronts += (!F.opaque && F.npiv + F.nbnd > 63);
     s->device_bytes = (int64_t)g->pool_total; s->ms_plan_host = P.ms_build; s->n_growths = P.n_growths;
     s->n_own_fronts = (int32_t)P.level_fronts_owned.size(); s->n_shared_fronts = (int32_t)P.level_fronts_shared.size();
+    s->n_subtrees = g->leaf_n >= 0 ? g->sub_n : 0;
 }
 
 extern "C" int gs_get_stats(gs_graph *g, gs_stats *s) {
@@ -1162,7 +1193,7 @@ extern "C" int gs_get_stats(gs_graph *g, gs_stats *s) {
 static int optimize_impl(gs_graph *g, int32_t iterations, double rel_tol, gs_stats *stats) {
     if (!g) return fail(GS_ERR_INVALID, "null graph");
     if (iterations < 0) return fail(GS_ERR_INVALID, "negative iteration count");
-    if (g->world > 1) return fail(GS_ERR_INVALID, "sharded graph: drive gs_dist_iterate_local / all-reduce / gs_dist_iterate_finish");
+    if (g->world > 1 || g->opt.force_shared_top > 0) return fail(GS_ERR_INVALID, "sharded graph: use gs_dist_optimize (RCCL inside the library), or drive gs_dist_iterate_local / all-reduce / gs_dist_iterate_finish");
     // g2o: optimize() is always preceded by initializeOptimization() (reference src/slam.cpp:480-481);
     // the plan is rebuilt only when the structure changed since the last call.
     int rc = ensure_ready(g); if (rc != GS_OK) return rc;
@@ -1330,7 +1361,7 @@ extern "C" int gs_export_delta(gs_graph *g, double *dpose, double *dlm) {
 }
 extern "C" int gs_time_iterations(gs_graph *g, int32_t reps, gs_stats *s) {
     if (!g || !s || reps <= 0) return fail(GS_ERR_INVALID, "bad argument");
-    if (g->world > 1) return fail(GS_ERR_INVALID, "sharded graph: time the two halves from the caller");
+    if (g->world > 1 || g->opt.force_shared_top > 0) return fail(GS_ERR_INVALID, "sharded graph: time the two halves from the caller");
     int rc = ensure_ready(g); if (rc != GS_OK) return rc;
     const int N = g->d.N + g->d.tN, M = g->d.M + g->d.tM;
     double *sp = nullptr, *sl = nullptr;                        // save estimates
@@ -1416,6 +1447,7 @@ void gs_frontend_release(gs_graph *g) {      // gs_destroy
     if (g->fe.map_xy) hipFree(g->fe.map_xy);
     if (g->fe.map_type) hipFree(g->fe.map_type);
     if (g->fe.pin_map) hipHostFree(g->fe.pin_map);
+    if (g->fe.grid_mem) hipFree(g->fe.grid_mem);
     g->fe = gs_graph::FrontEnd();
 }
 
@@ -1450,6 +1482,18 @@ extern "C" int gs_cone_to_global_batch(gs_graph *g, int32_t n, const double *pos
     HIP_TRY(hipStreamSynchronize(g->stream));
     return GS_OK;
 }
+// the grid of a map that is in device memory: built on the device (launch_grid_build), nothing crosses PCIe, nothing waits
+struct GridBufs { void *gp; int32_t *count, *start, *cursor, *items; long long max_cells; };
+static size_t grid_bytes(int n_map, long long &max_cells) {
+    max_cells = std::max<long long>(4096, 8 * (long long)n_map);
+    return padded(grid_params_bytes(), 1) + 3 * padded((size_t)max_cells + 1, 4) + padded((size_t)n_map, 4);
+}
+static GridBufs grid_carve(char *base, int n_map, long long max_cells) {
+    GridBufs b; size_t off = 0; auto take = [&](size_t bytes) { char *p = base + off; off += (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; return p; };
+    b.gp = take(grid_params_bytes()); b.count = (int32_t *)take(((size_t)max_cells + 1) * 4); b.start = (int32_t *)take(((size_t)max_cells + 1) * 4);
+    b.cursor = (int32_t *)take(((size_t)max_cells + 1) * 4); b.items = (int32_t *)take((size_t)n_map * 4); b.max_cells = max_cells;
+    return b;
+}
 extern "C" int gs_associate_batch(gs_graph *g, int32_t n, const double *poses, int32_t npose, const int32_t *pose_of_obs, const double *obs,
                                   int32_t n_map, const double *map_xy, const int32_t *map_type, double thr, double type_tol, int32_t *out) {
     if (!g || n < 0 || npose < 0 || n_map < 0 || (n > 0 && (!poses || !pose_of_obs || !obs || !out)) || (n_map > 0 && (!map_xy || !map_type)))
@@ -1458,49 +1502,79 @@ extern "C" int gs_associate_batch(gs_graph *g, int32_t n, const double *poses, i
     int rc = ensure_device(g); if (rc != GS_OK) return rc;
     if (n == 0) return GS_OK;
     // maps beyond a few LDS tiles go through a uniform grid (cell edge a hair above the threshold, so that every cone
-    // within the threshold sits in the 3 x 3 cells around the query); the brute-force kernel stays for small maps,
-    // non-positive thresholds and degenerate extents.  GS_ASSOC_GRID=0/1 forces either (A/B, tests).
+    // within the threshold sits in the 3 x 3 cells around the query) that is BUILT ON THE DEVICE from the uploaded map; the brute-force
+    // kernel stays for small maps and non-positive thresholds.  gs_debug_options.assoc_grid = 0 / 1 forces either (A/B, tests).
     bool grid = n_map >= 2048 && thr > 0.0;
     if (g->opt.assoc_grid >= 0) grid = g->opt.assoc_grid != 0 && n_map > 0 && thr > 0.0;
-    double minx = 0, miny = 0, maxx = 0, maxy = 0;
-    if (grid) { minx = maxx = map_xy[0]; miny = maxy = map_xy[1];
-        for (int j = 0; j < n_map; ++j) { const double x = map_xy[2 * (size_t)j], y = map_xy[2 * (size_t)j + 1];
-            if (!(std::isfinite(x) && std::isfinite(y))) { grid = false; break; }
-            minx = std::min(minx, x); maxx = std::max(maxx, x); miny = std::min(miny, y); maxy = std::max(maxy, y); } }
-    std::vector<int32_t> start, items; double inv_cell = 0; int64_t nx = 0, ny = 0;
-    if (grid) {
-        double cell = thr * (1.0 + 1e-9);
-        for (;;) { nx = (int64_t)std::floor((maxx - minx) / cell) + 1; ny = (int64_t)std::floor((maxy - miny) / cell) + 1;
-            if (nx * ny <= std::max<int64_t>(4096, 8 * (int64_t)n_map)) break;      // a sparse map (cones along a 25 km line) gets coarser cells, not millions of empty ones
-            cell *= 1.5; }
-        inv_cell = 1.0 / cell;
-        std::vector<int32_t> cell_of(n_map); start.assign((size_t)(nx * ny) + 1, 0); items.resize(n_map);
-        for (int j = 0; j < n_map; ++j) {
-            int64_t cx = (int64_t)std::floor((map_xy[2 * (size_t)j] - minx) * inv_cell), cy = (int64_t)std::floor((map_xy[2 * (size_t)j + 1] - miny) * inv_cell);
-            cx = std::min(std::max<int64_t>(cx, 0), nx - 1); cy = std::min(std::max<int64_t>(cy, 0), ny - 1);
-            cell_of[j] = (int32_t)(cy * nx + cx); start[(size_t)cell_of[j] + 1]++; }
-        for (size_t c = 0; c + 1 < start.size(); ++c) start[c + 1] += start[c];
-        { std::vector<int32_t> fill(start.begin(), start.end() - 1);
-          for (int j = 0; j < n_map; ++j) items[(size_t)fill[cell_of[j]]++] = j; }          // ascending map index inside a cell
-    }
+    long long max_cells = 0; const size_t gbytes = grid ? grid_bytes(n_map, max_cells) + 5 * 256 : 0;
     if ((rc = arena_reserve(g, padded(3 * (size_t)npose, 8) + padded(n, 4) + padded(4 * (size_t)n, 8) + padded(2 * (size_t)n_map, 8) +
-                               padded(n_map, 4) + padded(n, 4) + padded(start.size(), 4) + padded(items.size(), 4))) != GS_OK) return rc;
+                               padded(n_map, 4) + padded(n, 4) + gbytes)) != GS_OK) return rc;
     Carver c{g}; double *p = c.get<double>(3 * (size_t)npose); int32_t *po = c.get<int32_t>(n);
     double *ob = c.get<double>(4 * (size_t)n), *mx = c.get<double>(2 * (size_t)n_map);
-    int32_t *mt = c.get<int32_t>(n_map), *o = c.get<int32_t>(n), *cs = c.get<int32_t>(start.size()), *ci = c.get<int32_t>(items.size());
+    int32_t *mt = c.get<int32_t>(n_map), *o = c.get<int32_t>(n);
     HIP_TRY(hipMemcpyAsync(p, poses, 3 * (size_t)npose * 8, hipMemcpyHostToDevice, g->stream));
     HIP_TRY(hipMemcpyAsync(po, pose_of_obs, (size_t)n * 4, hipMemcpyHostToDevice, g->stream));
     HIP_TRY(hipMemcpyAsync(ob, obs, 4 * (size_t)n * 8, hipMemcpyHostToDevice, g->stream));
     if (n_map > 0) { HIP_TRY(hipMemcpyAsync(mx, map_xy, 2 * (size_t)n_map * 8, hipMemcpyHostToDevice, g->stream));
                      HIP_TRY(hipMemcpyAsync(mt, map_type, (size_t)n_map * 4, hipMemcpyHostToDevice, g->stream)); }
-    if (grid) {
-        HIP_TRY(hipMemcpyAsync(cs, start.data(), start.size() * 4, hipMemcpyHostToDevice, g->stream));
-        HIP_TRY(hipMemcpyAsync(ci, items.data(), items.size() * 4, hipMemcpyHostToDevice, g->stream));
-        launch_associate_grid(n, p, po, ob, g->cfg.lidar_to_cog, mx, mt, thr, type_tol, minx, miny, inv_cell, (int)nx, (int)ny, cs, ci, o, g->stream);
+    if (grid) { const GridBufs gb = grid_carve(c.get<char>(gbytes), n_map, max_cells);
+        launch_grid_build(n_map, mx, thr, max_cells, gb.gp, gb.count, gb.start, gb.cursor, gb.items, g->stream);
+        launch_associate_grid_dev(n, p, po, ob, g->cfg.lidar_to_cog, n_map, mx, mt, thr, type_tol, gb.gp, gb.start, gb.items, o, g->stream);
     } else launch_associate(n, p, po, ob, g->cfg.lidar_to_cog, n_map, mx, mt, thr, type_tol, o, g->stream);
     HIP_TRY(hipMemcpyAsync(out, o, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
-    HIP_TRY(hipStreamSynchronize(g->stream));        // (the host vectors above must outlive the uploads)
+    HIP_TRY(hipStreamSynchronize(g->stream));        // the one wait of the call: the result copy
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("association: ") + hipGetErrorString(e));
     return GS_OK;
+}
+// A1 batched with EVERYTHING resident: the map of gs_map_append (its grid is built on the device, once per map change or threshold),
+// poses / observations / result in device memory, asynchronous on the handle's stream (the caller waits: gs_stream_synchronize).
+static int resident_grid(gs_graph *g, double thr) {
+    auto &fe = g->fe;
+    if (fe.grid_valid && fe.grid_map_n == fe.map_n && fe.grid_thr == thr) return GS_OK;
+    long long max_cells = 0; const size_t bytes = grid_bytes(fe.map_n, max_cells) + 5 * 256;
+    if (bytes > fe.grid_bytes) { HIP_TRY(hipStreamSynchronize(g->stream));
+        if (fe.grid_mem) hipFree(fe.grid_mem);
+        fe.grid_mem = nullptr; fe.grid_bytes = 0;
+        HIP_TRY(hipMalloc((void **)&fe.grid_mem, bytes + bytes / 2)); fe.grid_bytes = bytes + bytes / 2; }
+    const GridBufs gb = grid_carve(fe.grid_mem, fe.map_n, max_cells);
+    launch_grid_build(fe.map_n, fe.map_xy, thr, max_cells, gb.gp, gb.count, gb.start, gb.cursor, gb.items, g->stream);
+    fe.grid_valid = true; fe.grid_map_n = fe.map_n; fe.grid_thr = thr; fe.grid_max_cells = max_cells;
+    return GS_OK;
+}
+extern "C" int gs_associate_resident(gs_graph *g, int32_t n, const double *dev_poses, int32_t npose, const int32_t *dev_pose_of_obs, const double *dev_obs,
+                                     double thr, double type_tol, int32_t *dev_out) {
+    if (!g || n < 0 || npose < 0 || (n > 0 && (!dev_poses || !dev_pose_of_obs || !dev_obs || !dev_out))) return fail(GS_ERR_INVALID, "bad argument");
+    int rc = ensure_device(g); if (rc != GS_OK) return rc;
+    if (n == 0) return GS_OK;
+    auto &fe = g->fe;
+    const bool grid = thr > 0.0 && fe.map_n > 0 && g->opt.assoc_grid != 0;
+    if (grid) { if ((rc = resident_grid(g, thr)) != GS_OK) return rc;
+        const GridBufs gb = grid_carve(fe.grid_mem, fe.map_n, fe.grid_max_cells);
+        launch_associate_grid_dev(n, dev_poses, dev_pose_of_obs, dev_obs, g->cfg.lidar_to_cog, fe.map_n, fe.map_xy, fe.map_type, thr, type_tol, gb.gp, gb.start, gb.items, dev_out, g->stream,
+                                  g->ev_lin[0], g->ev_lin[1]);
+    } else launch_associate(n, dev_poses, dev_pose_of_obs, dev_obs, g->cfg.lidar_to_cog, fe.map_n, fe.map_xy, fe.map_type, thr, type_tol, dev_out, g->stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("association: ") + hipGetErrorString(e));
+    return GS_OK;
+}
+// bench / profiling hook (graphslam_debug.h): `reps` launches of the resident association, each with a start / stop event pair attached to
+// its dispatch (the kernel's own begin -> end, as for the linearisation kernel); mean milliseconds per launch; the grid is built before
+extern "C" int gs_debug_time_associate_resident(gs_graph *g, int32_t n, const double *dev_poses, int32_t npose, const int32_t *dev_pose_of_obs,
+                                                const double *dev_obs, double thr, double type_tol, int32_t *dev_out, int32_t reps, double *out_ms) {
+    if (!g || !out_ms || reps <= 0) return fail(GS_ERR_INVALID, "bad argument");
+    int rc = gs_associate_resident(g, n, dev_poses, npose, dev_pose_of_obs, dev_obs, thr, type_tol, dev_out); if (rc != GS_OK) return rc;     // warm (and the grid)
+    std::vector<hipEvent_t> ev(2 * (size_t)reps); for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    for (int r = 0; r < reps && rc == GS_OK; ++r) { g->ev_lin[0] = ev[2 * (size_t)r]; g->ev_lin[1] = ev[2 * (size_t)r + 1];
+        rc = gs_associate_resident(g, n, dev_poses, npose, dev_pose_of_obs, dev_obs, thr, type_tol, dev_out); }
+    g->ev_lin[0] = g->ev_lin[1] = nullptr;
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    double tot = 0; int cnt = 0;
+    for (int r = 0; r < reps; ++r) { float ms = 0; if (hipEventElapsedTime(&ms, ev[2 * (size_t)r], ev[2 * (size_t)r + 1]) == hipSuccess && ms > 0) { tot += ms; ++cnt; } }
+    (void)hipGetLastError();
+    for (auto &e : ev) hipEventDestroy(e);
+    *out_ms = cnt ? tot / cnt : 0.0;
+    return rc;
 }
 
 // ---- the per-keyframe path: resident map + one fused launch -------------------------------------------------------
@@ -1529,7 +1603,7 @@ static int pin_map_reserve(gs_graph *g, size_t bytes) {
     return GS_OK;
 }
 extern "C" int gs_map_size(gs_graph *g) { return g ? g->fe.map_n : fail(GS_ERR_INVALID, "null graph"); }
-extern "C" int gs_map_clear(gs_graph *g) { if (!g) return fail(GS_ERR_INVALID, "null graph"); g->fe.map_n = 0; return GS_OK; }
+extern "C" int gs_map_clear(gs_graph *g) { if (!g) return fail(GS_ERR_INVALID, "null graph"); g->fe.map_n = 0; g->fe.grid_valid = false; return GS_OK; }
 extern "C" int gs_map_append(gs_graph *g, int32_t n, const double *xy, const int32_t *type) {
     if (!g || n < 0 || (n > 0 && (!xy || !type))) return fail(GS_ERR_INVALID, "bad argument");
     int rc = ensure_device(g); if (rc != GS_OK) return rc;
@@ -1544,7 +1618,7 @@ extern "C" int gs_map_append(gs_graph *g, int32_t n, const double *xy, const int
     HIP_TRY(hipMemcpyAsync(g->fe.map_xy + 2 * (size_t)g->fe.map_n, g->fe.pin_map, bx, hipMemcpyHostToDevice, g->stream));
     HIP_TRY(hipMemcpyAsync(g->fe.map_type + g->fe.map_n, g->fe.pin_map + bx, bt, hipMemcpyHostToDevice, g->stream));
     g->fe.pin_map_busy = true;                                      // no wait here: the next frame's launch is ordered behind the copies
-    g->fe.map_n += n;
+    g->fe.map_n += n; g->fe.grid_valid = false;
     return GS_OK;
 }
 extern "C" int gs_map_set_xy(gs_graph *g, int32_t first, int32_t n, const double *xy) {
@@ -1554,7 +1628,7 @@ extern "C" int gs_map_set_xy(gs_graph *g, int32_t first, int32_t n, const double
     if (n == 0) return GS_OK;
     HIP_TRY(hipMemcpyAsync(g->fe.map_xy + 2 * (size_t)first, xy, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));                       // pageable source: the caller's buffer is free on return
-    g->fe.pin_map_busy = false;
+    g->fe.pin_map_busy = false; g->fe.grid_valid = false;
     return GS_OK;
 }
 extern "C" int gs_frame_frontend(gs_graph *g, const double pose[3], const double *obs, int32_t k, double thr, double type_tol,
@@ -1603,7 +1677,7 @@ extern "C" int gs_dist_set_exchange_buffer(gs_graph *g, void *p) {
 static int dist_ready(gs_graph *g) {
     if (!g) return fail(GS_ERR_INVALID, "null graph");
     if (!g->dev_valid || g->plan_version != g->h.structure_version) return fail(GS_ERR_NOT_INITIALIZED, "call gs_initialize_optimization first");
-    if (g->plan.world > 1 && !g->d.exchange) return fail(GS_ERR_NOT_INITIALIZED, "no exchange buffer");
+    if (g->plan.dist && !g->d.exchange) return fail(GS_ERR_NOT_INITIALIZED, "no exchange buffer");
     return ensure_device(g);
 }
 extern "C" int gs_dist_iterate_local(gs_graph *g) {
@@ -1634,6 +1708,126 @@ extern "C" int gs_dist_write_exchange(gs_graph *g, const double *host) {
     if (g->plan.exchange_doubles > 0) HIP_TRY(hipMemcpyAsync(g->d.exchange, host, (size_t)g->plan.exchange_doubles * sizeof(double), hipMemcpyHostToDevice, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     return GS_OK;
+}
+
+// ---- RCCL inside the library: the host side of the sharded iteration stays C++ (north_star: "Host stays C++ ... RCCL all-reduce over
+// xGMI on the shared-landmark rows").  The RCCL library is resolved at run time — first the copy the process has loaded already (under
+// bench.py: torch's), then the system's — so libgraphslam_hip.so has no link-time dependency on it and a single-GPU consumer never loads it.
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr; decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr; decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr; decltype(&ncclCommCount) CommCount = nullptr;
+};
+RcclApi *rccl_api(std::string &err) {
+    static RcclApi api; static bool tried = false; static std::string why;
+    if (!tried) { tried = true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char *n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);     // a copy the process has loaded already
+        for (const char *n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!api.lib) why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "");
+        else {
+            api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId"); api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+            api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce"); api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+            api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString"); api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
+            if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) { why = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy"; api.lib = nullptr; } } }
+    if (!api.lib) { err = why; return nullptr; }
+    return &api;
+}
+int rccl_fail(RcclApi *R, ncclResult_t rc, const char *what) {
+    return fail(GS_ERR_HIP, std::string(what) + ": " + (R && R->GetErrorString ? R->GetErrorString(rc) : "RCCL error") + " (" + std::to_string((int)rc) + ")");
+}
+}  // namespace
+extern "C" int gs_dist_unique_id(void *out128) {
+    if (!out128) return fail(GS_ERR_INVALID, "null buffer");
+    std::string err; RcclApi *R = rccl_api(err); if (!R) return fail(GS_ERR_NO_DEVICE, err);
+    static_assert(sizeof(ncclUniqueId) == 128, "gs_dist_unique_id hands out NCCL_UNIQUE_ID_BYTES = 128 bytes");
+    ncclUniqueId id; ncclResult_t rc = R->GetUniqueId(&id); if (rc != ncclSuccess) return rccl_fail(R, rc, "ncclGetUniqueId");
+    std::memcpy(out128, &id, sizeof(id)); return GS_OK;
+}
+extern "C" int gs_dist_comm_init(gs_graph *g, const void *unique_id_128, int32_t rank, int32_t world) {
+    if (!g || !unique_id_128 || world < 1 || rank < 0 || rank >= world) return fail(GS_ERR_INVALID, "bad argument");
+    int rc = ensure_device(g); if (rc != GS_OK) return rc;
+    std::string err; RcclApi *R = rccl_api(err); if (!R) return fail(GS_ERR_NO_DEVICE, err);
+    if (g->comm && g->own_comm) { R->CommDestroy((ncclComm_t)g->comm); g->comm = nullptr; }
+    ncclUniqueId id; std::memcpy(&id, unique_id_128, sizeof(id));
+    ncclComm_t c = nullptr; ncclResult_t nr = R->CommInitRank(&c, world, id, rank);      // (collective: every rank of the group calls it; the current device is the handle's)
+    if (nr != ncclSuccess) return rccl_fail(R, nr, "ncclCommInitRank");
+    g->comm = c; g->own_comm = true; g->comm_world = world;
+    return GS_OK;
+}
+extern "C" int gs_dist_set_communicator(gs_graph *g, void *nccl_comm) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    std::string err; RcclApi *R = rccl_api(err); if (!R) return fail(GS_ERR_NO_DEVICE, err);
+    if (g->comm && g->own_comm) R->CommDestroy((ncclComm_t)g->comm);
+    g->comm = nccl_comm; g->own_comm = false; g->comm_world = 0;
+    if (nccl_comm && R->CommCount) { int n = 0; if (R->CommCount((ncclComm_t)nccl_comm, &n) == ncclSuccess) g->comm_world = n; }
+    return GS_OK;
+}
+void gs_dist_comm_release(gs_graph *g) {      // gs_destroy
+    if (!g->comm || !g->own_comm) { g->comm = nullptr; return; }
+    std::string err; if (RcclApi *R = rccl_api(err)) R->CommDestroy((ncclComm_t)g->comm);
+    g->comm = nullptr;
+}
+// the all-reduce of the shared fronts' slots (and of the ranks' failure flags at the buffer's tail), enqueued on the handle's stream
+static int enqueue_allreduce(gs_graph *g) {
+    if (!g->comm) return fail(GS_ERR_NOT_INITIALIZED, "no RCCL communicator: gs_dist_comm_init or gs_dist_set_communicator first");
+    if (g->comm_world > 0 && g->comm_world != g->world) return fail(GS_ERR_INVALID, "the communicator's size differs from gs_dist_configure's world");
+    std::string err; RcclApi *R = rccl_api(err); if (!R) return fail(GS_ERR_NO_DEVICE, err);
+    const int64_t n = g->plan.exchange_doubles;
+    if (n <= 0) return GS_OK;
+    ncclResult_t nr = R->AllReduce(g->d.exchange, g->d.exchange, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)g->comm, g->stream);
+    return nr == ncclSuccess ? GS_OK : rccl_fail(R, nr, "ncclAllReduce");
+}
+extern "C" int gs_dist_iterate(gs_graph *g) {
+    int rc = dist_ready(g); if (rc != GS_OK) return rc;
+    if (!g->plan.dist) return fail(GS_ERR_INVALID, "not a sharded graph: gs_iterate");
+    enqueue_local(g, false);
+    if ((rc = enqueue_allreduce(g)) != GS_OK) return rc;
+    enqueue_finish(g, false);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return 1;
+}
+// Slam's optimize(10) (reference src/slam.cpp:481) on a sharded graph: every rank makes the same call; g2o's failure rule holds across
+// ranks (a rank's failure flag rides through the all-reduce: no rank applies the update of that iteration or any later one).  Returns the
+// iterations whose update was applied, 0 when any rank's factorisation failed.  The estimates this rank tracks (gs_dist_known) come back.
+extern "C" int gs_dist_optimize(gs_graph *g, int32_t iterations, gs_stats *stats) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    if (iterations < 0) return fail(GS_ERR_INVALID, "negative iteration count");
+    int rc = ensure_ready(g); if (rc != GS_OK) return rc;
+    if (!g->plan.dist) return fail(GS_ERR_INVALID, "not a sharded graph: gs_optimize");
+    if ((rc = dist_ready(g)) != GS_OK) return rc;
+    HIP_TRY(hipMemsetAsync(g->d.fail, 0, 4 * sizeof(int32_t), g->stream));
+    g->d.conv_tol = -1.0;
+    hipEventRecord(g->ev[5], g->stream);
+    const int nh = std::min(iterations, 64);
+    for (int it = 0; it < iterations; ++it) {
+        g->d.hist_slot = it < nh ? it : -1;
+        enqueue_local(g, false);
+        if ((rc = enqueue_allreduce(g)) != GS_OK) { g->d.hist_slot = -1; return rc; }
+        enqueue_finish(g, false);
+    }
+    g->d.hist_slot = -1;
+    hipEventRecord(g->ev[6], g->stream);
+    int32_t ff[4] = {0, 0, 0, 0}; double hist[80];
+    HIP_TRY(hipMemcpyAsync(ff, g->d.fail, sizeof(ff), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipMemcpyAsync(hist, g->d.chi2, sizeof(hist), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("iteration: ") + hipGetErrorString(e));
+    float ms = 0; hipEventElapsedTime(&ms, g->ev[5], g->ev[6]);
+    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->struct_size = (int32_t)sizeof(*stats);
+        fill_plan_stats(g, stats); stats->iterations = ff[1]; stats->numeric_failure = ff[0]; stats->first_failure = ff[0];
+        stats->chi2_initial = iterations > 0 ? hist[1] : 0.0; stats->chi2_final = iterations > 0 ? hist[std::min(iterations, nh)] : 0.0;     // THIS rank's edges only (the ranks' sums add up to the graph's)
+        stats->ms_total = ms; }
+    if (ff[0]) { rc = reset_failure(g); if (rc != GS_OK) return rc;
+        if (ff[0] == 2) { g->d.tree = 0; g->fell_back = true; g_last_error = "a front's completion flag did not arrive in time: the handle now uses one launch per level"; }
+        else g_last_error = ff[0] == 3 ? "another rank met a zero pivot (g2o: optimize() returns 0, the vertices keep the last good iterate)" : "zero pivot: H is singular (g2o: optimize() returns 0, the vertices keep the last good iterate)";
+        return 0; }
+    return ff[1];
 }
 // which vertex estimates this rank tracks (its own subtrees + the shared top), insertion order; a vertex is
 // `primary` on exactly one rank (shared vertices: rank 0), so summing primary-masked estimates over ranks merges them

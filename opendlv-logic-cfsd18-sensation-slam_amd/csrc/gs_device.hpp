@@ -6,7 +6,7 @@
 //   pose p at idx = (s / T)*(T*N) + T*p + (s % T):
 //                                       ell_l[L] (landmark, -1 = empty) | ell_z [2][L] | ell_w [3][L] (xx xy yy)
 //   odometry edges, insertion order  :  pp_zinv [E][5] (x y theta cos sin of z^-1) | pp_info [E][6]
-//                                       ppinc [Q][4] {edge, role, i, j} per (pose, edge) incidence, grouped by pose
+//                                       ppinc [Q][2] {edge, other endpoint | role << 31} per (pose, edge) incidence, grouped by pose
 //   estimates                        :  pose_est [N][3], lm_est [M][2]           (AoS, gathered)
 //   block-sparse H and b (A6/A7 out) :  Hpl [6][L] | Hpp_off [9][Epp] | Hpp_diag [6][N] (xx xy xt yy yt tt)
 //                                       b_pose [3][N] | Hll_diag [3][M] (00 01 11) | b_lm [2][M]
@@ -37,15 +37,16 @@ struct DevGraph {
     int32_t *ell_l = nullptr; double *ell_z = nullptr, *ell_w = nullptr;
     // odometry edges; the measurement is stored inverted (g2o keeps _inverseMeasurement) with its cos/sin
     double *pp_zinv = nullptr, *pp_info = nullptr;              // zinv [E][5], info [E][6]
-    int32_t *ppinc = nullptr, *ppadj_start = nullptr;           // incidence records, pose -> incidence range
+    int32_t *ppinc = nullptr, *ppadj_start = nullptr;           // incidence records [Q][2] {edge, other endpoint | role << 31}, pose -> incidence range
     // landmark -> ELL indices of its edges (gather kernels)
     int32_t *lm_start = nullptr, *lm_edges = nullptr;
     // fused-kernel wave tiles
     int32_t n_wtiles = 0, n_groups = 0;
     int32_t *wt_desc = nullptr;                                 // [WT][4] first group, #groups, first position, #positions
-    int32_t *grp_pos_start = nullptr, *grp_slot = nullptr, *lm_grp_start = nullptr;
+    int32_t *grp_tab = nullptr, *lm_grp_start = nullptr;        // [groups][2] {first | end << 16 of the group's tile-local positions, partial-sum slot}; landmark -> its run of slots
     uint16_t *ell_dst = nullptr;        // per ELL entry: LDS position (group-sorted order inside its wave tile), 0xFFFF = padding
-    double *lm_part = nullptr;                                  // [5][n_groups] per-(wave tile, landmark) partial sums
+    double *lm_part = nullptr;                                  // [n_groups][8] per-(wave tile, landmark) partial sums {H00 H01 H11 b0 b1 - - -}: one 64-byte line per record,
+                                                                // written by one wave instruction, read as one line by the front that sums the landmark's run of slots
     // block-sparse H and b (A6/A7 output), SoA
     double *Hpp_diag = nullptr, *Hll_diag = nullptr, *Hpp_off = nullptr, *Hpl = nullptr, *b_pose = nullptr, *b_lm = nullptr;
     double *chi2_partial = nullptr; int32_t n_chi2_partial = 0; double *chi2 = nullptr;     // chi2[0] = last value
@@ -104,7 +105,8 @@ void launch_linearize_finalize(const DevGraph &d, hipStream_t st);   // H_ll, b_
 void launch_chi2_only(const DevGraph &d, hipStream_t st);
 // mode: 0 own front, 1 contribution of this rank to a shared front (-> exchange), 2 shared front from the exchange
 void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f, int mode, hipStream_t st);
-void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int leaf_max_f, int count, int n_block, hipStream_t st);   // variant 3: leaf level + every level above, two launches
+void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int leaf_max_f, int count, int n_block, int sub_first, int n_sub, hipStream_t st);   // variant 3: leaf level (+ the bottom subtrees: a level-1 front with its leaves per workgroup) + every level above
+size_t factor_sub_lds_bytes(int leaf_slot);                                  // LDS of one workgroup of k_factor3_sub
 void launch_factor_tree_top(const DevGraph &d, int first, int count, hipStream_t st);           // shared top of a sharded graph (mode TOP)
 void launch_backsolve_tree(const DevGraph &d, int first, int count, int max_npiv, int max_f, hipStream_t st);
 void launch_backsolve_level(const DevGraph &d, int level_off, int count, int max_npiv, int max_nbnd, hipStream_t st);
@@ -116,9 +118,13 @@ void launch_cone_to_global(int n, const double *poses, const int32_t *pose_of_ob
 void launch_associate(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar,
                       int n_map, const double *map_xy, const int32_t *map_type, double thr, double type_tol,
                       int32_t *out, hipStream_t st);
-void launch_associate_grid(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar,
-                           const double *map_xy, const int32_t *map_type, double thr, double type_tol, double minx, double miny,
-                           double inv_cell, int nx, int ny, const int32_t *cell_start, const int32_t *cell_items, int32_t *out, hipStream_t st);
+// batched A1 with the grid built on the device (no host pass over the map, no host round trip): launch_grid_build fills gp (grid_params_bytes()),
+// start / items (count, cursor: scratch of max_cells + 1 ints each); start / stop: events attached to the query kernel's dispatch
+void launch_grid_build(int n_map, const double *map_xy, double thr, long long max_cells, void *gp, int32_t *count, int32_t *start, int32_t *cursor, int32_t *items, hipStream_t st);
+void launch_associate_grid_dev(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar, int n_map, const double *map_xy,
+                               const int32_t *map_type, double thr, double type_tol, const void *gp, const int32_t *cell_start, const int32_t *cell_items,
+                               int32_t *out, hipStream_t st, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+size_t grid_params_bytes();
 // structure phase on the device: expand the block assembly records into scalar / landmark records (k_build_sc3)
 struct Sc3Args { int64_t off[8]; int64_t L; int32_t N, M, Epp, fused;
                  int64_t toff[6]; int32_t tcapN, tcapEpp, tcapEpl, tcapM; };   // tail blocks (grow_plan): arena offsets of t_Hpp_diag, t_b_pose, t_Hpp_off, t_Hpl, t_Hll_diag, t_b_lm; plane strides
@@ -135,7 +141,7 @@ void launch_frame_frontend(int k, const double *in, double lidar, int n_map, con
 // list != nullptr: only the level positions list[0 .. nq) (growth)
 void launch_build_f3(int nq, const int32_t *lf, const DevFront *fronts, const int32_t *children, const int32_t *child_map,
                      const int32_t *u3_off, const int32_t *u3_size, const int32_t *bf, const int32_t *xrow_off, const int64_t *x_off,
-                     int32_t *f3_desc, int32_t *f3_x, int x_stride, hipStream_t st, const int32_t *list = nullptr);
+                     int32_t *f3_desc, int32_t *f3_x, int x_stride, hipStream_t st, const int32_t *list = nullptr, const int32_t *pos_of = nullptr);   // pos_of: front -> level position (into the children's headers)
 // plans that hold a front of more than 63 scalars: table-driven whole-tree launches (workgroup -> {level position, kind | count << 8})
 void launch_factor_tab(const DevGraph &d, const int2 *wgt, int n_wg, int leaf_launch_preceded, size_t lds_bytes, int cls, hipStream_t st);      // cls: 0 fronts of 64-79, 1 small fronts + 80-111, 2 fronts of 112-159
 void launch_backsolve_tab(const DevGraph &d, const int2 *wgt, int n_wg, int max_npiv_small, int max_f_small, size_t lds_bytes, int cls, hipStream_t st);   // cls: 0 small fronts (a wave each), 1 big fronts

@@ -111,6 +111,7 @@ struct Plan {
     // multi-GPU
     int32_t world = 1, rank = 0;
     int32_t n_shared_fronts = 0;            // fronts with owner == -1
+    bool dist = false;                      // the iteration runs in two halves around an all-reduce of the exchange buffer: world > 1, or world 1 with a forced shared top
     int64_t exchange_doubles = 0;           // dense (f+1) x f slots of all shared fronts: the all-reduced buffer
     std::vector<int32_t> pl_rank, pp_rank;  // insertion order: the rank that evaluates the edge
     std::vector<uint8_t> pose_known, lm_known;   // this rank tracks the vertex's estimate (own subtree or shared top)
@@ -152,7 +153,8 @@ struct PlanOptions { int leaf_poses = 8; int world = 1; int rank = 0; int ell_la
                                                        // cones per frame, off below (there binary splits of wave fronts beat a workgroup front: lap-sized graphs 1.1 vs 1.9-2.6 ms per optimize(10))
                      int grow_headroom = 6;            // scalars a cluster front stays below the 63 of a wave: room for the boundary rows of two appended poses (grow_plan)
                      int grow_spine_headroom = 18;     // the same for the cluster front that holds the LAST pose: appended keyframes continue the track there (six poses)
-                     bool timing = false; };           // per-phase wall times on stderr (gs_debug_options.plan_timing)  // the same for the cluster front that holds the LAST pose: appended keyframes continue the track there (six poses)
+                     bool timing = false;              // per-phase wall times on stderr (gs_debug_options.plan_timing)
+                     int force_shared_top = 0; };      // world 1: treat the top k levels as the shared top of a sharded graph (gs_debug_options.force_shared_top)
 
 constexpr int LIN_R = 4;               // observation slots per lane handled by the fused linearisation kernel
 

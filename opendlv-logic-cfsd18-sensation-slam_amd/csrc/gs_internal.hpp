@@ -40,9 +40,12 @@ struct gs_graph {
     int leaf_max_f = 0;                     // largest leaf front (<= 47: the three-tile-row leaf instance)
     int block_n = -1;                       // trailing level positions of the whole-tree factor launch that get a workgroup each (-1: not decided yet)
     int leaf_n = -1, leaf_slot = 0;             // level-0 fronts handled by the leaf instance of the factor kernel, its LDS slot (doubles per wave)
+    int sub_n = 0, sub_first = 0, sub_free = 0; // bottom subtrees (k_factor3_sub): level-1 fronts [sub_first, sub_first + sub_n) each take the leaves below them; the leaf launch covers [0, sub_free)
+    int32_t *d_posof = nullptr;                 // device: front -> level position
     double ms_structure = 0;
     int rank = 0, world = 1;
     double *exchange = nullptr; bool exchange_external = false;   // caller-provided exchange buffer (e.g. a torch tensor)
+    void *comm = nullptr; bool own_comm = false; int comm_world = 0;   // RCCL communicator of gs_dist_iterate / gs_dist_optimize (ncclComm_t; own: created by gs_dist_comm_init)
     bool force_gather = false;              // cfg.linearize_gather
     // front end (A0 / A1): nothing is allocated or freed per call
     struct FrontEnd {
@@ -52,6 +55,8 @@ struct gs_graph {
         double *map_xy = nullptr; int32_t *map_type = nullptr;  // the resident association map (mirror of Slam::m_map), grow-only
         int map_n = 0, map_cap = 0;
         char *pin_map = nullptr; size_t pin_map_bytes = 0; bool pin_map_busy = false;   // pinned staging of map appends (busy: a copy out of it may be in flight)
+        char *grid_mem = nullptr; size_t grid_bytes = 0;        // the resident map's uniform grid, built on the device (gs_associate_resident): parameters, cell starts, items
+        bool grid_valid = false; int grid_map_n = 0; double grid_thr = 0.0; long long grid_max_cells = 0;
     } fe;
     int default_factor_variant = 0;         // see upload_graph
     // plans that hold a front of more than 63 scalars: table-driven whole-tree launches (workgroup -> {level position, kind | count << 8}),

@@ -25,6 +25,7 @@
 namespace gs {
 
 static constexpr int WAVE = 64;
+static constexpr int LM_REC = 8;       // doubles per (wave tile, landmark) partial-sum record: {H00, H01, H11, b0, b1, -, -, -} = one 64-byte line (gs_device.hpp: lm_part)
 // GS_G2O_ORDER (default 1): the edge residuals in g2o's operation order (inverse, then compose) without fused
 // multiply-adds; 0 = differences first (fewer rounding errors, but not the reference's numbers) — A/B builds only
 #ifndef GS_G2O_ORDER
@@ -116,34 +117,118 @@ __global__ void __launch_bounds__(256) k_associate(int n, const double *__restri
     if (live) out[i] = found;
 }
 
-// The same association against a uniform grid over the map (cell edge >= threshold, built by the caller: cones of a
-// cell listed in ascending map index): only the 3 x 3 cells around the query can hold a cone within the threshold,
-// and the LOWEST matching index over them is the reference's first match in insertion order.  Same pair test, same
-// arithmetic as k_associate => identical indices; O(n) instead of O(n * n_map).
-__global__ void __launch_bounds__(256) k_associate_grid(int n, const double *__restrict__ poses,
-        const int32_t *__restrict__ pose_of_obs, const double *__restrict__ obs, double lidar,
-        const double *__restrict__ map_xy, const int32_t *__restrict__ map_type, double thr, double type_tol,
-        double minx, double miny, double inv_cell, int nx, int ny, const int32_t *__restrict__ cell_start,
-        const int32_t *__restrict__ cell_items, int32_t *__restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// ---- batched A1 with the grid built ON THE DEVICE (round 4): bounds + cell size (k_grid_params), cones per cell (k_grid_count, integer
+// atomics: the counts do not depend on the order), exclusive scan (k_grid_scan), fill (k_grid_fill: the order inside a cell is whatever
+// the atomics give — the query takes the LOWEST matching index over the 3 x 3 cells, which does not depend on it), then the queries
+// (k_associate_grid_dev: grid parameters read from device memory, so no host round trip anywhere).  Same pair test, same arithmetic as
+// k_associate => identical indices.  gp = {minx, miny, inv_cell, nx, ny, ok}: ok = 0 (a non-finite map coordinate) -> the whole map is scanned.
+struct GridParams { double minx, miny, inv_cell; int nx, ny, ok, pad; };
+__global__ void __launch_bounds__(1024) k_grid_params(int n_map, const double *__restrict__ map_xy, double thr, long long max_cells, GridParams *__restrict__ gp) {
+    __shared__ double red[4][16]; __shared__ int bad[16];
+    double mnx = 1e300, mny = 1e300, mxx = -1e300, mxy = -1e300; int nf = 0;
+    for (int j = threadIdx.x; j < n_map; j += 1024) { const double x = map_xy[2 * j], y = map_xy[2 * j + 1];
+        if (!(isfinite(x) && isfinite(y))) { nf = 1; continue; }
+        mnx = fmin(mnx, x); mxx = fmax(mxx, x); mny = fmin(mny, y); mxy = fmax(mxy, y); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { mnx = fmin(mnx, __shfl_down(mnx, off, WAVE)); mny = fmin(mny, __shfl_down(mny, off, WAVE));
+        mxx = fmax(mxx, __shfl_down(mxx, off, WAVE)); mxy = fmax(mxy, __shfl_down(mxy, off, WAVE)); nf |= __shfl_down(nf, off, WAVE); }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = mnx; red[1][w] = mny; red[2][w] = mxx; red[3][w] = mxy; bad[w] = nf; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k) { mnx = fmin(mnx, red[0][k]); mny = fmin(mny, red[1][k]); mxx = fmax(mxx, red[2][k]); mxy = fmax(mxy, red[3][k]); nf |= bad[k]; }
+        // cell edge a hair above the threshold (every cone within the threshold sits in the 3 x 3 cells around the query); a sparse map
+        // (cones along a 25 km line) gets coarser cells, not millions of empty ones
+        double cell = thr * (1.0 + 1e-9); long long nx = 1, ny = 1;
+        if (!nf && n_map > 0) for (;;) { nx = (long long)floor((mxx - mnx) / cell) + 1; ny = (long long)floor((mxy - mny) / cell) + 1;
+            if (nx * ny <= max_cells) break;
+            cell *= 1.5; }
+        gp->minx = mnx; gp->miny = mny; gp->inv_cell = 1.0 / cell; gp->nx = (int)nx; gp->ny = (int)ny; gp->ok = (!nf && n_map > 0) ? 1 : 0; gp->pad = 0;
+    }
+}
+__device__ __forceinline__ int grid_cell_of(const GridParams &g, double x, double y) {
+    long long cx = (long long)floor((x - g.minx) * g.inv_cell), cy = (long long)floor((y - g.miny) * g.inv_cell);
+    cx = min(max(cx, 0LL), (long long)g.nx - 1); cy = min(max(cy, 0LL), (long long)g.ny - 1);
+    return (int)(cy * g.nx + cx);
+}
+__global__ void __launch_bounds__(256) k_grid_count(int n_map, const double *__restrict__ map_xy, const GridParams *__restrict__ gp, int32_t *__restrict__ count) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const GridParams g = *gp;
+    if (j >= n_map || !g.ok) return;
+    atomicAdd(count + grid_cell_of(g, map_xy[2 * j], map_xy[2 * j + 1]), 1);
+}
+// exclusive scan of count[0 .. nx * ny) into start[0 .. nx * ny], one workgroup (the grid has at most max(4096, 8 n_map) cells)
+__global__ void __launch_bounds__(1024) k_grid_scan(const GridParams *__restrict__ gp, const int32_t *__restrict__ count, int32_t *__restrict__ start) {
+    __shared__ int wsum[16]; __shared__ int carry_s;
+    const GridParams g = *gp;
+    const int n = g.ok ? g.nx * g.ny : 0, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid; const int v = i < n ? count[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off, WAVE); if (lane >= off) x += y; }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        int pre = carry_s;
+        for (int k = 0; k < w; ++k) pre += wsum[k];
+        if (i < n) start[i] = pre + x - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = pre + x;
+        __syncthreads();
+    }
+    if (tid == 0) start[n] = carry_s;
+}
+__global__ void __launch_bounds__(256) k_grid_fill(int n_map, const double *__restrict__ map_xy, const GridParams *__restrict__ gp, const int32_t *__restrict__ start,
+                                                   int32_t *__restrict__ cursor, int32_t *__restrict__ items) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const GridParams g = *gp;
+    if (j >= n_map || !g.ok) return;
+    const int c = grid_cell_of(g, map_xy[2 * j], map_xy[2 * j + 1]);
+    items[start[c] + atomicAdd(cursor + c, 1)] = j;
+}
+__global__ void __launch_bounds__(256) k_associate_grid_dev(int n, const double *__restrict__ poses, const int32_t *__restrict__ pose_of_obs,
+        const double *__restrict__ obs, double lidar, int n_map, const double *__restrict__ map_xy, const int32_t *__restrict__ map_type, double thr, double type_tol,
+        const GridParams *__restrict__ gp, const int32_t *__restrict__ cell_start, const int32_t *__restrict__ cell_items, int32_t *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    double gx, gy; cone_to_global(poses + 3 * pose_of_obs[i], obs + 4 * i, lidar, gx, gy);
-    const double ty = obs[4 * i + 3];
+    const GridParams g = *gp;                                          // (uniform: scalar loads)
+    const double4 o4 = reinterpret_cast<const double4 *>(obs)[i];      // the observation's 32 bytes in one load (az, zen, dist, type)
+    const double ob[4] = {o4.x, o4.y, o4.z, o4.w};
+    double gx, gy; cone_to_global(poses + 3 * pose_of_obs[i], ob, lidar, gx, gy);
+    const double ty = ob[3];
     int found = 0x7fffffff;
-    const double fx = (gx - minx) * inv_cell, fy = (gy - miny) * inv_cell;
-    if (fx >= -1.0 && fx < (double)nx + 1.0 && fy >= -1.0 && fy < (double)ny + 1.0) {       // false for NaN (azimuth 0)
-        const int cx = (int)floor(fx), cy = (int)floor(fy);
-        for (int dy = -1; dy <= 1; ++dy) { const int y = cy + dy; if (y < 0 || y >= ny) continue;
-            for (int dx = -1; dx <= 1; ++dx) { const int x = cx + dx; if (x < 0 || x >= nx) continue;
-                const int c = y * nx + x;
-                for (int q = cell_start[c]; q < cell_start[c + 1]; ++q) { const int j = cell_items[q];
-                    if (j >= found) break;                          // ascending inside a cell
-                    if (fabs((double)map_type[j] - ty) < type_tol) {
-                        const double ddx = map_xy[2 * j] - gx, ddy = map_xy[2 * j + 1] - gy;
-                        if (sqrt(ddx * ddx + ddy * ddy) < thr) { found = j; break; } } } } }
+    auto test = [&](int j) {
+        if (j < found && fabs((double)map_type[j] - ty) < type_tol) {
+            const double ddx = map_xy[2 * j] - gx, ddy = map_xy[2 * j + 1] - gy;
+            if (sqrt(ddx * ddx + ddy * ddy) < thr) found = j; } };
+    if (!g.ok) { for (int j = 0; j < n_map && found == 0x7fffffff; ++j) test(j); }      // degenerate map (a non-finite coordinate): insertion-order scan
+    else {
+        const double fx = (gx - g.minx) * g.inv_cell, fy = (gy - g.miny) * g.inv_cell;
+        if (fx >= -1.0 && fx < (double)g.nx + 1.0 && fy >= -1.0 && fy < (double)g.ny + 1.0) {       // false for NaN (azimuth 0)
+            const int cx = (int)floor(fx), cy = (int)floor(fy);
+            for (int dy = -1; dy <= 1; ++dy) { const int y = cy + dy; if (y < 0 || y >= g.ny) continue;
+                const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);      // the three cells of a row are adjacent: one run of items
+                if (x0 > x1) continue;
+                for (int q = cell_start[y * g.nx + x0]; q < cell_start[y * g.nx + x1 + 1]; ++q) test(cell_items[q]); } }
     }
     out[i] = found == 0x7fffffff ? -1 : found;
 }
+void launch_grid_build(int n_map, const double *map_xy, double thr, long long max_cells, void *gp, int32_t *count, int32_t *start, int32_t *cursor, int32_t *items, hipStream_t st) {
+    hipMemsetAsync(count, 0, (size_t)(max_cells + 1) * sizeof(int32_t), st); hipMemsetAsync(cursor, 0, (size_t)(max_cells + 1) * sizeof(int32_t), st);
+    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(1024), 0, st, n_map, map_xy, thr, max_cells, (GridParams *)gp);
+    if (n_map > 0) hipLaunchKernelGGL(k_grid_count, dim3((n_map + 255) / 256), dim3(256), 0, st, n_map, map_xy, (const GridParams *)gp, count);
+    hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, st, (const GridParams *)gp, count, start);
+    if (n_map > 0) hipLaunchKernelGGL(k_grid_fill, dim3((n_map + 255) / 256), dim3(256), 0, st, n_map, map_xy, (const GridParams *)gp, start, cursor, items);
+}
+void launch_associate_grid_dev(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar, int n_map, const double *map_xy,
+                               const int32_t *map_type, double thr, double type_tol, const void *gp, const int32_t *cell_start, const int32_t *cell_items,
+                               int32_t *out, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
+    if (n > 0) hipExtLaunchKernelGGL(k_associate_grid_dev, dim3((n + 255) / 256), dim3(256), 0, st, start, stop, 0, n, poses, pose_of_obs, obs, lidar, n_map, map_xy, map_type,
+                                     thr, type_tol, (const GridParams *)gp, cell_start, cell_items, out);
+}
+size_t grid_params_bytes() { return sizeof(GridParams); }
 
 // One keyframe's front end in ONE launch (A0 + A1 fused): workgroup i takes observation i of the frame — polar -> CoG-frame
 // XY (the edge measurement), -> global XY (the association query) — and its 256 threads scan the resident map for the
@@ -312,11 +397,14 @@ __device__ __forceinline__ double pp_incidence(const DevGraph &d, int k, int rol
     }
     return chi;
 }
-// the same with the operands fetched here (q = index of the incidence record)
+// the same with the operands fetched here.  An incidence record is 8 bytes: {edge (-1: another shard evaluates it), other endpoint | role << 31}
+// (role 0: the pose that holds the record is the edge's i endpoint, 1: its j endpoint) — the pose itself is known to whoever walks its
+// records (16-byte {edge, role, i, j} records until round 3: 32 of the pass's ~150 excess bytes per pose)
 template <bool WRITE_H>
-__device__ __forceinline__ double pp_incidence_rec(const DevGraph &d, const int4 inc, double H[6], double b[3], int own_pose = -1, double own_c = 1.0, double own_s = 0.0) {
-    const int k = inc.x, i = inc.z, j = inc.w;                                   // {edge, role, i, j}
+__device__ __forceinline__ double pp_incidence_rec(const DevGraph &d, const int2 inc, int p, double H[6], double b[3], bool have_cs = false, double own_c = 1.0, double own_s = 0.0) {
+    const int k = inc.x, role = (int)((uint32_t)inc.y >> 31), other = inc.y & 0x7fffffff;
     if (k < 0) return 0.0;                                                       // evaluated by another shard
+    const int i = role ? other : p, j = role ? p : other;
     double xi[3], xj[3], z5[5], w[6];
 #pragma unroll
     for (int t = 0; t < 3; ++t) { xi[t] = d.pose_est[3 * i + t]; xj[t] = d.pose_est[3 * j + t]; }
@@ -325,16 +413,21 @@ __device__ __forceinline__ double pp_incidence_rec(const DevGraph &d, const int4
 #pragma unroll
     for (int t = 0; t < 6; ++t) w[t] = d.pp_info[6 * (int64_t)k + t];
     double si, ci;
-    if (i == own_pose) { si = own_s; ci = own_c; }
-    else if (own_pose >= 0) { const double2 t2 = reinterpret_cast<const double2 *>(d.pose_cs)[i]; ci = t2.x; si = t2.y; }   // fused kernel: cached
+    if (have_cs && i == p) { si = own_s; ci = own_c; }
+    else if (have_cs) { const double2 t2 = reinterpret_cast<const double2 *>(d.pose_cs)[i]; ci = t2.x; si = t2.y; }   // fused kernel: cached
     else sincos(xi[2], &si, &ci);
-    return pp_incidence<WRITE_H>(d, k, inc.y, xi, xj, ci, si, z5, w, d.pose_fixed[i], d.pose_fixed[j], H, b);
+    return pp_incidence<WRITE_H>(d, k, role, xi, xj, ci, si, z5, w, d.pose_fixed[i], d.pose_fixed[j], H, b);
 }
 template <bool WRITE_H>
-__device__ __forceinline__ double pp_incidence_q(const DevGraph &d, int q, double H[6], double b[3], int own_pose = -1, double own_c = 1.0, double own_s = 0.0) {
-    return pp_incidence_rec<WRITE_H>(d, reinterpret_cast<const int4 *>(d.ppinc)[q], H, b, own_pose, own_c, own_s);
+__device__ __forceinline__ double pp_incidence_q(const DevGraph &d, int q, int p, double H[6], double b[3], bool have_cs = false, double own_c = 1.0, double own_s = 0.0) {
+    return pp_incidence_rec<WRITE_H>(d, reinterpret_cast<const int2 *>(d.ppinc)[q], p, H, b, have_cs, own_c, own_s);
 }
 
+// one partial-sum record (64-byte aligned line): two 16-byte loads and one 8-byte load instead of five scattered 8-byte ones
+__device__ __forceinline__ void lm_rec_load(const double *lm_part, int64_t slot, double (&v)[5]) {
+    const double2 *r = reinterpret_cast<const double2 *>(lm_part + slot * LM_REC);
+    const double2 a = r[0], b = r[1]; v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = lm_part[slot * LM_REC + 4];
+}
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -389,7 +482,7 @@ __global__ void __launch_bounds__(256) k_linearize_pose_gather(DevGraph d) {
                 for (int k = 0; k < 6; ++k) d.Hpl[k * L + e] = both ? q.W6[k] : 0.0;
             }
         }
-        for (int q = d.ppadj_start[p]; q < d.ppadj_start[p + 1]; ++q) chi += pp_incidence_q<WRITE_H>(d, q, H, b);
+        for (int q = d.ppadj_start[p]; q < d.ppadj_start[p + 1]; ++q) chi += pp_incidence_q<WRITE_H>(d, q, p, H, b);
         if (WRITE_H) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) d.Hpp_diag[(int64_t)k * d.N + p] = fp ? 0.0 : H[k];
@@ -489,6 +582,11 @@ template <class Tp> __device__ __forceinline__ void st_off_wt(Tp *base, uint32_t
 #ifndef LIN_TS
 #define LIN_TS 0
 #endif
+// LIN_ABL (tuning builds only, results are WRONG): pieces of the pass switched off to attribute its HBM traffic and time — bit 0 no odometry
+// incidences, bit 1 no landmark gathers, bit 2 no H_pl stores, bit 3 no landmark-group phase (scripts/r4_b.sh)
+#ifndef LIN_ABL
+#define LIN_ABL 0
+#endif
 #if LIN_TS
 #define LTS(i) do { if (ts_k >= 0 && lane == 0) d.dbg_ts[40 + 8 * ts_k + (i)] = wall_clock64(); } while (0)
 #else
@@ -532,13 +630,14 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
     Slots e0; load_slots(0, e0);
     // ---- second round trip: what needs a loaded index — first odometry incidence, landmark-sum item descriptors (and,
     // inside the chunk, the landmark estimates of slots 0-1)
-    int4 inc0 = make_int4(-1, 0, 0, 0);                           // this lane's first odometry incidence, fetched now, used after the edges
-    if (q0 + h < q1) inc0 = reinterpret_cast<const int4 *>(d.ppinc)[q0 + h];
-    const int g0 = wd.x, ng = wd.y, pos_off = wd.z, nitems = ng * 5;
+    int2 inc0 = make_int2(-1, 0);                                 // this lane's first odometry incidence, fetched now, used after the edges
+    if (q0 + h < q1) inc0 = reinterpret_cast<const int2 *>(d.ppinc)[q0 + h];
+    const int g0 = wd.x, ng = wd.y, nitems = ng * 5;
     int it_s[2] = {0, 0}, it_e[2] = {0, 0}, it_slot[2] = {0, 0};
 #pragma unroll
     for (int u = 0; u < 2; ++u) { const int item = lane + 64 * u;
-        if (item < nitems) { const int gl = item % ng; it_s[u] = d.grp_pos_start[g0 + gl] - pos_off; it_e[u] = d.grp_pos_start[g0 + gl + 1] - pos_off; it_slot[u] = d.grp_slot[g0 + gl]; } }
+        if (item < nitems) { const int2 gt = reinterpret_cast<const int2 *>(d.grp_tab)[g0 + item % ng];      // {first | end << 16 (tile-local positions), partial-sum slot}: one 8-byte load
+            it_s[u] = gt.x & 0xffff; it_e[u] = gt.x >> 16; it_slot[u] = gt.y; } }
     // ---- observation edges, two slots at a time: loads of both slots, both landmark gathers, then the arithmetic.
     // (All four slots at once need ~170 VGPRs = 3 waves per SIMD, and 100k poses are 3125 waves for 3072 slots: a
     // second round for 53 waves.  Two at a time fit 128 VGPRs = 4 waves per SIMD: one round, and the other three
@@ -548,7 +647,13 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
         double lx[2], ly[2]; bool fl[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) { lx[j] = ly[j] = 0.0; fl[j] = true;
-            if (e.l[j] >= 0) { lx[j] = d.lm_est[2 * e.l[j]]; ly[j] = d.lm_est[2 * e.l[j] + 1]; fl[j] = d.lm_fixed[e.l[j]]; } }
+            if (e.l[j] >= 0) {
+#if LIN_ABL & 2
+                lx[j] = 1.0; ly[j] = 2.0; fl[j] = false;
+#else
+                lx[j] = d.lm_est[2 * e.l[j]]; ly[j] = d.lm_est[2 * e.l[j] + 1]; fl[j] = d.lm_fixed[e.l[j]];
+#endif
+            } }
 #pragma unroll
         for (int j = 0; j < 2; ++j) { const int i = c + j;
             double hl0 = 0, hl1 = 0, hl2 = 0, bl0 = 0, bl1 = 0;
@@ -558,8 +663,10 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
                 quad_pl(px, py, cs, sn, lx[j], ly[j], e.zx[j], e.zy[j], e.w00[j], e.w01[j], e.w11[j], q);
                 if (!(fp && fl[j])) chi += q.chi;
                 const bool both = !fp && !fl[j];
+#if !(LIN_ABL & 4)
 #pragma unroll
                 for (int k = 0; k < 6; ++k) ST_S(d.Hpl + k * L, o, both ? q.W6[k] : 0.0);
+#endif
 #pragma unroll
                 for (int k = 0; k < 6; ++k) H[k] += q.Hp[k];
 #pragma unroll
@@ -576,8 +683,10 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
     if (R > 2) { Slots e1; load_slots(2, e1); do_slots(2, e1); }     // uniform (prefetching these under slots 0-1: measured, no change)
     LTS(3);
     // ---- odometry incidences: lane h takes incidences q0+h, q0+h+T, ... of its pose
-    if (q0 + h < q1) chi += pp_incidence_rec<true>(d, inc0, H, b, p, cs, sn);
-    for (int q = q0 + h + T; q < q1; q += T) chi += pp_incidence_q<true>(d, q, H, b, p, cs, sn);
+#if !(LIN_ABL & 1)
+    if (q0 + h < q1) chi += pp_incidence_rec<true>(d, inc0, p, H, b, true, cs, sn);
+    for (int q = q0 + h + T; q < q1; q += T) chi += pp_incidence_q<true>(d, q, p, H, b, true, cs, sn);
+#endif
     LTS(4);
     // ---- pose sums: xor-shuffle over the T lanes of the pose, then each lane stores its share of the 9 components
 #pragma unroll
@@ -601,6 +710,9 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
     LTS(5);
     // ---- landmark groups of this wave tile (wave-private LDS region; same-wave LDS accesses are ordered)
     wave_lds_sync();
+#if LIN_ABL & 8
+    if (lane == 0) d.chi2_partial[wt] = chi + s_lc[wave][0][0]; return;
+#endif
 #pragma unroll
     for (int u = 0; u < 2; ++u) { const int item = lane + 64 * u;
         if (item < nitems) { const int comp = item / ng;
@@ -609,11 +721,12 @@ __global__ void __launch_bounds__(256, LIN_WAVES_PER_SIMD) k_linearize_ell(DevGr
             for (int q = it_s[u]; q < e; q += 4) {                 // four LDS reads in flight, added in position order
                 const double a0 = col[q], a1 = col[min(q + 1, e - 1)], a2 = col[min(q + 2, e - 1)], a3 = col[min(q + 3, e - 1)];
                 sum += a0; sum += (q + 1 < e) ? a1 : 0.0; sum += (q + 2 < e) ? a2 : 0.0; sum += (q + 3 < e) ? a3 : 0.0; }
-            ST_O(d.lm_part + (int64_t)comp * d.n_groups + it_slot[u], sum); } }
+            ST_O(d.lm_part + (int64_t)it_slot[u] * LM_REC + comp, sum); } }
     for (int item = lane + 128; item < nitems; item += 64) { const int comp = item / ng, gl = item % ng;
         double sum = 0.0;
-        for (int q = d.grp_pos_start[g0 + gl] - pos_off; q < d.grp_pos_start[g0 + gl + 1] - pos_off; ++q) sum += s_lc[wave][comp][q];
-        d.lm_part[(int64_t)comp * d.n_groups + d.grp_slot[g0 + gl]] = sum; }
+        const int2 gt = reinterpret_cast<const int2 *>(d.grp_tab)[g0 + gl];
+        for (int q = gt.x & 0xffff; q < (gt.x >> 16); ++q) sum += s_lc[wave][comp][q];
+        d.lm_part[(int64_t)gt.y * LM_REC + comp] = sum; }
     chi = wave_sum(chi);
     if (lane == 0) d.chi2_partial[wt] = chi;
     LTS(6);
@@ -629,7 +742,7 @@ __global__ void __launch_bounds__(256) k_linearize_finalize(DevGraph d, int n_pa
         if (!d.lm_fixed[l]) {
             for (int q = d.lm_grp_start[l]; q < d.lm_grp_start[l + 1]; ++q) {
 #pragma unroll
-                for (int k = 0; k < 5; ++k) a[k] += d.lm_part[(int64_t)k * d.n_groups + q]; }
+                for (int k = 0; k < 5; ++k) a[k] += d.lm_part[(int64_t)q * LM_REC + k]; }
         }
         d.Hll_diag[l] = a[0]; d.Hll_diag[(int64_t)d.M + l] = a[1]; d.Hll_diag[2 * (int64_t)d.M + l] = a[2];
         d.b_lm[l] = a[3]; d.b_lm[(int64_t)d.M + l] = a[4];
@@ -721,9 +834,9 @@ __global__ void __launch_bounds__(256) k_linearize_tail(DevGraph d) {
             for (int k = 0; k < 5; ++k) a[k] += s_l[k][e]; }
         if (l >= d.M) { const int o = l - d.M; const int64_t S = d.tcapM;
             d.t_Hll_diag[o] = a[0]; d.t_Hll_diag[S + o] = a[1]; d.t_Hll_diag[2 * S + o] = a[2]; d.t_b_lm[o] = a[3]; d.t_b_lm[S + o] = a[4]; }
-        else { const int64_t G = d.n_groups; const int slot = d.lm_grp_start[l];
+        else { const int slot = d.lm_grp_start[l];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) d.lm_part[k * G + slot] += a[k]; }
+            for (int k = 0; k < 5; ++k) d.lm_part[(int64_t)slot * LM_REC + k] += a[k]; }
     }
     __syncthreads();
     double chi = 0.0;
@@ -797,7 +910,7 @@ __device__ __forceinline__ void apply_asm(const DevGraph &d, const int32_t *rec,
                 double a[5] = {0, 0, 0, 0, 0};
                 for (int q = d.lm_grp_start[src]; q < d.lm_grp_start[src + 1]; ++q) {
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) a[k] += d.lm_part[(int64_t)k * d.n_groups + q]; }
+                    for (int k = 0; k < 5; ++k) a[k] += d.lm_part[(int64_t)q * LM_REC + k]; }
                 F[(c0 + 0) * ld + r0 + 0] += a[0]; F[(c0 + 0) * ld + r0 + 1] += a[1]; F[(c0 + 1) * ld + r0 + 1] += a[2];
                 F[(c0 + 0) * ld + f] += a[3]; F[(c0 + 1) * ld + f] += a[4];
             } else {
@@ -1037,13 +1150,12 @@ __device__ __forceinline__ void asm3_load(const DevGraph &d, int kind_cnt, int s
 #pragma unroll
             for (int k = 0; k < 3; ++k) v[6 + k] = bp[k * S + i]; } break;
         case 1: {
-            if (d.n_wtiles > 0) { const int cnt = kind_cnt >> 8; const int64_t G = d.n_groups;
+            if (d.n_wtiles > 0) { const int cnt = kind_cnt >> 8;
                 for (int q0 = 0; q0 < cnt; q0 += 4) {                // four slots' loads in flight, added in slot order
                     double t[4][5];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { const int q = min(q0 + j, cnt - 1);
-#pragma unroll
-                        for (int k = 0; k < 5; ++k) t[j][k] = d.lm_part[k * G + src + q]; }
+                        lm_rec_load(d.lm_part, src + q, t[j]); }
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1395,7 +1507,41 @@ __device__ __forceinline__ void f3_block_scatter(double *img, const double *Uc, 
         const double v = ld_off_coh(Uc, (uint32_t)min(idx, usz) * 8u);
         img[idx < usz ? pl : 1] += v; }
 }
-__device__ __forceinline__ void f3_block_front(const DevGraph &d, int pos, int mode, int leaf_slot, double *smem, bool ts_on) {
+// a leaf's Schur complement (its accumulators, NT tile rows) added into its parent's LDS image: element (R, C) of the leaf front, R >= C,
+// both beyond its pivots (R = f: the rhs row), lands at rowpart(tab[R - npiv]) + colpart(tab[C - npiv]) — tab = the leaf's row table in the
+// parent (lane r' holds the place of boundary row r').  A child's places are distinct; lanes without an
+// element add 0 to image element 1 (don't care, as in the by-source gather).  The SAME values in the SAME order as a leaf that stores
+// its update matrix and a parent that gathers it: bit-identical.
+template <int NT>
+__device__ __forceinline__ void f3_sub_add(double *img, const v4d (&acc)[NT * (NT + 1) / 2], int tab, int npiv, int f, int lane) {
+    const int lc = lane & 15, lr = lane >> 4;
+    int cpart[NT], rpart[NT][4]; bool cok[NT], rok[NT][4];
+#pragma unroll
+    for (int J = 0; J < NT; ++J) { const int C = 16 * J + lc; cok[J] = C >= npiv && C < f;
+        cpart[J] = (int)((uint32_t)__shfl(tab, min(max(C - npiv, 0), 63), WAVE) >> 16); }
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int R = 16 * I + lr + 4 * q; rok[I][q] = R >= npiv && R <= f;
+            rpart[I][q] = __shfl(tab, min(max(R - npiv, 0), 63), WAVE) & 0xffff; }
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J) { const int t = mf_tile(I, J);      // a tile at a time (few registers): four reads, four writes
+            double o[4]; int pl[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const bool ok = rok[I][q] && cok[J] && (I != J || lr + 4 * q >= lc);
+                pl[q] = ok ? rpart[I][q] + cpart[J] : 1; o[q] = img[pl[q]] + (ok ? (double)acc[t][q] : 0.0); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) img[pl[q]] = o[q]; }
+}
+template <bool TREE, bool LEAF, int NT, bool MERGED = false>
+__device__ __forceinline__ void f3_wave_front(const DevGraph &d, int pos, int mode, int leaf_slot, double *smem, int wave, int lane, bool ts_on, bool first,
+                                              v4d (*acc_out)[NT * (NT + 1) / 2] = nullptr, int *npiv_out = nullptr, int *f_out = nullptr);
+// SUB: the front's children are LEAVES (level 0, <= 47 scalars) factorised by this workgroup's own waves, four at a time, their Schur
+// complements added into the image in list order — nothing of them goes to HBM but their L panels (k_factor3_sub)
+template <bool SUB = false, int NTL = 3>      // NTL: tile rows of the leaves (SUB)
+__device__ __forceinline__ void f3_block_front(const DevGraph &d, int pos, int mode, int leaf_slot, double *smem, bool ts_on, int sub_leaf_slot = 0) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 #define F3B_TS(i) do { if (ts_on) { __builtin_amdgcn_s_waitcnt(0); if (tid == 0) d.dbg_ts[i] = wall_clock64(); } } while (0)
     F3B_TS(0);
@@ -1406,10 +1552,12 @@ __device__ __forceinline__ void f3_block_front(const DevGraph &d, int pos, int m
     double *img = smem, *Pn = smem + MF_IMG, *Pw = smem + MF_IMG + 512 + wave * 256;
     StageT<false> P{img, f, (f + 1) | 1};
     int rc[4], own[4];                                               // (r', c') of this thread's elements of any packed matrix; their places in THIS front's image
+    auto own_places = [&]() {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { rc[k] = f3_rc_of(256 * k + tid);
-        own[k] = min(f3_img_rowpart(npiv + (rc[k] & 0xff)) + f3_img_colpart(npiv + (rc[k] >> 8)), MF_IMG - 1);
-        asm volatile("" : "+v"(own[k])); }
+        for (int k = 0; k < 4; ++k) { rc[k] = f3_rc_of(256 * k + tid);
+            own[k] = min(f3_img_rowpart(npiv + (rc[k] & 0xff)) + f3_img_colpart(npiv + (rc[k] >> 8)), MF_IMG - 1);
+            asm volatile("" : "+v"(own[k])); } };
+    if constexpr (!SUB) own_places();                                // before the wait for the children (SUB: nothing to wait for — computed behind the leaves, not kept alive across them)
     // ---- records (scalar records come in multiples of 64: a wave's 64 are all there or none)
     // mode TOP (the shared top of a sharded graph): the originals AND the contributions of the ranks' own subtrees arrive summed in
     // the front's exchange slot; only the shared children are gathered
@@ -1435,13 +1583,12 @@ __device__ __forceinline__ void f3_block_front(const DevGraph &d, int pos, int m
 #pragma unroll
         for (int u = 0; u < 2; ++u) if (256 * u + 64 * wave < nsc) val[u] = F3_LD_VAL(d.H_arena, (uint32_t)sc[u].x * 8u);
         double lv[5] = {0, 0, 0, 0, 0};
-        if (tid < nlm) { const int64_t G = d.n_groups;
+        if (tid < nlm) {
             for (int q0 = 0; q0 < lmr.x; q0 += 4) {                  // four slots' loads in flight, added in slot order
                 double t4[4][5];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { const int q = min(q0 + j, lmr.x - 1);
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) t4[j][k] = d.lm_part[k * G + lmr.y + q]; }
+                    lm_rec_load(d.lm_part, lmr.y + q, t4[j]); }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1452,10 +1599,10 @@ __device__ __forceinline__ void f3_block_front(const DevGraph &d, int pos, int m
         if (tid < nlm) { const int r0 = lmr.z, c0 = lmr.w;
             P.at(r0, c0) = lv[0]; P.at(r0 + 1, c0) = lv[1]; P.at(r0 + 1, c0 + 1) = lv[2]; P.at(f, c0) = lv[3]; P.at(f, c0 + 1) = lv[4]; }
         for (int t = 256 + tid; t < nlm; t += 256) {
-            const int4 r = reinterpret_cast<const int4 *>(d.lm3)[fr.lm_off + t]; const int64_t G = d.n_groups; double a[5] = {0, 0, 0, 0, 0};
+            const int4 r = reinterpret_cast<const int4 *>(d.lm3)[fr.lm_off + t]; double a[5] = {0, 0, 0, 0, 0};
             for (int q = 0; q < r.x; ++q)
 #pragma unroll
-                for (int k = 0; k < 5; ++k) a[k] += d.lm_part[k * G + r.y + q];
+                for (int k = 0; k < 5; ++k) a[k] += d.lm_part[(int64_t)(r.y + q) * LM_REC + k];
             P.at(r.z, r.w) = a[0]; P.at(r.z + 1, r.w) = a[1]; P.at(r.z + 1, r.w + 1) = a[2]; P.at(f, r.w) = a[3]; P.at(f, r.w + 1) = a[4]; }
         __syncthreads();
         if (fr.asm_dup > 0) {                                        // parallel edges: added one by one, in record order
@@ -1466,10 +1613,25 @@ __device__ __forceinline__ void f3_block_front(const DevGraph &d, int pos, int m
         }
     }
     F3B_TS(5);
+    if constexpr (SUB) {
+        // ---- the children are leaves of this workgroup: wave w factorises children w, w + 4, ... (the leaf instance's code, its staging slot
+        // behind the image), then the four Schur complements go into the image one after the other, in list order
+        const int32_t *xt = d.f3_x + fr.x_tab; const int XS = d.f3x_stride, XH = XS - 8;
+        for (int e0 = 0; e0 < fr.nchild; e0 += 4) {                  // (uniform over the workgroup)
+            const int e = e0 + wave; const bool has = e < fr.nchild;  // uniform per wave
+            v4d cacc[NTL * (NTL + 1) / 2]; int ctab = 0, cnp = 0, cf = 0;
+            if (has) { ctab = xt[e * XS + lane]; const int hd = xt[e * XS + XH + (lane & 7)];
+                f3_wave_front<true, true, NTL, true>(d, __builtin_amdgcn_readlane(hd, 4), FRONT_OWN, sub_leaf_slot, smem + MF_IMG, wave, lane, false, false, &cacc, &cnp, &cf); }
+            __syncthreads();
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) { if (wave == k && has) f3_sub_add<NTL>(img, cacc, ctab, cnp, cf, lane); __syncthreads(); }
+        }
+        own_places();
+    } else
     // ---- the children, by source, in list order, two at a time: places before the waits, both children's loads in flight
     // together, a barrier between two children's read-add-writes (their places overlap)
     if (fr.nchild > 0) {
-        const bool plain = fr.level == 1 && leaf_slot != 0;
+        const bool plain = leaf_slot != 0 && fr.level <= leaf_slot;   // (leaf_slot here: the highest level whose fronts have all their children in earlier launches)
         const int32_t *xt = d.f3_x + fr.x_tab;
         bool okw = true;
         for (int e = 0; e < fr.nchild; e += 2) {
@@ -1546,9 +1708,13 @@ __device__ __forceinline__ void f3_block_front(const DevGraph &d, int pos, int m
 // 6 tiles instead of 10 — a third fewer accumulator registers and spill traffic, five waves per SIMD instead of four)
 // one front on one wave (f <= 63): the body of the wave-per-front kernels.  pos = the front's level position (index of its
 // descriptor), smem = the workgroup's dynamic LDS (the wave takes slot `wave`), first = the launch's first position
-template <bool TREE, bool LEAF, int NT>
-__device__ __forceinline__ void f3_wave_front(const DevGraph &d, int pos, int mode, int leaf_slot, double *smem, int wave, int lane, bool ts_on, bool first) {
+// MERGED (leaf instance only): the leaf runs INSIDE its parent's workgroup (k_factor3_sub): its Schur complement is not stored — the
+// accumulators are handed back (acc_out, with the front's npiv and f) and the caller adds them into the parent's LDS image.
+template <bool TREE, bool LEAF, int NT, bool MERGED>
+__device__ __forceinline__ void f3_wave_front(const DevGraph &d, int pos, int mode, int leaf_slot, double *smem, int wave, int lane, bool ts_on, bool first,
+                                              v4d (*acc_out)[NT * (NT + 1) / 2], int *npiv_out, int *f_out) {
     static_assert(LEAF || NT == 4, "only the leaf instance has a three-tile-row form");
+    static_assert(!MERGED || LEAF, "only a leaf runs inside its parent's workgroup");
     constexpr int NTILE = NT * (NT + 1) / 2;
 #define F3_TS(i) do { if (ts_on) { __builtin_amdgcn_s_waitcnt(0); if (lane == 0) d.dbg_ts[i] = wall_clock64(); } } while (0)
     F3_TS(0);
@@ -1627,13 +1793,12 @@ __device__ __forceinline__ void f3_wave_front(const DevGraph &d, int pos, int mo
 #pragma unroll
         for (int u = 0; u < 8; ++u) if (64 * u < nsc) val[u] = F3_LD_VAL(d.H_arena, (uint32_t)sc[u].x * 8u);
         double lv[5] = {0, 0, 0, 0, 0};
-        if (lane < nlm) { const int64_t G = d.n_groups;
+        if (lane < nlm) {
             for (int q0 = 0; q0 < lmr.x; q0 += 4) {                  // four slots' loads in flight, added in slot order
                 double t[4][5];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { const int q = min(q0 + j, lmr.x - 1);
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) t[j][k] = d.lm_part[k * G + lmr.y + q]; }
+                    lm_rec_load(d.lm_part, lmr.y + q, t[j]); }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1644,10 +1809,10 @@ __device__ __forceinline__ void f3_wave_front(const DevGraph &d, int pos, int mo
         if (lane < nlm) { const int r0 = lmr.z, c0 = lmr.w;
             P.at(r0, c0) = lv[0]; P.at(r0 + 1, c0) = lv[1]; P.at(r0 + 1, c0 + 1) = lv[2]; P.at(f, c0) = lv[3]; P.at(f, c0 + 1) = lv[4]; }
         for (int t = 64 + lane; t < nlm; t += 64) {                  // fronts with > 64 landmark pivots (not on f <= 63 fronts; kept for safety)
-            const int4 r = reinterpret_cast<const int4 *>(d.lm3)[fr.lm_off + t]; const int64_t G = d.n_groups; double a[5] = {0, 0, 0, 0, 0};
+            const int4 r = reinterpret_cast<const int4 *>(d.lm3)[fr.lm_off + t]; double a[5] = {0, 0, 0, 0, 0};
             for (int q = 0; q < r.x; ++q)
 #pragma unroll
-                for (int k = 0; k < 5; ++k) a[k] += d.lm_part[k * G + r.y + q];
+                for (int k = 0; k < 5; ++k) a[k] += d.lm_part[(int64_t)(r.y + q) * LM_REC + k];
             P.at(r.z, r.w) = a[0]; P.at(r.z + 1, r.w) = a[1]; P.at(r.z + 1, r.w + 1) = a[2]; P.at(f, r.w) = a[3]; P.at(f, r.w + 1) = a[4]; }
         wave_lds_sync();
         if (fr.asm_dup > 0) {                                        // parallel edges: added one by one, in record order
@@ -1663,7 +1828,7 @@ __device__ __forceinline__ void f3_wave_front(const DevGraph &d, int pos, int mo
     // leaves have up to 8 children) come from the front's children table (f3_x: row table + {front, offset, size, owner} per
     // child), the next pair's while this pair is in flight.
     if constexpr (!LEAF) if (fr.nchild > 0) {
-        const bool plain = !TREE || (fr.level == 1 && leaf_slot != 0);     // children of an EARLIER launch: complete and visible — no flags to wait for
+        const bool plain = !TREE || (leaf_slot != 0 && fr.level <= leaf_slot);     // (non-leaf instances: leaf_slot = the highest level whose fronts have ALL their children in EARLIER launches — complete and visible, no flags to wait for; 0 = none)
         const int32_t *xt = d.f3_x + fr.x_tab;
         int tA = pv[0], tB = pv[1];
         int a_id = fr.c_id[0], a_uoff = fr.c_uoff[0], a_usz = fr.c_usize[0], a_own = fr.c_owner[0];
@@ -1728,6 +1893,16 @@ __device__ __forceinline__ void f3_wave_front(const DevGraph &d, int pos, int mo
     if (d.inject_iter != 0 && d.iter == d.inject_iter && pos == 0 && lane == 0) atomicMax(d.fail, d.inject_code);   // gs_debug_fail_at_iteration (fault injection for tests)
     if (bad && lane == 0) atomicMax(d.fail, 1);
     F3_TS(7);
+    if constexpr (MERGED) {                                          // the parent's workgroup takes the Schur complement from here
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) (*acc_out)[t] = acc[t];
+        *npiv_out = npiv; *f_out = f;
+#if F3_DONE_TS
+        if (lane == 0) d.done_ts[fr.s] = wall_clock64();
+#endif
+        if (lane == 0) d.done_f[fr.s] = d.epoch;
+        return;
+    }
     // ---- Schur complement out, packed: element (row, col) -> rowpart(row) + colpart(col) from the front's own table; pivot
     // rows / columns make the sum negative and the upper-triangle lanes of the diagonal tiles are forced there: the
     // unsigned min sends all of those to the spare double behind the matrix
@@ -1795,8 +1970,23 @@ __device__ __forceinline__ void f3_wave_front(const DevGraph &d, int pos, int mo
     F3_TS(8);
 }
 
+// ---- the bottom of the tree in one workgroup (round 4): a level-1 front and the leaves below it.  Before: the leaf launch wrote every
+// leaf's update matrix to HBM (45 MB at 100k poses, 0.4 GB at 1M), a kernel boundary, and 2 048 (16 384) level-1 fronts read them back
+// six at a time — 20 us of the 168 us factor phase at cfg4, 205 of 990 at cfg5.  Now workgroup b takes level-1 front b: its waves
+// factorise the leaves (the leaf instance's code), add their Schur complements into the front's LDS image in list order, and the four
+// waves factorise the front itself (the block form).  Same arithmetic, same order: bit-identical to the two-launch path.
+template <int NTL>      // tile rows of the leaves: 3 when every leaf has <= 47 scalars, else 4
+__global__ void __launch_bounds__(256, NTL == 3 ? 3 : 2) k_factor3_sub(DevGraph d, int first_pos, int count, int leaf_slot) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if ((int)blockIdx.x >= count) return;
+    f3_block_front<true, NTL>(d, first_pos + (int)blockIdx.x, FRONT_OWN, 0, smem, false, leaf_slot);
+}
+
+#ifndef F3_LEAF4_WPS
+#define F3_LEAF4_WPS 3      // waves per SIMD the four-tile-row leaf instance is compiled for
+#endif
 template <bool TREE, bool LEAF, int NT = 4>
-__global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : 3) : 2) k_factor3(DevGraph d, int level_off, int count, int mode, int leaf_slot, int n_wave_fronts) {
+__global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : F3_LEAF4_WPS) : 2) k_factor3(DevGraph d, int level_off, int count, int mode, int leaf_slot, int n_wave_fronts) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // whole-tree launches: the first n_wave_fronts level positions one wave each (four per workgroup), the rest — the upper
@@ -2036,13 +2226,12 @@ __device__ __forceinline__ void f3_big_front(const DevGraph &d, int pos, double 
           for (int u = 0; u < 4; ++u) if (base + 256 * u + tid < nsc) img[r4[u].y] = v4[u]; }
       // (with 24 cones in view a landmark is seen from ~30 wave tiles: eight slots' loads in flight, added in slot order)
       for (int t = tid; t < nlm; t += 256) {
-          const int4 r = reinterpret_cast<const int4 *>(d.lm3)[fr.lm_off + t]; const int64_t G = d.n_groups; double a[5] = {0, 0, 0, 0, 0};
+          const int4 r = reinterpret_cast<const int4 *>(d.lm3)[fr.lm_off + t]; double a[5] = {0, 0, 0, 0, 0};
           for (int q0 = 0; q0 < r.x; q0 += 8) {
               double t8[8][5];
 #pragma unroll
               for (int j = 0; j < 8; ++j) { const int q = min(q0 + j, r.x - 1);
-#pragma unroll
-                  for (int k = 0; k < 5; ++k) t8[j][k] = d.lm_part[k * G + r.y + q]; }
+                  lm_rec_load(d.lm_part, r.y + q, t8[j]); }
 #pragma unroll
               for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -2276,7 +2465,7 @@ __global__ void __launch_bounds__(256) k_build_f3(int nq, const int32_t *__restr
         const int32_t *__restrict__ children, const int32_t *__restrict__ child_map, const int32_t *__restrict__ u3_off,
         const int32_t *__restrict__ u3_size, const int32_t *__restrict__ bf /*[front][8]*/, const int32_t *__restrict__ xrow_off,
         const int64_t *__restrict__ x_off /* nullable */, int32_t *__restrict__ f3_desc, int32_t *__restrict__ f3_x, int x_stride,
-        const int32_t *__restrict__ list /* nullable: the level positions to (re)build */) {
+        const int32_t *__restrict__ list /* nullable: the level positions to (re)build */, const int32_t *__restrict__ pos_of /* nullable: front -> level position */) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 4 + wave;
     if (qi >= nq) return;
@@ -2327,13 +2516,13 @@ __global__ void __launch_bounds__(256) k_build_f3(int nq, const int32_t *__restr
                 v = (int32_t)((uint32_t)f3_img_rowpart(R) | ((uint32_t)f3_img_colpart(R) << 16)); }
             if (rp < x_stride - 8) xt[k * x_stride + rp] = v;
             if (k < 2 && r0 == 0) r[32 + 64 * k + lane] = v; }
-        if (lane < 8) xt[k * x_stride + (x_stride - 8) + lane] = lane == 0 ? c : (lane == 1 ? u3_off[c] : (lane == 2 ? u3_size[c] : (lane == 3 ? fronts[c].owner : 0)));
+        if (lane < 8) xt[k * x_stride + (x_stride - 8) + lane] = lane == 0 ? c : (lane == 1 ? u3_off[c] : (lane == 2 ? u3_size[c] : (lane == 3 ? fronts[c].owner : (lane == 4 && pos_of ? pos_of[c] : 0))));   // {front, update-matrix offset, size, owner, level position}
     }
 }
 void launch_build_f3(int nq, const int32_t *lf, const DevFront *fronts, const int32_t *children, const int32_t *child_map,
                      const int32_t *u3_off, const int32_t *u3_size, const int32_t *bf, const int32_t *xrow_off, const int64_t *x_off,
-                     int32_t *f3_desc, int32_t *f3_x, int x_stride, hipStream_t st, const int32_t *list) {
-    if (nq > 0) hipLaunchKernelGGL(k_build_f3, dim3((nq + 3) / 4), dim3(256), 0, st, nq, lf, fronts, children, child_map, u3_off, u3_size, bf, xrow_off, x_off, f3_desc, f3_x, x_stride, list);
+                     int32_t *f3_desc, int32_t *f3_x, int x_stride, hipStream_t st, const int32_t *list, const int32_t *pos_of) {
+    if (nq > 0) hipLaunchKernelGGL(k_build_f3, dim3((nq + 3) / 4), dim3(256), 0, st, nq, lf, fronts, children, child_map, u3_off, u3_size, bf, xrow_off, x_off, f3_desc, f3_x, x_stride, list, pos_of);
 }
 // growth: scattered rows of fronts / u3_off / u3_size / bf from one packed patch buffer (32 ints per front: front, DevFront as 20 ints,
 // u3_off, u3_size, bf[8], one spare)
@@ -2416,8 +2605,10 @@ void launch_build_sc3(const int32_t *bf, const int32_t *asm3, int32_t *sc3, int3
     if (n_fronts > 0) hipLaunchKernelGGL(k_build_sc3, dim3((n_fronts + 3) / 4), dim3(256), 0, st, bf, asm3, sc3, lm3, n_fronts, A, list);
 }
 
-// whole-tree launches of variant 3 (own fronts of a single-GPU graph): every level in one kernel each
-void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int leaf_max_f, int count, int n_block, hipStream_t st) {
+// whole-tree launches of variant 3 (own fronts of a single-GPU graph): the leaf instance (positions [0, n_leaf)), then — n_sub > 0 —
+// the bottom subtrees (level-1 fronts at positions [sub_first, sub_first + n_sub), each with the leaves below it, which are the
+// positions [n_leaf, sub_first) and get no launch of their own), then every level above in one flagged launch
+void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int leaf_max_f, int count, int n_block, int sub_first, int n_sub, hipStream_t st) {
     if (count <= 0) return;
     allow_max_lds((const void *)k_factor3<true, false>); allow_max_lds((const void *)k_factor3<true, true>); allow_max_lds((const void *)k_factor3<true, true, 3>);
     // level 0 (no children) through the high-occupancy leaf instance (three tile rows when every leaf has <= 47 scalars),
@@ -2425,10 +2616,16 @@ void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int leaf_m
     const int nt3 = d.leaf_nt3;                                      // gs_debug_options.leaf_nt3
     if (n_leaf > 0 && leaf_max_f <= 47 && nt3) hipLaunchKernelGGL((k_factor3<true, true, 3>), dim3((n_leaf + 3) / 4), dim3(256), (size_t)leaf_slot * 4 * sizeof(double), st, d, 0, n_leaf, FRONT_OWN, leaf_slot, 0);
     else if (n_leaf > 0) hipLaunchKernelGGL((k_factor3<true, true>), dim3((n_leaf + 3) / 4), dim3(256), (size_t)leaf_slot * 4 * sizeof(double), st, d, 0, n_leaf, FRONT_OWN, leaf_slot, 0);
+    int first = n_leaf, plain_level = n_leaf > 0 ? 1 : 0;
+    if (n_sub > 0) { allow_max_lds((const void *)k_factor3_sub<3>); allow_max_lds((const void *)k_factor3_sub<4>);
+        if (leaf_max_f <= 47 && nt3) hipLaunchKernelGGL(k_factor3_sub<3>, dim3(n_sub), dim3(256), factor_sub_lds_bytes(leaf_slot), st, d, sub_first, n_sub, leaf_slot);
+        else hipLaunchKernelGGL(k_factor3_sub<4>, dim3(n_sub), dim3(256), factor_sub_lds_bytes(leaf_slot), st, d, sub_first, n_sub, leaf_slot);
+        first = sub_first + n_sub; plain_level = 2; }
     // the last n_block level positions (whole upper levels) get a workgroup each, the others a wave each
-    if (count > n_leaf) { const int nw = count - n_leaf - n_block;
-        hipLaunchKernelGGL((k_factor3<true, false>), dim3((nw + 3) / 4 + n_block), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, n_leaf, count - n_leaf, FRONT_OWN, n_leaf > 0 ? 1 : 0, nw); }   // leaf_slot argument: a leaf launch preceded
+    if (count > first) { const int nw = count - first - n_block;
+        hipLaunchKernelGGL((k_factor3<true, false>), dim3((nw + 3) / 4 + n_block), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, first, count - first, FRONT_OWN, plain_level, nw); }   // leaf_slot argument: the highest level whose fronts have all their children in earlier launches
 }
+size_t factor_sub_lds_bytes(int leaf_slot) { return (size_t)(MF_IMG + std::max(1536, 4 * leaf_slot)) * sizeof(double); }
 // the shared top of a sharded graph (mode TOP: fronts start from the all-reduced exchange slots and gather their shared
 // children only): one flagged launch as well
 void launch_factor_tree_top(const DevGraph &d, int first, int count, hipStream_t st) {
@@ -2646,13 +2843,6 @@ void launch_associate(int n, const double *poses, const int32_t *pose_of_obs, co
                       int32_t *out, hipStream_t st) {
     if (n > 0) hipLaunchKernelGGL(k_associate, dim3((n + 255) / 256), dim3(256), 0, st, n, poses, pose_of_obs, obs, lidar,
                                   n_map, map_xy, map_type, thr, type_tol, out);
-}
-
-void launch_associate_grid(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar,
-                           const double *map_xy, const int32_t *map_type, double thr, double type_tol, double minx, double miny,
-                           double inv_cell, int nx, int ny, const int32_t *cell_start, const int32_t *cell_items, int32_t *out, hipStream_t st) {
-    if (n > 0) hipLaunchKernelGGL(k_associate_grid, dim3((n + 255) / 256), dim3(256), 0, st, n, poses, pose_of_obs, obs, lidar,
-                                  map_xy, map_type, thr, type_tol, minx, miny, inv_cell, nx, ny, cell_start, cell_items, out);
 }
 
 }  // namespace gs

@@ -486,10 +486,35 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
             plan.x_off[s] = plan.exchange_doubles; plan.exchange_doubles += (f + 1) * f; }
         plan.exchange_doubles += 2;                // tail: [0] the ranks' failure flags (summed by the same all-reduce), [1] spare
     }
-    // ---- wave tiles of the fused A5-A7 kernel: one wave = 64/T consecutive poses.  Per wave tile the distinct
-    // landmarks it touches ("groups") with the wave-local positions (slot*64 + lane) of their edges.  Partial-sum
-    // slots are ordered by (landmark, wave tile): the finalize pass reads one contiguous run per landmark and the
-    // summation order is fixed => bitwise reproducible without atomics.
+    else if (opt.force_shared_top > 0 && nlev > 1) {
+        // gs_debug_options.force_shared_top (world 1 only): the top k levels are treated like the shared top of a sharded graph — this
+        // rank's contribution goes to the exchange buffer, the caller (or gs_dist_iterate: RCCL) all-reduces it over a group of one, the
+        // top is then factorised from the buffer — so that the whole collective path runs with a NON-EMPTY exchange buffer on one GPU.
+        // Upward closed: a parent's level exceeds its children's.
+        const int k = std::min(opt.force_shared_top, nlev - 1);
+        for (int s = 0; s < S; ++s) plan.fronts[s].owner = plan.fronts[s].level >= nlev - k ? -1 : 0;
+        plan.level_start_owned.assign(nlev + 1, 0); plan.level_fronts_owned.clear(); plan.level_fronts_shared.clear();
+        for (int l = 0; l < nlev; ++l) {
+            for (int q = plan.level_start[l]; q < plan.level_start[l + 1]; ++q) { const int s = plan.level_fronts[q];
+                if (plan.fronts[s].owner < 0) plan.level_fronts_shared.push_back(s); else plan.level_fronts_owned.push_back(s); }
+            plan.level_start_owned[l + 1] = (int32_t)plan.level_fronts_owned.size();
+            plan.level_start_shared[l + 1] = (int32_t)plan.level_fronts_shared.size(); }
+        plan.n_shared_fronts = (int32_t)plan.level_fronts_shared.size();
+        plan.x_off.assign(S, -1);
+        for (int s = 0; s < S; ++s) if (plan.fronts[s].owner < 0) { const Front &F = plan.fronts[s]; const int64_t f = F.npiv + F.nbnd;
+            plan.x_off[s] = plan.exchange_doubles; plan.exchange_doubles += (f + 1) * f; }
+        plan.exchange_doubles += 2;
+    }
+    plan.dist = plan.world > 1 || plan.n_shared_fronts > 0;
+    // ---- the bottom subtrees (k_factor3_sub: a level-1 front and the leaves below it in one workgroup): this rank's level-0 fronts in two
+    // runs — first the leaves whose parent sits higher up (or belongs to somebody else): they keep the leaf launch —, then the leaves
+    // under this rank's level-1 fronts, which get no launch of their own.  Stable, plans without wave-only fronts keep their class order.
+    if (plan.max_front <= 63 && nlev >= 2) {
+        auto under_l1 = [&](int s) { const int P = plan.fronts[s].parent; return P >= 0 && plan.fronts[P].level == 1 && plan.fronts[P].owner == plan.fronts[s].owner && !plan.fronts[P].opaque; };
+        std::stable_partition(plan.level_fronts_owned.begin() + plan.level_start_owned[0], plan.level_fronts_owned.begin() + plan.level_start_owned[1],
+                              [&](int s) { return !under_l1(s); });
+        if (!plan.dist) plan.level_fronts = plan.level_fronts_owned;
+    }
     // ---- device layout of the observation edges: ELL, T lanes per pose, over the poses THIS RANK SWEEPS ------------------
     // (after the shard assignment: a rank lays out, uploads and linearises the pose range [ell_p0, ell_p0 + ell_np) that holds its
     // edges — its window plus the boundary poses of the shared top — and nothing of the other windows: 1 / world of the edge
@@ -626,7 +651,7 @@ bool grow_plan(const HostGraph &g, Plan &P, Growth &out, std::string &why) {
     out = Growth();
     auto no = [&](const char *m) { why = m; return false; };
     if (!P.valid) return no("no plan");
-    if (P.world > 1) return no("sharded plan");
+    if (P.dist) return no("sharded plan");
     if (!P.lin_ell_ok || P.max_front > 159) return no("plan outside the matrix-core forms");
     if (g.reshape_version != P.reshape_version) return no("a fixed flag changed (or the graph was cleared)");
     const int N0 = P.planned_N, N1 = g.n_poses(), M0 = P.planned_M, M1 = g.n_lms(), Epp0 = P.planned_Epp, Epp1 = g.n_pp(), Epl0 = P.planned_Epl, Epl1 = g.n_pl();

@@ -119,6 +119,49 @@ def test_association_grid_equals_brute_force_equals_oracle(G, frontend, bench_gr
     assert ref[7] == -1 and ref[11] == -1 and (ref >= 0).mean() > 0.9
 
 
+def test_association_with_everything_resident_builds_its_grid_on_the_device(pkg, frontend, bench_graphs):
+    """gs_associate_resident (round 4): the map lives in HBM (gs_map_append), poses / observations / result are the caller's device
+    arrays, the uniform grid is built ON THE DEVICE (bounds, count, scan, fill: no host pass over the map), nothing waits.  Bit-exact
+    against the oracle's insertion-order scan with the decoys of the host-pointer test (wrong colours on top of real cones, same-colour
+    duplicates later in the map, far queries, an azimuth-0 NaN query); the grid follows the map (append, set_xy) and the threshold."""
+    t, g = bench_graphs(10000, 2000)
+    Np, K = len(t["odom_poses"]), t["K"]
+    obs = t["obs"].reshape(-1, 4).copy(); po_ = np.repeat(np.arange(Np, dtype=np.int32), K)
+    base = t["cone_xy"][g["map_true_id"]]
+    map_xy = np.concatenate([base, base[:50] + 0.05, base[100:150] + [0.3, -0.2], [[1e4, 1e4], [-1e4, 3.0]]])
+    map_type = np.concatenate([g["lm_type"], (g["lm_type"][:50] % 4) + 1, g["lm_type"][100:150], [1, 2]]).astype(np.int32)
+    obs[7, 0] = 0.0; obs[11, 2] = 5e3
+    DA = pkg.binding.DeviceArray
+    G = pkg.Graph()
+    n = len(obs)
+    d_p, d_po, d_ob, d_out = DA(t["truth_poses"]), DA(po_), DA(obs), DA(nbytes=4 * n)
+    first = len(base)
+    G.map_append(map_xy[:first], map_type[:first])
+    G.associate_resident(d_p, Np, d_po, d_ob, n, 1.2, d_out); G.synchronize()
+    assert np.array_equal(d_out.to_host(np.int32, n), frontend.associate(t["truth_poses"], po_, obs, map_xy[:first], map_type[:first], 1.2))
+    G.map_append(map_xy[first:], map_type[first:])              # the map grew: the grid is rebuilt on the next call
+    G.associate_resident(d_p, Np, d_po, d_ob, n, 1.2, d_out); G.synchronize()
+    ref = frontend.associate(t["truth_poses"], po_, obs, map_xy, map_type, 1.2)
+    got = d_out.to_host(np.int32, n)
+    assert np.array_equal(got, ref) and ref[7] == -1 and ref[11] == -1 and (ref >= 0).mean() > 0.9
+    assert np.array_equal(got, G.associate(t["truth_poses"], po_, obs, map_xy, map_type, 1.2))      # = the host-pointer entry point
+    G.associate_resident(d_p, Np, d_po, d_ob, n, 3.0, d_out); G.synchronize()                      # another threshold: another grid
+    assert np.array_equal(d_out.to_host(np.int32, n), frontend.associate(t["truth_poses"], po_, obs, map_xy, map_type, 3.0))
+    moved = map_xy.copy(); moved[:200] += [0.9, 0.0]
+    G.map_set_xy(0, moved)                                       # updateMap rewrites positions (src/slam.cpp:713-732)
+    G.associate_resident(d_p, Np, d_po, d_ob, n, 1.2, d_out); G.synchronize()
+    assert np.array_equal(d_out.to_host(np.int32, n), frontend.associate(t["truth_poses"], po_, obs, moved, map_type, 1.2))
+    G.set_debug(assoc_grid=0)                                    # the brute-force kernel on the same resident data
+    G.associate_resident(d_p, Np, d_po, d_ob, n, 1.2, d_out); G.synchronize()
+    assert np.array_equal(d_out.to_host(np.int32, n), frontend.associate(t["truth_poses"], po_, obs, moved, map_type, 1.2))
+    G.set_debug(assoc_grid=-1)
+    ms = G.time_associate_resident(d_p, Np, d_po, d_ob, n, 1.2, d_out, 5)     # events attached to the query kernel's dispatch
+    assert 0 < ms < 5.0
+    for a in (d_p, d_po, d_ob, d_out):
+        a.free()
+    G.close()
+
+
 # ---------------------------------------------------------------- A5-A7
 @pytest.mark.parametrize("N,M", [(50, 30), (1000, 200)])
 def test_linearize_blocks_match_oracle(pkg, po, bench_graphs, N, M):
@@ -433,19 +476,24 @@ def test_factor_kernel_variants_match_oracle(pkg, po, bench_graphs, variant):
 
 @pytest.mark.parametrize("env", [dict(tree=0), dict(leaf_kernel=0), dict(tree=0, factor_variant=3),
                                  dict(block_fronts=0), dict(block_fronts=16), dict(leaf_kernel=2),
-                                 dict(leaf_kernel=2, block_fronts=0), dict(small_tree=0), dict(small_tree=1 << 20)])
+                                 dict(leaf_kernel=2, block_fronts=0), dict(small_tree=0), dict(small_tree=1 << 20),
+                                 dict(leaf_kernel=2, subtree=0), dict(leaf_kernel=2, subtree=1, block_fronts=0)])
 def test_solver_launch_modes_give_the_same_answer(pkg, po, bench_graphs, env):
     """The default solver runs one flagged launch for all levels above the leaves plus leaf-instance launches; the
     same kernels also run one launch per level (gs_debug_options.tree = 0, what the shared top of a sharded graph uses) and without
     the leaf instances (leaf_kernel = 0; the default below 2 049 leaves, 2 forces them).  The upper levels of the whole-tree launch give a front four waves instead of
     one (levels of at most block_fronts fronts; at this size the default puts every level above the leaves there, 0
     none, 16 the top five).  small_tree: the whole optimize() call as one persistent launch (off / forced at this size).
+    subtree: a level-1 front and the leaves below it in one workgroup (k_factor3_sub; needs the leaf launches: leaf_kernel = 2 here), off = the
+    leaf launch writes the leaves' update matrices to HBM and the flagged launch reads them back.
     Every mode must agree with the oracle and, bit for bit, with the default."""
     _, g = bench_graphs(10000, 2000)
     og = make_oracle_graph(po, g); og.optimize(4, ordering=1)
     A = fresh(pkg, g); A.optimize(4)
     B = fresh(pkg, g, debug=env); done, st = B.optimize(4)
     assert done == 4 and st.numeric_failure == 0
+    if env.get("leaf_kernel") == 2:                              # the bottom subtrees (a level-1 front + its leaves per workgroup) run exactly when asked for
+        assert (B.stats().n_subtrees > 0) == (env.get("subtree", 0) != 0), (env, B.stats().n_subtrees)
     assert rel(B.poses(), og.poses()) < 1e-9 and rel(B.landmarks(), og.landmarks()) < 1e-9
     assert np.array_equal(A.poses(), B.poses()) and np.array_equal(A.landmarks(), B.landmarks())     # same arithmetic, same order
     A.close(); B.close()
@@ -654,7 +702,13 @@ def test_cfg4_properties(pkg, frontend):
     rmse_truth = np.sqrt(((G.poses()[:, :2] - t["truth_poses"][:, :2]) ** 2).sum(1).mean())
     assert rmse_truth < 100.0                                   # the 25 km lap stays near the truth (ML uncertainty ~25 m)
     assert np.array_equal(G.poses()[:2], g["pose_est"][:2])
-    G.close()
+    # the bottom of the tree in one workgroup (opt-in: 12 288 leaves under 2 048 level-1 fronts here) against the default two-launch path:
+    # same arithmetic in the same order, bit for bit
+    assert G.stats().n_subtrees == 0
+    H = fresh(pkg, g, debug=dict(subtree=1)); done, _ = H.optimize(11)
+    assert done == 11 and H.stats().n_subtrees > 1000
+    assert np.array_equal(H.poses(), G.poses()) and np.array_equal(H.landmarks(), G.landmarks())
+    G.close(); H.close()
 
 
 # ---------------------------------------------------------------- config 5: 1M poses / 50k cones, 8 pose windows
@@ -861,6 +915,46 @@ def test_cfg5_single_handle_properties_and_eight_pose_windows(pkg, po, frontend)
     except OSError:
         pass
     assert not failures, failures
+
+
+# ---------------------------------------------------------------- the all-reduce inside the library: RCCL from C++, a non-empty exchange buffer on ONE GPU
+def test_rccl_all_reduce_inside_the_library_on_a_forced_shared_top(pkg, po, bench_graphs):
+    """SURVEY 8(e) / north_star "Host stays C++ ... RCCL all-reduce over xGMI on the shared-landmark rows": gs_dist_iterate enqueues local
+    half -> ncclAllReduce(sum, fp64) of the exchange buffer -> shared top + solve + update, all from C++ on the handle's stream.  A group of
+    one rank has no shared fronts, so gs_debug_options.force_shared_top = 3 makes the top three levels of the tree a shared top (7 fronts):
+    this rank's contributions go to the exchange buffer, RCCL (communicator of one rank, created inside the library from a
+    ncclGetUniqueId it hands out) reduces the NON-EMPTY buffer on hardware, the top is factorised from it.  Against the oracle, against
+    the plain single-GPU handle, and gs_dist_optimize (Slam's optimize(10) on a sharded graph) against the step-by-step loop bit for bit."""
+    _, g = bench_graphs(10000, 2000)
+    og = make_oracle_graph(po, g); og.optimize(4, ordering=1)
+    A = fresh(pkg, g); A.optimize(4)
+    G = fresh(pkg, g, debug=dict(force_shared_top=3)); G.initialize_optimization()
+    st = G.stats()
+    assert st.n_shared_fronts == 7 and st.n_own_fronts + 7 == st.n_fronts and G.dist_exchange_doubles() > 7 * 20
+    with pytest.raises(pkg.GsError):
+        G.iterate()                                              # a sharded graph refuses the single-GPU entry point
+    with pytest.raises(pkg.GsError):
+        G.dist_iterate()                                         # ... and gs_dist_iterate without a communicator
+    G.dist_comm_init(pkg.binding.dist_unique_id(), 0, 1)
+    for _ in range(4):
+        assert G.dist_iterate() == 1
+    G.sync_estimates()
+    x = G.dist_read_exchange()
+    assert np.isfinite(x).all() and np.abs(x[:-2]).max() > 0 and x[-2] == 0.0       # the reduced slots hold the shared fronts; nobody reported a failure
+    assert rel(G.poses(), og.poses()) < 1e-9 and rel(G.landmarks(), og.landmarks()) < 1e-9
+    assert rel(G.poses(), A.poses()) < 1e-11 and rel(G.landmarks(), A.landmarks()) < 1e-11
+    H = fresh(pkg, g, debug=dict(force_shared_top=3)); H.dist_comm_init(pkg.binding.dist_unique_id(), 0, 1)
+    done, sth = H.dist_optimize(4)
+    assert done == 4 and sth.numeric_failure == 0 and sth.n_shared_fronts == 7
+    assert np.array_equal(H.poses(), G.poses()) and np.array_equal(H.landmarks(), G.landmarks())
+    # g2o's failure rule through the collective path: a zero pivot injected into iteration 2 of 4 -> 0 returned, one update applied
+    F = fresh(pkg, g, debug=dict(force_shared_top=3)); F.dist_comm_init(pkg.binding.dist_unique_id(), 0, 1)
+    F.initialize_optimization(); F.debug_fail_at_iteration(2, 1)
+    done, stf = F.dist_optimize(4)
+    assert done == 0 and stf.iterations == 1 and stf.numeric_failure in (1, 3)      # (3: the flag came back through the all-reduce as well)
+    og1 = make_oracle_graph(po, g); og1.optimize(1, ordering=1)
+    assert rel(F.poses(), og1.poses()) < 1e-8                    # one iteration = one increment: the increment tolerance of this file's header
+    A.close(); G.close(); H.close(); F.close()
 
 
 # ---------------------------------------------------------------- the multi-GPU launch path: RCCL, torch side stream, device exchange buffer
