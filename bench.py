@@ -95,6 +95,30 @@ def linearize_roofline_of(pkg, name, device, reps=10):
                 iteration_ms=ph.ms_total, iterations_per_s=1e3 / ph.ms_total)
 
 
+def association_roofline(pkg, np, track, g, device, reps=20):
+    """Batched A1 with everything resident (gs_associate_resident, reference loop src/slam.cpp:570-607 over ALL keyframes at once): the
+    map in HBM with its grid built on the device, poses / observations / result in device memory; the query kernel's own begin -> end
+    from HIP events attached to its dispatch (gs_debug_time_associate_resident).  Algorithmic bytes: SURVEY 8(d), N K 36 + N 24 + M 20."""
+    DA = pkg.binding.DeviceArray
+    N, K = len(track["odom_poses"]), track["K"]
+    obs = np.ascontiguousarray(track["obs"].reshape(-1, 4)); po_ = np.repeat(np.arange(N, dtype=np.int32), K)
+    mxy, mty = np.ascontiguousarray(g["lm_est"]), g["lm_type"].astype(np.int32)
+    G = pkg.Graph(device=device); G.map_append(mxy, mty)
+    n = len(obs)
+    d_p, d_po, d_ob, d_out = DA(track["odom_poses"]), DA(po_), DA(obs), DA(nbytes=4 * n)      # (the map was built from these poses: track.bench_graph)
+    t0 = time.perf_counter(); G.associate_resident(d_p, N, d_po, d_ob, n, 1.2, d_out); G.synchronize(); first_ms = (time.perf_counter() - t0) * 1e3
+    ms = G.time_associate_resident(d_p, N, d_po, d_ob, n, 1.2, d_out, reps)
+    idx = d_out.to_host(np.int32, n)
+    for a in (d_p, d_po, d_ob, d_out):
+        a.free()
+    G.close()
+    B = n * 36 + N * 24 + len(mxy) * 20
+    return dict(kernel="k_associate_grid_dev: cone -> global + first match in map order over the 3 x 3 grid cells (A0 + A1, batched)", observations=int(n), map_cones=int(len(mxy)),
+                algorithmic_bytes=int(B), ms_per_launch=ms, achieved=B / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, bound="hbm",
+                matched_fraction=float((idx >= 0).mean()), first_call_ms_with_grid_build=first_ms,
+                note="everything resident in HBM (map, poses, observations, result); grid built on the device once per map change; HIP events attached to the kernel's dispatch, mean of %d launches" % reps)
+
+
 def frame_latency(pkg, np):
     """Per-keyframe latency of the real-time path (reference loop: src/slam.cpp:570-607, budgets of 20 ms gathering / 500 ms
     keyframe period in usecase/docker-compose.yml:16): A0 + A1 of ONE frame of K = 16 cones against a resident map of 200
@@ -196,21 +220,23 @@ def main():
     fe = pkg.Graph(device=local)
     g = pkg.track.bench_graph(track, fe)           # A0 on the device
     fe.close()
-    G = pkg.Graph(device=local)
+    # the multi-GPU branch at world size 1 (GS_BENCH_FORCE_DIST): the top three levels of the tree are made a SHARED top
+    # (gs_debug_options.force_shared_top), so that the exchange buffer the group of one all-reduces is not empty
+    dbg = dict(force_shared_top=3) if (dist_mode and world == 1) else None
+    G = pkg.Graph(device=local, debug=dbg)
     G.load_bench_graph(g)
-    stream = None
+    def library_communicator(H):
+        # RCCL INSIDE the library (north_star: the host side stays C++): rank 0 makes the unique id (ncclGetUniqueId through the C-ABI),
+        # torch.distributed only carries its 128 bytes to the other ranks, every rank calls ncclCommInitRank through the C-ABI
+        box = [pkg.binding.dist_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        H.dist_comm_init(box[0], rank, world)
     if dist_mode:
         G.dist_configure(rank, world)
-        stream = torch.cuda.Stream()               # kernels and the RCCL all-reduce are ordered on ONE stream
-        G.set_stream(stream.cuda_stream)
     G.initialize_optimization()                    # structure phase (iteration-0 work): plan + upload to HBM
     plan = G.stats()
-    xbuf = None
-    if dist_mode:
-        if backend != "gloo":
-            xbuf = torch.zeros(max(G.dist_exchange_doubles(), 1), dtype=torch.float64, device="cuda")
-            if G.dist_exchange_doubles() > 0:       # (a group of one rank has no shared fronts: nothing to hand over)
-                G.dist_set_exchange_buffer(xbuf.data_ptr())
+    if dist_mode and backend != "gloo":
+        library_communicator(G)
 
     def step():
         if not dist_mode:
@@ -221,12 +247,10 @@ def main():
             dist.all_reduce(xh, op=dist.ReduceOp.SUM)
             G.dist_write_exchange(xh.numpy()); G.dist_iterate_finish()
         else:
-            with torch.cuda.stream(stream):
-                G.dist_iterate_local()
-                dist.all_reduce(xbuf, op=dist.ReduceOp.SUM)     # shared rows of Omega / xi, fp64, over xGMI
-                G.dist_iterate_finish()
+            G.dist_iterate()                       # local half -> ncclAllReduce(sum, fp64) of the shared rows of Omega / xi over xGMI -> finish: all enqueued from C++ on the handle's stream
 
     def barrier():
+        G.synchronize()                            # the library's own stream
         if dist_mode:
             dist.barrier()
         torch.cuda.synchronize()
@@ -289,13 +313,19 @@ def main():
                                      "gauge = first 2 poses + first 2 cones" % (args.workload, world, N, M)),
                            n_poses=N, n_cones=M, n_odometry_edges=G.n_pp, n_observation_edges=G.n_pl,
                            unknowns=3 * plan.n_free_poses + 2 * plan.n_free_landmarks,
-                           parallelism=("%d pose windows, one per GPU; RCCL all-reduce of %d doubles per iteration"
-                                        % (world, G.dist_exchange_doubles())) if world > 1 else "single GPU",
+                           parallelism=("%d pose windows, one per GPU; one RCCL all-reduce (sum, fp64) of %d doubles (%d bytes) per iteration, enqueued by the library (gs_dist_iterate)"
+                                        % (world, G.dist_exchange_doubles(), 8 * G.dist_exchange_doubles())) if world > 1 else "single GPU",
                            fronts=plan.n_fronts, levels=plan.n_levels, max_front=plan.max_front),
                roofline=roofline)
+    if dist_mode and backend != "gloo":
+        # the collective alone: `reps` all-reduces of the exchange buffer back to back on the library's stream (every rank calls it)
+        out["exchange"] = dict(doubles=int(G.dist_exchange_doubles()), bytes=int(8 * G.dist_exchange_doubles()), ms_exchange=G.time_exchange(50),
+                               shared_fronts=int(plan.n_shared_fronts), own_fronts=int(plan.n_own_fronts),
+                               note="ms_exchange = one ncclAllReduce(sum, fp64) of the exchange buffer, mean of 50 back to back (HIP events on the library's stream); inside the iteration it sits between the local half and the shared top")
     if dist_mode and world == 1:
-        out["config"]["parallelism"] = "single GPU through the multi-GPU code path (GS_BENCH_FORCE_DIST): RCCL group of 1, side stream, gs_dist_iterate_local / all_reduce / gs_dist_iterate_finish"
-    if world == 1:
+        out["config"]["parallelism"] = ("single GPU through the multi-GPU code path (GS_BENCH_FORCE_DIST): RCCL group of 1 created inside the library, top 3 levels forced shared "
+                                        "(%d doubles all-reduced per iteration), gs_dist_iterate" % G.dist_exchange_doubles())
+    if world == 1 and not dist_mode:
         phases = G.time_iterations(20)
         out["phases_ms"] = dict(linearize=phases.ms_linearize, factor=phases.ms_factor, backsolve=phases.ms_backsolve,
                                 update=phases.ms_update, structure_once=plan.ms_structure)
@@ -345,8 +375,13 @@ def main():
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_baseline"] = value / cb["value"]
         # parity of what was timed: the same number of iterations from the same initial estimates
-        G2 = pkg.Graph(device=local); G2.load_bench_graph(g)
-        done, st = G2.optimize(args.cpu_iters)
+        G2 = pkg.Graph(device=local, debug=dbg); G2.load_bench_graph(g)
+        if dist_mode:                              # the same sharded arithmetic through gs_dist_optimize (Slam's optimize(10) on a sharded graph)
+            G2.dist_configure(rank, world); G2.initialize_optimization(); library_communicator(G2)
+            opt2 = G2.dist_optimize
+        else:
+            opt2 = G2.optimize
+        done, st = opt2(args.cpu_iters)
         P, Lm = G2.poses(), G2.landmarks()
         rms = float(np.sqrt((og.poses()[:, :2] ** 2).sum(1).mean()))
         out["pose_rmse_vs_oracle_rel"] = float(np.sqrt(((P[:, :2] - og.poses()[:, :2]) ** 2).sum(1).mean()) / rms)
@@ -368,7 +403,7 @@ def main():
         # gs_optimize on the second handle must reproduce its estimates bit for bit (every sum has a fixed order)
         more = args.warmup + args.steps - int(done)
         if more > 0:
-            G2.optimize(more)
+            opt2(more)
         same = bool(np.array_equal(G2.poses(), timed_poses) and np.array_equal(G2.landmarks(), timed_lms))
         out["timed_handle_bitwise_equals_optimize"] = same
         out["timed_handle_iterations"] = args.warmup + args.steps
@@ -377,6 +412,11 @@ def main():
         G2.close()
     else:
         out["cpu_baseline"] = None
+    if rank == 0 and world == 1 and not dist_mode and not args.no_extra_configs:
+        try:
+            out["association"] = association_roofline(pkg, np, track, g, local)
+        except Exception as e:                                  # an extra: never costs the bench line
+            out["association"] = dict(error=str(e))
     if rank == 0 and world == 1 and not dist_mode and not args.no_cpu and args.workload == "cfg4":
         out["frame_latency"] = frame_latency(pkg, np)
     if rank == 0 and world == 1 and not dist_mode and not args.no_extra_configs and args.workload == "cfg4":

@@ -30,7 +30,6 @@ extern "C" {
  *     f3_lds_kb       GS_F3_LDS_KB     plan  occupancy experiments: LDS per workgroup of the per-level factor launches, KB (0 = need)
  *     subtree         GS_SUBTREE       plan  1 (default): a level-1 front and the leaves below it run in ONE workgroup (k_factor3_sub: the leaves'
  *                                      update matrices stay in LDS); 0: leaf launch + flagged launch from level 1 up, as in rounds 1-3
- *     small_tree      GS_SMALL_TREE    plan  fronts up to which a whole optimize() call runs as ONE persistent launch (default 512; 0 off)
  *   plan shape — changes the elimination order, hence the last bits of the result (all are exact factorisations)
  *     leaf_poses      GS_LEAF_POSES    plan  nested-dissection leaf size in poses (0 = gs_config.leaf_poses / default 8)
  *     cluster_ways    GS_CLUSTER_WAYS  plan  fan-out of the multi-way split above the leaves (0 = default 8; 2 = binary)
@@ -55,7 +54,7 @@ extern "C" {
  * Two process-wide variables remain outside the struct: GS_THREADS (host threads of the plan build) and, Python binding only, GS_LIB. */
 typedef struct gs_debug_options {
     int32_t struct_size;
-    int32_t tree, block_fronts, leaf_kernel, leaf_min, bs_wide, leaf_nt3, f3_lds_kb, small_tree;
+    int32_t tree, block_fronts, leaf_kernel, leaf_min, bs_wide, leaf_nt3, f3_lds_kb, reserved0;
     int32_t leaf_poses, cluster_ways, ell_lanes, big_cluster, grow_headroom, factor_variant;
     int32_t grow, grow_min_poses;
     int32_t assoc_grid;
@@ -82,6 +81,9 @@ int gs_debug_fail_at_iteration(gs_graph *g, int32_t k, int32_t code);
  * start / stop event pair attached to the query kernel's dispatch (its own begin -> end, on the handle's stream); mean ms per launch. */
 int gs_debug_time_associate_resident(gs_graph *g, int32_t n, const double *dev_poses_xytheta, int32_t n_poses, const int32_t *dev_pose_of_obs,
                                      const double *dev_obs_4xn, double threshold, double type_tol, int32_t *dev_out_index, int32_t reps, double *out_ms);
+/* Measurement hook of the sharded iteration (bench.py's `ms_exchange`): `reps` RCCL all-reduces of the exchange buffer back to back on the
+ * handle's stream, HIP events around them; mean ms per all-reduce.  Collective: every rank of the communicator calls it. */
+int gs_debug_time_exchange(gs_graph *g, int32_t reps, double *out_ms);
 /* The factor-kernel variant a plan with the given largest front and H-arena size (doubles) is given for a requested variant
  * (gs_config.factor_variant; 0 = default): 3 = matrix-core LDL^T fronts with 32-bit byte offsets into the arena (a wave per front of
  * <= 63 scalars, a workgroup per front of 64 .. 159; arena < 2^29 doubles), 4 = block-per-front kernel with 64-bit addressing

@@ -67,7 +67,7 @@ class ShellMsg(C.Structure):
 class DebugOptions(C.Structure):
     """gs_debug_options (include/graphslam_debug.h): every tuning switch of a handle."""
     _fields_ = [("struct_size", C.c_int32)] + [(k, C.c_int32) for k in (
-        "tree", "block_fronts", "leaf_kernel", "leaf_min", "bs_wide", "leaf_nt3", "f3_lds_kb", "small_tree",
+        "tree", "block_fronts", "leaf_kernel", "leaf_min", "bs_wide", "leaf_nt3", "f3_lds_kb", "reserved0",
         "leaf_poses", "cluster_ways", "ell_lanes", "big_cluster", "grow_headroom", "factor_variant",
         "grow", "grow_min_poses", "assoc_grid", "force_shared_top", "host_trig", "pool_poison", "plan_timing", "dbg", "subtree")] + [("reserved", C.c_int32 * 7)]
 
@@ -181,6 +181,7 @@ def lib():
     L.gs_dist_set_communicator.argtypes = [vp, vp]
     L.gs_dist_iterate.argtypes = [vp]
     L.gs_dist_optimize.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
+    L.gs_debug_time_exchange.argtypes = [vp, C.c_int32, _dp]
     L.gs_dist_read_exchange.argtypes = [vp, _dp]
     L.gs_dist_write_exchange.argtypes = [vp, _dp]
     u8 = C.POINTER(C.c_uint8)
@@ -584,6 +585,9 @@ class Graph:
         st = Stats(); st.struct_size = C.sizeof(Stats)
         done = self._check(self.L.gs_dist_optimize(self.h, int(iterations), C.byref(st)))
         return done, st
+
+    def time_exchange(self, reps):
+        ms = C.c_double(); self._check(self.L.gs_debug_time_exchange(self.h, int(reps), C.byref(ms))); return ms.value
 
     def dist_iterate_local(self):
         self._check(self.L.gs_dist_iterate_local(self.h))

@@ -136,7 +136,7 @@ extern "C" int gs_debug_options_default(gs_debug_options *o) {
     std::memset(o, 0, sizeof(*o));
     o->struct_size = (int32_t)sizeof(*o);
     o->subtree = 0;
-    o->tree = 1; o->block_fronts = 512; o->leaf_kernel = -1; o->leaf_min = 2048; o->bs_wide = 2048; o->leaf_nt3 = 1; o->f3_lds_kb = 0; o->small_tree = 512;
+    o->tree = 1; o->block_fronts = 512; o->leaf_kernel = -1; o->leaf_min = 2048; o->bs_wide = 2048; o->leaf_nt3 = 1; o->f3_lds_kb = 0;
     o->leaf_poses = 0; o->cluster_ways = 0; o->ell_lanes = 0; o->big_cluster = -1; o->grow_headroom = -1; o->factor_variant = 0;
     o->grow = 1; o->grow_min_poses = 128;
     o->assoc_grid = -1;
@@ -149,7 +149,7 @@ static void options_from_environment(gs_debug_options &o) {
     gs_debug_options_default(&o);
     auto env = [](const char *name, int32_t &field) { if (const char *e = std::getenv(name)) field = (int32_t)std::atoi(e); };
     env("GS_TREE", o.tree); env("GS_BLOCK_FRONTS", o.block_fronts); env("GS_LEAF_KERNEL", o.leaf_kernel); env("GS_LEAF_MIN", o.leaf_min);
-    env("GS_SUBTREE", o.subtree); env("GS_BS_WIDE", o.bs_wide); env("GS_LEAF_NT3", o.leaf_nt3); env("GS_F3_LDS_KB", o.f3_lds_kb); env("GS_SMALL_TREE", o.small_tree);
+    env("GS_SUBTREE", o.subtree); env("GS_BS_WIDE", o.bs_wide); env("GS_LEAF_NT3", o.leaf_nt3); env("GS_F3_LDS_KB", o.f3_lds_kb);
     env("GS_LEAF_POSES", o.leaf_poses); env("GS_CLUSTER_WAYS", o.cluster_ways); env("GS_ELL_LANES", o.ell_lanes); env("GS_BIG_CLUSTER", o.big_cluster);
     env("GS_GROW_HEADROOM", o.grow_headroom); env("GS_FACTOR_VARIANT", o.factor_variant);
     env("GS_GROW", o.grow); env("GS_GROW_MIN_POSES", o.grow_min_poses); env("GS_ASSOC_GRID", o.assoc_grid); env("GS_FORCE_SHARED_TOP", o.force_shared_top);
@@ -167,7 +167,7 @@ extern "C" int gs_debug_set_options(gs_graph *g, const gs_debug_options *o) {
     const gs_debug_options &c = g->opt;
     // a "plan" field changed: the next structure phase is a full one (a grown plan keeps the launch shapes it was built with)
     const bool plan_changed = n.tree != c.tree || n.block_fronts != c.block_fronts || n.leaf_kernel != c.leaf_kernel || n.leaf_min != c.leaf_min ||
-        n.bs_wide != c.bs_wide || n.subtree != c.subtree || n.leaf_nt3 != c.leaf_nt3 || n.f3_lds_kb != c.f3_lds_kb || n.small_tree != c.small_tree || n.leaf_poses != c.leaf_poses ||
+        n.bs_wide != c.bs_wide || n.subtree != c.subtree || n.leaf_nt3 != c.leaf_nt3 || n.f3_lds_kb != c.f3_lds_kb || n.leaf_poses != c.leaf_poses ||
         n.cluster_ways != c.cluster_ways || n.ell_lanes != c.ell_lanes || n.big_cluster != c.big_cluster || n.grow_headroom != c.grow_headroom ||
         n.factor_variant != c.factor_variant || n.force_shared_top != c.force_shared_top || n.host_trig != c.host_trig || n.pool_poison != c.pool_poison ||
         n.dbg != c.dbg;
@@ -1789,6 +1789,20 @@ extern "C" int gs_dist_iterate(gs_graph *g) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return 1;
+}
+// measurement hook (graphslam_debug.h): `reps` all-reduces of the exchange buffer back to back on the handle's stream, HIP events around
+// them; mean milliseconds per all-reduce.  Collective: every rank of the communicator calls it.
+extern "C" int gs_debug_time_exchange(gs_graph *g, int32_t reps, double *out_ms) {
+    if (!out_ms || reps <= 0) return fail(GS_ERR_INVALID, "bad argument");
+    int rc = dist_ready(g); if (rc != GS_OK) return rc;
+    if ((rc = enqueue_allreduce(g)) != GS_OK) return rc;           // warm
+    hipEventRecord(g->ev[0], g->stream);
+    for (int r = 0; r < reps && rc == GS_OK; ++r) rc = enqueue_allreduce(g);
+    hipEventRecord(g->ev[1], g->stream);
+    HIP_TRY(hipEventSynchronize(g->ev[1]));
+    float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, g->ev[0], g->ev[1]));
+    *out_ms = (double)ms / reps;
+    return rc;
 }
 // Slam's optimize(10) (reference src/slam.cpp:481) on a sharded graph: every rank makes the same call; g2o's failure rule holds across
 // ranks (a rank's failure flag rides through the all-reduce: no rank applies the update of that iteration or any later one).  Returns the

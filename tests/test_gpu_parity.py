@@ -476,14 +476,14 @@ def test_factor_kernel_variants_match_oracle(pkg, po, bench_graphs, variant):
 
 @pytest.mark.parametrize("env", [dict(tree=0), dict(leaf_kernel=0), dict(tree=0, factor_variant=3),
                                  dict(block_fronts=0), dict(block_fronts=16), dict(leaf_kernel=2),
-                                 dict(leaf_kernel=2, block_fronts=0), dict(small_tree=0), dict(small_tree=1 << 20),
+                                 dict(leaf_kernel=2, block_fronts=0),
                                  dict(leaf_kernel=2, subtree=0), dict(leaf_kernel=2, subtree=1, block_fronts=0)])
 def test_solver_launch_modes_give_the_same_answer(pkg, po, bench_graphs, env):
     """The default solver runs one flagged launch for all levels above the leaves plus leaf-instance launches; the
     same kernels also run one launch per level (gs_debug_options.tree = 0, what the shared top of a sharded graph uses) and without
     the leaf instances (leaf_kernel = 0; the default below 2 049 leaves, 2 forces them).  The upper levels of the whole-tree launch give a front four waves instead of
     one (levels of at most block_fronts fronts; at this size the default puts every level above the leaves there, 0
-    none, 16 the top five).  small_tree: the whole optimize() call as one persistent launch (off / forced at this size).
+    none, 16 the top five).
     subtree: a level-1 front and the leaves below it in one workgroup (k_factor3_sub; needs the leaf launches: leaf_kernel = 2 here), off = the
     leaf launch writes the leaves' update matrices to HBM and the flagged launch reads them back.
     Every mode must agree with the oracle and, bit for bit, with the default."""
@@ -529,7 +529,7 @@ def test_fat_update_matrices_on_the_matrix_core_kernels(pkg, po, seed, shape):
     og = make_oracle_graph(po, g); og.build_system(); og.apply_update(og.solve_ldlt(0)); dp_o, dl_o = og.delta()
     scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
     outs = []
-    for env in ({}, dict(block_fronts=0), dict(tree=0), dict(small_tree=0)):
+    for env in ({}, dict(block_fronts=0), dict(tree=0)):
         G = fresh(pkg, g, debug=env); done, st = G.optimize(1); dp, dl = G.export_delta()
         assert st.max_front <= 63 and done == 1 and st.numeric_failure == 0, (env, st.max_front)
         assert np.abs(dp - dp_o).max() / scale < 1e-9 and np.abs(dl - dl_o).max() / scale < 1e-9, env
