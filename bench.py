@@ -113,10 +113,10 @@ def association_roofline(pkg, np, track, g, device, reps=20):
         a.free()
     G.close()
     B = n * 36 + N * 24 + len(mxy) * 20
-    return dict(kernel="k_associate_grid_dev: cone -> global + first match in map order over the 3 x 3 grid cells (A0 + A1, batched)", observations=int(n), map_cones=int(len(mxy)),
+    return dict(kernel="k_pose_trig + k_associate_grid_dev: cone -> global, then the first match in map order over the nine hashed grid cells around the query (A0 + A1, batched)", observations=int(n), map_cones=int(len(mxy)),
                 algorithmic_bytes=int(B), ms_per_launch=ms, achieved=B / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, bound="hbm",
                 matched_fraction=float((idx >= 0).mean()), first_call_ms_with_grid_build=first_ms,
-                note="everything resident in HBM (map, poses, observations, result); grid built on the device once per map change; HIP events attached to the kernel's dispatch, mean of %d launches" % reps)
+                note="everything resident in HBM (map, poses, observations, result); hashed grid built on the device once per map change; HIP start event attached to the first dispatch (cos / sin per pose), stop event to the second (the queries), mean of %d calls" % reps)
 
 
 def frame_latency(pkg, np):

@@ -289,7 +289,7 @@ int  gs_associate_batch(gs_graph *g, int32_t n, const double *poses_xytheta, int
                         int32_t n_map, const double *map_xy, const int32_t *map_type,
                         double threshold, double type_tol, int32_t *out_index);
 
-/* gs_associate_resident: the same association with EVERYTHING resident — the map of gs_map_append (below; its uniform grid is built on
+/* gs_associate_resident: the same association with EVERYTHING resident — the map of gs_map_append (below; its hashed uniform grid is built on
  *      the device, once per map change), poses, observations and the result in DEVICE memory — asynchronous on the handle's stream:
  *      nothing crosses PCIe, nothing waits (gs_stream_synchronize when the caller needs the indices).  The batched form of the loop
  *      that SURVEY 8(a) calls the dominant front-end cost at scale (src/slam.cpp:570-607). */

@@ -1448,6 +1448,7 @@ void gs_frontend_release(gs_graph *g) {      // gs_destroy
     if (g->fe.map_type) hipFree(g->fe.map_type);
     if (g->fe.pin_map) hipHostFree(g->fe.pin_map);
     if (g->fe.grid_mem) hipFree(g->fe.grid_mem);
+    if (g->fe.pcs) hipFree(g->fe.pcs);
     g->fe = gs_graph::FrontEnd();
 }
 
@@ -1482,16 +1483,16 @@ extern "C" int gs_cone_to_global_batch(gs_graph *g, int32_t n, const double *pos
     HIP_TRY(hipStreamSynchronize(g->stream));
     return GS_OK;
 }
-// the grid of a map that is in device memory: built on the device (launch_grid_build), nothing crosses PCIe, nothing waits
-struct GridBufs { void *gp; int32_t *count, *start, *cursor, *items; long long max_cells; };
-static size_t grid_bytes(int n_map, long long &max_cells) {
-    max_cells = std::max<long long>(4096, 8 * (long long)n_map);
-    return padded(grid_params_bytes(), 1) + 3 * padded((size_t)max_cells + 1, 4) + padded((size_t)n_map, 4);
+// the hashed grid of a map that is in device memory: built on the device (launch_grid_build), nothing crosses PCIe, nothing waits
+struct GridBufs { int32_t *count, *start, *cursor, *items; long long buckets; };
+static size_t grid_bytes(int n_map, long long &buckets) {
+    buckets = 4096; while (buckets < 4 * (long long)n_map) buckets <<= 1;      // a power of two >= 4 n_map: mostly empty buckets, L2-resident
+    return 3 * padded((size_t)buckets + 1, 4) + padded((size_t)n_map, 4);
 }
-static GridBufs grid_carve(char *base, int n_map, long long max_cells) {
+static GridBufs grid_carve(char *base, int n_map, long long buckets) {
     GridBufs b; size_t off = 0; auto take = [&](size_t bytes) { char *p = base + off; off += (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; return p; };
-    b.gp = take(grid_params_bytes()); b.count = (int32_t *)take(((size_t)max_cells + 1) * 4); b.start = (int32_t *)take(((size_t)max_cells + 1) * 4);
-    b.cursor = (int32_t *)take(((size_t)max_cells + 1) * 4); b.items = (int32_t *)take((size_t)n_map * 4); b.max_cells = max_cells;
+    b.count = (int32_t *)take(((size_t)buckets + 1) * 4); b.start = (int32_t *)take(((size_t)buckets + 1) * 4);
+    b.cursor = (int32_t *)take(((size_t)buckets + 1) * 4); b.items = (int32_t *)take((size_t)n_map * 4); b.buckets = buckets;
     return b;
 }
 extern "C" int gs_associate_batch(gs_graph *g, int32_t n, const double *poses, int32_t npose, const int32_t *pose_of_obs, const double *obs,
@@ -1501,15 +1502,15 @@ extern "C" int gs_associate_batch(gs_graph *g, int32_t n, const double *poses, i
     for (int i = 0; i < n; ++i) if (pose_of_obs[i] < 0 || pose_of_obs[i] >= npose) return fail(GS_ERR_INVALID, "pose_of_obs out of range");
     int rc = ensure_device(g); if (rc != GS_OK) return rc;
     if (n == 0) return GS_OK;
-    // maps beyond a few LDS tiles go through a uniform grid (cell edge a hair above the threshold, so that every cone
+    // maps beyond a few LDS tiles go through a hashed uniform grid (cell edge a hair above the threshold, so that every cone
     // within the threshold sits in the 3 x 3 cells around the query) that is BUILT ON THE DEVICE from the uploaded map; the brute-force
     // kernel stays for small maps and non-positive thresholds.  gs_debug_options.assoc_grid = 0 / 1 forces either (A/B, tests).
     bool grid = n_map >= 2048 && thr > 0.0;
     if (g->opt.assoc_grid >= 0) grid = g->opt.assoc_grid != 0 && n_map > 0 && thr > 0.0;
-    long long max_cells = 0; const size_t gbytes = grid ? grid_bytes(n_map, max_cells) + 5 * 256 : 0;
+    long long buckets = 0; const size_t gbytes = grid ? grid_bytes(n_map, buckets) + 5 * 256 : 0;
     if ((rc = arena_reserve(g, padded(3 * (size_t)npose, 8) + padded(n, 4) + padded(4 * (size_t)n, 8) + padded(2 * (size_t)n_map, 8) +
-                               padded(n_map, 4) + padded(n, 4) + gbytes)) != GS_OK) return rc;
-    Carver c{g}; double *p = c.get<double>(3 * (size_t)npose); int32_t *po = c.get<int32_t>(n);
+                               padded(n_map, 4) + padded(n, 4) + gbytes + padded(2 * (size_t)npose, 8))) != GS_OK) return rc;
+    Carver c{g}; double *p = c.get<double>(3 * (size_t)npose); int32_t *po = c.get<int32_t>(n); double *pcs = c.get<double>(2 * (size_t)npose);
     double *ob = c.get<double>(4 * (size_t)n), *mx = c.get<double>(2 * (size_t)n_map);
     int32_t *mt = c.get<int32_t>(n_map), *o = c.get<int32_t>(n);
     HIP_TRY(hipMemcpyAsync(p, poses, 3 * (size_t)npose * 8, hipMemcpyHostToDevice, g->stream));
@@ -1517,9 +1518,9 @@ extern "C" int gs_associate_batch(gs_graph *g, int32_t n, const double *poses, i
     HIP_TRY(hipMemcpyAsync(ob, obs, 4 * (size_t)n * 8, hipMemcpyHostToDevice, g->stream));
     if (n_map > 0) { HIP_TRY(hipMemcpyAsync(mx, map_xy, 2 * (size_t)n_map * 8, hipMemcpyHostToDevice, g->stream));
                      HIP_TRY(hipMemcpyAsync(mt, map_type, (size_t)n_map * 4, hipMemcpyHostToDevice, g->stream)); }
-    if (grid) { const GridBufs gb = grid_carve(c.get<char>(gbytes), n_map, max_cells);
-        launch_grid_build(n_map, mx, thr, max_cells, gb.gp, gb.count, gb.start, gb.cursor, gb.items, g->stream);
-        launch_associate_grid_dev(n, p, po, ob, g->cfg.lidar_to_cog, n_map, mx, mt, thr, type_tol, gb.gp, gb.start, gb.items, o, g->stream);
+    if (grid) { const GridBufs gb = grid_carve(c.get<char>(gbytes), n_map, buckets);
+        launch_grid_build(n_map, mx, thr, buckets, gb.count, gb.start, gb.cursor, gb.items, g->stream);
+        launch_associate_grid_dev(n, p, po, ob, g->cfg.lidar_to_cog, mx, mt, thr, type_tol, buckets, gb.start, gb.items, o, npose, pcs, g->stream);
     } else launch_associate(n, p, po, ob, g->cfg.lidar_to_cog, n_map, mx, mt, thr, type_tol, o, g->stream);
     HIP_TRY(hipMemcpyAsync(out, o, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));        // the one wait of the call: the result copy
@@ -1532,14 +1533,14 @@ extern "C" int gs_associate_batch(gs_graph *g, int32_t n, const double *poses, i
 static int resident_grid(gs_graph *g, double thr) {
     auto &fe = g->fe;
     if (fe.grid_valid && fe.grid_map_n == fe.map_n && fe.grid_thr == thr) return GS_OK;
-    long long max_cells = 0; const size_t bytes = grid_bytes(fe.map_n, max_cells) + 5 * 256;
+    long long buckets = 0; const size_t bytes = grid_bytes(fe.map_n, buckets) + 5 * 256;
     if (bytes > fe.grid_bytes) { HIP_TRY(hipStreamSynchronize(g->stream));
         if (fe.grid_mem) hipFree(fe.grid_mem);
         fe.grid_mem = nullptr; fe.grid_bytes = 0;
         HIP_TRY(hipMalloc((void **)&fe.grid_mem, bytes + bytes / 2)); fe.grid_bytes = bytes + bytes / 2; }
-    const GridBufs gb = grid_carve(fe.grid_mem, fe.map_n, max_cells);
-    launch_grid_build(fe.map_n, fe.map_xy, thr, max_cells, gb.gp, gb.count, gb.start, gb.cursor, gb.items, g->stream);
-    fe.grid_valid = true; fe.grid_map_n = fe.map_n; fe.grid_thr = thr; fe.grid_max_cells = max_cells;
+    const GridBufs gb = grid_carve(fe.grid_mem, fe.map_n, buckets);
+    launch_grid_build(fe.map_n, fe.map_xy, thr, buckets, gb.count, gb.start, gb.cursor, gb.items, g->stream);
+    fe.grid_valid = true; fe.grid_map_n = fe.map_n; fe.grid_thr = thr; fe.grid_max_cells = buckets;
     return GS_OK;
 }
 extern "C" int gs_associate_resident(gs_graph *g, int32_t n, const double *dev_poses, int32_t npose, const int32_t *dev_pose_of_obs, const double *dev_obs,
@@ -1550,9 +1551,14 @@ extern "C" int gs_associate_resident(gs_graph *g, int32_t n, const double *dev_p
     auto &fe = g->fe;
     const bool grid = thr > 0.0 && fe.map_n > 0 && g->opt.assoc_grid != 0;
     if (grid) { if ((rc = resident_grid(g, thr)) != GS_OK) return rc;
+        if ((size_t)npose * 2 * sizeof(double) > fe.pcs_bytes) { HIP_TRY(hipStreamSynchronize(g->stream));      // scratch for the poses' cos / sin, grow-only
+            if (fe.pcs) hipFree(fe.pcs);
+            fe.pcs = nullptr; fe.pcs_bytes = 0;
+            const size_t want = (size_t)npose * 2 * sizeof(double) * 3 / 2 + 4096;
+            HIP_TRY(hipMalloc((void **)&fe.pcs, want)); fe.pcs_bytes = want; }
         const GridBufs gb = grid_carve(fe.grid_mem, fe.map_n, fe.grid_max_cells);
-        launch_associate_grid_dev(n, dev_poses, dev_pose_of_obs, dev_obs, g->cfg.lidar_to_cog, fe.map_n, fe.map_xy, fe.map_type, thr, type_tol, gb.gp, gb.start, gb.items, dev_out, g->stream,
-                                  g->ev_lin[0], g->ev_lin[1]);
+        launch_associate_grid_dev(n, dev_poses, dev_pose_of_obs, dev_obs, g->cfg.lidar_to_cog, fe.map_xy, fe.map_type, thr, type_tol, gb.buckets, gb.start, gb.items, dev_out,
+                                  npose, fe.pcs, g->stream, g->ev_lin[0], g->ev_lin[1]);
     } else launch_associate(n, dev_poses, dev_pose_of_obs, dev_obs, g->cfg.lidar_to_cog, fe.map_n, fe.map_xy, fe.map_type, thr, type_tol, dev_out, g->stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("association: ") + hipGetErrorString(e));

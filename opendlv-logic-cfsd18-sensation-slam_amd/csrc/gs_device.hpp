@@ -118,13 +118,12 @@ void launch_cone_to_global(int n, const double *poses, const int32_t *pose_of_ob
 void launch_associate(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar,
                       int n_map, const double *map_xy, const int32_t *map_type, double thr, double type_tol,
                       int32_t *out, hipStream_t st);
-// batched A1 with the grid built on the device (no host pass over the map, no host round trip): launch_grid_build fills gp (grid_params_bytes()),
-// start / items (count, cursor: scratch of max_cells + 1 ints each); start / stop: events attached to the query kernel's dispatch
-void launch_grid_build(int n_map, const double *map_xy, double thr, long long max_cells, void *gp, int32_t *count, int32_t *start, int32_t *cursor, int32_t *items, hipStream_t st);
-void launch_associate_grid_dev(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar, int n_map, const double *map_xy,
-                               const int32_t *map_type, double thr, double type_tol, const void *gp, const int32_t *cell_start, const int32_t *cell_items,
-                               int32_t *out, hipStream_t st, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
-size_t grid_params_bytes();
+// batched A1 with a hashed uniform grid built on the device (no host pass over the map, no host round trip): buckets = a power of two,
+// count / start / cursor: buckets + 1 ints each, items: n_map ints; start / stop: events attached to the first / last dispatch of the query
+void launch_grid_build(int n_map, const double *map_xy, double thr, long long buckets, int32_t *count, int32_t *start, int32_t *cursor, int32_t *items, hipStream_t st);
+void launch_associate_grid_dev(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar, const double *map_xy,
+                               const int32_t *map_type, double thr, double type_tol, long long buckets, const int32_t *cell_start, const int32_t *cell_items,
+                               int32_t *out, int n_poses, double *pose_cs_scratch /* [n_poses][2] */, hipStream_t st, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 // structure phase on the device: expand the block assembly records into scalar / landmark records (k_build_sc3)
 struct Sc3Args { int64_t off[8]; int64_t L; int32_t N, M, Epp, fused;
                  int64_t toff[6]; int32_t tcapN, tcapEpp, tcapEpl, tcapM; };   // tail blocks (grow_plan): arena offsets of t_Hpp_diag, t_b_pose, t_Hpp_off, t_Hpl, t_Hll_diag, t_b_lm; plane strides

@@ -57,6 +57,7 @@ struct gs_graph {
         char *pin_map = nullptr; size_t pin_map_bytes = 0; bool pin_map_busy = false;   // pinned staging of map appends (busy: a copy out of it may be in flight)
         char *grid_mem = nullptr; size_t grid_bytes = 0;        // the resident map's uniform grid, built on the device (gs_associate_resident): parameters, cell starts, items
         bool grid_valid = false; int grid_map_n = 0; double grid_thr = 0.0; long long grid_max_cells = 0;
+        double *pcs = nullptr; size_t pcs_bytes = 0;            // cos / sin of the poses of a batched association (scratch, grow-only)
     } fe;
     int default_factor_variant = 0;         // see upload_graph
     // plans that hold a front of more than 63 scalars: table-driven whole-tree launches (workgroup -> {level position, kind | count << 8}),

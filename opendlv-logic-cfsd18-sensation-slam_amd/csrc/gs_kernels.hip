@@ -54,13 +54,15 @@ __device__ __forceinline__ void polar_to_xy(double az, double zen, double dist, 
     // transformConeToCoG: sign is NaN at az == 0 (kept)
     double sign = az / fabs(az);
     double ang = kPiF - fabs(az * kDeg2Rad);
-    double dnew = sqrt(lidar * lidar + dist * dist - 2.0 * lidar * dist * cos(ang));
-    double anew = asin((sin(ang) * dist) / dnew) * kRad2Deg;
+    double sa, ca; sincos(ang, &sa, &ca);                           // (one range reduction for the pair: the batched association is bound by these calls)
+    double dnew = sqrt(lidar * lidar + dist * dist - 2.0 * lidar * dist * ca);
+    double anew = asin((sa * dist) / dnew) * kRad2Deg;
     double az2 = anew * sign;
     // Spherical2Cartesian
     double cz = cos(zen * kDeg2Rad);
-    x = dnew * cz * cos(az2 * kDeg2Rad);
-    y = dnew * cz * sin(az2 * kDeg2Rad);
+    double s2, c2; sincos(az2 * kDeg2Rad, &s2, &c2);
+    x = dnew * cz * c2;
+    y = dnew * cz * s2;
 }
 
 __global__ void k_polar_to_xy(int n, const double *__restrict__ az, const double *__restrict__ zen,
@@ -71,11 +73,14 @@ __global__ void k_polar_to_xy(int n, const double *__restrict__ az, const double
     out[2 * i] = x; out[2 * i + 1] = y;
 }
 
-__device__ __forceinline__ void cone_to_global(const double *pose, const double *obs, double lidar, double &gx, double &gy) {
+__device__ __forceinline__ void cone_to_global_cs(double px, double py, double c, double s, const double *obs, double lidar, double &gx, double &gy) {
     double x, y; polar_to_xy(obs[0], obs[1], obs[2], lidar, x, y);
-    double c = cos(pose[2]), s = sin(pose[2]);
-    gx = (x * c - y * s) + pose[0];
-    gy = (x * s + y * c) + pose[1];
+    gx = (x * c - y * s) + px;
+    gy = (x * s + y * c) + py;
+}
+__device__ __forceinline__ void cone_to_global(const double *pose, const double *obs, double lidar, double &gx, double &gy) {
+    double s, c; sincos(pose[2], &s, &c);
+    cone_to_global_cs(pose[0], pose[1], c, s, obs, lidar, gx, gy);
 }
 
 __global__ void k_cone_to_global(int n, const double *__restrict__ poses, const int32_t *__restrict__ pose_of_obs,
@@ -117,118 +122,108 @@ __global__ void __launch_bounds__(256) k_associate(int n, const double *__restri
     if (live) out[i] = found;
 }
 
-// ---- batched A1 with the grid built ON THE DEVICE (round 4): bounds + cell size (k_grid_params), cones per cell (k_grid_count, integer
-// atomics: the counts do not depend on the order), exclusive scan (k_grid_scan), fill (k_grid_fill: the order inside a cell is whatever
-// the atomics give — the query takes the LOWEST matching index over the 3 x 3 cells, which does not depend on it), then the queries
-// (k_associate_grid_dev: grid parameters read from device memory, so no host round trip anywhere).  Same pair test, same arithmetic as
-// k_associate => identical indices.  gp = {minx, miny, inv_cell, nx, ny, ok}: ok = 0 (a non-finite map coordinate) -> the whole map is scanned.
-struct GridParams { double minx, miny, inv_cell; int nx, ny, ok, pad; };
-__global__ void __launch_bounds__(1024) k_grid_params(int n_map, const double *__restrict__ map_xy, double thr, long long max_cells, GridParams *__restrict__ gp) {
-    __shared__ double red[4][16]; __shared__ int bad[16];
-    double mnx = 1e300, mny = 1e300, mxx = -1e300, mxy = -1e300; int nf = 0;
-    for (int j = threadIdx.x; j < n_map; j += 1024) { const double x = map_xy[2 * j], y = map_xy[2 * j + 1];
-        if (!(isfinite(x) && isfinite(y))) { nf = 1; continue; }
-        mnx = fmin(mnx, x); mxx = fmax(mxx, x); mny = fmin(mny, y); mxy = fmax(mxy, y); }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { mnx = fmin(mnx, __shfl_down(mnx, off, WAVE)); mny = fmin(mny, __shfl_down(mny, off, WAVE));
-        mxx = fmax(mxx, __shfl_down(mxx, off, WAVE)); mxy = fmax(mxy, __shfl_down(mxy, off, WAVE)); nf |= __shfl_down(nf, off, WAVE); }
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[0][w] = mnx; red[1][w] = mny; red[2][w] = mxx; red[3][w] = mxy; bad[w] = nf; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < 16; ++k) { mnx = fmin(mnx, red[0][k]); mny = fmin(mny, red[1][k]); mxx = fmax(mxx, red[2][k]); mxy = fmax(mxy, red[3][k]); nf |= bad[k]; }
-        // cell edge a hair above the threshold (every cone within the threshold sits in the 3 x 3 cells around the query); a sparse map
-        // (cones along a 25 km line) gets coarser cells, not millions of empty ones
-        double cell = thr * (1.0 + 1e-9); long long nx = 1, ny = 1;
-        if (!nf && n_map > 0) for (;;) { nx = (long long)floor((mxx - mnx) / cell) + 1; ny = (long long)floor((mxy - mny) / cell) + 1;
-            if (nx * ny <= max_cells) break;
-            cell *= 1.5; }
-        gp->minx = mnx; gp->miny = mny; gp->inv_cell = 1.0 / cell; gp->nx = (int)nx; gp->ny = (int)ny; gp->ok = (!nf && n_map > 0) ? 1 : 0; gp->pad = 0;
-    }
+__global__ void k_pose_trig(int n, const double *__restrict__ pose_est, double *__restrict__ pose_cs);
+// ---- batched A1 with a HASHED uniform grid built ON THE DEVICE (round 4).  Cell edge = a hair above the threshold, so every cone within
+// the threshold of a query sits in the 3 x 3 cells around it; a cell (cx, cy) — unbounded integers, no bounding box, no coarsening for
+// sparse maps (a 25 km lap in a dense grid had 20 m cells of ~8 cones each: ~24 candidates per query) — hashes to one of B = 2^k >= 4 n_map
+// buckets.  Build: cones per bucket (k_grid_count, integer atomics: the counts do not depend on the order), exclusive scan (k_grid_scan),
+// fill (k_grid_fill: the order inside a bucket is whatever the atomics give — the query takes the LOWEST matching index over its nine
+// buckets, which does not depend on it; a colliding cone of some far cell is one more candidate that fails the distance test).  Same
+// pair test, same arithmetic as k_associate => identical indices.  No host pass over the map, no host round trip.
+struct GridParams { double inv_cell; uint32_t mask; int pad; };
+__device__ __forceinline__ long long grid_coord(double v, double inv_cell) { return (long long)fmin(fmax(floor(v * inv_cell), -4.0e15), 4.0e15); }   // (finite input; clamped: no overflow of the cast)
+__device__ __forceinline__ uint32_t grid_bucket(long long cx, long long cy, uint32_t mask) {
+    return (((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u)) & mask;
 }
-__device__ __forceinline__ int grid_cell_of(const GridParams &g, double x, double y) {
-    long long cx = (long long)floor((x - g.minx) * g.inv_cell), cy = (long long)floor((y - g.miny) * g.inv_cell);
-    cx = min(max(cx, 0LL), (long long)g.nx - 1); cy = min(max(cy, 0LL), (long long)g.ny - 1);
-    return (int)(cy * g.nx + cx);
-}
-__global__ void __launch_bounds__(256) k_grid_count(int n_map, const double *__restrict__ map_xy, const GridParams *__restrict__ gp, int32_t *__restrict__ count) {
+__global__ void __launch_bounds__(256) k_grid_count(int n_map, const double *__restrict__ map_xy, GridParams g, int32_t *__restrict__ count) {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    const GridParams g = *gp;
-    if (j >= n_map || !g.ok) return;
-    atomicAdd(count + grid_cell_of(g, map_xy[2 * j], map_xy[2 * j + 1]), 1);
+    if (j >= n_map) return;
+    const double x = map_xy[2 * j], y = map_xy[2 * j + 1];
+    if (!(isfinite(x) && isfinite(y))) return;                     // never within any threshold of anything: not in the grid
+    atomicAdd(count + grid_bucket(grid_coord(x, g.inv_cell), grid_coord(y, g.inv_cell), g.mask), 1);
 }
-// exclusive scan of count[0 .. nx * ny) into start[0 .. nx * ny], one workgroup (the grid has at most max(4096, 8 n_map) cells)
-__global__ void __launch_bounds__(1024) k_grid_scan(const GridParams *__restrict__ gp, const int32_t *__restrict__ count, int32_t *__restrict__ start) {
+// exclusive scan of count[0 .. n) into start[0 .. n], one workgroup
+__global__ void __launch_bounds__(1024) k_grid_scan(int n, const int32_t *__restrict__ count, int32_t *__restrict__ start) {
     __shared__ int wsum[16]; __shared__ int carry_s;
-    const GridParams g = *gp;
-    const int n = g.ok ? g.nx * g.ny : 0, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + tid; const int v = i < n ? count[i] : 0;
-        int x = v;
+    for (int base = 0; base < n; base += 4096) {                     // four consecutive buckets per thread
+        const int i0 = base + 4 * tid;
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = i0 + k < n ? count[i0 + k] : 0;
+        const int tsum = v[0] + v[1] + v[2] + v[3];
+        int x = tsum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off, WAVE); if (lane >= off) x += y; }
         if (lane == 63) wsum[w] = x;
         __syncthreads();
         int pre = carry_s;
         for (int k = 0; k < w; ++k) pre += wsum[k];
-        if (i < n) start[i] = pre + x - v;
+        int run = pre + x - tsum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (i0 + k < n) start[i0 + k] = run; run += v[k]; }
         __syncthreads();
         if (tid == 1023) carry_s = pre + x;
         __syncthreads();
     }
     if (tid == 0) start[n] = carry_s;
 }
-__global__ void __launch_bounds__(256) k_grid_fill(int n_map, const double *__restrict__ map_xy, const GridParams *__restrict__ gp, const int32_t *__restrict__ start,
+__global__ void __launch_bounds__(256) k_grid_fill(int n_map, const double *__restrict__ map_xy, GridParams g, const int32_t *__restrict__ start,
                                                    int32_t *__restrict__ cursor, int32_t *__restrict__ items) {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    const GridParams g = *gp;
-    if (j >= n_map || !g.ok) return;
-    const int c = grid_cell_of(g, map_xy[2 * j], map_xy[2 * j + 1]);
+    if (j >= n_map) return;
+    const double x = map_xy[2 * j], y = map_xy[2 * j + 1];
+    if (!(isfinite(x) && isfinite(y))) return;
+    const uint32_t c = grid_bucket(grid_coord(x, g.inv_cell), grid_coord(y, g.inv_cell), g.mask);
     items[start[c] + atomicAdd(cursor + c, 1)] = j;
 }
 __global__ void __launch_bounds__(256) k_associate_grid_dev(int n, const double *__restrict__ poses, const int32_t *__restrict__ pose_of_obs,
-        const double *__restrict__ obs, double lidar, int n_map, const double *__restrict__ map_xy, const int32_t *__restrict__ map_type, double thr, double type_tol,
-        const GridParams *__restrict__ gp, const int32_t *__restrict__ cell_start, const int32_t *__restrict__ cell_items, int32_t *__restrict__ out) {
+        const double *__restrict__ obs, double lidar, const double *__restrict__ map_xy, const int32_t *__restrict__ map_type, double thr, double type_tol,
+        GridParams g, const int32_t *__restrict__ cell_start, const int32_t *__restrict__ cell_items, int32_t *__restrict__ out,
+        const double *__restrict__ pose_cs /* cos, sin of every pose's heading (k_pose_trig): the observations of a pose share them */) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const GridParams g = *gp;                                          // (uniform: scalar loads)
     const double4 o4 = reinterpret_cast<const double4 *>(obs)[i];      // the observation's 32 bytes in one load (az, zen, dist, type)
     const double ob[4] = {o4.x, o4.y, o4.z, o4.w};
-    double gx, gy; cone_to_global(poses + 3 * pose_of_obs[i], ob, lidar, gx, gy);
+    const int pi = pose_of_obs[i]; const double2 cs = reinterpret_cast<const double2 *>(pose_cs)[pi];
+    double gx, gy; cone_to_global_cs(poses[3 * pi], poses[3 * pi + 1], cs.x, cs.y, ob, lidar, gx, gy);
     const double ty = ob[3];
     int found = 0x7fffffff;
-    auto test = [&](int j) {
-        if (j < found && fabs((double)map_type[j] - ty) < type_tol) {
-            const double ddx = map_xy[2 * j] - gx, ddy = map_xy[2 * j + 1] - gy;
-            if (sqrt(ddx * ddx + ddy * ddy) < thr) found = j; } };
-    if (!g.ok) { for (int j = 0; j < n_map && found == 0x7fffffff; ++j) test(j); }      // degenerate map (a non-finite coordinate): insertion-order scan
-    else {
-        const double fx = (gx - g.minx) * g.inv_cell, fy = (gy - g.miny) * g.inv_cell;
-        if (fx >= -1.0 && fx < (double)g.nx + 1.0 && fy >= -1.0 && fy < (double)g.ny + 1.0) {       // false for NaN (azimuth 0)
-            const int cx = (int)floor(fx), cy = (int)floor(fy);
-            for (int dy = -1; dy <= 1; ++dy) { const int y = cy + dy; if (y < 0 || y >= g.ny) continue;
-                const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);      // the three cells of a row are adjacent: one run of items
-                if (x0 > x1) continue;
-                for (int q = cell_start[y * g.nx + x0]; q < cell_start[y * g.nx + x1 + 1]; ++q) test(cell_items[q]); } }
+    if (isfinite(gx) && isfinite(gy)) {                              // (NaN: azimuth 0, SURVEY 8-B.3 — no match)
+        const long long cx = grid_coord(gx, g.inv_cell), cy = grid_coord(gy, g.inv_cell);
+        int s0[9], s1[9];                                            // the nine buckets' ranges first: independent loads
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { const uint32_t bk = grid_bucket(cx + (k % 3) - 1, cy + (k / 3) - 1, g.mask); s0[k] = cell_start[bk]; s1[k] = cell_start[bk + 1]; }
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            for (int q = s0[k]; q < s1[k]; ++q) { const int j = cell_items[q];
+                if (j < found && fabs((double)map_type[j] - ty) < type_tol) {
+                    const double ddx = map_xy[2 * j] - gx, ddy = map_xy[2 * j + 1] - gy;
+                    if (sqrt(ddx * ddx + ddy * ddy) < thr) found = j; } }
     }
     out[i] = found == 0x7fffffff ? -1 : found;
 }
-void launch_grid_build(int n_map, const double *map_xy, double thr, long long max_cells, void *gp, int32_t *count, int32_t *start, int32_t *cursor, int32_t *items, hipStream_t st) {
-    hipMemsetAsync(count, 0, (size_t)(max_cells + 1) * sizeof(int32_t), st); hipMemsetAsync(cursor, 0, (size_t)(max_cells + 1) * sizeof(int32_t), st);
-    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(1024), 0, st, n_map, map_xy, thr, max_cells, (GridParams *)gp);
-    if (n_map > 0) hipLaunchKernelGGL(k_grid_count, dim3((n_map + 255) / 256), dim3(256), 0, st, n_map, map_xy, (const GridParams *)gp, count);
-    hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, st, (const GridParams *)gp, count, start);
-    if (n_map > 0) hipLaunchKernelGGL(k_grid_fill, dim3((n_map + 255) / 256), dim3(256), 0, st, n_map, map_xy, (const GridParams *)gp, start, cursor, items);
+static GridParams grid_params_of(double thr, long long buckets) { GridParams g; g.inv_cell = 1.0 / (thr * (1.0 + 1e-9)); g.mask = (uint32_t)(buckets - 1); g.pad = 0; return g; }
+// buckets: a power of two; count / start / cursor: buckets + 1 ints each, items: n_map ints
+void launch_grid_build(int n_map, const double *map_xy, double thr, long long buckets, int32_t *count, int32_t *start, int32_t *cursor, int32_t *items, hipStream_t st) {
+    const GridParams g = grid_params_of(thr, buckets);
+    hipMemsetAsync(count, 0, (size_t)(buckets + 1) * sizeof(int32_t), st); hipMemsetAsync(cursor, 0, (size_t)(buckets + 1) * sizeof(int32_t), st);
+    if (n_map > 0) hipLaunchKernelGGL(k_grid_count, dim3((n_map + 255) / 256), dim3(256), 0, st, n_map, map_xy, g, count);
+    hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, st, (int)buckets, count, start);
+    if (n_map > 0) hipLaunchKernelGGL(k_grid_fill, dim3((n_map + 255) / 256), dim3(256), 0, st, n_map, map_xy, g, start, cursor, items);
 }
-void launch_associate_grid_dev(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar, int n_map, const double *map_xy,
-                               const int32_t *map_type, double thr, double type_tol, const void *gp, const int32_t *cell_start, const int32_t *cell_items,
-                               int32_t *out, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
-    if (n > 0) hipExtLaunchKernelGGL(k_associate_grid_dev, dim3((n + 255) / 256), dim3(256), 0, st, start, stop, 0, n, poses, pose_of_obs, obs, lidar, n_map, map_xy, map_type,
-                                     thr, type_tol, (const GridParams *)gp, cell_start, cell_items, out);
+void launch_associate_grid_dev(int n, const double *poses, const int32_t *pose_of_obs, const double *obs, double lidar, const double *map_xy,
+                               const int32_t *map_type, double thr, double type_tol, long long buckets, const int32_t *cell_start, const int32_t *cell_items,
+                               int32_t *out, int n_poses, double *pose_cs_scratch, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
+    if (n <= 0) return;
+    // cos / sin of every pose once (k_pose_trig), then the queries: start is attached to the first dispatch, stop to the second
+    hipExtLaunchKernelGGL(k_pose_trig, dim3((std::max(n_poses, 1) + 255) / 256), dim3(256), 0, st, start, nullptr, 0, n_poses, poses, pose_cs_scratch);
+    hipExtLaunchKernelGGL(k_associate_grid_dev, dim3((n + 255) / 256), dim3(256), 0, st, nullptr, stop, 0, n, poses, pose_of_obs, obs, lidar, map_xy, map_type,
+                          thr, type_tol, grid_params_of(thr, buckets), cell_start, cell_items, out, (const double *)pose_cs_scratch);
 }
-size_t grid_params_bytes() { return sizeof(GridParams); }
+
 
 // One keyframe's front end in ONE launch (A0 + A1 fused): workgroup i takes observation i of the frame — polar -> CoG-frame
 // XY (the edge measurement), -> global XY (the association query) — and its 256 threads scan the resident map for the
