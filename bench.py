@@ -235,8 +235,19 @@ def main():
         G.dist_configure(rank, world)
     G.initialize_optimization()                    # structure phase (iteration-0 work): plan + upload to HBM
     plan = G.stats()
+    lib_rccl, xbuf, stream = False, None, None
     if dist_mode and backend != "gloo":
-        library_communicator(G)
+        # every rank must take the same path: a rank whose library communicator failed tells the others (MIN over the ranks)
+        try:
+            library_communicator(G); ok_t = torch.ones(1, device="cuda")
+        except Exception as e:
+            sys.stderr.write("bench: RCCL inside the library unavailable on rank %d (%s): torch.distributed all-reduce instead\n" % (rank, e)); ok_t = torch.zeros(1, device="cuda")
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN); lib_rccl = bool(ok_t.item() > 0)
+        if not lib_rccl:                           # rounds 2-3's path: a torch side stream adopted by the library, the exchange buffer a torch tensor
+            stream = torch.cuda.Stream(); G.set_stream(stream.cuda_stream)
+            xbuf = torch.zeros(max(G.dist_exchange_doubles(), 1), dtype=torch.float64, device="cuda")
+            if G.dist_exchange_doubles() > 0:
+                G.dist_set_exchange_buffer(xbuf.data_ptr())
 
     def step():
         if not dist_mode:
@@ -246,8 +257,13 @@ def main():
             xh = torch.from_numpy(G.dist_read_exchange())
             dist.all_reduce(xh, op=dist.ReduceOp.SUM)
             G.dist_write_exchange(xh.numpy()); G.dist_iterate_finish()
-        else:
+        elif lib_rccl:
             G.dist_iterate()                       # local half -> ncclAllReduce(sum, fp64) of the shared rows of Omega / xi over xGMI -> finish: all enqueued from C++ on the handle's stream
+        else:
+            with torch.cuda.stream(stream):
+                G.dist_iterate_local()
+                dist.all_reduce(xbuf, op=dist.ReduceOp.SUM)
+                G.dist_iterate_finish()
 
     def barrier():
         G.synchronize()                            # the library's own stream
@@ -317,7 +333,10 @@ def main():
                                         % (world, G.dist_exchange_doubles(), 8 * G.dist_exchange_doubles())) if world > 1 else "single GPU",
                            fronts=plan.n_fronts, levels=plan.n_levels, max_front=plan.max_front),
                roofline=roofline)
-    if dist_mode and backend != "gloo":
+    if dist_mode and backend != "gloo" and not lib_rccl:
+        out["exchange"] = dict(doubles=int(G.dist_exchange_doubles()), bytes=int(8 * G.dist_exchange_doubles()), ms_exchange=None,
+                               note="the library's own RCCL communicator could not be created: torch.distributed.all_reduce on a torch side stream (rounds 2-3's path)")
+    if dist_mode and backend != "gloo" and lib_rccl:
         # the collective alone: `reps` all-reduces of the exchange buffer back to back on the library's stream (every rank calls it)
         out["exchange"] = dict(doubles=int(G.dist_exchange_doubles()), bytes=int(8 * G.dist_exchange_doubles()), ms_exchange=G.time_exchange(50),
                                shared_fronts=int(plan.n_shared_fronts), own_fronts=int(plan.n_own_fronts),
@@ -376,7 +395,7 @@ def main():
         out["speedup_vs_cpu_baseline"] = value / cb["value"]
         # parity of what was timed: the same number of iterations from the same initial estimates
         G2 = pkg.Graph(device=local, debug=dbg); G2.load_bench_graph(g)
-        if dist_mode:                              # the same sharded arithmetic through gs_dist_optimize (Slam's optimize(10) on a sharded graph)
+        if dist_mode and lib_rccl:                 # the same sharded arithmetic through gs_dist_optimize (Slam's optimize(10) on a sharded graph)
             G2.dist_configure(rank, world); G2.initialize_optimization(); library_communicator(G2)
             opt2 = G2.dist_optimize
         else:

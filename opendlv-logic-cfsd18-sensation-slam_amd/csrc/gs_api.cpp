@@ -1043,7 +1043,13 @@ template <class Launch> static void for_each_run(const std::vector<gs_graph::WgS
         i = j; }
 }
 static void enqueue_factor_big(gs_graph *g, const gs_graph::LevelSet &ls, bool tree) {
-    if (!g->d_wg_f && build_big_tables(g, ls) != GS_OK) return;     // (an allocation failure surfaces as a launch error on the next call)
+    // the workgroup tables of a plan with fronts beyond a wave are built on first use; if that fails (device memory), NO solver launch of
+    // this iteration may run and its update must not be applied: the failure is kept on the handle (enqueue_rc: every entry point that
+    // enqueues iterations returns it) and raised on the device like a failed solve, so that k_update applies nothing
+    if (!g->d_wg_f) { const int rc = build_big_tables(g, ls);
+        if (rc != GS_OK) { g->enqueue_rc = rc; g->enqueue_err = g_last_error; g->d_wg_f = g->d_wg_b = nullptr;
+            const int32_t one = 1; hipMemcpyAsync(g->d.fail, &one, sizeof(int32_t), hipMemcpyHostToDevice, g->stream); hipStreamSynchronize(g->stream);
+            return; } }
     if (g->leaf_n > 0) launch_factor_tree(g->d, g->leaf_n, g->leaf_slot, g->leaf_max_f, g->leaf_n, 0, 0, 0, g->stream);       // the leaf instance alone
     // "no flags to wait for at level 1" holds only if EVERY leaf went through the leaf launch (big leaves share the table launch with their parents)
     const int leaf_pre = (g->leaf_n > 0 && g->leaf_n == ls.start[1]) ? 1 : 0;
@@ -1152,6 +1158,12 @@ static void enqueue_finish(gs_graph *g, bool timed) {
     g->dev_estimates_newer = true;
 }
 static void enqueue_iteration(gs_graph *g, bool timed) { enqueue_local(g, timed); enqueue_finish(g, timed); }
+// a failure of the enqueue itself (not of the arithmetic): reported once by the entry point that enqueued
+static int take_enqueue_error(gs_graph *g) {
+    if (g->enqueue_rc == GS_OK) return GS_OK;
+    const int rc = g->enqueue_rc; g->enqueue_rc = GS_OK;
+    return fail(rc, "solver launch tables: " + g->enqueue_err + " (no update applied)");
+}
 
 extern "C" int gs_iterate(gs_graph *g) {
     if (!g) return fail(GS_ERR_INVALID, "null graph");
@@ -1159,6 +1171,7 @@ extern "C" int gs_iterate(gs_graph *g) {
     if (g->plan.dist) return fail(GS_ERR_INVALID, "sharded graph: use gs_dist_iterate (RCCL inside the library) or gs_dist_iterate_local / all-reduce / gs_dist_iterate_finish");
     int rc = ensure_device(g); if (rc != GS_OK) return rc;
     enqueue_iteration(g, false);
+    if (g->enqueue_rc != GS_OK) return take_enqueue_error(g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return 1;
@@ -1224,6 +1237,7 @@ static int optimize_impl(gs_graph *g, int32_t iterations, double rel_tol, gs_sta
             enqueue_iteration(g, false);
         }
         g->d.hist_slot = -1;
+        if (g->enqueue_rc != GS_OK) { g->d.conv_tol = -1.0; hipStreamSynchronize(g->stream); reset_failure(g); return take_enqueue_error(g); }
         enq = upto;
         HIP_TRY(hipMemcpyAsync(ff, g->d.fail, sizeof(ff), hipMemcpyDeviceToHost, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));

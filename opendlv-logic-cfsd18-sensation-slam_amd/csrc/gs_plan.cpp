@@ -252,11 +252,23 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
 #define GS_PT(i) do { if (pt_on) { auto n_ = std::chrono::steady_clock::now(); std::fprintf(stderr, "plan phase %d: %.2f ms\n", (i), std::chrono::duration<double, std::milli>(n_ - pt_prev).count()); pt_prev = n_; } } while (0)
     plan = Plan();
     PlanOptions opt = opt_in;
+    const bool leaf_auto = opt.leaf_poses <= 0;
     if (opt.leaf_poses <= 0) opt.leaf_poses = 8;
     if (opt.cluster_ways <= 0) opt.cluster_ways = 8;
     Builder B(g, opt);
     B.index_vertices();
     if (B.nv == 0) { err = "no free vertex"; return false; }
+    // Leaf size by the graph (round 4): the binary part of the dissection halves the pose range until a range fits one multi-way cluster
+    // (ways x (leaf + 1) - 1 poses); a smaller leaf that does NOT add a binary level makes every leaf front smaller at the same tree depth —
+    // at 100k poses leaves of 6 poses all fit 47 scalars (the three-tile-row leaf instance, 84 registers) where leaves of 8 reach 50: factor
+    // 0.170 -> 0.160 ms, backward solve 0.067 -> 0.065 (+3 % iterations/s); at 1M poses 6 would add a level (-10 %) and 8 stays; at 10k
+    // neutral (scripts/r4_e.sh).  Only when nobody asked for a size, and only for narrow views (wide views: workgroup fronts, measured best at 8).
+    if (leaf_auto) {
+        auto depth_of = [&](int leaf) { int64_t un = B.nfp, cap = (int64_t)opt.cluster_ways * (leaf + 1) - 1; int dd = 0; while (un > cap) { un = un / 2; ++dd; } return dd; };
+        const int d8 = depth_of(8);
+        const int best = depth_of(6) == d8 ? 6 : 8;                  // (7 keeps some leaves above 47 scalars: measured neutral at 100k, -2 % at 1M poses)
+        B.opt.leaf_poses = opt.leaf_poses = best;
+    }
     const int N = g.n_poses(), M = g.n_lms(), Epl = g.n_pl(), Epp = g.n_pp();
 
     GS_PT(0);
@@ -293,6 +305,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     // room to grow (grow_plan) only where fronts fit a wave anyway: with more than ~10 cones in view the cluster fronts are workgroup
     // fronts, such a plan cannot grow, and keeping them below 57 would only cost fronts (K = 16: 26 571 instead of 21 026, -5 % it/s)
     { int kmax0 = 0; for (int p = 0; p < N; ++p) kmax0 = std::max(kmax0, plan.pl_start[p + 1] - plan.pl_start[p]);
+      if (kmax0 > 10 && leaf_auto) B.opt.leaf_poses = 8;           // (wide views keep leaves of 8 poses)
       if (kmax0 > 10) B.opt.grow_headroom = B.opt.grow_spine_headroom = 0;
       if (B.opt.big_cluster_front < 0) B.opt.big_cluster_front = kmax0 > 10 ? 111 : 0; }
     // ---- elimination order by nested dissection ----

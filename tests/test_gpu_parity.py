@@ -930,7 +930,8 @@ def test_rccl_all_reduce_inside_the_library_on_a_forced_shared_top(pkg, po, benc
     A = fresh(pkg, g); A.optimize(4)
     G = fresh(pkg, g, debug=dict(force_shared_top=3)); G.initialize_optimization()
     st = G.stats()
-    assert st.n_shared_fronts == 7 and st.n_own_fronts + 7 == st.n_fronts and G.dist_exchange_doubles() > 7 * 20
+    ns = st.n_shared_fronts
+    assert 3 <= ns <= 7 and st.n_own_fronts + ns == st.n_fronts and G.dist_exchange_doubles() > ns * 20
     with pytest.raises(pkg.GsError):
         G.iterate()                                              # a sharded graph refuses the single-GPU entry point
     with pytest.raises(pkg.GsError):
@@ -945,7 +946,7 @@ def test_rccl_all_reduce_inside_the_library_on_a_forced_shared_top(pkg, po, benc
     assert rel(G.poses(), A.poses()) < 1e-11 and rel(G.landmarks(), A.landmarks()) < 1e-11
     H = fresh(pkg, g, debug=dict(force_shared_top=3)); H.dist_comm_init(pkg.binding.dist_unique_id(), 0, 1)
     done, sth = H.dist_optimize(4)
-    assert done == 4 and sth.numeric_failure == 0 and sth.n_shared_fronts == 7
+    assert done == 4 and sth.numeric_failure == 0 and sth.n_shared_fronts == ns
     assert np.array_equal(H.poses(), G.poses()) and np.array_equal(H.landmarks(), G.landmarks())
     # g2o's failure rule through the collective path: a zero pivot injected into iteration 2 of 4 -> 0 returned, one update applied
     F = fresh(pkg, g, debug=dict(force_shared_top=3)); F.dist_comm_init(pkg.binding.dist_unique_id(), 0, 1)
