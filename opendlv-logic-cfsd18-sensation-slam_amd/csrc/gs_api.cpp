@@ -640,9 +640,8 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
     { int v = g->default_factor_variant;
       if (g->opt.factor_variant > 0) v = g->opt.factor_variant;
       v = gs_debug_select_factor_variant(v, P.max_front, arena_doubles);
-      if (v == 3 && P.max_front > 63 && P.dist) v = 4;                // the workgroup-per-front form has no shard modes (contribution / shared top) yet
       if (v == 4) v = 0;                                              // device-side code for the block-per-front kernel
-      g->wg_f.clear(); g->wg_b.clear(); g->d_wg_f = g->d_wg_b = nullptr;
+      g->wg_f.clear(); g->wg_b.clear(); g->d_wg_f = g->d_wg_b = g->d_wgs_c = g->d_wgs_t = g->d_wgs_b = nullptr;
       d.factor_variant = v;
       d.dbg = g->opt.dbg; d.leaf_nt3 = g->opt.leaf_nt3 != 0 ? 1 : 0; d.f3_lds_kb = std::max(g->opt.f3_lds_kb, 0);
       if (v == 3) {
@@ -873,7 +872,7 @@ static int upload_growth(gs_graph *g, const Growth &gr) {
           for (int q = ls.start[l]; q < ls.start[l + 1]; ++q) { const Front &F = P.fronts[P.level_fronts_owned[q]];
               ls.max_f[l] = std::max(ls.max_f[l], F.npiv + F.nbnd); ls.max_npiv[l] = std::max(ls.max_npiv[l], F.npiv); ls.max_nbnd[l] = std::max(ls.max_nbnd[l], F.nbnd); } } }
     g->leaf_n = -1; g->block_n = -1;                                // the leaf instance and its LDS slot are chosen again from the grown fronts
-    g->wg_f.clear(); g->wg_b.clear(); g->d_wg_f = g->d_wg_b = nullptr;   // ... and so are the workgroup tables of a plan with workgroup fronts (a grown front may change its size class)
+    g->wg_f.clear(); g->wg_b.clear(); g->d_wg_f = g->d_wg_b = g->d_wgs_c = g->d_wgs_t = g->d_wgs_b = nullptr;   // ... and so are the workgroup tables of a plan with workgroup fronts (a grown front may change its size class)
     g->dev_estimate_version = h.estimate_version;
     return GS_OK;
 }
@@ -1005,8 +1004,9 @@ static int build_big_tables(gs_graph *g, const gs_graph::LevelSet &ls) {
     auto f_of = [&](int q) { const Front &F = P.fronts[P.level_fronts_owned[q]]; return F.npiv + F.nbnd; };
     auto big_kind = [&](int f) { return f <= 79 ? 4 : (f <= 111 ? 2 : 3); };        // 5, 7 or 10 tile rows
     g->wg_f.clear(); g->wg_b.clear(); g->seg_f.clear(); g->seg_b.clear();
+    g->wgs_c.clear(); g->wgs_t.clear(); g->wgs_b.clear(); g->segs_c.clear(); g->segs_t.clear(); g->segs_b.clear();
     g->small_max_npiv = 1; g->small_max_f = 1;
-    for (const Front &F : P.fronts) if (F.npiv + F.nbnd <= 63) { g->small_max_npiv = std::max(g->small_max_npiv, (int)F.npiv); g->small_max_f = std::max(g->small_max_f, F.npiv + F.nbnd); }
+    for (const Front &F : P.fronts) if (!F.opaque && F.npiv + F.nbnd <= 63) { g->small_max_npiv = std::max(g->small_max_npiv, (int)F.npiv); g->small_max_f = std::max(g->small_max_f, F.npiv + F.nbnd); }
     auto push = [&](std::vector<int32_t> &tab, std::vector<gs_graph::WgSeg> &segs, int pos, int kind_cnt, int level, size_t lds, int cls) {
         const int e = (int)tab.size() / 2; tab.push_back(pos); tab.push_back(kind_cnt);
         if (!segs.empty() && segs.back().level == level && segs.back().lds == lds && segs.back().cls == cls) ++segs.back().count; else segs.push_back({e, 1, level, lds, cls}); };
@@ -1027,10 +1027,33 @@ static int build_big_tables(gs_graph *g, const gs_graph::LevelSet &ls) {
                 push(g->wg_b, g->seg_b, q, k, l, backsolve_tab_lds_bytes(k, fc, 0), 1); --q; }
             else { int cnt = 1; while (cnt < 4 && q - cnt >= ls.start[l] && f_of(q - cnt) <= 63) ++cnt;
                 push(g->wg_b, g->seg_b, q, 0 | (cnt << 8), l, backsolve_tab_lds_bytes(0, g->small_max_f, g->small_max_npiv), 0); q -= cnt; } }
+    // ---- pose-window shards: the SHARED top of a plan with workgroup fronts (round 4).  Three tables over the shared level positions
+    // (shared_base + q): contributions (mode CONTRIB: no dependencies among them; a small front a wave — the four-wave form has no such
+    // mode —, a big one a workgroup), the top itself (mode TOP, children first: a small front four waves, a big one a workgroup), and
+    // the backward solve (root first).
+    { const gs_graph::LevelSet &sh = g->shared; const int nls = (int)sh.start.size() - 1, B0 = g->shared_base;
+      auto fs = [&](int q) { const Front &F = P.fronts[P.level_fronts_shared[q]]; return F.npiv + F.nbnd; };
+      for (int l = 0; l < nls; ++l)
+          for (int q = sh.start[l]; q < sh.start[l + 1]; ) { const int f = fs(q);
+              if (f > 63) { const int k = big_kind(f);
+                  push(g->wgs_c, g->segs_c, B0 + q, k, l, factor_tab_lds_bytes(k), fcls(k)); push(g->wgs_t, g->segs_t, B0 + q, k, l, factor_tab_lds_bytes(k), fcls(k)); ++q; }
+              else { push(g->wgs_t, g->segs_t, B0 + q, 1 | (1 << 8), l, factor_tab_lds_bytes(1), 1);
+                  int cnt = 1; while (cnt < 4 && q + cnt < sh.start[l + 1] && fs(q + cnt) <= 63) ++cnt;
+                  push(g->wgs_c, g->segs_c, B0 + q, 0 | (cnt << 8), l, factor_tab_lds_bytes(0), 1);
+                  for (int k2 = 1; k2 < cnt; ++k2) push(g->wgs_t, g->segs_t, B0 + q + k2, 1 | (1 << 8), l, factor_tab_lds_bytes(1), 1);
+                  q += cnt; } }
+      for (int l = nls - 1; l >= 0; --l)
+          for (int q = sh.start[l + 1] - 1; q >= sh.start[l]; ) { const int f = fs(q);
+              if (f > 63) { const int k = big_kind(f), fc = k == 4 ? 79 : (k == 2 ? 111 : 159); push(g->wgs_b, g->segs_b, B0 + q, k, l, backsolve_tab_lds_bytes(k, fc, 0), 1); --q; }
+              else { int cnt = 1; while (cnt < 4 && q - cnt >= sh.start[l] && fs(q - cnt) <= 63) ++cnt;
+                  push(g->wgs_b, g->segs_b, B0 + q, 0 | (cnt << 8), l, backsolve_tab_lds_bytes(0, g->small_max_f, g->small_max_npiv), 0); q -= cnt; } } }
     int rc;
-    if ((rc = dev_alloc(g, (int32_t **)&g->d_wg_f, g->wg_f.size())) != GS_OK || (rc = dev_alloc(g, (int32_t **)&g->d_wg_b, g->wg_b.size())) != GS_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(g->d_wg_f, g->wg_f.data(), g->wg_f.size() * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));     // the host vectors live on the handle
-    HIP_TRY(hipMemcpyAsync(g->d_wg_b, g->wg_b.data(), g->wg_b.size() * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
+    auto up = [&](int2 **dst, const std::vector<int32_t> &v) -> int {
+        int r2 = dev_alloc(g, (int32_t **)dst, v.size()); if (r2 != GS_OK) return r2;
+        if (!v.empty()) { hipError_t e = hipMemcpyAsync(*dst, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice, g->stream); if (e != hipSuccess) return fail(GS_ERR_HIP, hipGetErrorString(e)); }   // the host vectors live on the handle
+        return GS_OK; };
+    if ((rc = up(&g->d_wg_f, g->wg_f)) != GS_OK || (rc = up(&g->d_wg_b, g->wg_b)) != GS_OK || (rc = up(&g->d_wgs_c, g->wgs_c)) != GS_OK ||
+        (rc = up(&g->d_wgs_t, g->wgs_t)) != GS_OK || (rc = up(&g->d_wgs_b, g->wgs_b)) != GS_OK) return rc;
     return GS_OK;
 }
 // launches = maximal runs of table entries with the same LDS need (whole-tree mode: across levels; after a flag timeout: never
@@ -1042,14 +1065,19 @@ template <class Launch> static void for_each_run(const std::vector<gs_graph::WgS
         fn(segs[i].first, n, segs[i].lds, segs[i].cls);
         i = j; }
 }
-static void enqueue_factor_big(gs_graph *g, const gs_graph::LevelSet &ls, bool tree) {
+static bool ensure_big_tables(gs_graph *g) {
     // the workgroup tables of a plan with fronts beyond a wave are built on first use; if that fails (device memory), NO solver launch of
     // this iteration may run and its update must not be applied: the failure is kept on the handle (enqueue_rc: every entry point that
     // enqueues iterations returns it) and raised on the device like a failed solve, so that k_update applies nothing
-    if (!g->d_wg_f) { const int rc = build_big_tables(g, ls);
-        if (rc != GS_OK) { g->enqueue_rc = rc; g->enqueue_err = g_last_error; g->d_wg_f = g->d_wg_b = nullptr;
-            const int32_t one = 1; hipMemcpyAsync(g->d.fail, &one, sizeof(int32_t), hipMemcpyHostToDevice, g->stream); hipStreamSynchronize(g->stream);
-            return; } }
+    if (g->d_wg_f) return true;
+    const int rc = build_big_tables(g, g->own);
+    if (rc == GS_OK) return true;
+    g->enqueue_rc = rc; g->enqueue_err = g_last_error; g->d_wg_f = g->d_wg_b = g->d_wgs_c = g->d_wgs_t = g->d_wgs_b = nullptr;
+    const int32_t one = 1; hipMemcpyAsync(g->d.fail, &one, sizeof(int32_t), hipMemcpyHostToDevice, g->stream); hipStreamSynchronize(g->stream);
+    return false;
+}
+static void enqueue_factor_big(gs_graph *g, const gs_graph::LevelSet &ls, bool tree) {
+    if (!ensure_big_tables(g)) return;
     if (g->leaf_n > 0) launch_factor_tree(g->d, g->leaf_n, g->leaf_slot, g->leaf_max_f, g->leaf_n, 0, 0, 0, g->stream);       // the leaf instance alone
     // "no flags to wait for at level 1" holds only if EVERY leaf went through the leaf launch (big leaves share the table launch with their parents)
     const int leaf_pre = (g->leaf_n > 0 && g->leaf_n == ls.start[1]) ? 1 : 0;
@@ -1058,6 +1086,14 @@ static void enqueue_factor_big(gs_graph *g, const gs_graph::LevelSet &ls, bool t
 static void enqueue_backsolve_big(gs_graph *g, const gs_graph::LevelSet &, bool tree) {
     if (!g->d_wg_b) return;
     for_each_run(g->seg_b, tree, [&](int first, int n, size_t lds, int cls) { launch_backsolve_tab(g->d, g->d_wg_b + first, n, g->small_max_npiv, g->small_max_f, lds, cls, g->stream); });
+}
+// the shared top of a sharded plan with workgroup fronts: contributions (mode 1), the top from the exchange (mode 2), its backward solve
+static void enqueue_shared_big(gs_graph *g, int what) {
+    if (!ensure_big_tables(g)) return;
+    const bool tree = g->d.tree != 0;
+    if (what == 1) for_each_run(g->segs_c, true, [&](int first, int n, size_t lds, int cls) { launch_factor_tab(g->d, g->d_wgs_c + first, n, 0, lds, cls, g->stream, 1); });
+    else if (what == 2) for_each_run(g->segs_t, tree, [&](int first, int n, size_t lds, int cls) { launch_factor_tab(g->d, g->d_wgs_t + first, n, 0, lds, cls, g->stream, 2); });
+    else for_each_run(g->segs_b, tree, [&](int first, int n, size_t lds, int cls) { launch_backsolve_tab(g->d, g->d_wgs_b + first, n, g->small_max_npiv, g->small_max_f, lds, cls, g->stream); });
 }
 static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int base, int mode) {
     const int nlev = (int)ls.start.size() - 1;
@@ -1104,6 +1140,7 @@ static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int
         if (g->plan.max_front > 63) { enqueue_factor_big(g, ls, true); return; }
         launch_factor_tree(g->d, g->sub_n > 0 ? g->sub_free : g->leaf_n, g->leaf_slot, g->leaf_max_f, ls.start[nlev], g->block_n, g->sub_first, g->sub_n, g->stream); return; }
     if (g->d.factor_variant == 3 && !g->d.tree && mode == 0 && base == 0 && nlev > 0 && g->plan.max_front > 63) { ++g->d.epoch; enqueue_factor_big(g, ls, false); return; }
+    if (g->d.factor_variant == 3 && mode == 2 && nlev > 0 && ls.start[nlev] > 0 && g->plan.max_front > 63) { enqueue_shared_big(g, 2); return; }     // ... of a plan with workgroup fronts: table-driven
     if (g->d.factor_variant == 3 && g->d.tree && mode == 2 && nlev > 0 && ls.start[nlev] > 0) {     // the shared top of a sharded graph, one flagged launch
         launch_factor_tree_top(g->d, base, ls.start[nlev], g->stream); return; }
     for (int l = 0; l < nlev; ++l)
@@ -1112,6 +1149,7 @@ static void enqueue_factor_levels(gs_graph *g, const gs_graph::LevelSet &ls, int
 static void enqueue_backsolve_levels(gs_graph *g, const gs_graph::LevelSet &ls, int base) {
     const int nlev = (int)ls.start.size() - 1;
     if (g->d.factor_variant == 3 && base == 0 && nlev > 0 && g->plan.max_front > 63) { enqueue_backsolve_big(g, ls, g->d.tree != 0); return; }
+    if (g->d.factor_variant == 3 && base != 0 && nlev > 0 && ls.start[nlev] > 0 && g->plan.max_front > 63) { enqueue_shared_big(g, 3); return; }
     if (g->d.factor_variant == 3 && g->d.tree && base == 0 && nlev > 0) {
         // levels >= 1 in one launch (fronts wait for their parent's flag), then the leaf level on its own: by then every
         // parent is done, so it needs no flags, and its LDS slot is sized for the leaves alone (more resident waves)
@@ -1143,7 +1181,8 @@ static void enqueue_local(gs_graph *g, bool timed) {
     if (timed) hipEventRecord(g->ev[1], g->stream);
     enqueue_factor_levels(g, g->own, 0, 0);
     const int nshared = (int)g->plan.level_fronts_shared.size();
-    if (nshared > 0) { int mf = 0; for (int v : g->shared.max_f) mf = std::max(mf, v);
+    if (nshared > 0 && g->d.factor_variant == 3 && g->plan.max_front > 63) enqueue_shared_big(g, 1);      // a plan with workgroup fronts: table-driven
+    else if (nshared > 0) { int mf = 0; for (int v : g->shared.max_f) mf = std::max(mf, v);
         launch_factor_level(g->d, g->shared_base, nshared, mf, 1, g->stream); }
 }
 // second half: the shared top (redundantly on every rank), backward solve top-down, update

@@ -142,7 +142,7 @@ void launch_build_f3(int nq, const int32_t *lf, const DevFront *fronts, const in
                      const int32_t *u3_off, const int32_t *u3_size, const int32_t *bf, const int32_t *xrow_off, const int64_t *x_off,
                      int32_t *f3_desc, int32_t *f3_x, int x_stride, hipStream_t st, const int32_t *list = nullptr, const int32_t *pos_of = nullptr);   // pos_of: front -> level position (into the children's headers)
 // plans that hold a front of more than 63 scalars: table-driven whole-tree launches (workgroup -> {level position, kind | count << 8})
-void launch_factor_tab(const DevGraph &d, const int2 *wgt, int n_wg, int leaf_launch_preceded, size_t lds_bytes, int cls, hipStream_t st);      // cls: 0 fronts of 64-79, 1 small fronts + 80-111, 2 fronts of 112-159
+void launch_factor_tab(const DevGraph &d, const int2 *wgt, int n_wg, int leaf_launch_preceded, size_t lds_bytes, int cls, hipStream_t st, int mode = 0);      // cls: 0 fronts of 64-79, 1 small fronts + 80-111, 2 fronts of 112-159; mode: 0 own, 1 contribution to a shared front, 2 shared front from the exchange
 void launch_backsolve_tab(const DevGraph &d, const int2 *wgt, int n_wg, int max_npiv_small, int max_f_small, size_t lds_bytes, int cls, hipStream_t st);   // cls: 0 small fronts (a wave each), 1 big fronts
 size_t factor_tab_lds_bytes(int kind);                                       // LDS of one workgroup of k_factor3_tab by kind (0 waves, 1 four waves, 4 / 2 / 3 = 5 / 7 / 10 tile rows)
 size_t backsolve_tab_lds_bytes(int kind, int f_or_slot_f, int npiv_small);

@@ -2192,8 +2192,11 @@ __device__ __forceinline__ bool f3_big_panel(int B, bool &bad, v4d (&acc)[BigDim
     wave_lds_sync();
     return true;
 }
+// mode (pose-window shards, as for the small fronts): FRONT_OWN a front of this rank's own subtree; FRONT_CONTRIB this rank's share of a
+// shared front — the originals it evaluated + the update matrices of the children it owns — written to the front's exchange slot, no
+// factorisation; FRONT_TOP a shared front after the all-reduce: the image starts from the summed slot, only the shared children are added
 template <int NT>
-__device__ __forceinline__ void f3_big_front(const DevGraph &d, int pos, double *smem) {
+__device__ __forceinline__ void f3_big_front(const DevGraph &d, int pos, double *smem, int mode = FRONT_OWN) {
     using D = BigDims<NT>;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const F3 fr = f3_load(d.f3_desc, pos, lane);
@@ -2209,6 +2212,11 @@ __device__ __forceinline__ void f3_big_front(const DevGraph &d, int pos, double 
     __syncthreads();
     // ---- the original values: scalar records {offset in H_arena, offset in the image} (padded to multiples of 64), landmark
     // diagonal blocks of the fused linearisation as sums of their partial slots, parallel edges one by one
+    if (mode == FRONT_TOP) {                                         // the all-reduced slot: (f + 1) x f column-major, ld = f + 1
+        const double *X = d.exchange + fr.x_off;
+        for (int idx = tid; idx < (f + 1) * f; idx += 256) { const int c = idx / (f + 1), r = idx - c * (f + 1); if (r >= c) P.at(r, c) = X[idx]; }
+        __syncthreads();
+    } else
     { const int nsc = fr.sc_cnt, nlm = fr.lm_cnt;
       const int2 *sc3 = reinterpret_cast<const int2 *>(d.sc3) + fr.sc_off;
       for (int base = 0; base < nsc; base += 1024) {                 // four records per thread in flight
@@ -2244,7 +2252,8 @@ __device__ __forceinline__ void f3_big_front(const DevGraph &d, int pos, double 
     for (int e = 0; e < fr.nchild; ++e) {
         const int32_t *xt = d.f3_x + fr.x_tab + (int64_t)e * d.f3x_stride;
         const int hv = xt[BIG_TAB + (lane & 7)];
-        const int c_id = __builtin_amdgcn_readlane(hv, 0), c_uoff = __builtin_amdgcn_readlane(hv, 1), c_usz = __builtin_amdgcn_readlane(hv, 2);
+        const int c_id = __builtin_amdgcn_readlane(hv, 0), c_uoff = __builtin_amdgcn_readlane(hv, 1), c_usz = __builtin_amdgcn_readlane(hv, 2), c_own = __builtin_amdgcn_readlane(hv, 3);
+        if ((mode == FRONT_CONTRIB && c_own != d.rank) || (mode == FRONT_TOP && c_own >= 0)) continue;      // (uniform) another rank's subtree / came in with the slot
         if (tid < BIG_TAB) tab[tid] = xt[tid];
         okw = f3_wait_flag(d.done_f + c_id, d.epoch, d.fail) && okw;       // a child of an earlier launch has its flag set already
         __syncthreads();
@@ -2261,6 +2270,12 @@ __device__ __forceinline__ void f3_big_front(const DevGraph &d, int pos, double 
     }
     if (!okw && tid == 0) atomicMax(d.fail, 2);
     BIG_TS(2);
+    if (mode == FRONT_CONTRIB) {                                     // this rank's share of a shared front -> its exchange slot
+        double *X = d.exchange + fr.x_off;
+        for (int idx = tid; idx < (f + 1) * f; idx += 256) { const int c = idx / (f + 1), r = idx - c * (f + 1); X[idx] = r >= c ? P.at(r, c) : 0.0; }
+        if (blockIdx.x == 0 && tid == 0) contrib_publish_fail(d);
+        return;
+    }
     // ---- accumulators: wave w holds tiles w, w + 4, ...
     v4d acc[D::TPW];
 #pragma unroll
@@ -2372,17 +2387,18 @@ __device__ __forceinline__ void bs3_big_front(const DevGraph &d, int pos, double
 // inherit the registers (and with them the occupancy) of the others: 0 = fronts of 64-79 scalars (three workgroups per CU),
 // 1 = small fronts (a wave or four each) and fronts of 80-111 (two per CU), 2 = fronts of 112-159 (one per CU)
 template <int CLASS>
-__global__ void __launch_bounds__(256, CLASS == 0 ? 3 : (CLASS == 1 ? 2 : 1)) k_factor3_tab(DevGraph d, const int2 *__restrict__ wgt, int leaf_launch_preceded) {
+__global__ void __launch_bounds__(256, CLASS == 0 ? 3 : (CLASS == 1 ? 2 : 1)) k_factor3_tab(DevGraph d, const int2 *__restrict__ wgt, int leaf_launch_preceded, int mode) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int2 e = wgt[blockIdx.x];
     const int pos = __builtin_amdgcn_readfirstlane(e.x), kind = __builtin_amdgcn_readfirstlane(e.y) & 0xff, cnt = __builtin_amdgcn_readfirstlane(e.y) >> 8;
-    if constexpr (CLASS == 0) { f3_big_front<5>(d, pos, smem); }
-    else if constexpr (CLASS == 2) { f3_big_front<10>(d, pos, smem); }
+    if constexpr (CLASS == 0) { f3_big_front<5>(d, pos, smem, mode); }
+    else if constexpr (CLASS == 2) { f3_big_front<10>(d, pos, smem, mode); }
     else {
-        if (kind == WG_WAVES) { if (wave < cnt) f3_wave_front<true, false, 4>(d, pos + wave, FRONT_OWN, leaf_launch_preceded, smem, wave, lane, false, false); }
-        else if (kind == WG_BLOCK4) f3_block_front(d, pos, FRONT_OWN, leaf_launch_preceded, smem, false);
-        else f3_big_front<7>(d, pos, smem);
+        // (the host never puts a four-wave entry into a CONTRIB table: that form has the modes OWN and TOP)
+        if (kind == WG_WAVES) { if (wave < cnt) f3_wave_front<true, false, 4>(d, pos + wave, mode, leaf_launch_preceded, smem, wave, lane, false, blockIdx.x == 0 && wave == 0); }
+        else if (kind == WG_BLOCK4) f3_block_front(d, pos, mode, leaf_launch_preceded, smem, false);
+        else f3_big_front<7>(d, pos, smem, mode);
     }
 }
 template <bool BIG>      // BIG: a launch of big fronts only (few registers: as many workgroups per CU as the LDS allows); else small fronts, a wave each
@@ -2408,14 +2424,14 @@ size_t backsolve_tab_lds_bytes(int kind, int f_or_slot_f, int npiv_small) {     
     if (kind == WG_WAVES || kind == WG_BLOCK4) { const int slot = ((((f_or_slot_f + 1) | 1) * std::max(npiv_small, 1)) + 1) & ~1; return (size_t)slot * 4 * sizeof(double); }
     return (size_t)bs3_big_lds_doubles(f_or_slot_f) * sizeof(double);
 }
-void launch_factor_tab(const DevGraph &d, const int2 *wgt, int n_wg, int leaf_launch_preceded, size_t lds_bytes, int cls, hipStream_t st) {
+void launch_factor_tab(const DevGraph &d, const int2 *wgt, int n_wg, int leaf_launch_preceded, size_t lds_bytes, int cls, hipStream_t st, int mode) {
     if (n_wg <= 0) return;                                           // (a launch holds workgroups of ONE class: the host cut the table that way)
     if (cls == 0) { allow_max_lds((const void *)k_factor3_tab<0>);
-        hipLaunchKernelGGL(k_factor3_tab<0>, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, leaf_launch_preceded); }
+        hipLaunchKernelGGL(k_factor3_tab<0>, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, leaf_launch_preceded, mode); }
     else if (cls == 2) { allow_max_lds((const void *)k_factor3_tab<2>);
-        hipLaunchKernelGGL(k_factor3_tab<2>, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, leaf_launch_preceded); }
+        hipLaunchKernelGGL(k_factor3_tab<2>, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, leaf_launch_preceded, mode); }
     else { allow_max_lds((const void *)k_factor3_tab<1>);
-        hipLaunchKernelGGL(k_factor3_tab<1>, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, leaf_launch_preceded); }
+        hipLaunchKernelGGL(k_factor3_tab<1>, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, leaf_launch_preceded, mode); }
 }
 void launch_backsolve_tab(const DevGraph &d, const int2 *wgt, int n_wg, int max_npiv_small, int max_f_small, size_t lds_bytes, int cls, hipStream_t st) {
     if (n_wg <= 0) return;

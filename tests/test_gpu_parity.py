@@ -530,7 +530,7 @@ def test_fat_update_matrices_on_the_matrix_core_kernels(pkg, po, seed, shape):
     scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
     outs = []
     for env in ({}, dict(block_fronts=0), dict(tree=0)):
-        G = fresh(pkg, g, debug=env); done, st = G.optimize(1); dp, dl = G.export_delta()
+        G = fresh(pkg, g, leaf_poses=8, debug=env); done, st = G.optimize(1); dp, dl = G.export_delta()      # (leaves of 8 poses: the shapes these seeds were picked for)
         assert st.max_front <= 63 and done == 1 and st.numeric_failure == 0, (env, st.max_front)
         assert np.abs(dp - dp_o).max() / scale < 1e-9 and np.abs(dl - dl_o).max() / scale < 1e-9, env
         outs.append((dp.copy(), dl.copy())); G.close()
@@ -640,6 +640,42 @@ def test_sharded_iterations_match_oracle(pkg, po, bench_graphs, world, N, M):
     assert np.sqrt(((L - og.landmarks()) ** 2).sum(1).mean()) / rms < 1e-6
     assert np.abs(P[:, 2] - og.poses()[:, 2]).max() < 1e-6
     # every rank evaluated only its own share of the edges
+    for G in ranks:
+        G.close()
+
+
+@pytest.mark.parametrize("world,K,N,M,tree", [(2, 16, 1000, 200, 1), (4, 24, 10000, 2000, 1), (4, 16, 10000, 2000, 0)])
+def test_sharded_wide_view_tracks_keep_the_matrix_core_fronts(pkg, po, frontend, world, K, N, M, tree):
+    """Tracks with 16 / 24 cones in view (what coneMappingThreshold = 50 m gives, reference src/slam.cpp:608) spread over pose windows:
+    fronts of 64 .. 159 scalars in the ranks' own subtrees AND in the shared top.  Rounds 2-3 dropped such a sharded plan to the block
+    VALU kernels; now the workgroup-front kernels have the shard modes (contribution -> exchange slot, shared front from the summed
+    slot) and the plan stays on the matrix cores.  `world` rank handles on this one GPU, the exchange summed in-process; merged
+    estimates after 5 iterations against the oracle; tree = 0: one launch per level (the fallback after a flag timeout)."""
+    t = pkg.track.generate(N, M, K); g = pkg.track.bench_graph(t, frontend)
+    ranks = []
+    for r in range(world):
+        G = fresh(pkg, g, debug=dict(tree=tree)); G.dist_configure(r, world); G.initialize_optimization(); ranks.append(G)
+    st = ranks[0].stats()
+    assert st.factor_variant == 3 and st.max_front > 63 and st.n_big_fronts > 0 and st.n_shared_fronts > 0
+    assert ranks[0].dist_exchange_doubles() > 0
+    for _ in range(5):
+        for G in ranks:
+            G.dist_iterate_local()
+        total = sum(G.dist_read_exchange() for G in ranks)
+        for G in ranks:
+            G.dist_write_exchange(total); G.dist_iterate_finish()
+    Np, Mg = len(g["pose_est"]), len(g["lm_est"])
+    P = np.zeros((Np, 3)); L = np.zeros((Mg, 2)); cp = np.zeros(Np); cl = np.zeros(Mg)
+    for G in ranks:
+        G.sync_estimates()
+        pk, lk, pprim, lprim = G.dist_known()
+        P += G.poses() * pprim[:, None]; L += G.landmarks() * lprim[:, None]; cp += pprim; cl += lprim
+    assert np.all(cp == 1) and np.all(cl == 1)
+    og = make_oracle_graph(po, g); og.optimize(5, ordering=1)
+    rms = np.sqrt((og.poses()[:, :2] ** 2).sum(1).mean())
+    assert np.sqrt(((P[:, :2] - og.poses()[:, :2]) ** 2).sum(1).mean()) / rms < 1e-8
+    assert np.sqrt(((L - og.landmarks()) ** 2).sum(1).mean()) / rms < 1e-8
+    assert np.abs(P[:, 2] - og.poses()[:, 2]).max() < 1e-8
     for G in ranks:
         G.close()
 
@@ -1043,17 +1079,17 @@ def test_fronts_beyond_a_wave_run_on_the_matrix_cores_and_match_the_oracle(pkg, 
     oracle, whole-tree launch and one launch per level (bitwise equal), and a flag timeout injected into a big plan."""
     g = random_graph(seed, **shape)
     og = make_oracle_graph(po, g); og.build_system(); og.apply_update(og.solve_ldlt(0)); dp_o, dl_o = og.delta()
-    G = fresh(pkg, g); done, st = G.optimize(1); dp, dl = G.export_delta()
+    G = fresh(pkg, g, leaf_poses=8); done, st = G.optimize(1); dp, dl = G.export_delta()     # (leaves of 8 poses: the shapes these seeds were picked for; the planner's own choice is 6 at this size)
     assert done == 1 and st.numeric_failure == 0 and st.factor_variant == 3 and 63 < st.max_front <= 159 and st.n_big_fronts > 0
     scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
     assert np.abs(dp - dp_o).max() / scale < 1e-9 and np.abs(dl - dl_o).max() / scale < 1e-9, (st.max_front, st.n_big_fronts)
     og.optimize(4, ordering=0); done, st = G.optimize(4)
     assert done == 4 and rel(G.poses(), og.poses()) < 1e-8 and rel(G.landmarks(), og.landmarks()) < 1e-8
     P1, L1 = G.poses(), G.landmarks(); G.close()
-    H = fresh(pkg, g, debug=dict(tree=0)); done, st = H.optimize(5)
+    H = fresh(pkg, g, leaf_poses=8, debug=dict(tree=0)); done, st = H.optimize(5)
     assert done == 5 and st.factor_variant == 3 and np.array_equal(H.poses(), P1) and np.array_equal(H.landmarks(), L1)     # same arithmetic, same order
     H.close()
-    F = fresh(pkg, g); F.initialize_optimization(); F.debug_fail_at_iteration(2, 2)
+    F = fresh(pkg, g, leaf_poses=8); F.initialize_optimization(); F.debug_fail_at_iteration(2, 2)
     done, st = F.optimize(5)
     assert done == 5 and st.fell_back == 1 and st.first_failure == 2 and np.array_equal(F.poses(), P1)
     F.close()
