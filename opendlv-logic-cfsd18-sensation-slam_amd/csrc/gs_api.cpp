@@ -756,7 +756,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
     GS_UT("arenas+levels");
     HIP_TRY(hipStreamSynchronize(g->stream));
     GS_UT("final sync");
-    g->dev_valid = true; g->dev_estimates_newer = false;
+    g->dev_valid = true; g->dev_estimates_newer = false; g->tree_proven = false;
     g->dev_estimate_version = h.estimate_version;
     return GS_OK;
 }
@@ -871,7 +871,7 @@ static int upload_growth(gs_graph *g, const Growth &gr) {
       for (int l = 0; l < nlev; ++l) { ls.max_f[l] = ls.max_npiv[l] = ls.max_nbnd[l] = 0;
           for (int q = ls.start[l]; q < ls.start[l + 1]; ++q) { const Front &F = P.fronts[P.level_fronts_owned[q]];
               ls.max_f[l] = std::max(ls.max_f[l], F.npiv + F.nbnd); ls.max_npiv[l] = std::max(ls.max_npiv[l], F.npiv); ls.max_nbnd[l] = std::max(ls.max_nbnd[l], F.nbnd); } } }
-    g->leaf_n = -1; g->block_n = -1;                                // the leaf instance and its LDS slot are chosen again from the grown fronts
+    g->leaf_n = -1; g->block_n = -1; g->tree_proven = false;        // the leaf instance and its LDS slot are chosen again from the grown fronts
     g->wg_f.clear(); g->wg_b.clear(); g->d_wg_f = g->d_wg_b = g->d_wgs_c = g->d_wgs_t = g->d_wgs_b = nullptr;   // ... and so are the workgroup tables of a plan with workgroup fronts (a grown front may change its size class)
     g->dev_estimate_version = h.estimate_version;
     return GS_OK;
@@ -1270,7 +1270,10 @@ static int optimize_impl(gs_graph *g, int32_t iterations, double rel_tol, gs_sta
     int applied = 0, enq = 0, first_failure = 0; int32_t ff[4] = {0, 0, 0, 0}; bool fell_back = false;
     while (enq < iterations) {
         // (a remainder of up to 12 goes out as one chunk: the reference's optimize(10) is 1 + 9, two host round trips instead of three)
-        const int upto = std::min(iterations, enq == 0 ? 1 : (until ? enq + 4 : (iterations - enq <= 12 ? iterations : enq + 8)));
+        // (the FIRST iteration goes out alone only until a whole-tree launch of THIS plan has come back clean once: the flag hand-off
+        // depends on the launch geometry, not on the numbers — a repeated optimize(10), the reference's quirk path, is one host round trip)
+        const bool alone = enq == 0 && !(g->tree_proven && g->d.tree);
+        const int upto = std::min(iterations, alone ? 1 : (until ? enq + 4 : (iterations - enq <= 12 ? iterations : enq + 8)));
         for (int it = enq; it < upto; ++it) {
             g->d.hist_slot = it < nh ? it : -1;                      // k_update files the chi2 of this iteration's linearisation point itself
             enqueue_iteration(g, false);
@@ -1281,6 +1284,7 @@ static int optimize_impl(gs_graph *g, int32_t iterations, double rel_tol, gs_sta
         HIP_TRY(hipMemcpyAsync(ff, g->d.fail, sizeof(ff), hipMemcpyDeviceToHost, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
         applied = ff[1];
+        if (ff[0] == 0 && g->d.tree) g->tree_proven = true;
         if (ff[0] != 0 && first_failure == 0) first_failure = ff[0];
         if (ff[0] == 2 && g->d.tree && !fell_back) {
             g->d.tree = 0; fell_back = true; g->fell_back = true; g->d.inject_iter = 0;

@@ -69,6 +69,7 @@ struct gs_graph {
     std::vector<WgSeg> segs_c, segs_t, segs_b; std::vector<int32_t> wgs_c, wgs_t, wgs_b;     // the SHARED top of a sharded plan with workgroup fronts: contributions, top, backward solve
     int2 *d_wgs_c = nullptr, *d_wgs_t = nullptr, *d_wgs_b = nullptr;
     int enqueue_rc = 0; std::string enqueue_err;     // a failure of the enqueue itself (the lazily built launch tables): returned by the entry point that enqueued
+    bool tree_proven = false;               // a whole-tree launch sequence of the CURRENT plan has completed without a flag timeout (gs_optimize then sends all iterations of a call at once)
     bool fell_back = false;                 // a whole-tree launch gave up on a flag: this handle uses one launch per level until the next plan
     // append-only growth (gs::grow_plan): the full structure phase leaves room behind the plan's arrays; a growth step re-writes the
     // changed fronts' runs there and rebuilds those fronts' device tables.  used_* = entries taken so far, cap_* = allocated.

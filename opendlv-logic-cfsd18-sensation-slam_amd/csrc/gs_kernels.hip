@@ -777,6 +777,14 @@ void launch_linearize(const DevGraph &d, hipStream_t st, hipEvent_t start, hipEv
     if (d.n_wtiles <= 0) { launch_linearize_gather(d, st); return; }
     if (d.wt_hi <= d.wt_lo) return;
     const dim3 grid((d.wt_hi - d.wt_lo + 3) / 4), block(256);
+    // (without events: the plain launch — the kernel trace of a lap-sized optimize(10) shows 3 us between k_update and a linearisation
+    // dispatched through hipExtLaunchKernelGGL and none in front of the plainly launched kernels, scripts/r4_g.sh)
+    if (!start && !stop) { switch (d.ell_T) {
+        case 1: hipLaunchKernelGGL(k_linearize_ell<1>, grid, block, 0, st, d); break;
+        case 2: hipLaunchKernelGGL(k_linearize_ell<2>, grid, block, 0, st, d); break;
+        case 4: hipLaunchKernelGGL(k_linearize_ell<4>, grid, block, 0, st, d); break;
+        default: hipLaunchKernelGGL(k_linearize_ell<8>, grid, block, 0, st, d); break; }
+        return; }
     switch (d.ell_T) {
         case 1: hipExtLaunchKernelGGL(k_linearize_ell<1>, grid, block, 0, st, start, stop, 0, d); break;
         case 2: hipExtLaunchKernelGGL(k_linearize_ell<2>, grid, block, 0, st, start, stop, 0, d); break;
@@ -2809,8 +2817,9 @@ __global__ void __launch_bounds__(256) k_update(DevGraph d) {
         if (g >= 0) { dx = d.xe[g + c]; d.lm_est[u] += dx; }
         d.dlm[u] = dx;
     }
-    // fused linearisation leaves one chi2 partial per wave tile: total them here (fixed order), no extra launch
-    if (blockIdx.x == gridDim.x - 1) {
+    // fused linearisation leaves one chi2 partial per wave tile: total them here (fixed order), no extra launch.  By the FIRST workgroup
+    // (dispatched first: its chain of loads -> reduction runs beside the others; the last one, rounds 1-3, put it behind everything else)
+    if (blockIdx.x == 0) {
         __shared__ double red[8];
         double tot = 0.0;
         if (d.n_wtiles > 0) {
