@@ -28,8 +28,9 @@ extern "C" {
  *     bs_wide         GS_BS_WIDE       plan  backward solve: levels wider than this get a light launch of their own (default 2048)
  *     leaf_nt3        GS_LEAF_NT3      plan  1 three-tile-row leaf instance when every leaf has <= 47 scalars (default), 0 off
  *     f3_lds_kb       GS_F3_LDS_KB     plan  occupancy experiments: LDS per workgroup of the per-level factor launches, KB (0 = need)
- *     subtree         GS_SUBTREE       plan  1 (default): a level-1 front and the leaves below it run in ONE workgroup (k_factor3_sub: the leaves'
- *                                      update matrices stay in LDS); 0: leaf launch + flagged launch from level 1 up, as in rounds 1-3
+ *     subtree         GS_SUBTREE       plan  1: a level-1 front and the leaves below it run in ONE workgroup (k_factor3_sub: the leaves'
+ *                                      update matrices stay in LDS; measured slower); 0 (default): leaf launch + flagged
+ *                                      launch from level 1 up
  *   plan shape — changes the elimination order, hence the last bits of the result (all are exact factorisations)
  *     leaf_poses      GS_LEAF_POSES    plan  nested-dissection leaf size in poses (0 = gs_config.leaf_poses / default 8)
  *     cluster_ways    GS_CLUSTER_WAYS  plan  fan-out of the multi-way split above the leaves (0 = default 8; 2 = binary)

@@ -1,0 +1,77 @@
+// A C++ consumer of the sharded entry points (tests/test_gpu_parity.py::test_cpp_consumer_runs_the_sharded_optimize_through_rccl):
+// what the microservice — a C++ process, reference src/opendlv-logic-cfsd18-sensation-slam.cpp:49-119 — does to run its optimiser over
+// pose windows, with nothing but the C-ABI: no Python, no torch, no HIP header.  Plain g++ -std=c++14 against include/graphslam.h.
+//   1. build the graph the way Slam does (src/slam.cpp:433-459, 525-550): pose vertices with their odometry edges, cone vertices,
+//      observation edges (measurements from the library's own polar -> XY);
+//   2. handle A: gs_optimize(10)                                  (src/slam.cpp:480-481 on one GPU)
+//   3. handle B: gs_dist_configure(0, 1) + a shared top forced on the single rank (include/graphslam_debug.h: the only way to put a
+//      NON-EMPTY exchange buffer through RCCL on one GPU), gs_dist_unique_id -> gs_dist_comm_init -> gs_dist_optimize(10): local
+//      half -> ncclAllReduce(sum, fp64) -> shared top, all enqueued by the library;
+//   4. both must agree (1e-9 relative to the track's size) and report 10 iterations.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../include/graphslam.h"
+#include "../include/graphslam_debug.h"
+
+extern "C" int gs_track_generate(int32_t, int32_t, double *, double *, double *, int32_t *, double *, int32_t *);
+extern "C" int gs_track_obs_per_pose(void);
+
+#define CHECK(call) do { int rc_ = (call); if (rc_ < 0) { std::fprintf(stderr, "%s -> %d: %s\n", #call, rc_, gs_last_error()); return 1; } } while (0)
+
+static void se2_between(const double *a, const double *b, double *z) {      // z = a^-1 o b  (src/slam.cpp:451-454)
+    const double c = std::cos(a[2]), s = std::sin(a[2]), dx = b[0] - a[0], dy = b[1] - a[1];
+    z[0] = c * dx + s * dy; z[1] = -s * dx + c * dy; z[2] = std::atan2(std::sin(b[2] - a[2]), std::cos(b[2] - a[2]));
+}
+
+static int build(gs_graph *g, int N, int M, int K, const std::vector<double> &odom, const std::vector<double> &cxy,
+                 const std::vector<double> &obs, const std::vector<int32_t> &ocone, const std::vector<double> &zxy) {
+    std::vector<char> seen(M, 0);
+    for (int k = 0; k < N; ++k) {
+        CHECK(gs_add_pose(g, 1000 + k, &odom[3 * k]));
+        if (k > 0) { double z[3]; se2_between(&odom[3 * (k - 1)], &odom[3 * k], z);
+            const double info[9] = {5, 0, 0, 0, 5, 0, 0, 0, 5};
+            CHECK(gs_add_odometry_edge(g, 1000 + k - 1, 1000 + k, z, info)); }
+        for (int i = 0; i < K; ++i) { const int l = ocone[(size_t)k * K + i];
+            if (!seen[l]) { seen[l] = 1; const double e[2] = {cxy[2 * l] + 0.3, cxy[2 * l + 1] - 0.2}; CHECK(gs_add_landmark(g, l, e)); }
+            const double info[4] = {0.01, 0, 0, 0.01};
+            CHECK(gs_add_observation_edge(g, 1000 + k, l, &zxy[2 * ((size_t)k * K + i)], info)); }
+    }
+    CHECK(gs_set_fixed_pose(g, 1000, 1)); CHECK(gs_set_fixed_pose(g, 1001, 1));             // src/slam.cpp:464-474
+    int fixed = 0; for (int l = 0; l < M && fixed < 2; ++l) if (seen[l]) { CHECK(gs_set_fixed_landmark(g, l, 1)); ++fixed; }
+    return 0;
+}
+
+int main() {
+    const int N = 2000, M = 400, K = gs_track_obs_per_pose();
+    std::vector<double> truth(3 * N), odom(3 * N), cxy(2 * M), obs((size_t)4 * K * N), zxy((size_t)2 * K * N); std::vector<int32_t> ctype(M), ocone((size_t)K * N);
+    if (gs_track_generate(N, M, truth.data(), odom.data(), cxy.data(), ctype.data(), obs.data(), ocone.data()) != 0) return 3;
+    gs_graph *A = nullptr, *B = nullptr;
+    CHECK(gs_create(nullptr, &A)); CHECK(gs_create(nullptr, &B));
+    { std::vector<double> az((size_t)K * N), zen((size_t)K * N), di((size_t)K * N);
+      for (size_t i = 0; i < (size_t)K * N; ++i) { az[i] = obs[4 * i]; zen[i] = obs[4 * i + 1]; di[i] = obs[4 * i + 2]; }
+      CHECK(gs_polar_to_xy_batch(A, K * N, az.data(), zen.data(), di.data(), zxy.data())); }
+    if (build(A, N, M, K, odom, cxy, obs, ocone, zxy) || build(B, N, M, K, odom, cxy, obs, ocone, zxy)) return 1;
+    gs_stats sa, sb;
+    const int da = gs_optimize(A, 10, &sa); if (da < 0) { std::fprintf(stderr, "gs_optimize: %s\n", gs_last_error()); return 1; }
+    // ---- the sharded path on one rank: a forced shared top, RCCL inside the library
+    gs_debug_options o; CHECK(gs_debug_get_options(B, &o)); o.force_shared_top = 3; CHECK(gs_debug_set_options(B, &o));
+    CHECK(gs_dist_configure(B, 0, 1));
+    char id[128]; CHECK(gs_dist_unique_id(id));                     // (rank 0 makes it; the other ranks would receive these 128 bytes)
+    CHECK(gs_dist_comm_init(B, id, 0, 1));
+    const int db = gs_dist_optimize(B, 10, &sb); if (db < 0) { std::fprintf(stderr, "gs_dist_optimize: %s\n", gs_last_error()); return 1; }
+    std::vector<double> pa(3 * N), pb(3 * N);
+    CHECK(gs_get_poses(A, N, nullptr, pa.data())); CHECK(gs_get_poses(B, N, nullptr, pb.data()));
+    double rms = 0, worst = 0;
+    for (int k = 0; k < N; ++k) rms += pa[3 * k] * pa[3 * k] + pa[3 * k + 1] * pa[3 * k + 1];
+    rms = std::sqrt(rms / N);
+    for (int i = 0; i < 3 * N; ++i) worst = std::fmax(worst, std::fabs(pa[i] - pb[i]));
+    std::printf("iterations %d %d  shared fronts %d  exchange doubles %lld  max |pose diff| / rms %.3g  chi2 %.6g -> %.6g\n", da, db, sb.n_shared_fronts,
+                (long long)gs_dist_exchange_doubles(B), worst / rms, sa.chi2_initial, sa.chi2_final);
+    const bool ok = da == 10 && db == 10 && sb.n_shared_fronts > 0 && gs_dist_exchange_doubles(B) > 2 && worst / rms < 1e-9 && sa.chi2_final < sa.chi2_initial;
+    gs_destroy(A); gs_destroy(B);
+    std::puts(ok ? "OK" : "MISMATCH");
+    return ok ? 0 : 2;
+}

@@ -994,6 +994,24 @@ def test_rccl_all_reduce_inside_the_library_on_a_forced_shared_top(pkg, po, benc
     A.close(); G.close(); H.close(); F.close()
 
 
+def test_cpp_consumer_runs_the_sharded_optimize_through_rccl(pkg):
+    """tests/dist_cpp_consumer.cpp — plain g++ -std=c++14 against include/graphslam.h, no Python, no torch, no HIP header — builds a 2 000-pose
+    graph the way Slam does, runs gs_optimize(10) on one handle and gs_dist_unique_id -> gs_dist_comm_init -> gs_dist_optimize(10) (a forced
+    shared top: a non-empty exchange buffer through RCCL) on another, and compares: what the reference's C++ microservice
+    (src/opendlv-logic-cfsd18-sensation-slam.cpp:49-119) would call to run its optimiser over pose windows."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "_build", "dist_cpp_consumer")
+    if not os.path.exists(exe):
+        csrc = os.path.join(root, "opendlv-logic-cfsd18-sensation-slam_amd", "csrc")
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(["g++", "-std=c++14", "-O2", os.path.join(root, "tests", "dist_cpp_consumer.cpp"), "-o", exe, "-L" + csrc, "-lgraphslam_hip", "-lgstrack",
+                               "-Wl,-rpath,$ORIGIN/../../opendlv-logic-cfsd18-sensation-slam_amd/csrc"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "OK", (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    print(r.stdout.strip().splitlines()[-2])
+
+
 # ---------------------------------------------------------------- the multi-GPU launch path: RCCL, torch side stream, device exchange buffer
 def test_bench_nccl_branch_runs_for_real_at_world_size_one(pkg):
     """bench.py's multi-GPU branch — init_process_group("nccl") (= RCCL), a torch side stream adopted by the library,
