@@ -7,5 +7,5 @@ N, M = pkg.track.CONFIGS[name]
 t = pkg.track.generate(N, M); fe = pkg.Graph(); g = pkg.track.bench_graph(t, fe)
 G = pkg.Graph(); G.load_bench_graph(g); G.initialize_optimization(); st = G.stats()
 s = G.time_iterations(30)
-print("%s fronts %d levels %d maxf %d | lin %.3f factor %.3f back %.3f upd %.3f total %.3f ms -> %.1f it/s" % (
-    name, st.n_fronts, st.n_levels, st.max_front, s.ms_linearize, s.ms_factor, s.ms_backsolve, s.ms_update, s.ms_total, 1e3 / s.ms_total))
+print("%s fronts %d levels %d maxf %d | lin %.4f (kernel %.4f) factor %.3f back %.3f upd %.3f total %.4f ms -> %.1f it/s" % (
+    name, st.n_fronts, st.n_levels, st.max_front, s.ms_linearize, s.ms_linearize_kernel, s.ms_factor, s.ms_backsolve, s.ms_update, s.ms_total, 1e3 / s.ms_total))
