@@ -274,21 +274,44 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     GS_PT(0);
     // ---- edges grouped by pose and by landmark (insertion indices; the device layout of the observation edges follows the shard
     // assignment further down: a rank lays out the poses it sweeps only)
+    // (room for grow_plan's appended runs is reserved BEFORE the arrays are filled: reserving afterwards re-allocated and copied ~60 MB at 100k poses)
+    plan.pl_order.reserve((size_t)Epl + TAIL_PL); plan.pp_order.reserve((size_t)Epp + TAIL_PP);
+    // The reference adds a keyframe's observation edges behind its pose (src/slam.cpp:433-459, 525-550): the edges arrive grouped by pose.
+    // Then the grouping is the identity and the ranges come from a scan — on all host threads (a pose-window shard walks the edges of ALL
+    // windows here: these passes were 70 of a rank's 480 ms at 8 x 100k poses); any other insertion order takes the counting sort.
     plan.pl_start.assign(N + 1, 0);
-    for (int k = 0; k < Epl; ++k) plan.pl_start[g.pl_p[k] + 1]++;
-    for (int p = 0; p < N; ++p) plan.pl_start[p + 1] += plan.pl_start[p];
     plan.pl_order.resize(Epl);
-    { std::vector<int32_t> fill(plan.pl_start.begin(), plan.pl_start.end() - 1);
-      for (int k = 0; k < Epl; ++k) plan.pl_order[fill[g.pl_p[k]]++] = k; }
+    bool by_pose = true;
+    { std::vector<uint8_t> bad(host_threads() + 1, 0);
+      parallel_chunks(Epl, 65536, [&](int64_t b0, int64_t e0, int t) { for (int64_t k = b0; k < e0; ++k) if (k + 1 < Epl && g.pl_p[(size_t)k + 1] < g.pl_p[(size_t)k]) { bad[t] = 1; break; } });
+      for (uint8_t b : bad) by_pose = by_pose && !b; }
+    if (by_pose) {
+        parallel_chunks(Epl, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t k = b0; k < e0; ++k) plan.pl_order[(size_t)k] = (int32_t)k; });
+        parallel_chunks((int64_t)N + 1, 16384, [&](int64_t b0, int64_t e0, int) {
+            int64_t k = std::lower_bound(g.pl_p.begin(), g.pl_p.end(), (int32_t)b0) - g.pl_p.begin();
+            for (int64_t p = b0; p < e0; ++p) { while (k < Epl && g.pl_p[(size_t)k] < p) ++k; plan.pl_start[(size_t)p] = (int32_t)k; } });
+    } else {
+        for (int k = 0; k < Epl; ++k) plan.pl_start[g.pl_p[k] + 1]++;
+        for (int p = 0; p < N; ++p) plan.pl_start[p + 1] += plan.pl_start[p];
+        std::vector<int32_t> fill(plan.pl_start.begin(), plan.pl_start.end() - 1);
+        for (int k = 0; k < Epl; ++k) plan.pl_order[fill[g.pl_p[k]]++] = k; }
     plan.pp_order.resize(Epp);
     for (int k = 0; k < Epp; ++k) plan.pp_order[k] = k;
-    // landmark -> its edges (insertion indices, pose order); turned into ELL indices at the end (lm_edges, single GPU only)
+    // landmark -> its edges (insertion indices, pose order); turned into ELL indices at the end (lm_edges, single GPU only).  A stable
+    // counting sort by landmark over the pose-grouped sequence, in chunks: per chunk a histogram, offsets per (chunk, landmark), scatter.
     plan.lm_start.assign(M + 1, 0);
-    for (int k = 0; k < Epl; ++k) plan.lm_start[g.pl_l[k] + 1]++;
-    for (int l = 0; l < M; ++l) plan.lm_start[l + 1] += plan.lm_start[l];
     std::vector<int32_t> lm_k(Epl);
-    { std::vector<int32_t> fill(plan.lm_start.begin(), plan.lm_start.end() - 1);
-      for (int pos = 0; pos < Epl; ++pos) { const int k = plan.pl_order[pos]; lm_k[fill[g.pl_l[k]]++] = k; } }
+    { const int C = (int64_t)chunk_count(Epl, 1 << 18) * M <= ((int64_t)1 << 26) ? chunk_count(Epl, 1 << 18) : 1;
+      std::vector<std::vector<int32_t>> cnt(C);
+      auto lo = [&](int c) { return (int64_t)Epl * c / C; };
+      parallel_chunks(C, 1, [&](int64_t c0, int64_t c1, int) { for (int c = (int)c0; c < (int)c1; ++c) { auto &h = cnt[c]; h.assign((size_t)M, 0);
+          for (int64_t pos = lo(c); pos < lo(c + 1); ++pos) h[g.pl_l[plan.pl_order[(size_t)pos]]]++; } });
+      parallel_chunks(M, 16384, [&](int64_t b0, int64_t e0, int) { for (int64_t l = b0; l < e0; ++l) { int32_t n = 0;
+          for (int c = 0; c < C; ++c) { const int32_t v = cnt[c][(size_t)l]; cnt[c][(size_t)l] = n; n += v; }      // offset of chunk c inside landmark l's run
+          plan.lm_start[(size_t)l + 1] = n; } });
+      for (int l = 0; l < M; ++l) plan.lm_start[l + 1] += plan.lm_start[l];
+      parallel_chunks(C, 1, [&](int64_t c0, int64_t c1, int) { for (int c = (int)c0; c < (int)c1; ++c) { auto &h = cnt[c];
+          for (int64_t pos = lo(c); pos < lo(c + 1); ++pos) { const int k = plan.pl_order[(size_t)pos]; const int l = g.pl_l[k]; lm_k[(size_t)plan.lm_start[l] + h[l]++] = k; } } }); }
     // pose -> incident pp edges, and the flattened incidence records {edge, role, i, j}
     plan.ppadj_start.assign(N + 1, 0);
     for (int k = 0; k < Epp; ++k) { plan.ppadj_start[g.pp_i[k] + 1]++; plan.ppadj_start[g.pp_j[k] + 1]++; }
@@ -297,8 +320,9 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     { std::vector<int32_t> fill(plan.ppadj_start.begin(), plan.ppadj_start.end() - 1);
       for (int k = 0; k < Epp; ++k) { plan.ppadj[fill[g.pp_i[k]]++] = 2 * k; plan.ppadj[fill[g.pp_j[k]]++] = 2 * k + 1; } }
     plan.ppinc.resize(plan.ppadj.size() * 4);
-    for (size_t q = 0; q < plan.ppadj.size(); ++q) { const int code = plan.ppadj[q], k = code >> 1;
-        plan.ppinc[4 * q] = k; plan.ppinc[4 * q + 1] = code & 1; plan.ppinc[4 * q + 2] = g.pp_i[k]; plan.ppinc[4 * q + 3] = g.pp_j[k]; }
+    parallel_chunks((int64_t)plan.ppadj.size(), 65536, [&](int64_t b0, int64_t e0, int) {
+        for (size_t q = (size_t)b0; q < (size_t)e0; ++q) { const int code = plan.ppadj[q], k = code >> 1;
+            plan.ppinc[4 * q] = k; plan.ppinc[4 * q + 1] = code & 1; plan.ppinc[4 * q + 2] = g.pp_i[k]; plan.ppinc[4 * q + 3] = g.pp_j[k]; } });
 
     GS_PT(1);
     GS_PT(2);
@@ -320,6 +344,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
             sn_of[v] = s; vpos[v] = pos++; gidx[v] = sc; sc += B.dim(v); }
       if (pos != B.nv) { err = "ordering lost a vertex"; return false; }
       plan.n_scalar = sc; }
+    plan.pose_gidx.reserve((size_t)N + TAIL_POSES); plan.lm_gidx.reserve((size_t)M + TAIL_LMS);
     plan.pose_gidx.assign(N, -1); plan.lm_gidx.assign(M, -1);
     for (int i = 0; i < B.nfp; ++i) plan.pose_gidx[B.pose_of_fp[i]] = gidx[i];
     for (int l = 0; l < B.nfl; ++l) plan.lm_gidx[B.lm_of_fl[l]] = gidx[B.nfp + l];
@@ -378,6 +403,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
           for (int k = 0; k < F.npiv; ++k) { int64_t r2 = F.npiv + F.nbnd + 1 - k; plan.factor_flops += r2 * r2; }
       }
       if (na >= ((int64_t)1 << 31)) { err = "too many assembly records"; return false; }
+      plan.bnd_rows.reserve((size_t)nb + 64 * 1024); plan.child_map.reserve((size_t)nm + 64 * 1024); plan.asm_recs.reserve((size_t)na + 96 * 1024);
       plan.bnd_rows.resize((size_t)nb); plan.child_map.resize((size_t)nm); plan.asm_recs.resize((size_t)na); }
     parallel_chunks(S, 512, [&](int64_t b0, int64_t e0, int) {
         std::vector<int32_t> loc(B.nv, -1);                          // row of a vertex inside the current front (only entries set below are read)
@@ -445,6 +471,8 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     // separator poses and the landmarks seen from more than one window.  An edge is evaluated by exactly one rank,
     // one that knows both endpoint estimates (owner of an interior endpoint, else the window of the pose).
     plan.world = std::max(1, opt.world); plan.rank = opt.rank;
+    plan.pl_rank.reserve((size_t)Epl + TAIL_PL); plan.pp_rank.reserve((size_t)Epp + TAIL_PP);
+    plan.pose_known.reserve((size_t)N + TAIL_POSES); plan.lm_known.reserve((size_t)M + TAIL_LMS);
     plan.pl_rank.assign(Epl, 0); plan.pp_rank.assign(Epp, 0);
     plan.pose_known.assign(N, 1); plan.lm_known.assign(M, 1);
     plan.level_start_owned = plan.level_start; plan.level_fronts_owned = plan.level_fronts;
@@ -463,25 +491,23 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
             else F.owner = (wmin[s] == wmax[s]) ? wmin[s] : -1;
         }
         auto vowner = [&](int v) { return plan.fronts[sn_of[v]].owner; };
-        for (int k = 0; k < Epl; ++k) {
-            const int fp = B.fp_of_pose[g.pl_p[k]], fl = B.fl_of_lm[g.pl_l[k]];
+        parallel_chunks(Epl, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t k = b0; k < e0; ++k) {
+            const int fp = B.fp_of_pose[g.pl_p[(size_t)k]], fl = B.fl_of_lm[g.pl_l[(size_t)k]];
             int r = 0;
             if (fp >= 0 && vowner(fp) >= 0) r = vowner(fp);
             else if (fl >= 0 && vowner(B.nfp + fl) >= 0) r = vowner(B.nfp + fl);
             else if (fp >= 0) r = window(fp);
-            plan.pl_rank[k] = r;
-        }
-        for (int k = 0; k < Epp; ++k) {
-            const int fi = B.fp_of_pose[g.pp_i[k]], fj = B.fp_of_pose[g.pp_j[k]];
+            plan.pl_rank[(size_t)k] = r; } });
+        parallel_chunks(Epp, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t k = b0; k < e0; ++k) {
+            const int fi = B.fp_of_pose[g.pp_i[(size_t)k]], fj = B.fp_of_pose[g.pp_j[(size_t)k]];
             int r = 0;
             if (fi >= 0 && vowner(fi) >= 0) r = vowner(fi);
             else if (fj >= 0 && vowner(fj) >= 0) r = vowner(fj);
             else if (fi >= 0) r = window(fi);
             else if (fj >= 0) r = window(fj);
-            plan.pp_rank[k] = r;
-        }
-        for (int i = 0; i < B.nfp; ++i) { const int o = vowner(i); plan.pose_known[B.pose_of_fp[i]] = (o < 0 || o == plan.rank); }
-        for (int l = 0; l < B.nfl; ++l) { const int o = vowner(B.nfp + l); plan.lm_known[B.lm_of_fl[l]] = (o < 0 || o == plan.rank); }
+            plan.pp_rank[(size_t)k] = r; } });
+        parallel_chunks(B.nfp, 65536, [&](int64_t b0, int64_t e0, int) { for (int i = (int)b0; i < (int)e0; ++i) { const int o = vowner(i); plan.pose_known[B.pose_of_fp[i]] = (o < 0 || o == plan.rank); } });
+        parallel_chunks(B.nfl, 65536, [&](int64_t b0, int64_t e0, int) { for (int l = (int)b0; l < (int)e0; ++l) { const int o = vowner(B.nfp + l); plan.lm_known[B.lm_of_fl[l]] = (o < 0 || o == plan.rank); } });
         // per-rank level lists: owned fronts, then the shared top; exchange slots of the shared fronts
         plan.level_start_owned.assign(nlev + 1, 0); plan.level_fronts_owned.clear(); plan.level_fronts_shared.clear();
         for (int l = 0; l < nlev; ++l) {
@@ -540,11 +566,16 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     // points there (its block reads as zero).
     int plo = 0, phi = N;
     if (plan.world > 1) { plo = N; phi = 0;
-        for (int p = 0; p < N; ++p) { bool any = false;
-            for (int s2 = plan.pl_start[p]; s2 < plan.pl_start[p + 1] && !any; ++s2) any = plan.pl_rank[plan.pl_order[s2]] == plan.rank;
-            for (int q = plan.ppadj_start[p]; q < plan.ppadj_start[p + 1] && !any; ++q) any = plan.pp_rank[plan.ppadj[q] >> 1] == plan.rank;
-            if (any) { plo = std::min(plo, p); phi = std::max(phi, p + 1); } }
+        std::vector<int> lo_t(host_threads() + 1, N), hi_t(host_threads() + 1, 0);
+        parallel_chunks(N, 65536, [&](int64_t b0, int64_t e0, int t) { int lo2 = N, hi2 = 0;
+            for (int p = (int)b0; p < (int)e0; ++p) { bool any = false;
+                for (int s2 = plan.pl_start[p]; s2 < plan.pl_start[p + 1] && !any; ++s2) any = plan.pl_rank[plan.pl_order[s2]] == plan.rank;
+                for (int q = plan.ppadj_start[p]; q < plan.ppadj_start[p + 1] && !any; ++q) any = plan.pp_rank[plan.ppadj[q] >> 1] == plan.rank;
+                if (any) { lo2 = std::min(lo2, p); hi2 = std::max(hi2, p + 1); } }
+            lo_t[t] = lo2; hi_t[t] = hi2; });
+        for (size_t t = 0; t < lo_t.size(); ++t) { plo = std::min(plo, lo_t[t]); phi = std::max(phi, hi_t[t]); }
         if (phi <= plo) { plo = 0; phi = 0; } }
+GS_PT(70);
     int kmax = 0;
     for (int p = 0; p < N; ++p) kmax = std::max(kmax, plan.pl_start[p + 1] - plan.pl_start[p]);
     int T = 1;
@@ -561,6 +592,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     plan.ell_T = T; plan.ell_R = R; plan.ell_p0 = p0; plan.ell_np = np_;
     plan.ell_len = (int64_t)R * T * np_ + 1;
     plan.lin_ell_ok = R <= LIN_R;
+    plan.ell_ins.reserve((size_t)plan.ell_len + TAIL_PL); plan.ell_of_ins.reserve((size_t)Epl + TAIL_PL);
     plan.ell_ins.assign((size_t)plan.ell_len, -1);
     plan.ell_of_ins.assign(Epl, -1);
     parallel_chunks(np_, 8192, [&](int64_t b0, int64_t e0, int) {
@@ -569,16 +601,19 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
                 const int64_t idx = (int64_t)(s2 / T) * ((int64_t)T * np_) + (int64_t)T * (p - p0) + (s2 % T);
                 const int k = plan.pl_order[plan.pl_start[p] + s2];
                 plan.ell_ins[(size_t)idx] = k; plan.ell_of_ins[k] = (int32_t)idx; } });
+GS_PT(71);
     // the assembly records named observation edges by insertion index so far
     { const int32_t zero_slot = (int32_t)(plan.ell_len - 1);
       parallel_chunks((int64_t)plan.asm_recs.size(), 65536, [&](int64_t b0, int64_t e0, int) {
           for (int64_t t = b0; t < e0; ++t) { AsmRec &r = plan.asm_recs[(size_t)t];
               if (r.kind == ASM_PL || r.kind == ASM_PL_T) { const int32_t e = plan.ell_of_ins[r.src]; r.src = e >= 0 ? e : zero_slot; } } }); }
+GS_PT(72);
     // landmark -> ELL indices of its edges (the gather kernels: single GPU only)
     plan.lm_edges.clear();
     if (plan.world == 1) { plan.lm_edges.resize(Epl);
         parallel_chunks(Epl, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t q = b0; q < e0; ++q) plan.lm_edges[(size_t)q] = plan.ell_of_ins[lm_k[(size_t)q]]; }); }
     else plan.lm_edges.assign(1, 0);
+GS_PT(73);
     // ---- wave tiles of the fused A5-A7 kernel: one wave = 64/T consecutive poses.  Per wave tile the distinct
     // landmarks it touches ("groups") with the wave-local positions (slot*64 + lane) of their edges.  Partial-sum
     // slots are ordered by (landmark, wave tile): the finalize pass reads one contiguous run per landmark and the
@@ -595,7 +630,10 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         for (int c = 0; c <= C; ++c) cb[c] = plan.wt_lo + (int64_t)(plan.wt_hi - plan.wt_lo) * c / C;
         parallel_chunks(C, 1, [&](int64_t c0, int64_t c1, int) {
             for (int c = (int)c0; c < (int)c1; ++c) { TileOut &O = outs[c];
+                { const size_t nt = (size_t)(cb[c + 1] - cb[c]);     // (no re-allocation while the chunk's lists grow)
+                  O.grp_pos.reserve(nt * 64 * (size_t)R); O.grp_lm.reserve(nt * 48); O.grp_pos_start.reserve(nt * 48); O.tile_groups.reserve(nt); }
                 std::vector<std::pair<int32_t, int32_t>> tmp;          // (landmark, local position)
+                tmp.reserve(64 * (size_t)R);
                 for (int w = (int)cb[c]; w < (int)cb[c + 1]; ++w) {
                     tmp.clear();
                     for (int lane = 0; lane < 64; ++lane) { const int p = w * PW + lane / T, h = lane % T;
@@ -611,6 +649,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
                     }
                     O.tile_groups.push_back(ng);
                 } } });
+GS_PT(74);
         { size_t ng = 0, np2 = 0; for (auto &O : outs) { ng += O.grp_lm.size(); np2 += O.grp_pos.size(); }
           plan.grp_lm.reserve(ng); plan.grp_pos_start.reserve(ng + 1); plan.grp_pos.reserve(np2);
           int w = plan.wt_lo;                                          // tiles below wt_lo have no groups: wt_grp_start stays 0 there
@@ -620,6 +659,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
               plan.grp_pos.insert(plan.grp_pos.end(), O.grp_pos.begin(), O.grp_pos.end());
               for (int n : O.tile_groups) { plan.wt_grp_start[w + 1] = plan.wt_grp_start[w] + n; ++w; } }
           for (; w < WT; ++w) plan.wt_grp_start[w + 1] = plan.wt_grp_start[w]; }
+GS_PT(75);
         plan.grp_pos_start.push_back((int32_t)plan.grp_pos.size());
         plan.wt_desc.resize((size_t)WT * 4);
         for (int w = 0; w < WT; ++w) { const int a = plan.wt_grp_start[w], b = plan.wt_grp_start[w + 1];
@@ -634,6 +674,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         for (int q = 0; q < G; ++q) plan.grp_slot[q] = fill[plan.grp_lm[q]]++;
     }
 
+GS_PT(76);
     plan.base_N = plan.planned_N = N; plan.base_M = plan.planned_M = M; plan.base_Epp = plan.planned_Epp = Epp; plan.base_Epl = plan.planned_Epl = Epl;
     plan.n_growths = 0; plan.reshape_version = g.reshape_version; plan.front_limit = plan.max_front > 63 ? 159 : 63;
     plan.root_f0 = plan.fronts.empty() ? 0 : plan.fronts.back().npiv + plan.fronts.back().nbnd;

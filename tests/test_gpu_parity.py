@@ -1113,23 +1113,30 @@ def test_fronts_beyond_a_wave_run_on_the_matrix_cores_and_match_the_oracle(pkg, 
     F.close()
 
 
-@pytest.mark.parametrize("K,N,M", [(16, 1000, 200), (24, 1000, 200), (16, 10000, 2000), (24, 10000, 2000)])
-def test_wide_view_tracks_match_oracle(pkg, po, frontend, K, N, M):
+@pytest.mark.parametrize("K,N,M,more", [(16, 1000, 200, 9), (24, 1000, 200, 9), (16, 10000, 2000, 9), (24, 10000, 2000, 9),
+                                        (16, 100000, 10000, 9), (24, 100000, 10000, 5)])
+def test_wide_view_tracks_match_oracle(pkg, po, frontend, K, N, M, more):
     """Tracks with 16 / 24 cones in view — what the reference's coneMappingThreshold of 50 m lets a frame hold
     (usecase/docker-compose.yml:16, src/slam.cpp:608) instead of the 8 of SURVEY 8d: separators of 35 / 51 scalars, fronts up to
-    105 / 153.  The reference's 10 iterations against the oracle, increments of the first one too."""
+    105 / 153.  The reference's 10 iterations against the oracle, increments of the first one too; the sizes bench.py's
+    `wide_view_tracks` times (100k poses: 1.6M / 2.4M edges, 1 600 / 16 400 workgroup fronts) included — K = 24 there with 6 iterations,
+    the oracle's CPU solve is 4-5 s each."""
     t = pkg.track.generate(N, M, K); g = pkg.track.bench_graph(t, frontend)
     assert len(g["pl_p"]) == K * N
     og = make_oracle_graph(po, g); og.build_system(); x = og.solve_ldlt(1); og.apply_update(x); dp_o, dl_o = og.delta()
     G = fresh(pkg, g); done, st = G.optimize(1); dp, dl = G.export_delta()
     assert done == 1 and st.factor_variant == 3 and st.n_big_fronts > 0 and st.max_front > 63
     scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
-    tol1 = 1e-8 if N <= 1000 else 1e-4       # a single step of the 2.5 km lap is determined to ~1e-6 only (cond(H) ~ 1e8; two CPU orders differ alike), the iteration contracts it
+    # a single step of the 2.5 km lap is determined to ~1e-6 only (cond(H) ~ 1e8; two CPU orders differ alike), of the 25 km lap to ~1e-3; the iteration contracts it
+    tol1 = 1e-8 if N <= 1000 else (1e-4 if N <= 10000 else 1e-2)
     assert np.abs(dp - dp_o).max() / scale < tol1 and np.abs(dl - dl_o).max() / scale < tol1, (K, st.max_front)
-    og.optimize(9, ordering=1); done, st = G.optimize(9)
-    assert done == 9 and st.numeric_failure == 0
+    og.optimize(more, ordering=1); done, st = G.optimize(more)
+    assert done == more and st.numeric_failure == 0
     rms = float(np.sqrt((og.poses()[:, :2] ** 2).sum(1).mean()))
-    assert np.sqrt(((G.poses()[:, :2] - og.poses()[:, :2]) ** 2).sum(1).mean()) / rms < 1e-9      # north_star bar: 1e-6
+    err = np.sqrt(((G.poses()[:, :2] - og.poses()[:, :2]) ** 2).sum(1).mean()) / rms
+    print("K=%d N=%d: first step %.2e / %.2e, pose RMSE vs oracle after %d iterations %.2e (max front %d, %d workgroup fronts)"
+          % (K, N, np.abs(dp - dp_o).max() / scale, np.abs(dl - dl_o).max() / scale, 1 + more, err, st.max_front, st.n_big_fronts))
+    assert err < (1e-9 if N <= 10000 else 1e-8)                 # north_star bar: 1e-6
     assert np.array_equal(G.poses()[:2], g["pose_est"][:2])
     G.close()
 
