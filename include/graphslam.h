@@ -110,7 +110,9 @@ typedef struct gs_stats {
     double  ms_event_overhead;  /* gs_time_iterations: an empty event-to-event interval on the
                                    stream, i.e. the share of every phase time that is measurement */
     int32_t fell_back;          /* 1: the handle runs one launch per level (the slow path) because a whole-tree launch gave
-                                   up on a front's completion flag — in this call or an earlier one; 0: whole-tree launches */
+                                   up on a front's completion flag — in this call or an earlier one; 0: whole-tree launches.
+                                   Not for good: the 4th gs_optimize call after a fallback tries the whole-tree launches again
+                                   (then the 16th, 64th ... after each further timeout), and a new plan starts afresh */
     int32_t first_failure;      /* the first failure code this call met (0 none): a flag timeout (2) that the per-level
                                    fallback then repaired leaves numeric_failure 0 and first_failure 2 */
     int32_t factor_variant;     /* the front kernels this plan runs on (gs_config.factor_variant after the per-plan rules): 3 = LDL^T on

@@ -662,7 +662,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
           UP(u3_off, u3_off); UP(u3_size, u3_size);
           g->u3_off_host = u3_off; g->u3_size_host = u3_size;
           AL(done_f, P.fronts.size()); ZERO(done_f, P.fronts.size());
-          d.epoch = 0; d.tree = g->opt.tree != 0 ? 1 : 0; g->fell_back = false;   // whole-tree launches for this rank's own subtrees (gs_debug_options.tree = 0: one launch per level)
+          d.epoch = 0; d.tree = g->opt.tree != 0 ? 1 : 0; g->fell_back = false; g->fallback_calls = 0; g->fallback_retry_after = 4; g->fallback_retrying = false;   // whole-tree launches for this rank's own subtrees (gs_debug_options.tree = 0: one launch per level)
           // ---- everything below is expanded ON THE DEVICE from the compact plan arrays
           const bool fused = P.lin_ell_ok && d.n_wtiles > 0;
           // block assembly records: the plan's, as they are (AsmRec = 4 ints); landmark-diagonal records of the fused
@@ -1249,6 +1249,12 @@ static int optimize_impl(gs_graph *g, int32_t iterations, double rel_tol, gs_sta
     // g2o: optimize() is always preceded by initializeOptimization() (reference src/slam.cpp:480-481);
     // the plan is rebuilt only when the structure changed since the last call.
     int rc = ensure_ready(g); if (rc != GS_OK) return rc;
+    // A handle that fell back to one launch per level (a whole-tree launch gave up on a front's flag) does not stay there until the next plan:
+    // what makes a flag late — the chip shared with another process, a debugger, a profiler replaying kernels — passes.  After 4 calls on the
+    // slow path the whole-tree launches are tried again (first iteration on its own, like a new plan's); another timeout quadruples the wait
+    // (16, 64, ... 1024 calls), a clean launch ends the episode.
+    if (g->fell_back && iterations > 0 && g->opt.tree != 0 && !g->d.tree && ++g->fallback_calls >= g->fallback_retry_after) {
+        g->d.tree = 1; g->tree_proven = false; g->fallback_calls = 0; g->fallback_retrying = true; }
     { const int ii = g->d.inject_iter, ic = g->d.inject_code;       // an armed fault injection survives the reset below
       HIP_TRY(hipMemsetAsync(g->d.fail, 0, 4 * sizeof(int32_t), g->stream)); g->d.inject_iter = ii; g->d.inject_code = ic; }
     const bool until = rel_tol >= 0.0;
@@ -1284,9 +1290,12 @@ static int optimize_impl(gs_graph *g, int32_t iterations, double rel_tol, gs_sta
         HIP_TRY(hipMemcpyAsync(ff, g->d.fail, sizeof(ff), hipMemcpyDeviceToHost, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
         applied = ff[1];
-        if (ff[0] == 0 && g->d.tree) g->tree_proven = true;
+        if (ff[0] == 0 && g->d.tree) { g->tree_proven = true;
+            if (g->fallback_retrying) { g->fallback_retrying = false; g->fell_back = false; g->fallback_retry_after = 4; } }     // back on the whole-tree launches
         if (ff[0] != 0 && first_failure == 0) first_failure = ff[0];
         if (ff[0] == 2 && g->d.tree && !fell_back) {
+            if (g->fallback_retrying) { g->fallback_retrying = false; g->fallback_retry_after = std::min(g->fallback_retry_after * 4, 1024); }
+            g->fallback_calls = 0;
             g->d.tree = 0; fell_back = true; g->fell_back = true; g->d.inject_iter = 0;
             HIP_TRY(hipMemsetAsync(g->d.fail, 0, sizeof(int32_t), g->stream));      // the code only: the update count goes on
             enq = applied; ff[0] = 0; continue; }

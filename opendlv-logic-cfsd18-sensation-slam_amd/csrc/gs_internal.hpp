@@ -70,7 +70,8 @@ struct gs_graph {
     int2 *d_wgs_c = nullptr, *d_wgs_t = nullptr, *d_wgs_b = nullptr;
     int enqueue_rc = 0; std::string enqueue_err;     // a failure of the enqueue itself (the lazily built launch tables): returned by the entry point that enqueued
     bool tree_proven = false;               // a whole-tree launch sequence of the CURRENT plan has completed without a flag timeout (gs_optimize then sends all iterations of a call at once)
-    bool fell_back = false;                 // a whole-tree launch gave up on a flag: this handle uses one launch per level until the next plan
+    bool fell_back = false;                 // a whole-tree launch gave up on a flag: this handle uses one launch per level — until the next plan, or until a retry (below) comes back clean
+    int fallback_calls = 0, fallback_retry_after = 4; bool fallback_retrying = false;   // gs_optimize calls on the slow path since the fallback; the call that tries the whole-tree launches again
     // append-only growth (gs::grow_plan): the full structure phase leaves room behind the plan's arrays; a growth step re-writes the
     // changed fronts' runs there and rebuilds those fronts' device tables.  used_* = entries taken so far, cap_* = allocated.
     struct GrowRoom { int64_t cap_bnd = 0, cap_map = 0, cap_asm = 0, cap_sc = 0, used_sc = 0, cap_L = 0, cap_U = 0, used_U = 0, cap_xe = 0; bool ok = false; } room;
