@@ -903,7 +903,7 @@ static int build_plan_host(gs_graph *g) {
     o.timing = t.plan_timing > 0;
     o.force_shared_top = g->world <= 1 ? std::max(t.force_shared_top, 0) : 0;
     std::string err;
-    if (!build_plan(g->h, o, g->plan, err)) { g->plan_version = ~0ull; return fail(GS_ERR_EMPTY, "plan: " + err); }
+    if (!build_plan(g->h, o, g->plan, err, &g->plan_ws)) { g->plan_version = ~0ull; return fail(GS_ERR_EMPTY, "plan: " + err); }
     g->plan_version = g->h.structure_version;
     return GS_OK;
 }
@@ -966,15 +966,23 @@ extern "C" int gs_initialize_optimization(gs_graph *g) {
             g->no_growth_reason = g_last_error;                     // (the plan object is rebuilt from scratch below)
         } else g->no_growth_reason = why;
     }
+    const bool st_on = g->opt.plan_timing != 0; auto st_prev = std::chrono::steady_clock::now();      // gs_debug_options.plan_timing: the steps of this call on stderr
+    auto ST = [&](const char *what) { if (st_on) { auto n_ = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "structure %-24s %.2f ms\n", what, std::chrono::duration<double, std::milli>(n_ - st_prev).count()); st_prev = n_; } };
     dev_release(g, true);                                            // the handle keeps its device memory for the new plan
     RawUpload raw;
     rc = upload_raw_begin(g, raw); if (rc != GS_OK) { if (raw.th.joinable()) raw.th.join(); dev_free_all(g); return rc; }
+    ST("release + raw begin");
     rc = build_plan_host(g);                                        // the host threads build the plan while the raw arrays travel
+    ST("plan (host)");
     raw.th.join();
+    ST("wait for the raw upload");
     if (rc == GS_OK && raw.rc != GS_OK) rc = fail(raw.rc, raw.err);
     if (rc != GS_OK) { dev_free_all(g); return rc; }
     rc = upload_graph(g, raw); if (rc != GS_OK) { dev_free_all(g); return rc; }
+    ST("upload_graph");
     dev_trim(g);
+    ST("trim");
     g->ms_structure = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return GS_OK;
 }

@@ -159,7 +159,8 @@ struct PlanOptions { int leaf_poses = 8; int world = 1; int rank = 0; int ell_la
 constexpr int LIN_R = 4;               // observation slots per lane handled by the fused linearisation kernel
 
 // Builds the plan on the host (no device work).  Returns false (and sets err) on failure.
-bool build_plan(const HostGraph &g, const PlanOptions &opt, Plan &plan, std::string &err);
+// workspace (optional): where the scratch of the build lives between two builds of one handle (opaque; freed with the last reference)
+bool build_plan(const HostGraph &g, const PlanOptions &opt, Plan &plan, std::string &err, std::shared_ptr<void> *workspace = nullptr);
 
 // flat int32 dump for tests (layout documented in gs_plan.cpp)
 void export_plan(const Plan &plan, std::vector<int32_t> &out);

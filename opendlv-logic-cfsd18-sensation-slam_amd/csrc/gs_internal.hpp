@@ -21,6 +21,7 @@ struct gs_graph {
     bool host_only = false;                 // cfg.device == -2: no HIP calls, no arithmetic
     gs::HostGraph h;
     gs::Plan plan;
+    std::shared_ptr<void> plan_ws;          // scratch of gs::build_plan, kept between the plan builds of this handle
     uint64_t plan_version = ~0ull;          // h.structure_version the plan was built for
     gs::DevGraph d;
     // device memory of this handle: chunks the plan's small arrays are carved from, and one allocation per big array.  They SURVIVE a

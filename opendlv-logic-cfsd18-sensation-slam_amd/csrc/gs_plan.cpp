@@ -46,15 +46,24 @@ struct Builder {
     std::vector<int32_t> pose_of_fp, lm_of_fl;
     // vertex-level adjacency with edge references (both endpoints free)
     struct Inc { int32_t other; int32_t epos; int32_t kind; };   // kind: 0 pp (this is i), 1 pp (this is j), 2 pl (this is pose), 3 pl (this is lm)
-    std::vector<int32_t> inc_start; std::unique_ptr<Inc[]> inc_store; Inc *inc = nullptr;   // (not a vector: 21 MB at 100k poses that need no zero fill)
+    std::vector<int32_t> inc_start; std::unique_ptr<Inc[]> inc_store; size_t inc_cap = 0; Inc *inc = nullptr;   // (not a vector: 21 MB at 100k poses that need no zero fill)
     // ND helpers
     std::vector<int32_t> cone_obs_start, cone_obs;   // per free landmark: sorted free-pose positions
+    std::vector<int32_t> obs_lo, obs_hi;             // ... and the first / last of them
     std::vector<uint8_t> assigned;
     std::vector<uint8_t> opaque_pose;                // pose-window shards: the pose belongs to an opaque supernode (a whole subtree of another rank)
     std::vector<std::vector<int32_t>> sn;            // supernodes (vertex lists) in elimination order
     int window(int fpos) const { return (int)((int64_t)fpos * std::max(1, opt.world) / std::max(1, nfp)); }
 
     explicit Builder(const HostGraph &gg, const PlanOptions &o) : g(gg), opt(o) {}
+    // the buffers of the previous plan build of this handle (a workspace: no allocation, no first-touch page faults, nothing to free on the way out)
+    void adopt(Builder &o) {
+#define GS_ADOPT(m) do { m = std::move(o.m); m.clear(); } while (0)
+        GS_ADOPT(fp_of_pose); GS_ADOPT(fl_of_lm); GS_ADOPT(pose_of_fp); GS_ADOPT(lm_of_fl); GS_ADOPT(inc_start); GS_ADOPT(cone_obs_start); GS_ADOPT(cone_obs);
+        GS_ADOPT(obs_lo); GS_ADOPT(obs_hi); GS_ADOPT(assigned); GS_ADOPT(opaque_pose); GS_ADOPT(sn); GS_ADOPT(lazy_pose); GS_ADOPT(lazy_lm);
+#undef GS_ADOPT
+        inc_store = std::move(o.inc_store); inc_cap = o.inc_cap; o.inc_cap = 0;
+    }
 
     int dim(int v) const { return v < nfp ? 3 : 2; }
 
@@ -69,40 +78,78 @@ struct Builder {
     // and observation edges, landmark -> its edges): every vertex fills its own range, so the build runs on all host
     // threads.  Order inside a vertex: odometry edges (insertion order), then observation edges (insertion order for a
     // pose, pose order for a landmark).
+    // Pose-window shards: the incidence list of a pose of ANOTHER rank's window is not stored (7/8 of the pose side at world 8); the few
+    // places that need one — the top-level splits, the boundary of an opaque supernode, a shared separator's records — enumerate it from the
+    // grouped edge arrays, in the same order.
+    // The same for a landmark all of whose observers lie in one window of another rank (it lives inside that rank's opaque supernode, or in a
+    // separator a split inside that window makes): its observer positions are kept (the dissection asks for them), its list is not.
+    const Plan *plan_ = nullptr; const std::vector<int32_t> *lm_k_ = nullptr;
+    std::vector<uint8_t> lazy_pose, lazy_lm;
+    template <class F> void for_inc(int v, F &&fn) const {
+        if (v >= nfp ? !lazy_lm[v - nfp] : !lazy_pose[v]) { for (int q = inc_start[v]; q < inc_start[v + 1]; ++q) fn(inc[q]); return; }
+        const Plan &P = *plan_;
+        if (v >= nfp) { const int l = lm_of_fl[v - nfp];
+            for (int q = P.lm_start[l]; q < P.lm_start[l + 1]; ++q) { const int k = (*lm_k_)[q]; const int fp = fp_of_pose[g.pl_p[k]];
+                if (fp >= 0) fn(Inc{fp, k, 3}); }
+            return; }
+        const int p = pose_of_fp[v];
+        for (int q = P.ppadj_start[p]; q < P.ppadj_start[p + 1]; ++q) { const int code = P.ppadj[q], k = code >> 1, role = code & 1;
+            const int other = fp_of_pose[role ? g.pp_i[k] : g.pp_j[k]];
+            if (other >= 0) fn(Inc{other, k, role}); }
+        for (int s = P.pl_start[p]; s < P.pl_start[p + 1]; ++s) { const int k = P.pl_order[s], fl = fl_of_lm[g.pl_l[k]];
+            if (fl >= 0) fn(Inc{nfp + fl, k, 2}); }
+    }
     void build_adjacency(const Plan &P, const std::vector<int32_t> &lm_k) {
+        plan_ = &P; lm_k_ = &lm_k;
+        lazy_pose.assign(nfp, 0); lazy_lm.assign(nfl, 0);
+        if (opt.world > 1) for (int v = 0; v < nfp; ++v) lazy_pose[v] = window(v) != opt.rank;
+        std::vector<int32_t> obs_cnt(nfl, 0);
         inc_start.assign(nv + 1, 0);
         parallel_chunks(nv, 4096, [&](int64_t b0, int64_t e0, int) {
             for (int v = (int)b0; v < (int)e0; ++v) { int n = 0;
-                if (v < nfp) { const int p = pose_of_fp[v];
+                if (v < nfp && lazy_pose[v]) { }
+                else if (v < nfp) { const int p = pose_of_fp[v];
                     for (int q = P.ppadj_start[p]; q < P.ppadj_start[p + 1]; ++q) { const int code = P.ppadj[q], k = code >> 1;
                         n += fp_of_pose[(code & 1) ? g.pp_i[k] : g.pp_j[k]] >= 0; }
                     for (int s = P.pl_start[p]; s < P.pl_start[p + 1]; ++s) n += fl_of_lm[g.pl_l[P.pl_order[s]]] >= 0;
-                } else { const int l = lm_of_fl[v - nfp];
-                    for (int q = P.lm_start[l]; q < P.lm_start[l + 1]; ++q) n += fp_of_pose[g.pl_p[lm_k[q]]] >= 0; }
+                } else { const int l = lm_of_fl[v - nfp]; int wlo = INT32_MAX, whi = -1;
+                    for (int q = P.lm_start[l]; q < P.lm_start[l + 1]; ++q) { const int fp = fp_of_pose[g.pl_p[lm_k[q]]];
+                        if (fp >= 0) { ++n; if (opt.world > 1) { const int w = window(fp); wlo = std::min(wlo, w); whi = std::max(whi, w); } } }
+                    obs_cnt[v - nfp] = n;
+                    if (opt.world > 1 && n > 0 && wlo == whi && wlo != opt.rank) { lazy_lm[v - nfp] = 1; n = 0; } }
                 inc_start[v + 1] = n; } });
         for (int v = 0; v < nv; ++v) inc_start[v + 1] += inc_start[v];
-        inc_store.reset(new Inc[(size_t)inc_start[nv] + 1]); inc = inc_store.get();
+        if (inc_cap < (size_t)inc_start[nv] + 1) { inc_cap = (size_t)inc_start[nv] + 1; inc_store.reset(new Inc[inc_cap]); }
+        inc = inc_store.get();
         cone_obs_start.assign(nfl + 1, 0);
-        for (int l = 0; l < nfl; ++l) cone_obs_start[l + 1] = cone_obs_start[l] + (inc_start[nfp + l + 1] - inc_start[nfp + l]);
-        cone_obs.resize(cone_obs_start[nfl]);
+        for (int l = 0; l < nfl; ++l) cone_obs_start[l + 1] = cone_obs_start[l] + obs_cnt[l];
+        cone_obs.resize(cone_obs_start[nfl]); obs_lo.assign(nfl, INT32_MAX); obs_hi.assign(nfl, -1);
         // an observation edge is named by its INSERTION index here (epos); the assembly records are translated to the device
         // layout once it exists
         parallel_chunks(nv, 4096, [&](int64_t b0, int64_t e0, int) {
             for (int v = (int)b0; v < (int)e0; ++v) { Inc *o = &inc[inc_start[v]];
-                if (v < nfp) { const int p = pose_of_fp[v];
+                if (v < nfp && lazy_pose[v]) { }
+                else if (v < nfp) { const int p = pose_of_fp[v];
                     for (int q = P.ppadj_start[p]; q < P.ppadj_start[p + 1]; ++q) { const int code = P.ppadj[q], k = code >> 1, role = code & 1;
                         const int other = fp_of_pose[role ? g.pp_i[k] : g.pp_j[k]];
                         if (other >= 0) *o++ = {other, k, role}; }
                     for (int s = P.pl_start[p]; s < P.pl_start[p + 1]; ++s) { const int k = P.pl_order[s], fl = fl_of_lm[g.pl_l[k]];
                         if (fl >= 0) *o++ = {nfp + fl, k, 2}; }
-                } else { const int lf = v - nfp, l = lm_of_fl[lf]; int32_t *co = &cone_obs[cone_obs_start[lf]];
+                } else { const int lf = v - nfp, l = lm_of_fl[lf]; int32_t *co = &cone_obs[cone_obs_start[lf]]; const bool keep = !lazy_lm[lf];
                     for (int q = P.lm_start[l]; q < P.lm_start[l + 1]; ++q) { const int k = lm_k[q]; const int fp = fp_of_pose[g.pl_p[k]];
-                        if (fp >= 0) { *o++ = {fp, k, 3}; *co++ = fp; } }
-                    std::sort(&cone_obs[cone_obs_start[lf]], co); }      // landmark observer lists (free-pose positions, ascending)
+                        if (fp >= 0) { if (keep) *o++ = {fp, k, 3}; *co++ = fp; } }
+                    int32_t *c0 = &cone_obs[cone_obs_start[lf]];
+                    if (!std::is_sorted(c0, co)) std::sort(c0, co);
+                    obs_lo[lf] = co > c0 ? c0[0] : INT32_MAX; obs_hi[lf] = co > c0 ? co[-1] : -1; }    // landmark observer lists (free-pose positions, ascending; edges grouped by pose arrive in that order)
             } });
     }
 
     bool has_observer(int l, int lo, int hi) const {   // any unassigned observer position in [lo, hi)
+        // (most questions are settled by the landmark's first and last observer: 1.3 MB that stay in cache, where the lists are 25 MB at 800k poses)
+        const int o0 = obs_lo[l], o1 = obs_hi[l];
+        if (o1 < lo || o0 >= hi) return false;
+        if (o0 >= lo && !assigned[o0]) return true;
+        if (o1 < hi && !assigned[o1]) return true;
         auto b = cone_obs.begin() + cone_obs_start[l], e = cone_obs.begin() + cone_obs_start[l + 1];
         for (auto it = std::lower_bound(b, e, lo); it != e && *it < hi; ++it) if (!assigned[*it]) return true;
         return false;
@@ -131,9 +178,9 @@ struct Builder {
         int nb = 0;
         { std::vector<int32_t> seen_p, seen_c;
           auto alive = [&](int l) { return std::find(cones.begin(), cones.end(), l) != cones.end(); };
-          for (int i : un_pos) for (int q = inc_start[i]; q < inc_start[i + 1]; ++q) { const int o = inc[q].other;
-              if (inc[q].kind <= 1) { if ((o < a || o >= b || assigned[o]) && std::find(seen_p.begin(), seen_p.end(), o) == seen_p.end()) seen_p.push_back(o); }
-              else { const int l = o - nfp; if (std::find(seen_c.begin(), seen_c.end(), l) == seen_c.end()) seen_c.push_back(l); } }
+          for (int i : un_pos) for_inc(i, [&](const Inc &e) { const int o = e.other;
+              if (e.kind <= 1) { if ((o < a || o >= b || assigned[o]) && std::find(seen_p.begin(), seen_p.end(), o) == seen_p.end()) seen_p.push_back(o); }
+              else { const int l = o - nfp; if (std::find(seen_c.begin(), seen_c.end(), l) == seen_c.end()) seen_c.push_back(l); } });
           int bc = 0; for (int l : seen_c) bc += !alive(l);
           nb = 3 * (int)seen_p.size() + 2 * bc; }
         std::vector<int32_t> sep_poses, cut, sep_cones, orphans;
@@ -164,9 +211,9 @@ struct Builder {
             auto part_of = [&](int i) { int k = 0; while (k + 1 < np && i > cut[k + 1]) ++k; return k; };
             // pose-pose edges that still span two parts pull their later endpoint into the separator
             for (int i : un_pos) { if (assigned[i]) continue;
-                for (int q = inc_start[i]; q < inc_start[i + 1]; ++q) { if (inc[q].kind > 1) continue;
-                    const int j = inc[q].other; if (j <= i || j < a || j >= b || assigned[j]) continue;
-                    if (part_of(j) != part_of(i)) { assigned[j] = 1; sep_poses.push_back(j); } } }
+                for_inc(i, [&](const Inc &e) { if (e.kind > 1) return;
+                    const int j = e.other; if (j <= i || j < a || j >= b || assigned[j]) return;
+                    if (part_of(j) != part_of(i)) { assigned[j] = 1; sep_poses.push_back(j); } }); }
             part_cones.assign(np, {});
             for (int l : cones) { int hit = -1, n = 0;
                 for (int k = 0; k < np && n < 2; ++k) if (has_observer(l, cut[k] + 1, cut[k + 1])) { hit = k; ++n; }
@@ -216,8 +263,8 @@ struct Builder {
         assigned[m] = 1;
         // pose-pose edges that still span the split pull their far endpoint into the separator
         for (int i = a; i < m; ++i) { if (assigned[i]) continue;
-            for (int q = inc_start[i]; q < inc_start[i + 1]; ++q) { if (inc[q].kind > 1) continue;
-                int j = inc[q].other; if (j > m && j < b && !assigned[j]) { assigned[j] = 1; sep_poses.push_back(j); } } }
+            for_inc(i, [&](const Inc &e) { if (e.kind > 1) return;
+                const int j = e.other; if (j > m && j < b && !assigned[j]) { assigned[j] = 1; sep_poses.push_back(j); } }); }
         std::vector<int32_t> left, right, sep_cones, orphans;
         for (int l : cones) {
             bool hl = has_observer(l, a, m), hr = has_observer(l, m + 1, b);
@@ -230,14 +277,18 @@ struct Builder {
         if (!orphans.empty()) { std::vector<int32_t> v; for (int l : orphans) v.push_back(nfp + l); emit(out, std::move(v)); }
         // the two halves touch disjoint pose ranges (and only read the shared tables): the top levels of the recursion
         // run them on separate host threads, each into its own list, concatenated in elimination order
-        if ((1 << depth) < host_threads() && un > 2048) {
+        // (pose-window shards: a half that lies in one window of another rank is an opaque supernode at once — no work to share; the other
+        // half keeps this level's thread budget, so a rank's own window is dissected on as many threads as a whole graph's)
+        auto foreign = [&](int x, int y) { return opt.world > 1 && y > x && window(x) == window(y - 1) && window(x) != opt.rank; };
+        const bool one_sided = foreign(a, m) || foreign(m + 1, b);
+        if (!one_sided && (1 << depth) < host_threads() && un > 2048) {
             SnList lo;
             std::thread th([&] { nd(a, m, left, lo, depth + 1); });
             SnList hi; nd(m + 1, b, right, hi, depth + 1);
             th.join();
             for (auto &v : lo) out.push_back(std::move(v));
             for (auto &v : hi) out.push_back(std::move(v));
-        } else { nd(a, m, left, out, depth + 1); nd(m + 1, b, right, out, depth + 1); }
+        } else { const int dn = one_sided ? depth : depth + 1; nd(a, m, left, out, dn); nd(m + 1, b, right, out, dn); }
         std::vector<int32_t> verts(sep_poses.begin(), sep_poses.end());
         for (int l : sep_cones) verts.push_back(nfp + l);
         emit(out, std::move(verts));
@@ -246,16 +297,35 @@ struct Builder {
 
 }  // namespace
 
-bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::string &err) {
+namespace {
+struct PlanScratch { std::unique_ptr<Builder> B; std::vector<int32_t> lm_k, sn_of, vpos, gidx, parent, stamp, asm_n; std::vector<std::vector<int32_t>> bndv, kids; };
+}
+bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::string &err, std::shared_ptr<void> *workspace) {
     auto t0 = std::chrono::steady_clock::now();
     const bool pt_on = opt_in.timing; auto pt_prev = t0;              // gs_debug_options.plan_timing: phase times on stderr
 #define GS_PT(i) do { if (pt_on) { auto n_ = std::chrono::steady_clock::now(); std::fprintf(stderr, "plan phase %d: %.2f ms\n", (i), std::chrono::duration<double, std::milli>(n_ - pt_prev).count()); pt_prev = n_; } } while (0)
-    plan = Plan();
+    // A handle that plans again keeps its memory: the arrays of the previous plan are emptied, not freed (their pages are mapped already —
+    // freeing and re-allocating ~60 MB at 100k poses, ~200 MB for a pose-window shard of 800k, was up to a third of a structure phase), and so
+    // is the scratch of this function (adjacency, supernode lists, boundaries) when the caller lends a workspace.
+    { Plan old = std::move(plan); plan = Plan();
+#define GS_KEEP(m) do { plan.m = std::move(old.m); plan.m.clear(); } while (0)
+      GS_KEEP(pose_gidx); GS_KEEP(lm_gidx); GS_KEEP(pl_order); GS_KEEP(pp_order); GS_KEEP(pl_start); GS_KEEP(lm_start); GS_KEEP(lm_edges); GS_KEEP(ppadj_start); GS_KEEP(ppadj);
+      GS_KEEP(ell_ins); GS_KEEP(ell_of_ins); GS_KEEP(ppinc); GS_KEEP(wt_grp_start); GS_KEEP(wt_desc); GS_KEEP(grp_lm); GS_KEEP(grp_pos_start); GS_KEEP(grp_pos); GS_KEEP(ell_dst);
+      GS_KEEP(lm_grp_start); GS_KEEP(grp_slot); GS_KEEP(fronts); GS_KEEP(bnd_rows); GS_KEEP(child_map); GS_KEEP(children); GS_KEEP(asm_recs); GS_KEEP(level_start); GS_KEEP(level_fronts);
+      GS_KEEP(pl_rank); GS_KEEP(pp_rank); GS_KEEP(pose_known); GS_KEEP(lm_known); GS_KEEP(level_start_owned); GS_KEEP(level_fronts_owned); GS_KEEP(level_start_shared);
+      GS_KEEP(level_fronts_shared); GS_KEEP(x_off);
+#undef GS_KEEP
+    }
     PlanOptions opt = opt_in;
     const bool leaf_auto = opt.leaf_poses <= 0;
     if (opt.leaf_poses <= 0) opt.leaf_poses = 8;
     if (opt.cluster_ways <= 0) opt.cluster_ways = 8;
-    Builder B(g, opt);
+    std::unique_ptr<PlanScratch> local_scratch; PlanScratch *scratch;
+    if (workspace) { if (!*workspace) *workspace = std::shared_ptr<void>(new PlanScratch, [](void *p) { delete static_cast<PlanScratch *>(p); });
+        scratch = static_cast<PlanScratch *>(workspace->get()); }
+    else { local_scratch = std::make_unique<PlanScratch>(); scratch = local_scratch.get(); }
+    { auto nb = std::make_unique<Builder>(g, opt); if (scratch->B) nb->adopt(*scratch->B); scratch->B = std::move(nb); }
+    Builder &B = *scratch->B;
     B.index_vertices();
     if (B.nv == 0) { err = "no free vertex"; return false; }
     // Leaf size by the graph (round 4): the binary part of the dissection halves the pose range until a range fits one multi-way cluster
@@ -300,7 +370,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     // landmark -> its edges (insertion indices, pose order); turned into ELL indices at the end (lm_edges, single GPU only).  A stable
     // counting sort by landmark over the pose-grouped sequence, in chunks: per chunk a histogram, offsets per (chunk, landmark), scatter.
     plan.lm_start.assign(M + 1, 0);
-    std::vector<int32_t> lm_k(Epl);
+    std::vector<int32_t> &lm_k = scratch->lm_k; lm_k.resize(Epl);
     { const int C = (int64_t)chunk_count(Epl, 1 << 18) * M <= ((int64_t)1 << 26) ? chunk_count(Epl, 1 << 18) : 1;
       std::vector<std::vector<int32_t>> cnt(C);
       auto lo = [&](int c) { return (int64_t)Epl * c / C; };
@@ -338,7 +408,8 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     B.assigned.assign(B.nfp, 0); B.opaque_pose.assign(B.nfp, 0);
     { std::vector<int32_t> all(B.nfl); for (int l = 0; l < B.nfl; ++l) all[l] = l; B.nd(0, B.nfp, all, B.sn, 0); }
     const int S = (int)B.sn.size();
-    std::vector<int32_t> sn_of(B.nv, -1), vpos(B.nv, -1), gidx(B.nv, -1);
+    std::vector<int32_t> &sn_of = scratch->sn_of, &vpos = scratch->vpos, &gidx = scratch->gidx;
+    sn_of.assign(B.nv, -1); vpos.assign(B.nv, -1); gidx.assign(B.nv, -1);
     { int pos = 0, sc = 0;
       for (int s = 0; s < S; ++s) for (int v : B.sn[s]) { if (sn_of[v] != -1) { err = "vertex emitted twice"; return false; }
             sn_of[v] = s; vpos[v] = pos++; gidx[v] = sc; sc += B.dim(v); }
@@ -353,13 +424,28 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     // ---- symbolic factorisation over supernodes ----
     // boundary of a supernode = the later-eliminated vertices its own vertices touch (independent per supernode: host
     // threads) + what its children's boundaries carry beyond it (one sequential bottom-up sweep, elimination order)
-    std::vector<std::vector<int32_t>> bndv(S), kids(S);
-    std::vector<int32_t> parent(S, -1), stamp(B.nv, -1);
+    std::vector<std::vector<int32_t>> &bndv = scratch->bndv, &kids = scratch->kids; bndv.resize(S); kids.resize(S);
+    for (auto &v : bndv) v.clear();
+    for (auto &v : kids) v.clear();                                   // (a workspace's lists keep their capacity)
+    std::vector<int32_t> &parent = scratch->parent, &stamp = scratch->stamp; parent.assign(S, -1); stamp.assign(B.nv, -1);
+    auto is_opaque = [&](int s) { return B.sn[s][0] < B.nfp && B.opaque_pose[B.sn[s][0]] != 0; };      // (an opaque supernode lists its poses first)
     parallel_chunks(S, 512, [&](int64_t b0, int64_t e0, int) {
         std::vector<int32_t> st(B.nv, -1);
         for (int s = (int)b0; s < (int)e0; ++s) { auto &bd = bndv[s];
-            for (int v : B.sn[s]) for (int q = B.inc_start[v]; q < B.inc_start[v + 1]; ++q) { const int w = B.inc[q].other;
-                if (sn_of[w] > s && st[w] != s) { st[w] = s; bd.push_back(w); } } } });
+            if (is_opaque(s)) continue;
+            for (int v : B.sn[s]) B.for_inc(v, [&](const Builder::Inc &e) { const int w = e.other;
+                if (sn_of[w] > s && st[w] != s) { st[w] = s; bd.push_back(w); } }); } });
+    // another rank's window (one supernode of ~100k poses + its cones): its vertices in chunks on the host threads.  Nearly everything they
+    // touch is inside; the few later-eliminated neighbours are collected per chunk (short lists, searched linearly) and merged — the order
+    // does not matter, a boundary is sorted by elimination position below
+    for (int s = 0; s < S; ++s) if (is_opaque(s)) {
+        const auto &vs = B.sn[s]; const int C = chunk_count((int64_t)vs.size(), 8192);
+        std::vector<std::vector<int32_t>> cand(C);
+        parallel_chunks(C, 1, [&](int64_t c0, int64_t c1, int) { for (int c = (int)c0; c < (int)c1; ++c) { auto &cd = cand[c];
+            for (size_t i = vs.size() * c / C; i < vs.size() * (c + 1) / C; ++i) B.for_inc(vs[i], [&](const Builder::Inc &e) { const int w = e.other;
+                if (sn_of[w] > s && std::find(cd.begin(), cd.end(), w) == cd.end()) cd.push_back(w); }); } });
+        auto &bd = bndv[s];
+        for (auto &cd : cand) for (int w : cd) if (std::find(bd.begin(), bd.end(), w) == bd.end()) bd.push_back(w); }
     for (int s = 0; s < S; ++s) {
         auto &bd = bndv[s];
         if (!kids[s].empty()) {
@@ -372,7 +458,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     GS_PT(4);
     // ---- fronts ----  (three passes: sizes in parallel, offsets in one sweep, contents in parallel)
     plan.fronts.resize(S);
-    std::vector<int32_t> asm_n(S);
+    std::vector<int32_t> &asm_n = scratch->asm_n; asm_n.resize(S);
     parallel_chunks(S, 512, [&](int64_t b0, int64_t e0, int) {
         for (int s = (int)b0; s < (int)e0; ++s) {
             Front &F = plan.fronts[s];
@@ -382,7 +468,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
             F.opaque = (B.sn[s][0] < B.nfp && B.opaque_pose[B.sn[s][0]]) ? 1 : 0;     // (an opaque supernode lists its poses first)
             int n = 0;
             if (!F.opaque) for (int v : B.sn[s]) { ++n;
-                for (int q = B.inc_start[v]; q < B.inc_start[v + 1]; ++q) n += vpos[B.inc[q].other] > vpos[v]; }     // the earlier endpoint owns the block
+                B.for_inc(v, [&](const Builder::Inc &e) { n += vpos[e.other] > vpos[v]; }); }     // the earlier endpoint owns the block
             asm_n[s] = n;
         } });
     { int64_t nb = 0, nm = 0, na = 0;
@@ -423,8 +509,8 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
             if (!F.opaque) for (int v : B.sn[s]) {
                 if (v < B.nfp) recs.push_back({ASM_POSE_DIAG, B.pose_of_fp[v], loc[v], loc[v]});
                 else recs.push_back({ASM_LM_DIAG, B.lm_of_fl[v - B.nfp], loc[v], loc[v]});
-                for (int q = B.inc_start[v]; q < B.inc_start[v + 1]; ++q) { const auto &e = B.inc[q];
-                    if (vpos[e.other] <= vpos[v]) continue;             // the earlier endpoint owns the block
+                B.for_inc(v, [&](const Builder::Inc &e) {
+                    if (vpos[e.other] <= vpos[v]) return;               // the earlier endpoint owns the block
                     int kind;
                     switch (e.kind) {                                    // e.kind describes v's role; `other` is the later vertex
                         case 0: kind = ASM_PP_T; break;                  // v = i earlier, j later: F = Hpp_off^T
@@ -433,7 +519,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
                         default: kind = ASM_PL; break;                   // v = landmark earlier, pose later
                     }
                     recs.push_back({kind, e.epos, loc[e.other], loc[v]});
-                }
+                });
             }
             // duplicates (parallel edges between the same two vertices) go to the tail
             std::stable_sort(recs.begin(), recs.end(), [](const AsmRec &x, const AsmRec &y) {
@@ -688,6 +774,7 @@ GS_PT(76);
     plan.ell_ins.reserve((size_t)plan.ell_len + TAIL_PL); plan.pp_order.reserve((size_t)Epp + TAIL_PP); plan.pp_rank.reserve((size_t)Epp + TAIL_PP);
     plan.valid = true;
     GS_PT(7);
+
     plan.ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return true;
 }

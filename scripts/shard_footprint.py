@@ -11,7 +11,7 @@ def build(N, M, rank=None):
     t = pkg.track.generate(N, M); fe = pkg.Graph(); g = pkg.track.bench_graph(t, fe); fe.close()
     G = pkg.Graph(); G.load_bench_graph(g)
     if rank is not None: G.dist_configure(rank, world)
-    G.initialize_optimization(); G.initialize_optimization()      # second call: warm host threads / page cache, as in a running service
+    G.initialize_optimization(); time.sleep(0.2); G.initialize_optimization()      # second call: warm host threads / page cache, as in a running service (the pause: the first build's scratch is freed on a short-lived thread)
     st = G.stats(); G.close(); return st
 s1 = build(Nw, Mw)
 print("single GPU %s: structure %.1f ms (plan %.1f), device %.1f MB, fronts %d" % (name, s1.ms_structure, s1.ms_plan_host, s1.device_bytes / 1e6, s1.n_fronts))
