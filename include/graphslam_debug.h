@@ -31,6 +31,10 @@ extern "C" {
  *     subtree         GS_SUBTREE       plan  1: a level-1 front and the leaves below it run in ONE workgroup (k_factor3_sub: the leaves'
  *                                      update matrices stay in LDS; measured slower); 0 (default): leaf launch + flagged
  *                                      launch from level 1 up
+ *     tickets         GS_TICKETS       plan  1: a workgroup of a whole-tree launch takes its number from a counter in HBM — the launch's own order,
+ *                                      whatever order the hardware dispatches in (measured: -2.4 % iterations/s at 100k poses, -5 % at 10k, -9 % on
+ *                                      24-cones-in-view tracks: one same-address atomic per workgroup); 0 (default): blockIdx — grid-order dispatch,
+ *                                      with the bounded polls, the per-level fallback and the retry behind it
  *   plan shape — changes the elimination order, hence the last bits of the result (all are exact factorisations)
  *     leaf_poses      GS_LEAF_POSES    plan  nested-dissection leaf size in poses (0 = gs_config.leaf_poses / default 8)
  *     cluster_ways    GS_CLUSTER_WAYS  plan  fan-out of the multi-way split above the leaves (0 = default 8; 2 = binary)
@@ -62,7 +66,8 @@ typedef struct gs_debug_options {
     int32_t force_shared_top;
     int32_t host_trig, pool_poison, plan_timing, dbg;
     int32_t subtree;
-    int32_t reserved[7];
+    int32_t tickets;
+    int32_t reserved[6];
 } gs_debug_options;
 
 int gs_debug_options_default(gs_debug_options *o);                     /* the library's defaults (the environment is NOT consulted) */

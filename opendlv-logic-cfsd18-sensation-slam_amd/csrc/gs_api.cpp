@@ -135,7 +135,7 @@ extern "C" int gs_debug_options_default(gs_debug_options *o) {
     if (!o) return fail(GS_ERR_INVALID, "null options");
     std::memset(o, 0, sizeof(*o));
     o->struct_size = (int32_t)sizeof(*o);
-    o->subtree = 0;
+    o->subtree = 0; o->tickets = 0;
     o->tree = 1; o->block_fronts = 512; o->leaf_kernel = -1; o->leaf_min = 2048; o->bs_wide = 2048; o->leaf_nt3 = 1; o->f3_lds_kb = 0;
     o->leaf_poses = 0; o->cluster_ways = 0; o->ell_lanes = 0; o->big_cluster = -1; o->grow_headroom = -1; o->factor_variant = 0;
     o->grow = 1; o->grow_min_poses = 128;
@@ -149,7 +149,7 @@ static void options_from_environment(gs_debug_options &o) {
     gs_debug_options_default(&o);
     auto env = [](const char *name, int32_t &field) { if (const char *e = std::getenv(name)) field = (int32_t)std::atoi(e); };
     env("GS_TREE", o.tree); env("GS_BLOCK_FRONTS", o.block_fronts); env("GS_LEAF_KERNEL", o.leaf_kernel); env("GS_LEAF_MIN", o.leaf_min);
-    env("GS_SUBTREE", o.subtree); env("GS_BS_WIDE", o.bs_wide); env("GS_LEAF_NT3", o.leaf_nt3); env("GS_F3_LDS_KB", o.f3_lds_kb);
+    env("GS_SUBTREE", o.subtree); env("GS_TICKETS", o.tickets); env("GS_BS_WIDE", o.bs_wide); env("GS_LEAF_NT3", o.leaf_nt3); env("GS_F3_LDS_KB", o.f3_lds_kb);
     env("GS_LEAF_POSES", o.leaf_poses); env("GS_CLUSTER_WAYS", o.cluster_ways); env("GS_ELL_LANES", o.ell_lanes); env("GS_BIG_CLUSTER", o.big_cluster);
     env("GS_GROW_HEADROOM", o.grow_headroom); env("GS_FACTOR_VARIANT", o.factor_variant);
     env("GS_GROW", o.grow); env("GS_GROW_MIN_POSES", o.grow_min_poses); env("GS_ASSOC_GRID", o.assoc_grid); env("GS_FORCE_SHARED_TOP", o.force_shared_top);
@@ -167,7 +167,7 @@ extern "C" int gs_debug_set_options(gs_graph *g, const gs_debug_options *o) {
     const gs_debug_options &c = g->opt;
     // a "plan" field changed: the next structure phase is a full one (a grown plan keeps the launch shapes it was built with)
     const bool plan_changed = n.tree != c.tree || n.block_fronts != c.block_fronts || n.leaf_kernel != c.leaf_kernel || n.leaf_min != c.leaf_min ||
-        n.bs_wide != c.bs_wide || n.subtree != c.subtree || n.leaf_nt3 != c.leaf_nt3 || n.f3_lds_kb != c.f3_lds_kb || n.leaf_poses != c.leaf_poses ||
+        n.bs_wide != c.bs_wide || n.subtree != c.subtree || n.tickets != c.tickets || n.leaf_nt3 != c.leaf_nt3 || n.f3_lds_kb != c.f3_lds_kb || n.leaf_poses != c.leaf_poses ||
         n.cluster_ways != c.cluster_ways || n.ell_lanes != c.ell_lanes || n.big_cluster != c.big_cluster || n.grow_headroom != c.grow_headroom ||
         n.factor_variant != c.factor_variant || n.force_shared_top != c.force_shared_top || n.host_trig != c.host_trig || n.pool_poison != c.pool_poison ||
         n.dbg != c.dbg;
@@ -387,6 +387,8 @@ static int read_failure(gs_graph *g, int32_t out[2]) {
 static int reset_failure(gs_graph *g) {
     g->d.inject_iter = 0; g->d.inject_code = 0;
     HIP_TRY(hipMemsetAsync(g->d.fail, 0, 4 * sizeof(int32_t), g->stream));
+    // the ticket counter and its host-side running sum start again together (a launch that failed to ENQUEUE was counted on the host only)
+    if (g->d.tickets) { HIP_TRY(hipMemsetAsync(g->d.tickets, 0, 2 * sizeof(uint32_t), g->stream)); g->d.ticket_base = 0; }
     return GS_OK;
 }
 // After gs_iterate / gs_dist_iterate_*: report a failure of the iterations run since the last report (once), apply the
@@ -662,6 +664,8 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
           UP(u3_off, u3_off); UP(u3_size, u3_size);
           g->u3_off_host = u3_off; g->u3_size_host = u3_size;
           AL(done_f, P.fronts.size()); ZERO(done_f, P.fronts.size());
+          d.tickets = nullptr; d.ticket_base = 0;
+          if (g->opt.tickets != 0) { AL(tickets, 2); ZERO(tickets, 2); }    // workgroups of the whole-tree launches take their number from this counter (gs_kernels.hip, "tickets")
           d.epoch = 0; d.tree = g->opt.tree != 0 ? 1 : 0; g->fell_back = false; g->fallback_calls = 0; g->fallback_retry_after = 4; g->fallback_retrying = false;   // whole-tree launches for this rank's own subtrees (gs_debug_options.tree = 0: one launch per level)
           // ---- everything below is expanded ON THE DEVICE from the compact plan arrays
           const bool fused = P.lin_ell_ok && d.n_wtiles > 0;
@@ -1325,7 +1329,7 @@ static int optimize_impl(gs_graph *g, int32_t iterations, double rel_tol, gs_sta
     HIP_TRY(hipStreamSynchronize(g->stream));
     if (pull) g->dev_estimates_newer = false;
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("iteration: ") + hipGetErrorString(e));
+    if (e != hipSuccess) { reset_failure(g); return fail(GS_ERR_HIP, std::string("iteration: ") + hipGetErrorString(e)); }      // (a launch that never ran: the ticket counter and its running sum start again)
     float ms = 0; hipEventElapsedTime(&ms, g->ev[5], g->ev[6]);
     if (g->cfg.verbose) for (int it = 0; it < nshow; ++it)  // g2o prints the chi2 AFTER the update of iteration it
         std::fprintf(stderr, "iteration= %d\t chi2= %.6f\t edges= %d\t schur= 0\n", it, it + 1 < applied ? hist[2 + it] : hist[1 + nh], g->h.n_pp() + g->h.n_pl());
@@ -1911,7 +1915,7 @@ extern "C" int gs_dist_optimize(gs_graph *g, int32_t iterations, gs_stats *stats
     HIP_TRY(hipStreamSynchronize(g->stream));
     rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("iteration: ") + hipGetErrorString(e));
+    if (e != hipSuccess) { reset_failure(g); return fail(GS_ERR_HIP, std::string("iteration: ") + hipGetErrorString(e)); }      // (a launch that never ran: the ticket counter and its running sum start again)
     float ms = 0; hipEventElapsedTime(&ms, g->ev[5], g->ev[6]);
     if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->struct_size = (int32_t)sizeof(*stats);
         fill_plan_stats(g, stats); stats->iterations = ff[1]; stats->numeric_failure = ff[0]; stats->first_failure = ff[0];

@@ -76,6 +76,7 @@ struct DevGraph {
     int32_t *f3_x = nullptr;                                    // row tables + headers of the children of a front (f3x_stride ints per child)
     int32_t f3x_stride = 72;                                    // 72 = a 64-entry table + 8 header ints; 168 = a 160-entry table (plans with a front of more than 63 scalars)
     int32_t *f3_desc = nullptr, *asm3 = nullptr, *pinv = nullptr, *sc3 = nullptr, *lm3 = nullptr, *u3_off = nullptr, *u3_size = nullptr;
+    uint32_t *tickets = nullptr; mutable uint32_t ticket_base = 0; // whole-tree launches: a workgroup's work is named by the ticket it takes, not by blockIdx (gs_kernels.hip, "tickets"); ticket_base = the counter's value at the launch's first workgroup (host-side running sum of the ticketed grids; nullptr: blockIdx)
     int32_t *done_f = nullptr; int32_t epoch = 0, tree = 0;     // whole-tree factor launches: per-front completion flags (= epoch when done); the backward solve polls xe itself
     double *H_arena = nullptr;                                  // Hpp_diag | b_pose | Hpp_off | Hpl | lm_part | Hll_diag | b_lm, one allocation
     // append-only growth (grow_plan): the TAIL — poses / edges added after the plan was built.  N, Epp, Epl and ell_len above stay the

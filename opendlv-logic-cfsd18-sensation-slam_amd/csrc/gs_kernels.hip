@@ -1420,6 +1420,21 @@ __device__ __forceinline__ void f3_publish(int32_t *flag, int epoch, int lane) {
     if (lane == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- tickets (round 4).  The whole-tree launches rest on "a front's children sit in earlier workgroups": with workgroups handed out in
+// grid order, whatever a resident wave waits for is resident or done.  Grid-order dispatch is how the hardware behaves, not something the
+// programming model promises.  With tickets the order is the launch's own: a workgroup's first act is to take the next number of a counter in
+// HBM, and that number — not blockIdx — names its work.  The numbers taken at any moment are a prefix of the launch, so a waiting workgroup's
+// children belong to workgroups that have started: progress no longer depends on the dispatcher.  One device-scope atomic per workgroup; the
+// counter is never reset inside an iteration — the host knows how many workgroups every ticketed launch of the stream has had (ticket_base).
+__device__ __forceinline__ int wg_ticket(const DevGraph &d, double *slot) {      // slot: 8 bytes of LDS nobody else touches before the second barrier
+    if (d.tickets == nullptr) return (int)blockIdx.x;
+    volatile unsigned *s = reinterpret_cast<volatile unsigned *>(slot);
+    if (threadIdx.x == 0) *s = atomicAdd(d.tickets, 1u) - d.ticket_base;
+    __syncthreads();
+    const unsigned t = *s;
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane((int)t);
+}
 // two children of a front into its LDS image, by source.  flag != nullptr: a child of the SAME launch — its flag is awaited
 // (the places are computed first: nothing but the loads and the read-add-writes is behind the wait).  The loads are
 // device-scope either way: in storage order every line is fetched once, so there is nothing a cached load would save.
@@ -1994,12 +2009,14 @@ __global__ void __launch_bounds__(256, LEAF ? (NT == 3 ? 5 : F3_LEAF4_WPS) : 2) 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // whole-tree launches: the first n_wave_fronts level positions one wave each (four per workgroup), the rest — the upper
     // levels — one workgroup each
+    int bid = (int)blockIdx.x;
     if constexpr (TREE && !LEAF) {
+        bid = wg_ticket(d, smem);                                    // (the flagged launch: its fronts wait for each other)
         const int wave_blocks = (n_wave_fronts + 3) >> 2;
-        if ((int)blockIdx.x >= wave_blocks) { const int pos = level_off + n_wave_fronts + ((int)blockIdx.x - wave_blocks);
+        if (bid >= wave_blocks) { const int pos = level_off + n_wave_fronts + (bid - wave_blocks);
             f3_block_front(d, pos, mode, leaf_slot, smem, (d.dbg & 16) && pos == (d.dbg >> 8)); return; }
     }
-    const int fi = blockIdx.x * 4 + wave;
+    const int fi = bid * 4 + wave;
     if (fi >= (TREE && !LEAF ? n_wave_fronts : count)) return;      // whole wave leaves; no block barrier below
     const bool ts_on = ((d.dbg & 8) && count == (d.dbg >> 8) && fi == 0) || ((d.dbg & 16) && level_off + fi == (d.dbg >> 8));   // 16: probe the front at a level POSITION
     f3_wave_front<TREE, LEAF, NT>(d, level_off + fi, mode, leaf_slot, smem, wave, lane, ts_on, fi == 0);
@@ -2097,7 +2114,8 @@ template <bool TREE>      // TREE: one launch, root first (wave w takes level po
 __global__ void __launch_bounds__(256) k_backsolve3(DevGraph d, int level_off, int count, int slot_doubles) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int fi = blockIdx.x * 4 + wave;
+    const int bid = TREE ? wg_ticket(d, smem) : (int)blockIdx.x;     // (TREE: a front polls its ancestors' values — they must belong to workgroups that have started)
+    const int fi = bid * 4 + wave;
     if (fi >= count) return;
     const int pos = TREE ? level_off + (count - 1 - fi) : level_off + fi;
     const bool ts_on = ((d.dbg & 8) && count == (d.dbg >> 8) && fi == 0) || ((d.dbg & 16) && pos == (d.dbg >> 8));   // 16: probe the front at a level POSITION
@@ -2398,13 +2416,14 @@ template <int CLASS>
 __global__ void __launch_bounds__(256, CLASS == 0 ? 3 : (CLASS == 1 ? 2 : 1)) k_factor3_tab(DevGraph d, const int2 *__restrict__ wgt, int leaf_launch_preceded, int mode) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int2 e = wgt[blockIdx.x];
+    const int bid = wg_ticket(d, smem);
+    const int2 e = wgt[bid];
     const int pos = __builtin_amdgcn_readfirstlane(e.x), kind = __builtin_amdgcn_readfirstlane(e.y) & 0xff, cnt = __builtin_amdgcn_readfirstlane(e.y) >> 8;
     if constexpr (CLASS == 0) { f3_big_front<5>(d, pos, smem, mode); }
     else if constexpr (CLASS == 2) { f3_big_front<10>(d, pos, smem, mode); }
     else {
         // (the host never puts a four-wave entry into a CONTRIB table: that form has the modes OWN and TOP)
-        if (kind == WG_WAVES) { if (wave < cnt) f3_wave_front<true, false, 4>(d, pos + wave, mode, leaf_launch_preceded, smem, wave, lane, false, blockIdx.x == 0 && wave == 0); }
+        if (kind == WG_WAVES) { if (wave < cnt) f3_wave_front<true, false, 4>(d, pos + wave, mode, leaf_launch_preceded, smem, wave, lane, false, bid == 0 && wave == 0); }
         else if (kind == WG_BLOCK4) f3_block_front(d, pos, mode, leaf_launch_preceded, smem, false);
         else f3_big_front<7>(d, pos, smem, mode);
     }
@@ -2413,11 +2432,13 @@ template <bool BIG>      // BIG: a launch of big fronts only (few registers: as 
 __global__ void __launch_bounds__(256, BIG ? 4 : 2) k_backsolve3_tab(DevGraph d, const int2 *__restrict__ wgt, int slot_doubles) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int2 e = wgt[blockIdx.x];
+    const int2 e = wgt[wg_ticket(d, smem)];
     const int pos = __builtin_amdgcn_readfirstlane(e.x), cnt = __builtin_amdgcn_readfirstlane(e.y) >> 8;
     if constexpr (BIG) bs3_big_front<true>(d, pos, smem);
     else { if (wave < cnt) bs3_wave_front<true>(d, pos - wave, smem, slot_doubles, wave, lane, false); }     // root first: positions downwards
 }
+// the kernel's copy of the handle's device view for a ticketed launch of `grid` workgroups: the counter's value when its first workgroup starts
+static DevGraph ticketed(const DevGraph &d, unsigned grid) { DevGraph dd = d; if (d.tickets) d.ticket_base += grid; return dd; }
 // LDS of one workgroup of a table-driven launch, by kind (a launch takes the maximum over its workgroups: the host cuts the table
 // into launches of equal need, so that the many fronts just beyond a wave do not run at the occupancy of the ten-tile-row ones)
 size_t factor_tab_lds_bytes(int kind) {
@@ -2435,19 +2456,19 @@ size_t backsolve_tab_lds_bytes(int kind, int f_or_slot_f, int npiv_small) {     
 void launch_factor_tab(const DevGraph &d, const int2 *wgt, int n_wg, int leaf_launch_preceded, size_t lds_bytes, int cls, hipStream_t st, int mode) {
     if (n_wg <= 0) return;                                           // (a launch holds workgroups of ONE class: the host cut the table that way)
     if (cls == 0) { allow_max_lds((const void *)k_factor3_tab<0>);
-        hipLaunchKernelGGL(k_factor3_tab<0>, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, leaf_launch_preceded, mode); }
+        hipLaunchKernelGGL(k_factor3_tab<0>, dim3(n_wg), dim3(256), lds_bytes, st, ticketed(d, (unsigned)n_wg), wgt, leaf_launch_preceded, mode); }
     else if (cls == 2) { allow_max_lds((const void *)k_factor3_tab<2>);
-        hipLaunchKernelGGL(k_factor3_tab<2>, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, leaf_launch_preceded, mode); }
+        hipLaunchKernelGGL(k_factor3_tab<2>, dim3(n_wg), dim3(256), lds_bytes, st, ticketed(d, (unsigned)n_wg), wgt, leaf_launch_preceded, mode); }
     else { allow_max_lds((const void *)k_factor3_tab<1>);
-        hipLaunchKernelGGL(k_factor3_tab<1>, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, leaf_launch_preceded, mode); }
+        hipLaunchKernelGGL(k_factor3_tab<1>, dim3(n_wg), dim3(256), lds_bytes, st, ticketed(d, (unsigned)n_wg), wgt, leaf_launch_preceded, mode); }
 }
 void launch_backsolve_tab(const DevGraph &d, const int2 *wgt, int n_wg, int max_npiv_small, int max_f_small, size_t lds_bytes, int cls, hipStream_t st) {
     if (n_wg <= 0) return;
     const int slot = ((((max_f_small + 1) | 1) * std::max(max_npiv_small, 1)) + 1) & ~1;
     if (cls == 1) { allow_max_lds((const void *)k_backsolve3_tab<true>);
-        hipLaunchKernelGGL(k_backsolve3_tab<true>, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, slot); }
+        hipLaunchKernelGGL(k_backsolve3_tab<true>, dim3(n_wg), dim3(256), lds_bytes, st, ticketed(d, (unsigned)n_wg), wgt, slot); }
     else { allow_max_lds((const void *)k_backsolve3_tab<false>);
-        hipLaunchKernelGGL(k_backsolve3_tab<false>, dim3(n_wg), dim3(256), lds_bytes, st, d, wgt, slot); }
+        hipLaunchKernelGGL(k_backsolve3_tab<false>, dim3(n_wg), dim3(256), lds_bytes, st, ticketed(d, (unsigned)n_wg), wgt, slot); }
 }
 
 // ---- structure phase on the device: the ELL streams of the observation edges, permuted out of the insertion-order
@@ -2641,8 +2662,8 @@ void launch_factor_tree(const DevGraph &d, int n_leaf, int leaf_slot, int leaf_m
         else hipLaunchKernelGGL(k_factor3_sub<4>, dim3(n_sub), dim3(256), factor_sub_lds_bytes(leaf_slot), st, d, sub_first, n_sub, leaf_slot);
         first = sub_first + n_sub; plain_level = 2; }
     // the last n_block level positions (whole upper levels) get a workgroup each, the others a wave each
-    if (count > first) { const int nw = count - first - n_block;
-        hipLaunchKernelGGL((k_factor3<true, false>), dim3((nw + 3) / 4 + n_block), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, first, count - first, FRONT_OWN, plain_level, nw); }   // leaf_slot argument: the highest level whose fronts have all their children in earlier launches
+    if (count > first) { const int nw = count - first - n_block; const unsigned grid = (unsigned)((nw + 3) / 4 + n_block);
+        hipLaunchKernelGGL((k_factor3<true, false>), dim3(grid), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, ticketed(d, grid), first, count - first, FRONT_OWN, plain_level, nw); }   // leaf_slot argument: the highest level whose fronts have all their children in earlier launches
 }
 size_t factor_sub_lds_bytes(int leaf_slot) { return (size_t)(MF_IMG + std::max(1536, 4 * leaf_slot)) * sizeof(double); }
 // the shared top of a sharded graph (mode TOP: fronts start from the all-reduced exchange slots and gather their shared
@@ -2651,13 +2672,13 @@ void launch_factor_tree_top(const DevGraph &d, int first, int count, hipStream_t
     if (count <= 0) return;
     allow_max_lds((const void *)k_factor3<true, false>);
     // every shared front four waves (the chain of the top levels is all there is to this launch): n_wave_fronts = 0
-    hipLaunchKernelGGL((k_factor3<true, false>), dim3(count), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, d, first, count, FRONT_TOP, 0, 0);
+    hipLaunchKernelGGL((k_factor3<true, false>), dim3(count), dim3(256), (size_t)MF_IMG * 4 * sizeof(double), st, ticketed(d, (unsigned)count), first, count, FRONT_TOP, 0, 0);
 }
 void launch_backsolve_tree(const DevGraph &d, int first, int count, int max_npiv, int max_f, hipStream_t st) {
     if (count <= 0) return;                                          // positions [first, first + count), root first
     const int slot = ((((max_f + 1) | 1) * max_npiv) + 1) & ~1;
     allow_max_lds((const void *)k_backsolve3<true>);
-    hipLaunchKernelGGL(k_backsolve3<true>, dim3((count + 3) / 4), dim3(256), (size_t)slot * 4 * sizeof(double), st, d, first, count, slot);
+    hipLaunchKernelGGL(k_backsolve3<true>, dim3((count + 3) / 4), dim3(256), (size_t)slot * 4 * sizeof(double), st, ticketed(d, (unsigned)((count + 3) / 4)), first, count, slot);
 }
 
 void launch_factor_level(const DevGraph &d, int level_off, int count, int max_f, int mode, hipStream_t st) {
