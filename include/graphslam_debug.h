@@ -51,6 +51,9 @@ extern "C" {
  *     force_shared_top GS_FORCE_SHARED_TOP plan  world 1 only: the top k levels of the tree are treated as the SHARED top of a sharded
  *                                      graph (contribution -> exchange buffer -> all-reduce -> redundant top), so that the collective
  *                                      path runs with a non-empty exchange buffer on one GPU (default 0 = off)
+ *     shard_by_window GS_SHARD_BY_WINDOW plan 1 (default): a rank builds the top of the tree from per-landmark window masks and touches only its own
+ *                                      window's edges beyond one pass (gs_plan.cpp, nd_top); 0: the general recursion over every edge (the same plan
+ *                                      for equal windows, a power of two of them)
  *   experiments / diagnostics
  *     host_trig       GS_HOST_TRIG     plan  1: cos / sin of the INITIAL pose angles from the host's libm (scripts/parity_spread.py)
  *     pool_poison     GS_POOL_POISON   plan  1: device chunks are filled with 0xFF when taken and when released
@@ -67,7 +70,8 @@ typedef struct gs_debug_options {
     int32_t host_trig, pool_poison, plan_timing, dbg;
     int32_t subtree;
     int32_t tickets;
-    int32_t reserved[6];
+    int32_t shard_by_window;
+    int32_t reserved[5];
 } gs_debug_options;
 
 int gs_debug_options_default(gs_debug_options *o);                     /* the library's defaults (the environment is NOT consulted) */

@@ -69,7 +69,7 @@ class DebugOptions(C.Structure):
     _fields_ = [("struct_size", C.c_int32)] + [(k, C.c_int32) for k in (
         "tree", "block_fronts", "leaf_kernel", "leaf_min", "bs_wide", "leaf_nt3", "f3_lds_kb", "reserved0",
         "leaf_poses", "cluster_ways", "ell_lanes", "big_cluster", "grow_headroom", "factor_variant",
-        "grow", "grow_min_poses", "assoc_grid", "force_shared_top", "host_trig", "pool_poison", "plan_timing", "dbg", "subtree", "tickets")] + [("reserved", C.c_int32 * 6)]
+        "grow", "grow_min_poses", "assoc_grid", "force_shared_top", "host_trig", "pool_poison", "plan_timing", "dbg", "subtree", "tickets", "shard_by_window")] + [("reserved", C.c_int32 * 5)]
 
 
 # switches applied to every handle this process creates through the binding (tests: conftest sets grow_min_poses = 0)

@@ -135,7 +135,7 @@ extern "C" int gs_debug_options_default(gs_debug_options *o) {
     if (!o) return fail(GS_ERR_INVALID, "null options");
     std::memset(o, 0, sizeof(*o));
     o->struct_size = (int32_t)sizeof(*o);
-    o->subtree = 0; o->tickets = 0;
+    o->subtree = 0; o->tickets = 0; o->shard_by_window = 1;
     o->tree = 1; o->block_fronts = 512; o->leaf_kernel = -1; o->leaf_min = 2048; o->bs_wide = 2048; o->leaf_nt3 = 1; o->f3_lds_kb = 0;
     o->leaf_poses = 0; o->cluster_ways = 0; o->ell_lanes = 0; o->big_cluster = -1; o->grow_headroom = -1; o->factor_variant = 0;
     o->grow = 1; o->grow_min_poses = 128;
@@ -149,7 +149,7 @@ static void options_from_environment(gs_debug_options &o) {
     gs_debug_options_default(&o);
     auto env = [](const char *name, int32_t &field) { if (const char *e = std::getenv(name)) field = (int32_t)std::atoi(e); };
     env("GS_TREE", o.tree); env("GS_BLOCK_FRONTS", o.block_fronts); env("GS_LEAF_KERNEL", o.leaf_kernel); env("GS_LEAF_MIN", o.leaf_min);
-    env("GS_SUBTREE", o.subtree); env("GS_TICKETS", o.tickets); env("GS_BS_WIDE", o.bs_wide); env("GS_LEAF_NT3", o.leaf_nt3); env("GS_F3_LDS_KB", o.f3_lds_kb);
+    env("GS_SUBTREE", o.subtree); env("GS_TICKETS", o.tickets); env("GS_SHARD_BY_WINDOW", o.shard_by_window); env("GS_BS_WIDE", o.bs_wide); env("GS_LEAF_NT3", o.leaf_nt3); env("GS_F3_LDS_KB", o.f3_lds_kb);
     env("GS_LEAF_POSES", o.leaf_poses); env("GS_CLUSTER_WAYS", o.cluster_ways); env("GS_ELL_LANES", o.ell_lanes); env("GS_BIG_CLUSTER", o.big_cluster);
     env("GS_GROW_HEADROOM", o.grow_headroom); env("GS_FACTOR_VARIANT", o.factor_variant);
     env("GS_GROW", o.grow); env("GS_GROW_MIN_POSES", o.grow_min_poses); env("GS_ASSOC_GRID", o.assoc_grid); env("GS_FORCE_SHARED_TOP", o.force_shared_top);
@@ -167,7 +167,7 @@ extern "C" int gs_debug_set_options(gs_graph *g, const gs_debug_options *o) {
     const gs_debug_options &c = g->opt;
     // a "plan" field changed: the next structure phase is a full one (a grown plan keeps the launch shapes it was built with)
     const bool plan_changed = n.tree != c.tree || n.block_fronts != c.block_fronts || n.leaf_kernel != c.leaf_kernel || n.leaf_min != c.leaf_min ||
-        n.bs_wide != c.bs_wide || n.subtree != c.subtree || n.tickets != c.tickets || n.leaf_nt3 != c.leaf_nt3 || n.f3_lds_kb != c.f3_lds_kb || n.leaf_poses != c.leaf_poses ||
+        n.bs_wide != c.bs_wide || n.subtree != c.subtree || n.tickets != c.tickets || n.shard_by_window != c.shard_by_window || n.leaf_nt3 != c.leaf_nt3 || n.f3_lds_kb != c.f3_lds_kb || n.leaf_poses != c.leaf_poses ||
         n.cluster_ways != c.cluster_ways || n.ell_lanes != c.ell_lanes || n.big_cluster != c.big_cluster || n.grow_headroom != c.grow_headroom ||
         n.factor_variant != c.factor_variant || n.force_shared_top != c.force_shared_top || n.host_trig != c.host_trig || n.pool_poison != c.pool_poison ||
         n.dbg != c.dbg;
@@ -905,6 +905,7 @@ static int build_plan_host(gs_graph *g) {
     if (t.big_cluster >= 0) o.big_cluster_front = t.big_cluster;         // 0 = clusters only where they fit a wave
     if (t.grow_headroom >= 0) { o.grow_headroom = t.grow_headroom; o.grow_spine_headroom = std::min(o.grow_spine_headroom, 3 * o.grow_headroom); }   // 0 = cluster fronts up to the full 63 scalars
     o.timing = t.plan_timing > 0;
+    o.by_window = t.shard_by_window != 0;
     o.force_shared_top = g->world <= 1 ? std::max(t.force_shared_top, 0) : 0;
     std::string err;
     if (!build_plan(g->h, o, g->plan, err, &g->plan_ws)) { g->plan_version = ~0ull; return fail(GS_ERR_EMPTY, "plan: " + err); }

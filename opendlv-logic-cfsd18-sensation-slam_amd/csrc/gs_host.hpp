@@ -148,6 +148,7 @@ struct Growth {
 bool grow_plan(const HostGraph &g, Plan &plan, Growth &out, std::string &why_not);
 
 struct PlanOptions { int leaf_poses = 8; int world = 1; int rank = 0; int ell_lanes = 0;
+                     bool by_window = true;        // pose-window shards: the top of the tree from per-landmark window masks (Builder::nd_top) where the graph allows; false: the general recursion
                      int cluster_ways = 0;         // fan-out of the multi-way split above the leaves (0 = default 8, <= 2 = binary all the way down)
                      int big_cluster_front = -1;       // second-pass bound of a cluster front when 63 scalars cannot be met (0 .. 63: off); -1 = by the view: 111 with more than 10
                                                        // cones per frame, off below (there binary splits of wave fronts beat a workgroup front: lap-sized graphs 1.1 vs 1.9-2.6 ms per optimize(10))

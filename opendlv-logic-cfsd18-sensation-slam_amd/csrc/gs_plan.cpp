@@ -38,6 +38,13 @@ void HostGraph::clear() {
 
 namespace {
 
+// fill on the host threads; a vector that already has the size (a handle that plans again: build_plan's recycled arrays) is not re-initialised first
+template <class V, class T> void pfill(V &v, size_t n, T value) {
+    if (v.size() != n) { v.clear(); v.resize(n); }
+    auto *p = v.data();
+    parallel_chunks((int64_t)n, 1 << 18, [&](int64_t b0, int64_t e0, int) { std::fill(p + b0, p + e0, value); });
+}
+
 struct Builder {
     const HostGraph &g;
     PlanOptions opt;
@@ -61,6 +68,7 @@ struct Builder {
 #define GS_ADOPT(m) do { m = std::move(o.m); m.clear(); } while (0)
         GS_ADOPT(fp_of_pose); GS_ADOPT(fl_of_lm); GS_ADOPT(pose_of_fp); GS_ADOPT(lm_of_fl); GS_ADOPT(inc_start); GS_ADOPT(cone_obs_start); GS_ADOPT(cone_obs);
         GS_ADOPT(obs_lo); GS_ADOPT(obs_hi); GS_ADOPT(assigned); GS_ADOPT(opaque_pose); GS_ADOPT(sn); GS_ADOPT(lazy_pose); GS_ADOPT(lazy_lm);
+        GS_ADOPT(wf); GS_ADOPT(seen_nb); GS_ADOPT(seen_b); GS_ADOPT(opaque_of_pose); GS_ADOPT(pp_touch);
 #undef GS_ADOPT
         inc_store = std::move(o.inc_store); inc_cap = o.inc_cap; o.inc_cap = 0;
     }
@@ -231,6 +239,56 @@ struct Builder {
         return true;
     }
 
+    // ---- pose-window shards, the top of the tree by WINDOWS (round 4).  Which windows see a landmark is one pass over the edges (two bit
+    // masks per landmark); with them the splits between windows — a window's first pose and the cones seen from both sides — and the boundary
+    // of another rank's window need neither that window's observer lists nor a walk over its edges.  Taken when the poses of different windows
+    // are tied by the odometry chain only (an edge between two windows ends in the later window's first pose); any other graph takes the general
+    // recursion below, which gives the same plan wherever its middle pose is a window's first one (windows of equal size, a power of two of them).
+    bool by_window = false;
+    std::vector<int32_t> wf;                         // wf[w] = first free-pose position of window w; wf[world] = nfp
+    std::vector<uint64_t> seen_nb, seen_b;           // per free landmark: windows with an observer that is not / that is the window's first pose (w >= 1)
+    std::vector<int32_t> opaque_window;              // supernode (emission index within its list is not stable: keyed by first pose) -> see opaque_of_pose
+    std::vector<int32_t> opaque_of_pose;             // first pose position of an opaque supernode -> its window (-1)
+    std::vector<uint64_t> pp_touch;                  // [world] bit x: the first pose of window x has an odometry edge into window w's interior
+    static uint64_t wbits(int lo, int hi) { return hi <= lo ? 0 : ((hi >= 64 ? ~0ull : ((1ull << hi) - 1)) & ~((1ull << lo) - 1)); }
+    void nd_top(int w0, int w1, std::vector<int32_t> &cones, SnList &out, int depth) {
+        const int a = w0 == 0 ? 0 : wf[w0] + 1, b = wf[w1];          // the range's poses: behind the first pose of w0 (a separator higher up) up to the next window's
+        if (w1 - w0 == 1) {
+            if (w0 == opt.rank) { nd(a, b, cones, out, depth); return; }
+            std::vector<int32_t> verts; verts.reserve((size_t)std::max(b - a, 0) + cones.size());
+            for (int i = a; i < b; ++i) if (!assigned[i]) { verts.push_back(i); assigned[i] = 1; opaque_pose[i] = 1; }
+            if (!verts.empty()) opaque_of_pose[verts[0]] = w0;
+            else if (!cones.empty()) { /* a window without a free pose of its own: its cones go up as they are */ }
+            for (int l : cones) verts.push_back(nfp + l);
+            emit(out, std::move(verts));
+            return; }
+        const int wm = (w0 + w1 + 1) / 2, m = wf[wm];
+        std::vector<int32_t> sep_poses;
+        if (m < b && !assigned[m]) { assigned[m] = 1; sep_poses.push_back(m); }
+        std::vector<int32_t> left, right, sep_cones, orphans;
+        const uint64_t nl = wbits(w0, wm), bl = wbits(w0 + 1, wm), nr = wbits(wm, w1), br = wbits(wm + 1, w1);
+        for (int l : cones) {
+            const bool hl = ((seen_nb[l] & nl) | (seen_b[l] & bl)) != 0, hr = ((seen_nb[l] & nr) | (seen_b[l] & br)) != 0;
+            if (hl && hr) sep_cones.push_back(l);
+            else if (hl) left.push_back(l);
+            else if (hr) right.push_back(l);
+            else orphans.push_back(l);
+        }
+        cones.clear(); cones.shrink_to_fit();
+        if (!orphans.empty()) { std::vector<int32_t> v; for (int l : orphans) v.push_back(nfp + l); emit(out, std::move(v)); }
+        const bool mine_l = opt.rank >= w0 && opt.rank < wm, mine_r = opt.rank >= wm && opt.rank < w1;
+        if (mine_l == mine_r && (1 << depth) < host_threads()) {      // (neither half holds this rank's window: both are cheap; kept parallel for symmetry with the general path)
+            SnList lo; std::thread th([&] { nd_top(w0, wm, left, lo, depth + 1); });
+            SnList hi; nd_top(wm, w1, right, hi, depth + 1);
+            th.join();
+            for (auto &v : lo) out.push_back(std::move(v));
+            for (auto &v : hi) out.push_back(std::move(v));
+        } else { nd_top(w0, wm, left, out, depth); nd_top(wm, w1, right, out, depth); }
+        std::vector<int32_t> verts(sep_poses.begin(), sep_poses.end());
+        for (int l : sep_cones) verts.push_back(nfp + l);
+        emit(out, std::move(verts));
+    }
+
     // nested dissection over free-pose positions [a, b); `cones` = free landmarks alive in this range
     void nd(int a, int b, std::vector<int32_t> &cones, SnList &out, int depth) {
         int un = 0;
@@ -309,12 +367,14 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     // is the scratch of this function (adjacency, supernode lists, boundaries) when the caller lends a workspace.
     { Plan old = std::move(plan); plan = Plan();
 #define GS_KEEP(m) do { plan.m = std::move(old.m); plan.m.clear(); } while (0)
-      GS_KEEP(pose_gidx); GS_KEEP(lm_gidx); GS_KEEP(pl_order); GS_KEEP(pp_order); GS_KEEP(pl_start); GS_KEEP(lm_start); GS_KEEP(lm_edges); GS_KEEP(ppadj_start); GS_KEEP(ppadj);
-      GS_KEEP(ell_ins); GS_KEEP(ell_of_ins); GS_KEEP(ppinc); GS_KEEP(wt_grp_start); GS_KEEP(wt_desc); GS_KEEP(grp_lm); GS_KEEP(grp_pos_start); GS_KEEP(grp_pos); GS_KEEP(ell_dst);
+#define GS_KEEP_SIZED(m) do { plan.m = std::move(old.m); } while (0)      /* overwritten in full by a parallel fill (pfill): the size stays, nothing is re-initialised */
+      GS_KEEP_SIZED(pose_gidx); GS_KEEP_SIZED(lm_gidx); GS_KEEP(pl_order); GS_KEEP(pp_order); GS_KEEP(pl_start); GS_KEEP(lm_start); GS_KEEP(lm_edges); GS_KEEP_SIZED(ppadj_start); GS_KEEP(ppadj);
+      GS_KEEP(ell_ins); GS_KEEP_SIZED(ell_of_ins); GS_KEEP(ppinc); GS_KEEP(wt_grp_start); GS_KEEP(wt_desc); GS_KEEP(grp_lm); GS_KEEP(grp_pos_start); GS_KEEP(grp_pos); GS_KEEP(ell_dst);
       GS_KEEP(lm_grp_start); GS_KEEP(grp_slot); GS_KEEP(fronts); GS_KEEP(bnd_rows); GS_KEEP(child_map); GS_KEEP(children); GS_KEEP(asm_recs); GS_KEEP(level_start); GS_KEEP(level_fronts);
-      GS_KEEP(pl_rank); GS_KEEP(pp_rank); GS_KEEP(pose_known); GS_KEEP(lm_known); GS_KEEP(level_start_owned); GS_KEEP(level_fronts_owned); GS_KEEP(level_start_shared);
+      GS_KEEP_SIZED(pl_rank); GS_KEEP_SIZED(pp_rank); GS_KEEP_SIZED(pose_known); GS_KEEP_SIZED(lm_known); GS_KEEP(level_start_owned); GS_KEEP(level_fronts_owned); GS_KEEP(level_start_shared);
       GS_KEEP(level_fronts_shared); GS_KEEP(x_off);
 #undef GS_KEEP
+#undef GS_KEEP_SIZED
     }
     PlanOptions opt = opt_in;
     const bool leaf_auto = opt.leaf_poses <= 0;
@@ -367,10 +427,60 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         for (int k = 0; k < Epl; ++k) plan.pl_order[fill[g.pl_p[k]]++] = k; }
     plan.pp_order.resize(Epp);
     for (int k = 0; k < Epp; ++k) plan.pp_order[k] = k;
+    // ---- pose-window shards: which windows see a landmark (Builder::nd_top)
+    B.by_window = false;
+    if (opt.world > 1 && opt.world <= 64 && by_pose && B.nfp >= 4 * opt.world && opt.by_window) {
+        const int W = opt.world;
+        B.wf.assign(W + 1, 0);
+        for (int w = 0; w <= W; ++w) B.wf[w] = (int32_t)(((int64_t)w * B.nfp + W - 1) / W);
+        std::vector<uint8_t> win_of(B.nfp);
+        parallel_chunks(B.nfp, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t i = b0; i < e0; ++i) win_of[(size_t)i] = (uint8_t)B.window((int)i); });
+        auto is_first = [&](int fp, int w) { return w >= 1 && fp == B.wf[w]; };
+        // odometry edges between windows must end in the later window's first pose
+        std::vector<uint8_t> bad(host_threads() + 1, 0);
+        B.pp_touch.assign(W, 0);
+        std::vector<std::vector<uint64_t>> touch_t(host_threads() + 1, std::vector<uint64_t>(W, 0));
+        parallel_chunks(Epp, 65536, [&](int64_t b0, int64_t e0, int t) { auto &tt = touch_t[t];
+            for (int64_t k = b0; k < e0; ++k) { const int fi = B.fp_of_pose[g.pp_i[(size_t)k]], fj = B.fp_of_pose[g.pp_j[(size_t)k]];
+                if (fi < 0 || fj < 0) continue;
+                const int wi = win_of[fi], wj = win_of[fj]; const bool bi = is_first(fi, wi), bj = is_first(fj, wj);
+                if (!bi && !bj) { if (wi != wj) bad[t] = 1; continue; }
+                if (bi && !bj) tt[wj] |= 1ull << wi;
+                if (bj && !bi) tt[wi] |= 1ull << wj; } });
+        bool ok = true; for (uint8_t v : bad) ok = ok && !v;
+        if (ok) {
+            for (auto &tt : touch_t) for (int w = 0; w < W; ++w) B.pp_touch[w] |= tt[w];
+            B.seen_nb.assign(B.nfl, 0); B.seen_b.assign(B.nfl, 0);
+            parallel_chunks(Epl, 65536, [&](int64_t b0, int64_t e0, int) {
+                for (int64_t k = b0; k < e0; ++k) { const int fp = B.fp_of_pose[g.pl_p[(size_t)k]]; if (fp < 0) continue;
+                    const int fl = B.fl_of_lm[g.pl_l[(size_t)k]]; if (fl < 0) continue;
+                    const int w = win_of[fp]; uint64_t *tgt = is_first(fp, w) ? &B.seen_b[fl] : &B.seen_nb[fl]; const uint64_t bit = 1ull << w;
+                    if (!(__atomic_load_n(tgt, __ATOMIC_RELAXED) & bit)) __atomic_fetch_or(tgt, bit, __ATOMIC_RELAXED); } });
+            B.opaque_of_pose.assign(B.nfp, -1);
+            B.by_window = true; } }
+    // by windows: the poses whose edges this rank's plan is built from — its own window, every window's first pose (the separators of the
+    // shared top) and the fixed poses; everything else of the other windows is summarised by the masks above
+    std::vector<int32_t> ing;                                         // insertion indices, ascending
+    std::vector<uint8_t> ing_flag;
+    if (B.by_window) { const int W = opt.world;
+        ing_flag.assign(N, 0);
+        parallel_chunks(N, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t p = b0; p < e0; ++p) { const int fp = B.fp_of_pose[(size_t)p];
+            ing_flag[(size_t)p] = fp < 0 || (fp >= B.wf[opt.rank] && fp < B.wf[opt.rank + 1]); } });
+        for (int x = 1; x < W; ++x) if (B.wf[x] < B.nfp) ing_flag[B.pose_of_fp[B.wf[x]]] = 1;
+        for (int p = 0; p < N; ++p) if (ing_flag[p]) ing.push_back(p); }
+    GS_PT(2);
     // landmark -> its edges (insertion indices, pose order); turned into ELL indices at the end (lm_edges, single GPU only).  A stable
     // counting sort by landmark over the pose-grouped sequence, in chunks: per chunk a histogram, offsets per (chunk, landmark), scatter.
     plan.lm_start.assign(M + 1, 0);
-    std::vector<int32_t> &lm_k = scratch->lm_k; lm_k.resize(Epl);
+    std::vector<int32_t> &lm_k = scratch->lm_k;
+    if (B.by_window) {                                                // the edges of the poses in `ing` only (pose order = insertion order here)
+        for (int p : ing) for (int q = plan.pl_start[p]; q < plan.pl_start[p + 1]; ++q) plan.lm_start[g.pl_l[q] + 1]++;
+        for (int l = 0; l < M; ++l) plan.lm_start[l + 1] += plan.lm_start[l];
+        lm_k.resize((size_t)plan.lm_start[M]);
+        std::vector<int32_t> fill(plan.lm_start.begin(), plan.lm_start.end() - 1);
+        for (int p : ing) for (int q = plan.pl_start[p]; q < plan.pl_start[p + 1]; ++q) lm_k[(size_t)fill[g.pl_l[q]]++] = q;
+    } else {
+    lm_k.resize(Epl);
     { const int C = (int64_t)chunk_count(Epl, 1 << 18) * M <= ((int64_t)1 << 26) ? chunk_count(Epl, 1 << 18) : 1;
       std::vector<std::vector<int32_t>> cnt(C);
       auto lo = [&](int c) { return (int64_t)Epl * c / C; };
@@ -382,20 +492,30 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
       for (int l = 0; l < M; ++l) plan.lm_start[l + 1] += plan.lm_start[l];
       parallel_chunks(C, 1, [&](int64_t c0, int64_t c1, int) { for (int c = (int)c0; c < (int)c1; ++c) { auto &h = cnt[c];
           for (int64_t pos = lo(c); pos < lo(c + 1); ++pos) { const int k = plan.pl_order[(size_t)pos]; const int l = g.pl_l[k]; lm_k[(size_t)plan.lm_start[l] + h[l]++] = k; } } }); }
+    }
     // pose -> incident pp edges, and the flattened incidence records {edge, role, i, j}
-    plan.ppadj_start.assign(N + 1, 0);
+    pfill(plan.ppadj_start, (size_t)N + 1, (int32_t)0);
+    if (B.by_window) {                                                // incidences of the poses in `ing` only: the edges that touch one, picked on the host threads
+        const int T = host_threads() + 1; std::vector<std::vector<int32_t>> pick(T);
+        parallel_chunks(Epp, 65536, [&](int64_t b0, int64_t e0, int t) { for (int64_t k = b0; k < e0; ++k) if (ing_flag[g.pp_i[(size_t)k]] | ing_flag[g.pp_j[(size_t)k]]) pick[t].push_back((int32_t)k); });
+        for (auto &v : pick) for (int k : v) { if (ing_flag[g.pp_i[k]]) plan.ppadj_start[g.pp_i[k] + 1]++; if (ing_flag[g.pp_j[k]]) plan.ppadj_start[g.pp_j[k] + 1]++; }
+        for (int p = 0; p < N; ++p) plan.ppadj_start[p + 1] += plan.ppadj_start[p];
+        plan.ppadj.resize((size_t)plan.ppadj_start[N]);
+        std::vector<int32_t> fill(plan.ppadj_start.begin(), plan.ppadj_start.end() - 1);
+        for (auto &v : pick) for (int k : v) { if (ing_flag[g.pp_i[k]]) plan.ppadj[fill[g.pp_i[k]]++] = 2 * k; if (ing_flag[g.pp_j[k]]) plan.ppadj[fill[g.pp_j[k]]++] = 2 * k + 1; }
+    } else {
     for (int k = 0; k < Epp; ++k) { plan.ppadj_start[g.pp_i[k] + 1]++; plan.ppadj_start[g.pp_j[k] + 1]++; }
     for (int p = 0; p < N; ++p) plan.ppadj_start[p + 1] += plan.ppadj_start[p];
     plan.ppadj.resize(2 * (size_t)Epp);
     { std::vector<int32_t> fill(plan.ppadj_start.begin(), plan.ppadj_start.end() - 1);
       for (int k = 0; k < Epp; ++k) { plan.ppadj[fill[g.pp_i[k]]++] = 2 * k; plan.ppadj[fill[g.pp_j[k]]++] = 2 * k + 1; } }
+    }
     plan.ppinc.resize(plan.ppadj.size() * 4);
     parallel_chunks((int64_t)plan.ppadj.size(), 65536, [&](int64_t b0, int64_t e0, int) {
         for (size_t q = (size_t)b0; q < (size_t)e0; ++q) { const int code = plan.ppadj[q], k = code >> 1;
             plan.ppinc[4 * q] = k; plan.ppinc[4 * q + 1] = code & 1; plan.ppinc[4 * q + 2] = g.pp_i[k]; plan.ppinc[4 * q + 3] = g.pp_j[k]; } });
 
     GS_PT(1);
-    GS_PT(2);
     // room to grow (grow_plan) only where fronts fit a wave anyway: with more than ~10 cones in view the cluster fronts are workgroup
     // fronts, such a plan cannot grow, and keeping them below 57 would only cost fronts (K = 16: 26 571 instead of 21 026, -5 % it/s)
     { int kmax0 = 0; for (int p = 0; p < N; ++p) kmax0 = std::max(kmax0, plan.pl_start[p + 1] - plan.pl_start[p]);
@@ -406,7 +526,8 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     B.build_adjacency(plan, lm_k);
     GS_PT(21);
     B.assigned.assign(B.nfp, 0); B.opaque_pose.assign(B.nfp, 0);
-    { std::vector<int32_t> all(B.nfl); for (int l = 0; l < B.nfl; ++l) all[l] = l; B.nd(0, B.nfp, all, B.sn, 0); }
+    { std::vector<int32_t> all(B.nfl); for (int l = 0; l < B.nfl; ++l) all[l] = l;
+      if (B.by_window) B.nd_top(0, opt.world, all, B.sn, 0); else B.nd(0, B.nfp, all, B.sn, 0); }
     const int S = (int)B.sn.size();
     std::vector<int32_t> &sn_of = scratch->sn_of, &vpos = scratch->vpos, &gidx = scratch->gidx;
     sn_of.assign(B.nv, -1); vpos.assign(B.nv, -1); gidx.assign(B.nv, -1);
@@ -416,7 +537,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
       if (pos != B.nv) { err = "ordering lost a vertex"; return false; }
       plan.n_scalar = sc; }
     plan.pose_gidx.reserve((size_t)N + TAIL_POSES); plan.lm_gidx.reserve((size_t)M + TAIL_LMS);
-    plan.pose_gidx.assign(N, -1); plan.lm_gidx.assign(M, -1);
+    pfill(plan.pose_gidx, (size_t)N, (int32_t)-1); pfill(plan.lm_gidx, (size_t)M, (int32_t)-1);
     for (int i = 0; i < B.nfp; ++i) plan.pose_gidx[B.pose_of_fp[i]] = gidx[i];
     for (int l = 0; l < B.nfl; ++l) plan.lm_gidx[B.lm_of_fl[l]] = gidx[B.nfp + l];
 
@@ -438,6 +559,17 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     // another rank's window (one supernode of ~100k poses + its cones): its vertices in chunks on the host threads.  Nearly everything they
     // touch is inside; the few later-eliminated neighbours are collected per chunk (short lists, searched linearly) and merged — the order
     // does not matter, a boundary is sorted by elimination position below
+    if (B.by_window) {
+        // by windows: what another rank's window touches outside itself are the cones its poses see that it does not own (the masks) and the
+        // first poses of windows that see one of its own cones or follow / precede it on the odometry chain — no walk over its edges
+        std::vector<int32_t> own(B.nfl, -1);
+        for (int s = 0; s < S; ++s) if (is_opaque(s)) { const int w = B.opaque_of_pose[B.sn[s][0]]; auto &bd = bndv[s];
+            uint64_t firsts = B.pp_touch[w];
+            for (int v : B.sn[s]) if (v >= B.nfp) { own[v - B.nfp] = s; firsts |= B.seen_b[v - B.nfp]; }
+            for (int x = 1; x < opt.world; ++x) if ((firsts >> x) & 1) { const int m = B.wf[x]; if (sn_of[m] > s) bd.push_back(m); }
+            const uint64_t bit = 1ull << w;
+            for (int l = 0; l < B.nfl; ++l) if ((B.seen_nb[l] & bit) && own[l] != s && sn_of[B.nfp + l] > s) bd.push_back(B.nfp + l); }
+    } else
     for (int s = 0; s < S; ++s) if (is_opaque(s)) {
         const auto &vs = B.sn[s]; const int C = chunk_count((int64_t)vs.size(), 8192);
         std::vector<std::vector<int32_t>> cand(C);
@@ -559,8 +691,8 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     plan.world = std::max(1, opt.world); plan.rank = opt.rank;
     plan.pl_rank.reserve((size_t)Epl + TAIL_PL); plan.pp_rank.reserve((size_t)Epp + TAIL_PP);
     plan.pose_known.reserve((size_t)N + TAIL_POSES); plan.lm_known.reserve((size_t)M + TAIL_LMS);
-    plan.pl_rank.assign(Epl, 0); plan.pp_rank.assign(Epp, 0);
-    plan.pose_known.assign(N, 1); plan.lm_known.assign(M, 1);
+    pfill(plan.pl_rank, (size_t)Epl, (int32_t)(B.by_window ? -1 : 0)); pfill(plan.pp_rank, (size_t)Epp, (int32_t)(B.by_window ? -1 : 0));      // (by windows: -1 = an edge of another window's interior, somebody else's)
+    pfill(plan.pose_known, (size_t)N, (uint8_t)1); pfill(plan.lm_known, (size_t)M, (uint8_t)1);
     plan.level_start_owned = plan.level_start; plan.level_fronts_owned = plan.level_fronts;
     plan.level_start_shared.assign(nlev + 1, 0);
     if (plan.world > 1) {
@@ -568,7 +700,8 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         auto window = [&](int fpos) { return (int)((int64_t)fpos * W / std::max(1, B.nfp)); };
         std::vector<int32_t> wmin(S, INT32_MAX), wmax(S, -1);
         for (int s = 0; s < S; ++s) {
-            for (int v : B.sn[s]) if (v < B.nfp) { const int w = window(v); wmin[s] = std::min(wmin[s], w); wmax[s] = std::max(wmax[s], w); }
+            if (B.by_window && is_opaque(s)) wmin[s] = wmax[s] = B.opaque_of_pose[B.sn[s][0]];      // (another rank's window: no walk over its ~100k poses)
+            else for (int v : B.sn[s]) if (v < B.nfp) { const int w = window(v); wmin[s] = std::min(wmin[s], w); wmax[s] = std::max(wmax[s], w); }
             for (int c : kids[s]) { wmin[s] = std::min(wmin[s], wmin[c]); wmax[s] = std::max(wmax[s], wmax[c]); }
         }
         for (int s = S - 1; s >= 0; --s) {
@@ -577,21 +710,27 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
             else F.owner = (wmin[s] == wmax[s]) ? wmin[s] : -1;
         }
         auto vowner = [&](int v) { return plan.fronts[sn_of[v]].owner; };
-        parallel_chunks(Epl, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t k = b0; k < e0; ++k) {
-            const int fp = B.fp_of_pose[g.pl_p[(size_t)k]], fl = B.fl_of_lm[g.pl_l[(size_t)k]];
+        auto rank_of_pl = [&](int64_t k) { const int fp = B.fp_of_pose[g.pl_p[(size_t)k]], fl = B.fl_of_lm[g.pl_l[(size_t)k]];
             int r = 0;
             if (fp >= 0 && vowner(fp) >= 0) r = vowner(fp);
             else if (fl >= 0 && vowner(B.nfp + fl) >= 0) r = vowner(B.nfp + fl);
             else if (fp >= 0) r = window(fp);
-            plan.pl_rank[(size_t)k] = r; } });
-        parallel_chunks(Epp, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t k = b0; k < e0; ++k) {
-            const int fi = B.fp_of_pose[g.pp_i[(size_t)k]], fj = B.fp_of_pose[g.pp_j[(size_t)k]];
+            return r; };
+        auto rank_of_pp = [&](int64_t k) { const int fi = B.fp_of_pose[g.pp_i[(size_t)k]], fj = B.fp_of_pose[g.pp_j[(size_t)k]];
             int r = 0;
             if (fi >= 0 && vowner(fi) >= 0) r = vowner(fi);
             else if (fj >= 0 && vowner(fj) >= 0) r = vowner(fj);
             else if (fi >= 0) r = window(fi);
             else if (fj >= 0) r = window(fj);
-            plan.pp_rank[(size_t)k] = r; } });
+            return r; };
+        if (B.by_window) {                                            // the edges of the poses this rank's plan is built from: every edge it evaluates is among them
+            parallel_chunks((int64_t)ing.size(), 4096, [&](int64_t b0, int64_t e0, int) { for (int64_t u = b0; u < e0; ++u) { const int p = ing[(size_t)u];
+                for (int q = plan.pl_start[p]; q < plan.pl_start[p + 1]; ++q) plan.pl_rank[(size_t)q] = rank_of_pl(q);
+                for (int q = plan.ppadj_start[p]; q < plan.ppadj_start[p + 1]; ++q) { const int k = plan.ppadj[q] >> 1; plan.pp_rank[(size_t)k] = rank_of_pp(k); } } });
+        } else {
+        parallel_chunks(Epl, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t k = b0; k < e0; ++k) plan.pl_rank[(size_t)k] = rank_of_pl(k); });
+        parallel_chunks(Epp, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t k = b0; k < e0; ++k) plan.pp_rank[(size_t)k] = rank_of_pp(k); });
+        }
         parallel_chunks(B.nfp, 65536, [&](int64_t b0, int64_t e0, int) { for (int i = (int)b0; i < (int)e0; ++i) { const int o = vowner(i); plan.pose_known[B.pose_of_fp[i]] = (o < 0 || o == plan.rank); } });
         parallel_chunks(B.nfl, 65536, [&](int64_t b0, int64_t e0, int) { for (int l = (int)b0; l < (int)e0; ++l) { const int o = vowner(B.nfp + l); plan.lm_known[B.lm_of_fl[l]] = (o < 0 || o == plan.rank); } });
         // per-rank level lists: owned fronts, then the shared top; exchange slots of the shared fronts
@@ -655,6 +794,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         std::vector<int> lo_t(host_threads() + 1, N), hi_t(host_threads() + 1, 0);
         parallel_chunks(N, 65536, [&](int64_t b0, int64_t e0, int t) { int lo2 = N, hi2 = 0;
             for (int p = (int)b0; p < (int)e0; ++p) { bool any = false;
+                if (B.by_window && !ing_flag[p]) continue;
                 for (int s2 = plan.pl_start[p]; s2 < plan.pl_start[p + 1] && !any; ++s2) any = plan.pl_rank[plan.pl_order[s2]] == plan.rank;
                 for (int q = plan.ppadj_start[p]; q < plan.ppadj_start[p + 1] && !any; ++q) any = plan.pp_rank[plan.ppadj[q] >> 1] == plan.rank;
                 if (any) { lo2 = std::min(lo2, p); hi2 = std::max(hi2, p + 1); } }
@@ -680,7 +820,7 @@ GS_PT(70);
     plan.lin_ell_ok = R <= LIN_R;
     plan.ell_ins.reserve((size_t)plan.ell_len + TAIL_PL); plan.ell_of_ins.reserve((size_t)Epl + TAIL_PL);
     plan.ell_ins.assign((size_t)plan.ell_len, -1);
-    plan.ell_of_ins.assign(Epl, -1);
+    pfill(plan.ell_of_ins, (size_t)Epl, (int32_t)-1);
     parallel_chunks(np_, 8192, [&](int64_t b0, int64_t e0, int) {
         for (int p = p0 + (int)b0; p < p0 + (int)e0; ++p)
             for (int s2 = 0; s2 < plan.pl_start[p + 1] - plan.pl_start[p]; ++s2) {

@@ -150,6 +150,30 @@ def test_a_rank_plans_its_own_window_and_the_shared_top_only(pkg, bench_graphs):
     assert len(slots) >= world - 1
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_a_rank_builds_the_top_of_the_tree_from_window_masks(pkg, po, world):
+    """Round 4: a rank of a sharded graph builds the shared top from two bit masks per landmark (which windows see it) and otherwise
+    touches only the edges of its own window and of the windows' first poses (gs_plan.cpp, nd_top) — instead of grouping, listing and
+    walking every edge of every window.  Where the general recursion's middle pose is a window's first one (windows of equal size, a power of
+    two of them) the two constructions must give the SAME plan, field by field; the per-edge owner arrays differ only in that another
+    window's interior edges are marked "not mine" (-1) instead of carrying their owner."""
+    t = pkg.track.generate(1602, 320); g = pkg.track.bench_graph(t, po.OracleFrontend())      # 1 600 free poses: divisible by 8
+    for rank in range(world):
+        P = []
+        for by_window in (0, 1):
+            H = pkg.Graph(device=-2, debug=dict(shard_by_window=by_window)); H.load_bench_graph(g); H.dist_configure(rank, world); H.plan_build_host()
+            P.append(Plan(H.plan_export())); H.close()
+        A, B = P
+        for k, v in A.__dict__.items():
+            w = B.__dict__[k]
+            if k in ("pl_rank", "pp_rank"):
+                assert np.array_equal(v == rank, w == rank), (k, rank)          # the edges this rank evaluates: the same set
+                assert ((w == -1) | (w == v)).all(), (k, rank)                  # every other entry: the owner, or "not mine"
+            elif isinstance(v, np.ndarray): assert v.shape == w.shape and np.array_equal(v, w), (k, rank)
+            else: assert v == w, (k, rank)
+        assert (B.pl_rank == -1).any()
+
+
 @pytest.mark.parametrize("N,M,h,steps,keep", [(50, 30, 1, 1, None), (1000, 200, 3, 1, None), (1000, 200, 4, 2, None), (1000, 200, 6, 3, 600), (10000, 2000, 4, 2, 4007)])
 def test_appended_poses_grow_the_plan_instead_of_rebuilding_it(pkg, po, bench_graphs, N, M, h, steps, keep):
     """Append-only growth (reference src/slam.cpp:433-459, 525-550; gs::grow_plan): the last h poses of the track — with `keep`, of an
