@@ -40,10 +40,14 @@ namespace {
 
 // fill on the host threads; a vector that already has the size (a handle that plans again: build_plan's recycled arrays) is not re-initialised first
 template <class V, class T> void pfill(V &v, size_t n, T value) {
-    if (v.size() != n) { v.clear(); v.resize(n); }
+    if (v.size() != n) { v.clear(); v.reserve(n); hint_huge(v); v.resize(n); }
     auto *p = v.data();
     parallel_chunks((int64_t)n, 1 << 18, [&](int64_t b0, int64_t e0, int) { std::fill(p + b0, p + e0, value); });
 }
+
+// resize / assign of a big array with the huge-page hint placed before its first touch
+template <class V> void big_resize(V &v, size_t n) { if (v.capacity() < n) { v.clear(); v.reserve(n); hint_huge(v); } v.resize(n); }
+template <class V, class T> void big_assign(V &v, size_t n, T value) { if (v.capacity() < n) { v.clear(); v.reserve(n); hint_huge(v); } v.assign(n, value); }
 
 struct Builder {
     const HostGraph &g;
@@ -112,7 +116,7 @@ struct Builder {
         lazy_pose.assign(nfp, 0); lazy_lm.assign(nfl, 0);
         if (opt.world > 1) for (int v = 0; v < nfp; ++v) lazy_pose[v] = window(v) != opt.rank;
         std::vector<int32_t> obs_cnt(nfl, 0);
-        inc_start.assign(nv + 1, 0);
+        big_assign(inc_start, (size_t)nv + 1, 0);
         parallel_chunks(nv, 4096, [&](int64_t b0, int64_t e0, int) {
             for (int v = (int)b0; v < (int)e0; ++v) { int n = 0;
                 if (v < nfp && lazy_pose[v]) { }
@@ -127,11 +131,11 @@ struct Builder {
                     if (opt.world > 1 && n > 0 && wlo == whi && wlo != opt.rank) { lazy_lm[v - nfp] = 1; n = 0; } }
                 inc_start[v + 1] = n; } });
         for (int v = 0; v < nv; ++v) inc_start[v + 1] += inc_start[v];
-        if (inc_cap < (size_t)inc_start[nv] + 1) { inc_cap = (size_t)inc_start[nv] + 1; inc_store.reset(new Inc[inc_cap]); }
+        if (inc_cap < (size_t)inc_start[nv] + 1) { inc_cap = (size_t)inc_start[nv] + 1; inc_store.reset(new Inc[inc_cap]); hint_huge_pages(inc_store.get(), inc_cap * sizeof(Inc)); }
         inc = inc_store.get();
         cone_obs_start.assign(nfl + 1, 0);
         for (int l = 0; l < nfl; ++l) cone_obs_start[l + 1] = cone_obs_start[l] + obs_cnt[l];
-        cone_obs.resize(cone_obs_start[nfl]); obs_lo.assign(nfl, INT32_MAX); obs_hi.assign(nfl, -1);
+        big_resize(cone_obs, (size_t)cone_obs_start[nfl]); obs_lo.assign(nfl, INT32_MAX); obs_hi.assign(nfl, -1);
         // an observation edge is named by its INSERTION index here (epos); the assembly records are translated to the device
         // layout once it exists
         parallel_chunks(nv, 4096, [&](int64_t b0, int64_t e0, int) {
@@ -406,10 +410,11 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     // assignment further down: a rank lays out the poses it sweeps only)
     // (room for grow_plan's appended runs is reserved BEFORE the arrays are filled: reserving afterwards re-allocated and copied ~60 MB at 100k poses)
     plan.pl_order.reserve((size_t)Epl + TAIL_PL); plan.pp_order.reserve((size_t)Epp + TAIL_PP);
+    hint_huge(plan.pl_order);
     // The reference adds a keyframe's observation edges behind its pose (src/slam.cpp:433-459, 525-550): the edges arrive grouped by pose.
     // Then the grouping is the identity and the ranges come from a scan — on all host threads (a pose-window shard walks the edges of ALL
     // windows here: these passes were 70 of a rank's 480 ms at 8 x 100k poses); any other insertion order takes the counting sort.
-    plan.pl_start.assign(N + 1, 0);
+    big_assign(plan.pl_start, (size_t)N + 1, 0);
     plan.pl_order.resize(Epl);
     bool by_pose = true;
     { std::vector<uint8_t> bad(host_threads() + 1, 0);
@@ -476,11 +481,11 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     if (B.by_window) {                                                // the edges of the poses in `ing` only (pose order = insertion order here)
         for (int p : ing) for (int q = plan.pl_start[p]; q < plan.pl_start[p + 1]; ++q) plan.lm_start[g.pl_l[q] + 1]++;
         for (int l = 0; l < M; ++l) plan.lm_start[l + 1] += plan.lm_start[l];
-        lm_k.resize((size_t)plan.lm_start[M]);
+        big_resize(lm_k, (size_t)plan.lm_start[M]);
         std::vector<int32_t> fill(plan.lm_start.begin(), plan.lm_start.end() - 1);
         for (int p : ing) for (int q = plan.pl_start[p]; q < plan.pl_start[p + 1]; ++q) lm_k[(size_t)fill[g.pl_l[q]]++] = q;
     } else {
-    lm_k.resize(Epl);
+    big_resize(lm_k, (size_t)Epl);
     { const int C = (int64_t)chunk_count(Epl, 1 << 18) * M <= ((int64_t)1 << 26) ? chunk_count(Epl, 1 << 18) : 1;
       std::vector<std::vector<int32_t>> cnt(C);
       auto lo = [&](int c) { return (int64_t)Epl * c / C; };
@@ -506,11 +511,11 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     } else {
     for (int k = 0; k < Epp; ++k) { plan.ppadj_start[g.pp_i[k] + 1]++; plan.ppadj_start[g.pp_j[k] + 1]++; }
     for (int p = 0; p < N; ++p) plan.ppadj_start[p + 1] += plan.ppadj_start[p];
-    plan.ppadj.resize(2 * (size_t)Epp);
+    big_resize(plan.ppadj, 2 * (size_t)Epp);
     { std::vector<int32_t> fill(plan.ppadj_start.begin(), plan.ppadj_start.end() - 1);
       for (int k = 0; k < Epp; ++k) { plan.ppadj[fill[g.pp_i[k]]++] = 2 * k; plan.ppadj[fill[g.pp_j[k]]++] = 2 * k + 1; } }
     }
-    plan.ppinc.resize(plan.ppadj.size() * 4);
+    big_resize(plan.ppinc, plan.ppadj.size() * 4);
     parallel_chunks((int64_t)plan.ppadj.size(), 65536, [&](int64_t b0, int64_t e0, int) {
         for (size_t q = (size_t)b0; q < (size_t)e0; ++q) { const int code = plan.ppadj[q], k = code >> 1;
             plan.ppinc[4 * q] = k; plan.ppinc[4 * q + 1] = code & 1; plan.ppinc[4 * q + 2] = g.pp_i[k]; plan.ppinc[4 * q + 3] = g.pp_j[k]; } });
@@ -530,7 +535,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
       if (B.by_window) B.nd_top(0, opt.world, all, B.sn, 0); else B.nd(0, B.nfp, all, B.sn, 0); }
     const int S = (int)B.sn.size();
     std::vector<int32_t> &sn_of = scratch->sn_of, &vpos = scratch->vpos, &gidx = scratch->gidx;
-    sn_of.assign(B.nv, -1); vpos.assign(B.nv, -1); gidx.assign(B.nv, -1);
+    big_assign(sn_of, (size_t)B.nv, -1); big_assign(vpos, (size_t)B.nv, -1); big_assign(gidx, (size_t)B.nv, -1);
     { int pos = 0, sc = 0;
       for (int s = 0; s < S; ++s) for (int v : B.sn[s]) { if (sn_of[v] != -1) { err = "vertex emitted twice"; return false; }
             sn_of[v] = s; vpos[v] = pos++; gidx[v] = sc; sc += B.dim(v); }
@@ -622,6 +627,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
       }
       if (na >= ((int64_t)1 << 31)) { err = "too many assembly records"; return false; }
       plan.bnd_rows.reserve((size_t)nb + 64 * 1024); plan.child_map.reserve((size_t)nm + 64 * 1024); plan.asm_recs.reserve((size_t)na + 96 * 1024);
+      hint_huge(plan.bnd_rows); hint_huge(plan.child_map); hint_huge(plan.asm_recs);
       plan.bnd_rows.resize((size_t)nb); plan.child_map.resize((size_t)nm); plan.asm_recs.resize((size_t)na); }
     parallel_chunks(S, 512, [&](int64_t b0, int64_t e0, int) {
         std::vector<int32_t> loc(B.nv, -1);                          // row of a vertex inside the current front (only entries set below are read)
@@ -690,6 +696,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     // one that knows both endpoint estimates (owner of an interior endpoint, else the window of the pose).
     plan.world = std::max(1, opt.world); plan.rank = opt.rank;
     plan.pl_rank.reserve((size_t)Epl + TAIL_PL); plan.pp_rank.reserve((size_t)Epp + TAIL_PP);
+    hint_huge(plan.pl_rank);
     plan.pose_known.reserve((size_t)N + TAIL_POSES); plan.lm_known.reserve((size_t)M + TAIL_LMS);
     pfill(plan.pl_rank, (size_t)Epl, (int32_t)(B.by_window ? -1 : 0)); pfill(plan.pp_rank, (size_t)Epp, (int32_t)(B.by_window ? -1 : 0));      // (by windows: -1 = an edge of another window's interior, somebody else's)
     pfill(plan.pose_known, (size_t)N, (uint8_t)1); pfill(plan.lm_known, (size_t)M, (uint8_t)1);
@@ -819,6 +826,7 @@ GS_PT(70);
     plan.ell_len = (int64_t)R * T * np_ + 1;
     plan.lin_ell_ok = R <= LIN_R;
     plan.ell_ins.reserve((size_t)plan.ell_len + TAIL_PL); plan.ell_of_ins.reserve((size_t)Epl + TAIL_PL);
+    hint_huge(plan.ell_ins); hint_huge(plan.ell_of_ins);
     plan.ell_ins.assign((size_t)plan.ell_len, -1);
     pfill(plan.ell_of_ins, (size_t)Epl, (int32_t)-1);
     parallel_chunks(np_, 8192, [&](int64_t b0, int64_t e0, int) {
@@ -847,7 +855,7 @@ GS_PT(73);
     if (plan.lin_ell_ok) {
         plan.n_wtiles = WT;
         plan.wt_grp_start.assign(WT + 1, 0);
-        plan.ell_dst.assign((size_t)plan.ell_len, (uint16_t)0xFFFF);
+        big_assign(plan.ell_dst, (size_t)plan.ell_len, (uint16_t)0xFFFF);
         // every wave tile is independent: chunks of tiles on the host threads, each into its own lists, stitched afterwards
         const int C = chunk_count(std::max(1, plan.wt_hi - plan.wt_lo), 256);
         struct TileOut { std::vector<int32_t> grp_lm, grp_pos_start, grp_pos, tile_groups; };
