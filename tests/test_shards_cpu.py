@@ -88,3 +88,46 @@ def test_sharded_increment_over_gloo_equals_joint_solve(po, bench_graphs, tmp_pa
     assert sum(int(o["my_pl"]) for o in outs) == len(g["pl_p"]) and sum(int(o["my_pp"]) for o in outs) == len(g["pp_i"])
     assert all(int(o["owned"]) > 0 for o in outs)
     assert int(outs[0]["exchange"]) * 8 < 2_000_000
+
+
+@pytest.mark.parametrize("world", [3, 5, 7, 8])
+@pytest.mark.parametrize("by_window", [1, 0])
+def test_odd_worlds_and_fixed_poses_in_one_process(pkg, po, bench_graphs, world, by_window):
+    """The per-rank plans of worlds that are no power of two, on a lap with fixed poses sprinkled through it (windows count FREE poses): every
+    rank's part replayed in numpy, the exchange buffers summed as the all-reduce would, the shared top finished on every rank, the merged
+    increment against the oracle's joint solve — for the plan built by windows (round 4: per-landmark window masks, a rank's lists from its own
+    window's edges) and for the general recursion.  Every edge has exactly one evaluator, every vertex one primary rank."""
+    from conftest import make_oracle_graph
+    from plan_exec import Plan
+    _, g0 = bench_graphs(1000, 200)
+    g = dict(g0); g["fixed_poses"] = np.array(sorted(set([0, 1] + list(range(90, 1000, 97)))), dtype=np.int32)
+    og = make_oracle_graph(po, g); og.build_system(); og.apply_update(og.solve_ldlt(1)); dp_o, dl_o = og.delta()
+    scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
+    plans, locals_, prim = [], [], []
+    n_pl, n_pp = len(g["pl_p"]), len(g["pp_i"])
+    seen_pl, seen_pp = np.zeros(n_pl, int), np.zeros(n_pp, int)
+    for rank in range(world):
+        G = pkg.Graph(device=-2, debug=dict(shard_by_window=by_window)); G.load_bench_graph(g); G.dist_configure(rank, world); G.plan_build_host()
+        P = Plan(G.plan_export()); P.check_invariants()
+        kp = P.pp_rank == rank; kl = P.pl_rank == rank
+        seen_pl += kl; seen_pp += kp
+        sub = dict(g)
+        for k in ("pp_i", "pp_j", "pp_z", "pp_info"): sub[k] = g[k][kp]
+        for k in ("pl_p", "pl_l", "pl_z", "pl_info"): sub[k] = g[k][kl]
+        blk_sub = make_oracle_graph(po, sub).linearize_blocks()
+        blocks = dict(blk_sub)
+        blocks["Hpp_off"] = np.zeros((n_pp, 9)); blocks["Hpp_off"][kp] = blk_sub["Hpp_off"]
+        blocks["Hpl"] = np.zeros((n_pl, 6)); blocks["Hpl"][kl] = blk_sub["Hpl"]
+        X, ok = P.shard_local(blocks); assert ok
+        plans.append(P); locals_.append(X); prim.append(G.dist_known()); G.close()
+    assert (seen_pl == 1).all() and (seen_pp == 1).all()          # every edge: exactly one evaluator
+    assert len({P.exchange_doubles for P in plans}) == 1 and len({P.n_shared for P in plans}) == 1
+    Xsum = np.sum(locals_, axis=0)                                 # the all-reduce
+    dp = np.zeros_like(dp_o); dl = np.zeros_like(dl_o); cnt_p = np.zeros(len(dp_o)); cnt_l = np.zeros(len(dl_o))
+    for P, (pk, lk, pprim, lprim) in zip(plans, prim):
+        a, b, ok = P.shard_finish(Xsum.copy()); assert ok
+        dp += a * pprim[:, None]; dl += b * lprim[:, None]; cnt_p += pprim; cnt_l += lprim
+    free_p = np.ones(len(dp_o), bool); free_p[g["fixed_poses"]] = False
+    free_l = np.ones(len(dl_o), bool); free_l[g["fixed_landmarks"]] = False
+    assert (cnt_p[free_p] == 1).all() and (cnt_l[free_l] == 1).all()
+    assert np.abs(dp - dp_o).max() / scale < 1e-8 and np.abs(dl - dl_o).max() / scale < 1e-8
