@@ -341,6 +341,12 @@ def main():
         out["exchange"] = dict(doubles=int(G.dist_exchange_doubles()), bytes=int(8 * G.dist_exchange_doubles()), ms_exchange=G.time_exchange(50),
                                shared_fronts=int(plan.n_shared_fronts), own_fronts=int(plan.n_own_fronts),
                                note="ms_exchange = one ncclAllReduce(sum, fp64) of the exchange buffer, mean of 50 back to back (HIP events on the library's stream); inside the iteration it sits between the local half and the shared top")
+    if dist_mode:
+        # the structure phase of the sharded graph (once per graph change, outside the timed region): a rank plans its own window and the shared
+        # top from per-landmark window masks; the slowest rank's time
+        ts = torch.tensor([plan.ms_structure], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        out["structure_ms_slowest_rank"] = float(ts.item())
     if dist_mode and world == 1:
         out["config"]["parallelism"] = ("single GPU through the multi-GPU code path (GS_BENCH_FORCE_DIST): RCCL group of 1 created inside the library, top 3 levels forced shared "
                                         "(%d doubles all-reduced per iteration), gs_dist_iterate" % G.dist_exchange_doubles())
