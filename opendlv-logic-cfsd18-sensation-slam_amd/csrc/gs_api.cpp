@@ -544,16 +544,21 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
           if ((rc = dev_upload(g, &ins, P.ell_ins)) != GS_OK) return rc;
           launch_build_ell((int64_t)L, ins, raw.pl_l, raw.pl_z, raw.pl_info, nullptr, P.rank, d.ell_l, d.ell_z, d.ell_w, g->stream);
       } else {                                                       // pose-window shard: only the poses it sweeps are laid out; the streams are filled on the host
+          // ... on a thread of its own, beside the rest of this function (nothing here reads the streams; joined before the final wait): the fill
+          // and three copies out of pageable memory were 2.5-5 of a rank's ~8 ms of upload at 8 x 100k poses
           raw.ell_l.resize(L); raw.ell_z.resize(2 * L); raw.ell_w.resize(3 * L);        // (threads) with the edges this rank evaluates, the others stay empty (l = -1)
-          parallel_chunks((int64_t)L, 16384, [&](int64_t b, int64_t e2, int) {
-              for (int64_t e = b; e < e2; ++e) { int k = P.ell_ins[(size_t)e]; if (k >= 0 && P.pl_rank[k] != P.rank) k = -1;
-                  raw.ell_l[e] = k >= 0 ? h.pl_l[k] : -1;
-                  raw.ell_z[e] = k >= 0 ? h.pl_z[2 * (size_t)k] : 0.0; raw.ell_z[L + e] = k >= 0 ? h.pl_z[2 * (size_t)k + 1] : 0.0;
-                  raw.ell_w[e] = k >= 0 ? h.pl_info[3 * (size_t)k] : 0.0; raw.ell_w[L + e] = k >= 0 ? h.pl_info[3 * (size_t)k + 1] : 0.0;
-                  raw.ell_w[2 * L + e] = k >= 0 ? h.pl_info[3 * (size_t)k + 2] : 0.0; } });
-          HIP_TRY(hipMemcpyAsync(d.ell_l, raw.ell_l.data(), L * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
-          HIP_TRY(hipMemcpyAsync(d.ell_z, raw.ell_z.data(), 2 * L * sizeof(double), hipMemcpyHostToDevice, g->stream));
-          HIP_TRY(hipMemcpyAsync(d.ell_w, raw.ell_w.data(), 3 * L * sizeof(double), hipMemcpyHostToDevice, g->stream)); } }
+          raw.th = std::thread([g, &raw, L] { const HostGraph &h = g->h; const Plan &P = g->plan; DevGraph &d = g->d;
+              if (hipSetDevice(g->device) != hipSuccess) { raw.rc = GS_ERR_HIP; raw.err = "hipSetDevice failed on the upload thread"; return; }
+              parallel_chunks((int64_t)L, 16384, [&](int64_t b, int64_t e2, int) {
+                  for (int64_t e = b; e < e2; ++e) { int k = P.ell_ins[(size_t)e]; if (k >= 0 && P.pl_rank[k] != P.rank) k = -1;
+                      raw.ell_l[e] = k >= 0 ? h.pl_l[k] : -1;
+                      raw.ell_z[e] = k >= 0 ? h.pl_z[2 * (size_t)k] : 0.0; raw.ell_z[L + e] = k >= 0 ? h.pl_z[2 * (size_t)k + 1] : 0.0;
+                      raw.ell_w[e] = k >= 0 ? h.pl_info[3 * (size_t)k] : 0.0; raw.ell_w[L + e] = k >= 0 ? h.pl_info[3 * (size_t)k + 1] : 0.0;
+                      raw.ell_w[2 * L + e] = k >= 0 ? h.pl_info[3 * (size_t)k + 2] : 0.0; } });
+              hipError_t e1 = hipMemcpyAsync(d.ell_l, raw.ell_l.data(), L * sizeof(int32_t), hipMemcpyHostToDevice, g->stream);
+              hipError_t e2 = hipMemcpyAsync(d.ell_z, raw.ell_z.data(), 2 * L * sizeof(double), hipMemcpyHostToDevice, g->stream);
+              hipError_t e3 = hipMemcpyAsync(d.ell_w, raw.ell_w.data(), 3 * L * sizeof(double), hipMemcpyHostToDevice, g->stream);
+              if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { raw.rc = GS_ERR_HIP; raw.err = "edge streams: copy to the device failed"; } }); } }
     GS_UT("estimates+edges");
     UP(lm_start, P.lm_start); UP(lm_edges, P.lm_edges); UP(ppadj_start, P.ppadj_start);
     { const size_t Q = P.ppinc.size() / 4;                                // device records are 8 bytes: {edge, other endpoint | role << 31}; the pose that
@@ -758,6 +763,7 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
 #undef AL
 #undef ZERO
     GS_UT("arenas+levels");
+    if (raw.th.joinable()) { raw.th.join(); if (raw.rc != GS_OK) return fail(raw.rc, raw.err); }      // a shard's edge streams (above)
     HIP_TRY(hipStreamSynchronize(g->stream));
     GS_UT("final sync");
     g->dev_valid = true; g->dev_estimates_newer = false; g->tree_proven = false;

@@ -114,7 +114,10 @@ struct Builder {
     void build_adjacency(const Plan &P, const std::vector<int32_t> &lm_k) {
         plan_ = &P; lm_k_ = &lm_k;
         lazy_pose.assign(nfp, 0); lazy_lm.assign(nfl, 0);
-        if (opt.world > 1) for (int v = 0; v < nfp; ++v) lazy_pose[v] = window(v) != opt.rank;
+        if (opt.world > 1) {                                          // (a range test: window() is a 64-bit division per pose)
+            const int W = opt.world, lo = (int)(((int64_t)opt.rank * nfp + W - 1) / W), hi = (int)(((int64_t)(opt.rank + 1) * nfp + W - 1) / W);
+            std::fill(lazy_pose.begin(), lazy_pose.end(), (uint8_t)1);
+            std::fill(lazy_pose.begin() + std::min(lo, nfp), lazy_pose.begin() + std::min(hi, nfp), (uint8_t)0); }
         std::vector<int32_t> obs_cnt(nfl, 0);
         big_assign(inc_start, (size_t)nv + 1, 0);
         parallel_chunks(nv, 4096, [&](int64_t b0, int64_t e0, int) {
@@ -259,11 +262,13 @@ struct Builder {
         const int a = w0 == 0 ? 0 : wf[w0] + 1, b = wf[w1];          // the range's poses: behind the first pose of w0 (a separator higher up) up to the next window's
         if (w1 - w0 == 1) {
             if (w0 == opt.rank) { nd(a, b, cones, out, depth); return; }
-            std::vector<int32_t> verts; verts.reserve((size_t)std::max(b - a, 0) + cones.size());
-            for (int i = a; i < b; ++i) if (!assigned[i]) { verts.push_back(i); assigned[i] = 1; opaque_pose[i] = 1; }
-            if (!verts.empty()) opaque_of_pose[verts[0]] = w0;
-            else if (!cones.empty()) { /* a window without a free pose of its own: its cones go up as they are */ }
-            for (int l : cones) verts.push_back(nfp + l);
+            // (nothing inside another rank's window has been assigned: only the windows' first poses are separators up here)
+            const int np_ = std::max(b - a, 0);
+            std::vector<int32_t> verts((size_t)np_ + cones.size());
+            for (int i = 0; i < np_; ++i) verts[(size_t)i] = a + i;
+            if (np_ > 0) { std::fill(assigned.begin() + a, assigned.begin() + b, (uint8_t)1); std::fill(opaque_pose.begin() + a, opaque_pose.begin() + b, (uint8_t)1);
+                opaque_of_pose[a] = w0; }
+            for (size_t c = 0; c < cones.size(); ++c) verts[(size_t)np_ + c] = nfp + cones[c];
             emit(out, std::move(verts));
             return; }
         const int wm = (w0 + w1 + 1) / 2, m = wf[wm];
@@ -708,7 +713,9 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         std::vector<int32_t> wmin(S, INT32_MAX), wmax(S, -1);
         for (int s = 0; s < S; ++s) {
             if (B.by_window && is_opaque(s)) wmin[s] = wmax[s] = B.opaque_of_pose[B.sn[s][0]];      // (another rank's window: no walk over its ~100k poses)
-            else for (int v : B.sn[s]) if (v < B.nfp) { const int w = window(v); wmin[s] = std::min(wmin[s], w); wmax[s] = std::max(wmax[s], w); }
+            else for (int v : B.sn[s]) if (v < B.nfp) {
+                const int w = B.by_window ? (int)(std::upper_bound(B.wf.begin(), B.wf.end(), v) - B.wf.begin()) - 1 : window(v);      // (the table of window starts instead of a 64-bit division per pose)
+                wmin[s] = std::min(wmin[s], w); wmax[s] = std::max(wmax[s], w); }
             for (int c : kids[s]) { wmin[s] = std::min(wmin[s], wmin[c]); wmax[s] = std::max(wmax[s], wmax[c]); }
         }
         for (int s = S - 1; s >= 0; --s) {
