@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 namespace gs {
@@ -180,7 +181,7 @@ struct Builder {
     // by all its split poses AT ONCE: they form one separator supernode (3 (p - 1) pivots) whose p children are the
     // leaves.  Bounded so that neither the cluster front nor a leaf can exceed the 63 scalars of the wave-per-front
     // kernels: rows <= separator poses + cones alive in the range + the two poses outside it.
-    bool nd_multi(int a, int b, int un, std::vector<int32_t> &cones, SnList &out, int depth) {
+    bool nd_multi(int a, int b, int un, std::vector<int32_t> &cones, SnList &out, int depth, bool in_own) {
         const int ways = opt.cluster_ways;
         if (ways <= 2) return false;
         int p = std::min(ways, (un + 1 + opt.leaf_poses) / (opt.leaf_poses + 1));       // ceil((un + 1) / (leaf + 1)) parts
@@ -239,7 +240,7 @@ struct Builder {
         const int np = (int)cut.size() - 1;
         cones.clear(); cones.shrink_to_fit();
         if (!orphans.empty()) { std::vector<int32_t> v; for (int l : orphans) v.push_back(nfp + l); emit(out, std::move(v)); }
-        for (int k = 0; k < np; ++k) nd(cut[k] + 1, cut[k + 1], part_cones[k], out, depth + 1);
+        for (int k = 0; k < np; ++k) nd(cut[k] + 1, cut[k + 1], part_cones[k], out, depth + 1, in_own);
         std::vector<int32_t> verts(sep_poses.begin(), sep_poses.end());
         for (int l : sep_cones) verts.push_back(nfp + l);
         emit(out, std::move(verts));
@@ -261,7 +262,7 @@ struct Builder {
     void nd_top(int w0, int w1, std::vector<int32_t> &cones, SnList &out, int depth) {
         const int a = w0 == 0 ? 0 : wf[w0] + 1, b = wf[w1];          // the range's poses: behind the first pose of w0 (a separator higher up) up to the next window's
         if (w1 - w0 == 1) {
-            if (w0 == opt.rank) { nd(a, b, cones, out, depth); return; }
+            if (w0 == opt.rank) { const size_t n0 = out.size(); nd(a, b, cones, out, depth, true); mark_own_range(out, n0); return; }
             // (nothing inside another rank's window has been assigned: only the windows' first poses are separators up here)
             const int np_ = std::max(b - a, 0);
             std::vector<int32_t> verts((size_t)np_ + cones.size());
@@ -299,9 +300,20 @@ struct Builder {
     }
 
     // nested dissection over free-pose positions [a, b); `cones` = free landmarks alive in this range
-    void nd(int a, int b, std::vector<int32_t> &cones, SnList &out, int depth) {
+    // Pose-window shards: the ranges of THIS rank's window that another rank sees as one opaque supernode (first and last supernode of the range,
+    // named by their first vertex).  The shared top must come out the same on every rank: the owner therefore hands the shared fronts the
+    // boundary the others compute for the range as a whole — the union over its supernodes — and not only what each of its subtrees carries up
+    // (a window that falls apart, e.g. at a fixed pose between cones that all sit in separators, has several roots with smaller boundaries
+    // hanging under different shared fronts: ranks then disagreed on the rows of the shared fronts).
+    std::vector<std::pair<int32_t, int32_t>> own_ranges; std::mutex own_mu;
+    void mark_own_range(const SnList &out, size_t n0) { if (out.size() > n0) { std::lock_guard<std::mutex> lk(own_mu); own_ranges.push_back({out[n0][0], out.back()[0]}); } }
+    void nd(int a, int b, std::vector<int32_t> &cones, SnList &out, int depth, bool in_own = false) {
         int un = 0;
         for (int i = a; i < b; ++i) un += !assigned[i];
+        if (opt.world > 1 && !in_own && un > 0) {                     // (the general recursion: a range that lies in this rank's window alone)
+            int first = -1, last = -1;
+            for (int i = a; i < b; ++i) if (!assigned[i]) { if (first < 0) first = i; last = i; }
+            if (window(first) == window(last) && window(first) == opt.rank) { const size_t n0 = out.size(); nd(a, b, cones, out, depth, true); mark_own_range(out, n0); return; } }
         // pose-window shards: a range that lies in ONE window of ANOTHER rank is that rank's business — here it stays one opaque
         // supernode (its poses + the cones alive in it): the symbolic factorisation gives it the boundary the owner's whole
         // subtree has (the rows of the shared fronts above are the same on every rank), nothing below it is planned, stored or
@@ -322,7 +334,7 @@ struct Builder {
             emit(out, std::move(verts));
             return;
         }
-        if (nd_multi(a, b, un, cones, out, depth)) return;
+        if (nd_multi(a, b, un, cones, out, depth, in_own)) return;
         // split pose: the middle unassigned one
         int m = -1, seen = 0;
         for (int i = a; i < b; ++i) if (!assigned[i]) { if (seen == un / 2) { m = i; break; } ++seen; }
@@ -350,12 +362,12 @@ struct Builder {
         const bool one_sided = foreign(a, m) || foreign(m + 1, b);
         if (!one_sided && (1 << depth) < host_threads() && un > 2048) {
             SnList lo;
-            std::thread th([&] { nd(a, m, left, lo, depth + 1); });
-            SnList hi; nd(m + 1, b, right, hi, depth + 1);
+            std::thread th([&] { nd(a, m, left, lo, depth + 1, in_own); });
+            SnList hi; nd(m + 1, b, right, hi, depth + 1, in_own);
             th.join();
             for (auto &v : lo) out.push_back(std::move(v));
             for (auto &v : hi) out.push_back(std::move(v));
-        } else { const int dn = one_sided ? depth : depth + 1; nd(a, m, left, out, dn); nd(m + 1, b, right, out, dn); }
+        } else { const int dn = one_sided ? depth : depth + 1; nd(a, m, left, out, dn, in_own); nd(m + 1, b, right, out, dn, in_own); }
         std::vector<int32_t> verts(sep_poses.begin(), sep_poses.end());
         for (int l : sep_cones) verts.push_back(nfp + l);
         emit(out, std::move(verts));
@@ -588,11 +600,25 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
                 if (sn_of[w] > s && std::find(cd.begin(), cd.end(), w) == cd.end()) cd.push_back(w); }); } });
         auto &bd = bndv[s];
         for (auto &cd : cand) for (int w : cd) if (std::find(bd.begin(), bd.end(), w) == bd.end()) bd.push_back(w); }
+    // this rank's own ranges as the other ranks see them: the union of what their supernodes touch beyond the range, handed to the shared front
+    // that eliminates its first vertex like a child's boundary (no extend-add comes with it: the range's real roots keep their own parents,
+    // whose rows hold everything a root carries — they lie on the path this union travels)
+    std::vector<std::vector<std::vector<int32_t>>> virt;
+    if (opt.world > 1 && !B.own_ranges.empty()) { virt.resize(S);
+        for (auto &r : B.own_ranges) { const int s0 = sn_of[r.first], s1 = sn_of[r.second];
+            std::vector<int32_t> U;
+            for (int s = s0; s <= s1; ++s) for (int w : bndv[s]) if (sn_of[w] > s1 && stamp[w] != -2 - s1) { stamp[w] = -2 - s1; U.push_back(w); }
+            if (U.empty()) continue;
+            int first = U[0]; for (int w : U) if (vpos[w] < vpos[first]) first = w;
+            virt[sn_of[first]].push_back(std::move(U)); }
+        std::fill(stamp.begin(), stamp.end(), -1); }
     for (int s = 0; s < S; ++s) {
         auto &bd = bndv[s];
-        if (!kids[s].empty()) {
+        const bool has_virt = !virt.empty() && !virt[s].empty();
+        if (!kids[s].empty() || has_virt) {
             for (int w : bd) stamp[w] = s;
-            for (int c : kids[s]) for (int w : bndv[c]) if (sn_of[w] != s && stamp[w] != s) { stamp[w] = s; bd.push_back(w); } }
+            for (int c : kids[s]) for (int w : bndv[c]) if (sn_of[w] != s && stamp[w] != s) { stamp[w] = s; bd.push_back(w); }
+            if (has_virt) for (auto &U : virt[s]) for (int w : U) if (sn_of[w] != s && stamp[w] != s) { stamp[w] = s; bd.push_back(w); } }
         std::sort(bd.begin(), bd.end(), [&](int x, int y) { return vpos[x] < vpos[y]; });
         if (!bd.empty()) { parent[s] = sn_of[bd[0]]; kids[parent[s]].push_back(s); }
     }

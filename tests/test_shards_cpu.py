@@ -131,3 +131,47 @@ def test_odd_worlds_and_fixed_poses_in_one_process(pkg, po, bench_graphs, world,
     free_l = np.ones(len(dl_o), bool); free_l[g["fixed_landmarks"]] = False
     assert (cnt_p[free_p] == 1).all() and (cnt_l[free_l] == 1).all()
     assert np.abs(dp - dp_o).max() / scale < 1e-8 and np.abs(dl - dl_o).max() / scale < 1e-8
+
+
+@pytest.mark.parametrize("seed", [31, 33, 36, 37, 5, 12])
+def test_windows_that_fall_apart_still_give_every_rank_the_same_shared_top(pkg, po, seed):
+    """Irregular graphs (random observations: every cone is seen from everywhere and sits in a separator) with poses fixed in the middle of the
+    chain: a rank's window then falls into several subtrees with smaller boundaries, hanging under different shared fronts — while the other
+    ranks see the window as ONE opaque supernode.  The owner hands the shared top the union boundary the others compute (round 4; before, ranks
+    disagreed on the rows of shared fronts — seeds 31 / 33 / 36 / 37 here — and the exchange buffers did not even have the same length).
+    Worlds 2-8, by windows and by the general recursion: same exchange layout on every rank, every edge one evaluator, the merged increment
+    against the oracle's joint solve."""
+    from conftest import make_oracle_graph, random_graph
+    from plan_exec import Plan
+    rng = np.random.default_rng(1000 + seed)
+    n_poses = int(rng.integers(60, 400)); n_lms = int(rng.integers(10, 80)); opp = int(rng.integers(1, 4))
+    g = random_graph(seed, n_poses=n_poses, n_lms=n_lms, extra_pp=0, obs_per_pose=opp, dup_edges=0)
+    g["fixed_poses"] = np.array(sorted(set([0] + list(rng.choice(n_poses, int(rng.integers(0, 4)), replace=False)))), dtype=np.int32)
+    og = make_oracle_graph(po, g); og.build_system(); og.apply_update(og.solve_ldlt(1)); dp_o, dl_o = og.delta()
+    scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
+    n_pl, n_pp = len(g["pl_p"]), len(g["pp_i"])
+    for world in (2, 3, 4, 6, 8):
+        if n_poses < 6 * world: continue
+        for by_window in (1, 0):
+            plans, locals_, prim = [], [], []
+            seen_pl, seen_pp = np.zeros(n_pl, int), np.zeros(n_pp, int)
+            for rank in range(world):
+                G = pkg.Graph(device=-2, debug=dict(shard_by_window=by_window)); G.load_bench_graph(g); G.dist_configure(rank, world); G.plan_build_host()
+                P = Plan(G.plan_export()); P.check_invariants()
+                kp = P.pp_rank == rank; kl = P.pl_rank == rank; seen_pl += kl; seen_pp += kp
+                sub = dict(g)
+                for k in ("pp_i", "pp_j", "pp_z", "pp_info"): sub[k] = g[k][kp]
+                for k in ("pl_p", "pl_l", "pl_z", "pl_info"): sub[k] = g[k][kl]
+                bs = make_oracle_graph(po, sub).linearize_blocks(); blocks = dict(bs)
+                blocks["Hpp_off"] = np.zeros((n_pp, 9)); blocks["Hpp_off"][kp] = bs["Hpp_off"]
+                blocks["Hpl"] = np.zeros((n_pl, 6)); blocks["Hpl"][kl] = bs["Hpl"]
+                X, ok = P.shard_local(blocks); assert ok
+                plans.append(P); locals_.append(X); prim.append(G.dist_known()); G.close()
+            assert (seen_pl == 1).all() and (seen_pp == 1).all(), (world, by_window)
+            assert len({len(x) for x in locals_}) == 1 and len({P.exchange_doubles for P in plans}) == 1, (world, by_window, [P.exchange_doubles for P in plans])
+            Xsum = np.sum(locals_, axis=0)
+            dp = np.zeros_like(dp_o); dl = np.zeros_like(dl_o)
+            for P, (pk, lk, pprim, lprim) in zip(plans, prim):
+                a, b, ok = P.shard_finish(Xsum.copy()); assert ok
+                dp += a * pprim[:, None]; dl += b * lprim[:, None]
+            assert max(np.abs(dp - dp_o).max(), np.abs(dl - dl_o).max()) / scale < 1e-7, (world, by_window)
