@@ -255,8 +255,7 @@ struct Builder {
     bool by_window = false;
     std::vector<int32_t> wf;                         // wf[w] = first free-pose position of window w; wf[world] = nfp
     std::vector<uint64_t> seen_nb, seen_b;           // per free landmark: windows with an observer that is not / that is the window's first pose (w >= 1)
-    std::vector<int32_t> opaque_window;              // supernode (emission index within its list is not stable: keyed by first pose) -> see opaque_of_pose
-    std::vector<int32_t> opaque_of_pose;             // first pose position of an opaque supernode -> its window (-1)
+    std::vector<int32_t> opaque_of_pose;             // first pose position of an opaque supernode -> its window (-1); (a supernode's index in its list is not stable: the lists of the halves are concatenated)
     std::vector<uint64_t> pp_touch;                  // [world] bit x: the first pose of window x has an odometry edge into window w's interior
     static uint64_t wbits(int lo, int hi) { return hi <= lo ? 0 : ((hi >= 64 ? ~0ull : ((1ull << hi) - 1)) & ~((1ull << lo) - 1)); }
     void nd_top(int w0, int w1, std::vector<int32_t> &cones, SnList &out, int depth) {
