@@ -108,7 +108,8 @@ def test_plan_edge_orders_are_permutations(pkg, bench_graphs):
 
 def test_plan_is_the_same_for_any_number_of_host_threads(pkg):
     """The structure phase runs on several host threads (csrc/gs_parallel.hpp: adjacency, the top levels of the nested
-    dissection, wave tiles, fronts); the plan must not depend on how many: same bytes with GS_THREADS = 1, 3 and 8."""
+    dissection, wave tiles, fronts; round 4: grouping, window masks, numbering, fills); the plan — of the whole graph and of a rank of 8 —
+    must not depend on how many: same bytes with GS_THREADS = 1, 3 and 8."""
     import hashlib
     import subprocess
     import sys
@@ -116,7 +117,9 @@ def test_plan_is_the_same_for_any_number_of_host_threads(pkg):
     code = ("import importlib, sys, hashlib; sys.path.insert(0, %r); from oracle import pyoracle as po; "
             "pkg = importlib.import_module('opendlv-logic-cfsd18-sensation-slam_amd'); "
             "t = pkg.track.generate(10000, 2000); g = pkg.track.bench_graph(t, po.OracleFrontend()); "
-            "H = pkg.Graph(device=-2); H.load_bench_graph(g); H.plan_build_host(); print(hashlib.md5(H.plan_export().tobytes()).hexdigest())" % root)
+            "H = pkg.Graph(device=-2); H.load_bench_graph(g); H.plan_build_host(); d = hashlib.md5(H.plan_export().tobytes()); "
+            "R = pkg.Graph(device=-2); R.load_bench_graph(g); R.dist_configure(3, 8); R.plan_build_host(); d.update(R.plan_export().tobytes()); "       # + a rank of 8 (planned by windows)
+            "print(d.hexdigest())" % root)
     digests = set()
     for n in ("1", "3", "8"):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GS_THREADS=n), capture_output=True, text=True, timeout=300)
