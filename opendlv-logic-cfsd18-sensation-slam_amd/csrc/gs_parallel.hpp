@@ -4,8 +4,14 @@
 // known, so it is split over the host cores next to the GPU (GS_THREADS, default min(16, hardware threads)).
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
+#include <mutex>
 #include <thread>
+#include <type_traits>
+#include <unistd.h>
 #include <vector>
 
 #include <cstdint>
@@ -34,10 +40,68 @@ inline int host_threads() {
     return n;
 }
 
-// fn(begin, end, thread index): contiguous chunks of [0, n), one per thread; runs inline when the range is small
+// The workers of the structure phase.  A plan build is ~40 parallel regions of 0.1-1 ms each; creating and joining 15 threads per region cost
+// 0.2-0.35 ms a time on the GPU box (tests/_build/pc_bench: ~20 us per thread) — 8-12 of a 20 ms structure phase at 100k poses.  The pool keeps
+// host_threads() - 1 threads: between the regions of a build they spin on a generation counter (1.5 ms at most), then sleep on a condition
+// variable.  One job at a time: a caller that finds the pool busy (another handle planning on another host thread, the upload helper) or that IS a
+// worker runs its region the old way (fresh threads / in order on its own thread) — same parts, same results.  Parts, not threads, carry the index
+// handed to fn: part t is run exactly once, by whoever takes it.  A forked child gets a pool of its own on first use.
+class WorkerPool {
+  public:
+    static WorkerPool &get() {
+        static WorkerPool *p = nullptr; static std::mutex mu; static pid_t owner = 0;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!p || owner != getpid()) { p = new WorkerPool(host_threads() - 1); owner = getpid(); }     // (never destroyed: its threads end with the process)
+        return *p;
+    }
+    static bool &in_worker() { static thread_local bool v = false; return v; }
+    // runs parts 0 .. T-1 of job(ctx, part); false: the pool is busy (or has no workers) — the caller falls back
+    bool run(int T, void (*job)(void *, int), void *ctx) {
+        if (workers_.empty() || in_worker() || !busy_.try_lock()) return false;
+        // (a worker may still be leaving the previous job's loop: it can take a part of this job the moment next_ is reset — so the count of parts left
+        // is set first, and the reset publishes job / context / part count)
+        job_ = job; ctx_ = ctx; parts_ = T; left_.store(T, std::memory_order_relaxed); next_.store(0, std::memory_order_release);
+        { std::lock_guard<std::mutex> lk(m_); gen_.fetch_add(1, std::memory_order_release); }
+        if (sleepers_.load(std::memory_order_acquire) != 0) cv_.notify_all();
+        take_parts();
+        while (left_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+        busy_.unlock();
+        return true;
+    }
+  private:
+    explicit WorkerPool(int n) { for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); }); for (auto &t : workers_) t.detach(); }
+    void take_parts() {
+        for (;;) { const int t = next_.fetch_add(1, std::memory_order_acq_rel); if (t >= parts_) return;
+            job_(ctx_, t); left_.fetch_sub(1, std::memory_order_acq_rel); }
+    }
+    void loop() {
+        in_worker() = true;
+        uint64_t seen = gen_.load(std::memory_order_acquire);
+        for (;;) {
+            bool got = false;
+            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(1500);     // (waking a sleeping thread costs ~20 us — per thread, one after the other)
+            while (!got) { for (int spin = 0; spin < 256 && !got; ++spin) { got = gen_.load(std::memory_order_acquire) != seen; if (!got) __builtin_ia32_pause(); }
+                if (!got && std::chrono::steady_clock::now() > until) break; }
+            if (!got) { std::unique_lock<std::mutex> lk(m_); sleepers_.fetch_add(1, std::memory_order_acq_rel);
+                cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; }); sleepers_.fetch_sub(1, std::memory_order_acq_rel); }
+            seen = gen_.load(std::memory_order_acquire);
+            take_parts();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_, busy_; std::condition_variable cv_;
+    std::atomic<uint64_t> gen_{0}; std::atomic<int> next_{0}, left_{0}, sleepers_{0};
+    void (*job_)(void *, int) = nullptr; void *ctx_ = nullptr; int parts_ = 0;
+};
+
+// fn(begin, end, part index): contiguous chunks of [0, n), one per part (as many parts as host threads, fewer for small ranges); inline when the range is small
 template <class F> void parallel_chunks(int64_t n, int64_t min_per_thread, F &&fn) {
     int T = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n / std::max<int64_t>(1, min_per_thread)));
     if (T <= 1) { fn((int64_t)0, n, 0); return; }
+    typedef typename std::remove_reference<F>::type Fn;
+    struct Ctx { Fn *fn; int64_t n; int T; } ctx{&fn, n, T};
+    if (WorkerPool::get().run(T, [](void *c, int t) { auto *x = static_cast<Ctx *>(c); (*x->fn)(x->n * t / x->T, x->n * (t + 1) / x->T, t); }, &ctx)) return;
+    if (WorkerPool::in_worker()) { for (int t = 0; t < T; ++t) fn(n * t / T, n * (t + 1) / T, t); return; }      // a region inside a region: in order, on this thread
     std::vector<std::thread> th; th.reserve(T - 1);
     for (int t = 1; t < T; ++t) th.emplace_back([&, t] { fn(n * t / T, n * (t + 1) / T, t); });
     fn((int64_t)0, n / T, 0);
