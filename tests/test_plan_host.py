@@ -286,3 +286,23 @@ def test_plans_with_workgroup_fronts_grow_up_to_159_scalars(pkg, po, frontend, N
     scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
     assert ok and np.abs(dp - dp_o).max() / scale < 1e-8 and np.abs(dl - dl_o).max() / scale < 1e-8
     G.close()
+
+
+def test_the_host_worker_pool_survives_a_fork(pkg, po):
+    """The structure phase runs on a pool of host threads (csrc/gs_parallel.hpp, round 4) that lives as long as the process.  A forked child has none of
+    the parent's threads: it must get a pool of its own on first use (and the parent must go on with its own) instead of waiting for workers that do not
+    exist.  subprocess: a fork of the pytest process itself would duplicate its state."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import importlib, os, sys; sys.path.insert(0, %r); from oracle import pyoracle as po; "
+            "pkg = importlib.import_module('opendlv-logic-cfsd18-sensation-slam_amd'); "
+            "t = pkg.track.generate(3000, 600); g = pkg.track.bench_graph(t, po.OracleFrontend())\n"
+            "def plan():\n"
+            "    H = pkg.Graph(device=-2); H.load_bench_graph(g); H.plan_build_host(); n = H.stats().n_fronts; H.close(); return n\n"
+            "a = plan(); pid = os.fork()\n"
+            "if pid == 0:\n"
+            "    b = plan(); c = plan(); os._exit(0 if (b == a and c == a) else 3)\n"
+            "_, status = os.waitpid(pid, 0); d = plan(); print('ok' if (d == a and os.WEXITSTATUS(status) == 0) else 'bad')" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "ok", (r.stdout[-500:], r.stderr[-1000:])
