@@ -231,8 +231,12 @@ struct Builder {
                     const int j = e.other; if (j <= i || j < a || j >= b || assigned[j]) return;
                     if (part_of(j) != part_of(i)) { assigned[j] = 1; sep_poses.push_back(j); } }); }
             part_cones.assign(np, {});
-            for (int l : cones) { int hit = -1, n = 0;
-                for (int k = 0; k < np && n < 2; ++k) if (has_observer(l, cut[k] + 1, cut[k + 1])) { hit = k; ++n; }
+            for (int l : cones) { int hit = -1, n = 0, k = 0;
+                // one walk over the cone's observers inside the range (ascending: the part index only moves forward) instead of a search per part
+                auto it = std::lower_bound(cone_obs.begin() + cone_obs_start[l], cone_obs.begin() + cone_obs_start[l + 1], a), e = cone_obs.begin() + cone_obs_start[l + 1];
+                for (; it != e && *it < b && n < 2; ++it) { const int i = *it; if (assigned[i]) continue;      // (the split poses are assigned: no part)
+                    while (k + 1 < np && i > cut[k + 1]) ++k;
+                    if (k != hit) { hit = k; ++n; } }
                 if (n >= 2) sep_cones.push_back(l); else if (n == 1) part_cones[hit].push_back(l); else orphans.push_back(l); }
             if (3 * (int)sep_poses.size() + 2 * (int)sep_cones.size() + nb <= limit) break;    // the cluster front fits a wave (or, second pass, a 7-tile-row workgroup)
             for (int m : sep_poses) assigned[m] = 0;                // too big: fewer parts (their larger pieces are dissected further)
