@@ -64,7 +64,6 @@ struct Builder {
     std::vector<int32_t> obs_lo, obs_hi;             // ... and the first / last of them
     std::vector<uint8_t> assigned;
     std::vector<uint8_t> opaque_pose;                // pose-window shards: the pose belongs to an opaque supernode (a whole subtree of another rank)
-    std::vector<std::vector<int32_t>> sn;            // supernodes (vertex lists) in elimination order
     int window(int fpos) const { return (int)((int64_t)fpos * std::max(1, opt.world) / std::max(1, nfp)); }
 
     explicit Builder(const HostGraph &gg, const PlanOptions &o) : g(gg), opt(o) {}
@@ -171,8 +170,25 @@ struct Builder {
         return false;
     }
 
-    typedef std::vector<std::vector<int32_t>> SnList;
-    static void emit(SnList &out, std::vector<int32_t> &&verts) { if (!verts.empty()) out.push_back(std::move(verts)); }
+    // supernodes in elimination order, flat: the vertices of all of them in one array + offsets (18 000 little vectors at 100k poses — allocated one by
+    // one in the recursion, moved list to list where its halves meet, freed one by one before the next plan — were ~1.5 ms of a 15 ms structure phase)
+    struct SnList {
+        std::vector<int32_t> v; std::vector<int64_t> off{0};
+        struct View { const int32_t *b, *e;
+            const int32_t *begin() const { return b; } const int32_t *end() const { return e; }
+            size_t size() const { return (size_t)(e - b); } bool empty() const { return b == e; }
+            int32_t operator[](size_t i) const { return b[i]; } };
+        size_t size() const { return off.size() - 1; }
+        bool empty() const { return off.size() == 1; }
+        View operator[](size_t s) const { return View{v.data() + off[s], v.data() + off[s + 1]}; }
+        View back() const { return (*this)[size() - 1]; }
+        void push(const std::vector<int32_t> &verts) { v.insert(v.end(), verts.begin(), verts.end()); off.push_back((int64_t)v.size()); }
+        void append(const SnList &o) { const int64_t base = (int64_t)v.size(); v.insert(v.end(), o.v.begin(), o.v.end());
+            off.reserve(off.size() + o.size()); for (size_t s = 1; s < o.off.size(); ++s) off.push_back(base + o.off[s]); }
+        void clear() { v.clear(); off.assign(1, 0); }
+    };
+    static void emit(SnList &out, const std::vector<int32_t> &verts) { if (!verts.empty()) out.push(verts); }
+    SnList sn;                                       // supernodes (vertex lists) in elimination order
 
     // Multi-way split at the bottom of the tree.  Binary dissection down to the leaves leaves three levels of
     // separators that are ONE pose each (3 pivots: the cones around them are seen from far outside such a short range
@@ -243,11 +259,11 @@ struct Builder {
         }
         const int np = (int)cut.size() - 1;
         cones.clear(); cones.shrink_to_fit();
-        if (!orphans.empty()) { std::vector<int32_t> v; for (int l : orphans) v.push_back(nfp + l); emit(out, std::move(v)); }
+        if (!orphans.empty()) { std::vector<int32_t> v; for (int l : orphans) v.push_back(nfp + l); emit(out, v); }
         for (int k = 0; k < np; ++k) nd(cut[k] + 1, cut[k + 1], part_cones[k], out, depth + 1, in_own);
         std::vector<int32_t> verts(sep_poses.begin(), sep_poses.end());
         for (int l : sep_cones) verts.push_back(nfp + l);
-        emit(out, std::move(verts));
+        emit(out, verts);
         return true;
     }
 
@@ -273,7 +289,7 @@ struct Builder {
             if (np_ > 0) { std::fill(assigned.begin() + a, assigned.begin() + b, (uint8_t)1); std::fill(opaque_pose.begin() + a, opaque_pose.begin() + b, (uint8_t)1);
                 opaque_of_pose[a] = w0; }
             for (size_t c = 0; c < cones.size(); ++c) verts[(size_t)np_ + c] = nfp + cones[c];
-            emit(out, std::move(verts));
+            emit(out, verts);
             return; }
         const int wm = (w0 + w1 + 1) / 2, m = wf[wm];
         std::vector<int32_t> sep_poses;
@@ -288,18 +304,17 @@ struct Builder {
             else orphans.push_back(l);
         }
         cones.clear(); cones.shrink_to_fit();
-        if (!orphans.empty()) { std::vector<int32_t> v; for (int l : orphans) v.push_back(nfp + l); emit(out, std::move(v)); }
+        if (!orphans.empty()) { std::vector<int32_t> v; for (int l : orphans) v.push_back(nfp + l); emit(out, v); }
         const bool mine_l = opt.rank >= w0 && opt.rank < wm, mine_r = opt.rank >= wm && opt.rank < w1;
         if (mine_l == mine_r && (1 << depth) < host_threads()) {      // (neither half holds this rank's window: both are cheap; kept parallel for symmetry with the general path)
             SnList lo; std::thread th([&] { nd_top(w0, wm, left, lo, depth + 1); });
             SnList hi; nd_top(wm, w1, right, hi, depth + 1);
             th.join();
-            for (auto &v : lo) out.push_back(std::move(v));
-            for (auto &v : hi) out.push_back(std::move(v));
+            out.append(lo); out.append(hi);
         } else { nd_top(w0, wm, left, out, depth); nd_top(wm, w1, right, out, depth); }
         std::vector<int32_t> verts(sep_poses.begin(), sep_poses.end());
         for (int l : sep_cones) verts.push_back(nfp + l);
-        emit(out, std::move(verts));
+        emit(out, verts);
     }
 
     // nested dissection over free-pose positions [a, b); `cones` = free landmarks alive in this range
@@ -328,13 +343,13 @@ struct Builder {
                 std::vector<int32_t> verts; verts.reserve((size_t)un + 2 * cones.size());
                 for (int i = a; i < b; ++i) if (!assigned[i]) { verts.push_back(i); assigned[i] = 1; opaque_pose[i] = 1; }
                 for (int l : cones) verts.push_back(nfp + l);
-                emit(out, std::move(verts));
+                emit(out, verts);
                 return; } }
         if (un <= opt.leaf_poses) {
             std::vector<int32_t> verts;
             for (int i = a; i < b; ++i) if (!assigned[i]) { verts.push_back(i); assigned[i] = 1; }
             for (int l : cones) verts.push_back(nfp + l);
-            emit(out, std::move(verts));
+            emit(out, verts);
             return;
         }
         if (nd_multi(a, b, un, cones, out, depth, in_own)) return;
@@ -356,7 +371,7 @@ struct Builder {
             else orphans.push_back(l);
         }
         cones.clear(); cones.shrink_to_fit();
-        if (!orphans.empty()) { std::vector<int32_t> v; for (int l : orphans) v.push_back(nfp + l); emit(out, std::move(v)); }
+        if (!orphans.empty()) { std::vector<int32_t> v; for (int l : orphans) v.push_back(nfp + l); emit(out, v); }
         // the two halves touch disjoint pose ranges (and only read the shared tables): the top levels of the recursion
         // run them on separate host threads, each into its own list, concatenated in elimination order
         // (pose-window shards: a half that lies in one window of another rank is an opaque supernode at once — no work to share; the other
@@ -368,12 +383,11 @@ struct Builder {
             std::thread th([&] { nd(a, m, left, lo, depth + 1, in_own); });
             SnList hi; nd(m + 1, b, right, hi, depth + 1, in_own);
             th.join();
-            for (auto &v : lo) out.push_back(std::move(v));
-            for (auto &v : hi) out.push_back(std::move(v));
+            out.append(lo); out.append(hi);
         } else { const int dn = one_sided ? depth : depth + 1; nd(a, m, left, out, dn, in_own); nd(m + 1, b, right, out, dn, in_own); }
         std::vector<int32_t> verts(sep_poses.begin(), sep_poses.end());
         for (int l : sep_cones) verts.push_back(nfp + l);
-        emit(out, std::move(verts));
+        emit(out, verts);
     }
 };
 
@@ -596,7 +610,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
             for (int l = 0; l < B.nfl; ++l) if ((B.seen_nb[l] & bit) && own[l] != s && sn_of[B.nfp + l] > s) bd.push_back(B.nfp + l); }
     } else
     for (int s = 0; s < S; ++s) if (is_opaque(s)) {
-        const auto &vs = B.sn[s]; const int C = chunk_count((int64_t)vs.size(), 8192);
+        const auto vs = B.sn[s]; const int C = chunk_count((int64_t)vs.size(), 8192);
         std::vector<std::vector<int32_t>> cand(C);
         parallel_chunks(C, 1, [&](int64_t c0, int64_t c1, int) { for (int c = (int)c0; c < (int)c1; ++c) { auto &cd = cand[c];
             for (size_t i = vs.size() * c / C; i < vs.size() * (c + 1) / C; ++i) B.for_inc(vs[i], [&](const Builder::Inc &e) { const int w = e.other;
