@@ -55,24 +55,29 @@ class WorkerPool {
         return *p;
     }
     static bool &in_worker() { static thread_local bool v = false; return v; }
-    // runs parts 0 .. T-1 of job(ctx, part); false: the pool is busy (or has no workers) — the caller falls back
-    bool run(int T, void (*job)(void *, int), void *ctx) {
+    // runs parts 0 .. T-1 of job(ctx, part); false: the pool is busy (or has no workers) — the caller falls back.
+    // A job lives on its caller's stack and is published by pointer.  A worker announces itself (active_) BEFORE it looks at the pointer; the caller takes
+    // the pointer back when every part is done and leaves only when no worker is announced any more: nobody can hold a job that has gone, and a worker that
+    // wakes late — the job it was woken for long finished, the next one half set up — finds either nothing or a complete job.
+    bool run(int T, void (*fn)(void *, int), void *ctx) {
         if (workers_.empty() || in_worker() || !busy_.try_lock()) return false;
-        // (a worker may still be leaving the previous job's loop: it can take a part of this job the moment next_ is reset — so the count of parts left
-        // is set first, and the reset publishes job / context / part count)
-        job_ = job; ctx_ = ctx; parts_ = T; left_.store(T, std::memory_order_relaxed); next_.store(0, std::memory_order_release);
+        Job job; job.fn = fn; job.ctx = ctx; job.parts = T; job.left.store(T, std::memory_order_relaxed);
+        cur_.store(&job, std::memory_order_seq_cst);
         { std::lock_guard<std::mutex> lk(m_); gen_.fetch_add(1, std::memory_order_release); }
         if (sleepers_.load(std::memory_order_acquire) != 0) cv_.notify_all();
-        take_parts();
-        while (left_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+        work(&job);
+        while (job.left.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+        cur_.store(nullptr, std::memory_order_seq_cst);
+        while (active_.load(std::memory_order_seq_cst) != 0) __builtin_ia32_pause();
         busy_.unlock();
         return true;
     }
   private:
+    struct Job { void (*fn)(void *, int) = nullptr; void *ctx = nullptr; int parts = 0; std::atomic<int> next{0}, left{0}; };
     explicit WorkerPool(int n) { for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); }); for (auto &t : workers_) t.detach(); }
-    void take_parts() {
-        for (;;) { const int t = next_.fetch_add(1, std::memory_order_acq_rel); if (t >= parts_) return;
-            job_(ctx_, t); left_.fetch_sub(1, std::memory_order_acq_rel); }
+    static void work(Job *j) {
+        for (;;) { const int t = j->next.fetch_add(1, std::memory_order_acq_rel); if (t >= j->parts) return;
+            j->fn(j->ctx, t); j->left.fetch_sub(1, std::memory_order_acq_rel); }
     }
     void loop() {
         in_worker() = true;
@@ -85,13 +90,15 @@ class WorkerPool {
             if (!got) { std::unique_lock<std::mutex> lk(m_); sleepers_.fetch_add(1, std::memory_order_acq_rel);
                 cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; }); sleepers_.fetch_sub(1, std::memory_order_acq_rel); }
             seen = gen_.load(std::memory_order_acquire);
-            take_parts();
+            active_.fetch_add(1, std::memory_order_seq_cst);
+            if (Job *j = cur_.load(std::memory_order_seq_cst)) work(j);
+            active_.fetch_sub(1, std::memory_order_seq_cst);
         }
     }
     std::vector<std::thread> workers_;
     std::mutex m_, busy_; std::condition_variable cv_;
-    std::atomic<uint64_t> gen_{0}; std::atomic<int> next_{0}, left_{0}, sleepers_{0};
-    void (*job_)(void *, int) = nullptr; void *ctx_ = nullptr; int parts_ = 0;
+    std::atomic<uint64_t> gen_{0}; std::atomic<int> sleepers_{0}, active_{0};
+    std::atomic<Job *> cur_{nullptr};
 };
 
 // fn(begin, end, part index): contiguous chunks of [0, n), one per part (as many parts as host threads, fewer for small ranges); inline when the range is small
