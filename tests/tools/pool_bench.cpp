@@ -1,3 +1,5 @@
+// cost of one (nearly empty) parallel region of csrc/gs_parallel.hpp: g++ -O2 -std=c++17 -I opendlv-logic-cfsd18-sensation-slam_amd/csrc tests/tools/pool_bench.cpp -o tests/_build/pc_bench -lpthread
+// GPU box, 16 threads: 320 us with a thread created per part (rounds 1-3), 5.7 us with the pool.
 #include "gs_parallel.hpp"
 #include <chrono>
 #include <cstdio>

@@ -1,3 +1,5 @@
+// ThreadSanitizer check of the host worker pool (csrc/gs_parallel.hpp): many regions in a row, three concurrent callers (two fall back to fresh threads),
+// a region inside a region.  g++ -O1 -g -std=c++17 -fsanitize=thread -I opendlv-logic-cfsd18-sensation-slam_amd/csrc tests/tools/pool_tsan.cpp -o /tmp/pool_tsan -lpthread && GS_THREADS=6 /tmp/pool_tsan
 #include "gs_parallel.hpp"
 #include <cstdio>
 #include <numeric>
