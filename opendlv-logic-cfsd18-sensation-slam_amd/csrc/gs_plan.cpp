@@ -49,6 +49,17 @@ template <class V, class T> void pfill(V &v, size_t n, T value) {
 // resize / assign of a big array with the huge-page hint placed before its first touch
 template <class V> void big_resize(V &v, size_t n) { if (v.capacity() < n) { v.clear(); v.reserve(n); hint_huge(v); } v.resize(n); }
 template <class V, class T> void big_assign(V &v, size_t n, T value) { if (v.capacity() < n) { v.clear(); v.reserve(n); hint_huge(v); } v.assign(n, value); }
+// counts -> inclusive running sums in place, v[i] += v[i - 1] for i = 1 .. n (v has n + 1 entries), on the host threads: a pose-window shard of
+// 8 x 100k poses has half a dozen of these over 0.8 M entries
+inline void parallel_prefix(int32_t *v, int64_t n) {
+    const int T = chunk_count(n, 65536);
+    if (T <= 1) { for (int64_t i = 1; i <= n; ++i) v[i] += v[i - 1]; return; }
+    std::vector<int64_t> part((size_t)T + 1, 0);
+    parallel_chunks(n, 65536, [&](int64_t b0, int64_t e0, int t) { int64_t a = 0; for (int64_t i = b0 + 1; i <= e0; ++i) a += v[i]; part[(size_t)t + 1] = a; });
+    part[0] = v[0];
+    for (int t = 0; t < T; ++t) part[(size_t)t + 1] += part[(size_t)t];
+    parallel_chunks(n, 65536, [&](int64_t b0, int64_t e0, int t) { int32_t run = (int32_t)part[(size_t)t]; for (int64_t i = b0 + 1; i <= e0; ++i) { run += v[i]; v[i] = run; } });
+}
 
 struct Builder {
     const HostGraph &g;
@@ -70,7 +81,8 @@ struct Builder {
     // the buffers of the previous plan build of this handle (a workspace: no allocation, no first-touch page faults, nothing to free on the way out)
     void adopt(Builder &o) {
 #define GS_ADOPT(m) do { m = std::move(o.m); m.clear(); } while (0)
-        GS_ADOPT(fp_of_pose); GS_ADOPT(fl_of_lm); GS_ADOPT(pose_of_fp); GS_ADOPT(lm_of_fl); GS_ADOPT(inc_start); GS_ADOPT(cone_obs_start); GS_ADOPT(cone_obs);
+        fp_of_pose = std::move(o.fp_of_pose); fl_of_lm = std::move(o.fl_of_lm);      // (rewritten in full by index_vertices: the size stays)
+        pose_of_fp = std::move(o.pose_of_fp); lm_of_fl = std::move(o.lm_of_fl); GS_ADOPT(inc_start); GS_ADOPT(cone_obs_start); GS_ADOPT(cone_obs);
         GS_ADOPT(obs_lo); GS_ADOPT(obs_hi); GS_ADOPT(assigned); GS_ADOPT(opaque_pose); GS_ADOPT(sn); GS_ADOPT(lazy_pose); GS_ADOPT(lazy_lm);
         GS_ADOPT(wf); GS_ADOPT(seen_nb); GS_ADOPT(seen_b); GS_ADOPT(opaque_of_pose); GS_ADOPT(pp_touch);
 #undef GS_ADOPT
@@ -79,10 +91,18 @@ struct Builder {
 
     int dim(int v) const { return v < nfp ? 3 : 2; }
 
-    void index_vertices() {
-        fp_of_pose.assign(g.n_poses(), -1); fl_of_lm.assign(g.n_lms(), -1);
-        for (int p = 0; p < g.n_poses(); ++p) if (!g.pose_fixed[p]) { fp_of_pose[p] = nfp++; pose_of_fp.push_back(p); }
-        for (int l = 0; l < g.n_lms(); ++l) if (!g.lm_fixed[l]) { fl_of_lm[l] = nfl++; lm_of_fl.push_back(l); }
+    void index_vertices() {                                            // (on the host threads: counts per part, then every part numbers its own)
+        auto index = [](const std::vector<uint8_t> &fixed, std::vector<int32_t> &free_of, std::vector<int32_t> &of_free) {
+            const int64_t n = (int64_t)fixed.size();
+            if (free_of.size() != (size_t)n) { free_of.clear(); free_of.resize((size_t)n); }
+            std::vector<int32_t> cnt((size_t)chunk_count(n, 65536) + 1, 0);
+            parallel_chunks(n, 65536, [&](int64_t b0, int64_t e0, int t) { int32_t c = 0; for (int64_t i = b0; i < e0; ++i) c += !fixed[(size_t)i]; cnt[(size_t)t + 1] = c; });
+            for (size_t t = 1; t < cnt.size(); ++t) cnt[t] += cnt[t - 1];
+            if (of_free.size() != (size_t)cnt.back()) { of_free.clear(); of_free.resize((size_t)cnt.back()); }
+            parallel_chunks(n, 65536, [&](int64_t b0, int64_t e0, int t) { int32_t c = cnt[(size_t)t];
+                for (int64_t i = b0; i < e0; ++i) { if (fixed[(size_t)i]) free_of[(size_t)i] = -1; else { free_of[(size_t)i] = c; of_free[(size_t)c++] = (int32_t)i; } } });
+            return (int)cnt.back(); };
+        nfp = index(g.pose_fixed, fp_of_pose, pose_of_fp); nfl = index(g.lm_fixed, fl_of_lm, lm_of_fl);
         nv = nfp + nfl;
     }
 
@@ -133,7 +153,7 @@ struct Builder {
                     obs_cnt[v - nfp] = n;
                     if (opt.world > 1 && n > 0 && wlo == whi && wlo != opt.rank) { lazy_lm[v - nfp] = 1; n = 0; } }
                 inc_start[v + 1] = n; } });
-        for (int v = 0; v < nv; ++v) inc_start[v + 1] += inc_start[v];
+        parallel_prefix(inc_start.data(), nv);
         if (inc_cap < (size_t)inc_start[nv] + 1) { inc_cap = (size_t)inc_start[nv] + 1; inc_store.reset(new Inc[inc_cap]); hint_huge_pages(inc_store.get(), inc_cap * sizeof(Inc)); }
         inc = inc_store.get();
         cone_obs_start.assign(nfl + 1, 0);
@@ -406,7 +426,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     { Plan old = std::move(plan); plan = Plan();
 #define GS_KEEP(m) do { plan.m = std::move(old.m); plan.m.clear(); } while (0)
 #define GS_KEEP_SIZED(m) do { plan.m = std::move(old.m); } while (0)      /* overwritten in full by a parallel fill (pfill): the size stays, nothing is re-initialised */
-      GS_KEEP_SIZED(pose_gidx); GS_KEEP_SIZED(lm_gidx); GS_KEEP(pl_order); GS_KEEP(pp_order); GS_KEEP(pl_start); GS_KEEP(lm_start); GS_KEEP(lm_edges); GS_KEEP_SIZED(ppadj_start); GS_KEEP(ppadj);
+      GS_KEEP_SIZED(pose_gidx); GS_KEEP_SIZED(lm_gidx); GS_KEEP_SIZED(pl_order); GS_KEEP(pp_order); GS_KEEP_SIZED(pl_start); GS_KEEP(lm_start); GS_KEEP(lm_edges); GS_KEEP_SIZED(ppadj_start); GS_KEEP(ppadj);
       GS_KEEP(ell_ins); GS_KEEP_SIZED(ell_of_ins); GS_KEEP(ppinc); GS_KEEP(wt_grp_start); GS_KEEP(wt_desc); GS_KEEP(grp_lm); GS_KEEP(grp_pos_start); GS_KEEP(grp_pos); GS_KEEP(ell_dst);
       GS_KEEP(lm_grp_start); GS_KEEP(grp_slot); GS_KEEP(fronts); GS_KEEP(bnd_rows); GS_KEEP(child_map); GS_KEEP(children); GS_KEEP(asm_recs); GS_KEEP(level_start); GS_KEEP(level_fronts);
       GS_KEEP_SIZED(pl_rank); GS_KEEP_SIZED(pp_rank); GS_KEEP_SIZED(pose_known); GS_KEEP_SIZED(lm_known); GS_KEEP(level_start_owned); GS_KEEP(level_fronts_owned); GS_KEEP(level_start_shared);
@@ -443,38 +463,27 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     // ---- edges grouped by pose and by landmark (insertion indices; the device layout of the observation edges follows the shard
     // assignment further down: a rank lays out the poses it sweeps only)
     // (room for grow_plan's appended runs is reserved BEFORE the arrays are filled: reserving afterwards re-allocated and copied ~60 MB at 100k poses)
-    plan.pl_order.reserve((size_t)Epl + TAIL_PL); plan.pp_order.reserve((size_t)Epp + TAIL_PP);
-    hint_huge(plan.pl_order);
-    // The reference adds a keyframe's observation edges behind its pose (src/slam.cpp:433-459, 525-550): the edges arrive grouped by pose.
-    // Then the grouping is the identity and the ranges come from a scan — on all host threads (a pose-window shard walks the edges of ALL
-    // windows here: these passes were 70 of a rank's 480 ms at 8 x 100k poses); any other insertion order takes the counting sort.
-    big_assign(plan.pl_start, (size_t)N + 1, 0);
-    plan.pl_order.resize(Epl);
-    bool by_pose = true;
-    { std::vector<uint8_t> bad(host_threads() + 1, 0);
-      parallel_chunks(Epl, 65536, [&](int64_t b0, int64_t e0, int t) { for (int64_t k = b0; k < e0; ++k) if (k + 1 < Epl && g.pl_p[(size_t)k + 1] < g.pl_p[(size_t)k]) { bad[t] = 1; break; } });
-      for (uint8_t b : bad) by_pose = by_pose && !b; }
-    if (by_pose) {
-        parallel_chunks(Epl, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t k = b0; k < e0; ++k) plan.pl_order[(size_t)k] = (int32_t)k; });
-        parallel_chunks((int64_t)N + 1, 16384, [&](int64_t b0, int64_t e0, int) {
-            int64_t k = std::lower_bound(g.pl_p.begin(), g.pl_p.end(), (int32_t)b0) - g.pl_p.begin();
-            for (int64_t p = b0; p < e0; ++p) { while (k < Epl && g.pl_p[(size_t)k] < p) ++k; plan.pl_start[(size_t)p] = (int32_t)k; } });
-    } else {
-        for (int k = 0; k < Epl; ++k) plan.pl_start[g.pl_p[k] + 1]++;
-        for (int p = 0; p < N; ++p) plan.pl_start[p + 1] += plan.pl_start[p];
-        std::vector<int32_t> fill(plan.pl_start.begin(), plan.pl_start.end() - 1);
-        for (int k = 0; k < Epl; ++k) plan.pl_order[fill[g.pl_p[k]]++] = k; }
+    plan.pp_order.reserve((size_t)Epp + TAIL_PP);
+    auto size_only = [](std::vector<int32_t> &v, size_t n, size_t room) { if (v.size() != n) { v.clear(); v.reserve(n + room); hint_huge(v); v.resize(n); } };      // (every entry is written below: a recycled array is not initialised again)
+    size_only(plan.pl_order, (size_t)Epl, TAIL_PL); size_only(plan.pl_start, (size_t)N + 1, 0);
     plan.pp_order.resize(Epp);
     for (int k = 0; k < Epp; ++k) plan.pp_order[k] = k;
-    // ---- pose-window shards: which windows see a landmark (Builder::nd_top)
+    // The reference adds a keyframe's observation edges behind its pose (src/slam.cpp:433-459, 525-550): the edges arrive grouped by pose.
+    // Then the grouping is the identity and the ranges come from a scan — on all host threads; any other insertion order takes the counting sort.
+    // A pose-window shard walks the edges of ALL windows here, and only here: ONE pass checks the order, writes the identity and the ranges and
+    // collects, per landmark, which windows see it (Builder::nd_top) — these passes were 70 of a rank's 480 ms at 8 x 100k poses when they were
+    // four and sequential, 3 of 31 as three parallel ones.
     B.by_window = false;
-    if (opt.world > 1 && opt.world <= 64 && by_pose && B.nfp >= 4 * opt.world && opt.by_window) {
+    const bool want_win = opt.world > 1 && opt.world <= 64 && B.nfp >= 4 * opt.world && opt.by_window;
+    std::vector<uint8_t> win_of;
+    bool chain_ok = false;
+    auto is_first = [&](int fp, int w) { return w >= 1 && fp == B.wf[w]; };
+    if (want_win) {
         const int W = opt.world;
         B.wf.assign(W + 1, 0);
         for (int w = 0; w <= W; ++w) B.wf[w] = (int32_t)(((int64_t)w * B.nfp + W - 1) / W);
-        std::vector<uint8_t> win_of(B.nfp);
+        win_of.resize(B.nfp);
         parallel_chunks(B.nfp, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t i = b0; i < e0; ++i) win_of[(size_t)i] = (uint8_t)B.window((int)i); });
-        auto is_first = [&](int fp, int w) { return w >= 1 && fp == B.wf[w]; };
         // odometry edges between windows must end in the later window's first pose
         std::vector<uint8_t> bad(host_threads() + 1, 0);
         B.pp_touch.assign(W, 0);
@@ -486,17 +495,32 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
                 if (!bi && !bj) { if (wi != wj) bad[t] = 1; continue; }
                 if (bi && !bj) tt[wj] |= 1ull << wi;
                 if (bj && !bi) tt[wi] |= 1ull << wj; } });
-        bool ok = true; for (uint8_t v : bad) ok = ok && !v;
-        if (ok) {
-            for (auto &tt : touch_t) for (int w = 0; w < W; ++w) B.pp_touch[w] |= tt[w];
-            B.seen_nb.assign(B.nfl, 0); B.seen_b.assign(B.nfl, 0);
-            parallel_chunks(Epl, 65536, [&](int64_t b0, int64_t e0, int) {
-                for (int64_t k = b0; k < e0; ++k) { const int fp = B.fp_of_pose[g.pl_p[(size_t)k]]; if (fp < 0) continue;
-                    const int fl = B.fl_of_lm[g.pl_l[(size_t)k]]; if (fl < 0) continue;
-                    const int w = win_of[fp]; uint64_t *tgt = is_first(fp, w) ? &B.seen_b[fl] : &B.seen_nb[fl]; const uint64_t bit = 1ull << w;
-                    if (!(__atomic_load_n(tgt, __ATOMIC_RELAXED) & bit)) __atomic_fetch_or(tgt, bit, __ATOMIC_RELAXED); } });
-            B.opaque_of_pose.assign(B.nfp, -1);
-            B.by_window = true; } }
+        chain_ok = true; for (uint8_t v : bad) chain_ok = chain_ok && !v;
+        if (chain_ok) { for (auto &tt : touch_t) for (int w = 0; w < W; ++w) B.pp_touch[w] |= tt[w];
+            B.seen_nb.assign(B.nfl, 0); B.seen_b.assign(B.nfl, 0); } }
+    bool by_pose = true;
+    { std::vector<uint8_t> bad(host_threads() + 1, 0);
+      parallel_chunks(Epl, 65536, [&](int64_t b0, int64_t e0, int t) {
+          int32_t prev = b0 > 0 ? g.pl_p[(size_t)b0 - 1] : -1;
+          for (int64_t k = b0; k < e0; ++k) { const int32_t p = g.pl_p[(size_t)k];
+              plan.pl_order[(size_t)k] = (int32_t)k;
+              if (p < prev) bad[t] = 1;
+              for (int32_t q = prev + 1; q <= p; ++q) plan.pl_start[(size_t)q] = (int32_t)k;      // (out of order: nothing is written; the counting sort below redoes all of it)
+              prev = p;
+              if (chain_ok) { const int fp = B.fp_of_pose[(size_t)p]; if (fp < 0) continue;
+                  const int fl = B.fl_of_lm[g.pl_l[(size_t)k]]; if (fl < 0) continue;
+                  const int w = win_of[fp]; uint64_t *tgt = is_first(fp, w) ? &B.seen_b[fl] : &B.seen_nb[fl]; const uint64_t bit = 1ull << w;
+                  if (!(__atomic_load_n(tgt, __ATOMIC_RELAXED) & bit)) __atomic_fetch_or(tgt, bit, __ATOMIC_RELAXED); } } });
+      for (uint8_t b : bad) by_pose = by_pose && !b; }
+    if (by_pose) { for (int32_t q = (Epl > 0 ? g.pl_p[(size_t)Epl - 1] + 1 : 0); q <= N; ++q) plan.pl_start[(size_t)q] = Epl; }
+    else {
+        std::fill(plan.pl_start.begin(), plan.pl_start.end(), 0);
+        for (int k = 0; k < Epl; ++k) plan.pl_start[g.pl_p[k] + 1]++;
+        for (int p = 0; p < N; ++p) plan.pl_start[p + 1] += plan.pl_start[p];
+        std::vector<int32_t> fill(plan.pl_start.begin(), plan.pl_start.end() - 1);
+        for (int k = 0; k < Epl; ++k) plan.pl_order[fill[g.pl_p[k]]++] = k; }
+    // ---- pose-window shards: which windows see a landmark (Builder::nd_top)
+    if (want_win && chain_ok && by_pose) { B.opaque_of_pose.assign(B.nfp, -1); B.by_window = true; }
     // by windows: the poses whose edges this rank's plan is built from — its own window, every window's first pose (the separators of the
     // shared top) and the fixed poses; everything else of the other windows is summarised by the masks above
     std::vector<int32_t> ing;                                         // insertion indices, ascending
@@ -513,11 +537,21 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     plan.lm_start.assign(M + 1, 0);
     std::vector<int32_t> &lm_k = scratch->lm_k;
     if (B.by_window) {                                                // the edges of the poses in `ing` only (pose order = insertion order here)
-        for (int p : ing) for (int q = plan.pl_start[p]; q < plan.pl_start[p + 1]; ++q) plan.lm_start[g.pl_l[q] + 1]++;
+        // (the same stable counting sort as below, in chunks of `ing`)
+        const int64_t U = (int64_t)ing.size();
+        const int C = (int64_t)chunk_count(U, 8192) * M <= ((int64_t)1 << 26) ? chunk_count(U, 8192) : 1;
+        std::vector<std::vector<int32_t>> cnt(C);
+        auto lo = [&](int c) { return U * c / C; };
+        parallel_chunks(C, 1, [&](int64_t c0, int64_t c1, int) { for (int c = (int)c0; c < (int)c1; ++c) { auto &h = cnt[c]; h.assign((size_t)M, 0);
+            for (int64_t u = lo(c); u < lo(c + 1); ++u) { const int p = ing[(size_t)u]; for (int q = plan.pl_start[p]; q < plan.pl_start[p + 1]; ++q) h[g.pl_l[q]]++; } } });
+        parallel_chunks(M, 16384, [&](int64_t b0, int64_t e0, int) { for (int64_t l = b0; l < e0; ++l) { int32_t n = 0;
+            for (int c = 0; c < C; ++c) { const int32_t v = cnt[c][(size_t)l]; cnt[c][(size_t)l] = n; n += v; }
+            plan.lm_start[(size_t)l + 1] = n; } });
         for (int l = 0; l < M; ++l) plan.lm_start[l + 1] += plan.lm_start[l];
         big_resize(lm_k, (size_t)plan.lm_start[M]);
-        std::vector<int32_t> fill(plan.lm_start.begin(), plan.lm_start.end() - 1);
-        for (int p : ing) for (int q = plan.pl_start[p]; q < plan.pl_start[p + 1]; ++q) lm_k[(size_t)fill[g.pl_l[q]]++] = q;
+        parallel_chunks(C, 1, [&](int64_t c0, int64_t c1, int) { for (int c = (int)c0; c < (int)c1; ++c) { auto &h = cnt[c];
+            for (int64_t u = lo(c); u < lo(c + 1); ++u) { const int p = ing[(size_t)u];
+                for (int q = plan.pl_start[p]; q < plan.pl_start[p + 1]; ++q) { const int l = g.pl_l[q]; lm_k[(size_t)plan.lm_start[l] + h[l]++] = q; } } } });
     } else {
     big_resize(lm_k, (size_t)Epl);
     { const int C = (int64_t)chunk_count(Epl, 1 << 18) * M <= ((int64_t)1 << 26) ? chunk_count(Epl, 1 << 18) : 1;
@@ -538,7 +572,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         const int T = host_threads() + 1; std::vector<std::vector<int32_t>> pick(T);
         parallel_chunks(Epp, 65536, [&](int64_t b0, int64_t e0, int t) { for (int64_t k = b0; k < e0; ++k) if (ing_flag[g.pp_i[(size_t)k]] | ing_flag[g.pp_j[(size_t)k]]) pick[t].push_back((int32_t)k); });
         for (auto &v : pick) for (int k : v) { if (ing_flag[g.pp_i[k]]) plan.ppadj_start[g.pp_i[k] + 1]++; if (ing_flag[g.pp_j[k]]) plan.ppadj_start[g.pp_j[k] + 1]++; }
-        for (int p = 0; p < N; ++p) plan.ppadj_start[p + 1] += plan.ppadj_start[p];
+        parallel_prefix(plan.ppadj_start.data(), N);
         plan.ppadj.resize((size_t)plan.ppadj_start[N]);
         std::vector<int32_t> fill(plan.ppadj_start.begin(), plan.ppadj_start.end() - 1);
         for (auto &v : pick) for (int k : v) { if (ing_flag[g.pp_i[k]]) plan.ppadj[fill[g.pp_i[k]]++] = 2 * k; if (ing_flag[g.pp_j[k]]) plan.ppadj[fill[g.pp_j[k]]++] = 2 * k + 1; }
@@ -557,7 +591,11 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     GS_PT(1);
     // room to grow (grow_plan) only where fronts fit a wave anyway: with more than ~10 cones in view the cluster fronts are workgroup
     // fronts, such a plan cannot grow, and keeping them below 57 would only cost fronts (K = 16: 26 571 instead of 21 026, -5 % it/s)
-    { int kmax0 = 0; for (int p = 0; p < N; ++p) kmax0 = std::max(kmax0, plan.pl_start[p + 1] - plan.pl_start[p]);
+    int kmax_all = 0;                                                 // most observation edges at one pose
+    { std::vector<int> kt(host_threads() + 1, 0);
+      parallel_chunks(N, 65536, [&](int64_t b0, int64_t e0, int t) { int m = 0; for (int64_t p = b0; p < e0; ++p) m = std::max(m, plan.pl_start[(size_t)p + 1] - plan.pl_start[(size_t)p]); kt[t] = m; });
+      for (int m : kt) kmax_all = std::max(kmax_all, m); }
+    { const int kmax0 = kmax_all;
       if (kmax0 > 10 && leaf_auto) B.opt.leaf_poses = 8;           // (wide views keep leaves of 8 poses)
       if (kmax0 > 10) B.opt.grow_headroom = B.opt.grow_spine_headroom = 0;
       if (B.opt.big_cluster_front < 0) B.opt.big_cluster_front = kmax0 > 10 ? 111 : 0; }
@@ -569,16 +607,26 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
       if (B.by_window) B.nd_top(0, opt.world, all, B.sn, 0); else B.nd(0, B.nfp, all, B.sn, 0); }
     const int S = (int)B.sn.size();
     std::vector<int32_t> &sn_of = scratch->sn_of, &vpos = scratch->vpos, &gidx = scratch->gidx;
-    big_assign(sn_of, (size_t)B.nv, -1); big_assign(vpos, (size_t)B.nv, -1); big_assign(gidx, (size_t)B.nv, -1);
-    { int pos = 0, sc = 0;
-      for (int s = 0; s < S; ++s) for (int v : B.sn[s]) { if (sn_of[v] != -1) { err = "vertex emitted twice"; return false; }
-            sn_of[v] = s; vpos[v] = pos++; gidx[v] = sc; sc += B.dim(v); }
-      if (pos != B.nv) { err = "ordering lost a vertex"; return false; }
-      plan.n_scalar = sc; }
+    size_only(sn_of, (size_t)B.nv, 0); size_only(vpos, (size_t)B.nv, 0); size_only(gidx, (size_t)B.nv, 0);      // (written in full just below)
+    // the supernode lists are one flat array in elimination order: a vertex's position is its index there, its first scalar the running sum of
+    // the dimensions before it — supernodes in chunks on the host threads (a pose-window shard numbers 0.9 M vertices here)
+    { const auto &sv = B.sn.v; const auto &so = B.sn.off;
+      if ((int64_t)sv.size() != B.nv) { err = sv.size() < (size_t)B.nv ? "ordering lost a vertex" : "vertex emitted twice"; return false; }
+      const int T = chunk_count(S, 256);
+      std::vector<int64_t> sc0((size_t)T + 1, 0);
+      parallel_chunks(S, 256, [&](int64_t s0, int64_t s1, int t) { int64_t a = 0; for (int64_t j = so[(size_t)s0]; j < so[(size_t)s1]; ++j) a += B.dim(sv[(size_t)j]); sc0[(size_t)t + 1] = a; });
+      for (int t = 0; t < T; ++t) sc0[(size_t)t + 1] += sc0[(size_t)t];
+      parallel_chunks(S, 256, [&](int64_t s0, int64_t s1, int t) { int32_t sc = (int32_t)sc0[(size_t)t];
+          for (int64_t s2 = s0; s2 < s1; ++s2) for (int64_t j = so[(size_t)s2]; j < so[(size_t)s2 + 1]; ++j) { const int v = sv[(size_t)j];
+              sn_of[v] = (int32_t)s2; vpos[v] = (int32_t)j; gidx[v] = sc; sc += B.dim(v); } });
+      std::vector<uint8_t> twice(host_threads() + 1, 0);                // (nv entries for nv vertices: a vertex emitted twice leaves another one out — and one of its two places disagrees)
+      parallel_chunks(B.nv, 65536, [&](int64_t b0, int64_t e0, int t) { for (int64_t j = b0; j < e0; ++j) if (vpos[sv[(size_t)j]] != (int32_t)j) twice[t] = 1; });
+      for (uint8_t b : twice) if (b) { err = "vertex emitted twice"; return false; }
+      plan.n_scalar = (int32_t)sc0[(size_t)T]; }
     plan.pose_gidx.reserve((size_t)N + TAIL_POSES); plan.lm_gidx.reserve((size_t)M + TAIL_LMS);
     pfill(plan.pose_gidx, (size_t)N, (int32_t)-1); pfill(plan.lm_gidx, (size_t)M, (int32_t)-1);
-    for (int i = 0; i < B.nfp; ++i) plan.pose_gidx[B.pose_of_fp[i]] = gidx[i];
-    for (int l = 0; l < B.nfl; ++l) plan.lm_gidx[B.lm_of_fl[l]] = gidx[B.nfp + l];
+    parallel_chunks(B.nfp, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t i = b0; i < e0; ++i) plan.pose_gidx[B.pose_of_fp[(size_t)i]] = gidx[(size_t)i]; });
+    parallel_chunks(B.nfl, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t l = b0; l < e0; ++l) plan.lm_gidx[B.lm_of_fl[(size_t)l]] = gidx[(size_t)B.nfp + (size_t)l]; });
 
     GS_PT(3);
     // ---- symbolic factorisation over supernodes ----
@@ -859,8 +907,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         for (size_t t = 0; t < lo_t.size(); ++t) { plo = std::min(plo, lo_t[t]); phi = std::max(phi, hi_t[t]); }
         if (phi <= plo) { plo = 0; phi = 0; } }
 GS_PT(70);
-    int kmax = 0;
-    for (int p = 0; p < N; ++p) kmax = std::max(kmax, plan.pl_start[p + 1] - plan.pl_start[p]);
+    const int kmax = kmax_all;
     int T = 1;
     while (T < 8 && (kmax + T - 1) / T > LIN_R) T *= 2;
     // fewer, fatter lanes give more loads in flight per wave, but the chip wants >= ~3 waves per SIMD
