@@ -140,8 +140,14 @@ struct Builder {
             std::fill(lazy_pose.begin() + std::min(lo, nfp), lazy_pose.begin() + std::min(hi, nfp), (uint8_t)0); }
         std::vector<int32_t> obs_cnt(nfl, 0);
         big_assign(inc_start, (size_t)nv + 1, 0);
-        parallel_chunks(nv, 4096, [&](int64_t b0, int64_t e0, int) {
-            for (int v = (int)b0; v < (int)e0; ++v) { int n = 0;
+        // (the poses with a stored list — all of them, or a shard's own window: an eighth of the range at world 8 — and the landmarks are two
+        // regions of their own: split evenly over ALL vertices, two of sixteen threads did a shard's pose work)
+        int own_lo = 0, own_hi = nfp;
+        if (opt.world > 1) { const int W = opt.world; own_lo = std::min(nfp, (int)(((int64_t)opt.rank * nfp + W - 1) / W)); own_hi = std::min(nfp, (int)(((int64_t)(opt.rank + 1) * nfp + W - 1) / W)); }
+        auto both = [&](auto &&body) { parallel_chunks(own_hi - own_lo, 2048, [&](int64_t b0, int64_t e0, int) { body(own_lo + (int)b0, own_lo + (int)e0); });
+                                       parallel_chunks(nfl, 2048, [&](int64_t b0, int64_t e0, int) { body(nfp + (int)b0, nfp + (int)e0); }); };
+        both([&](int v0, int v1) {
+            for (int v = v0; v < v1; ++v) { int n = 0;
                 if (v < nfp && lazy_pose[v]) { }
                 else if (v < nfp) { const int p = pose_of_fp[v];
                     for (int q = P.ppadj_start[p]; q < P.ppadj_start[p + 1]; ++q) { const int code = P.ppadj[q], k = code >> 1;
@@ -161,8 +167,8 @@ struct Builder {
         big_resize(cone_obs, (size_t)cone_obs_start[nfl]); obs_lo.assign(nfl, INT32_MAX); obs_hi.assign(nfl, -1);
         // an observation edge is named by its INSERTION index here (epos); the assembly records are translated to the device
         // layout once it exists
-        parallel_chunks(nv, 4096, [&](int64_t b0, int64_t e0, int) {
-            for (int v = (int)b0; v < (int)e0; ++v) { Inc *o = &inc[inc_start[v]];
+        both([&](int v0, int v1) {
+            for (int v = v0; v < v1; ++v) { Inc *o = &inc[inc_start[v]];
                 if (v < nfp && lazy_pose[v]) { }
                 else if (v < nfp) { const int p = pose_of_fp[v];
                     for (int q = P.ppadj_start[p]; q < P.ppadj_start[p + 1]; ++q) { const int code = P.ppadj[q], k = code >> 1, role = code & 1;
@@ -612,13 +618,14 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     // the dimensions before it — supernodes in chunks on the host threads (a pose-window shard numbers 0.9 M vertices here)
     { const auto &sv = B.sn.v; const auto &so = B.sn.off;
       if ((int64_t)sv.size() != B.nv) { err = sv.size() < (size_t)B.nv ? "ordering lost a vertex" : "vertex emitted twice"; return false; }
-      const int T = chunk_count(S, 256);
+      const int64_t nvv = B.nv; const int T = chunk_count(nvv, 16384);      // (by position, not by supernode: another rank's window is ONE supernode of 110k vertices)
       std::vector<int64_t> sc0((size_t)T + 1, 0);
-      parallel_chunks(S, 256, [&](int64_t s0, int64_t s1, int t) { int64_t a = 0; for (int64_t j = so[(size_t)s0]; j < so[(size_t)s1]; ++j) a += B.dim(sv[(size_t)j]); sc0[(size_t)t + 1] = a; });
+      parallel_chunks(nvv, 16384, [&](int64_t b0, int64_t e0, int t) { int64_t a = 0; for (int64_t j = b0; j < e0; ++j) a += B.dim(sv[(size_t)j]); sc0[(size_t)t + 1] = a; });
       for (int t = 0; t < T; ++t) sc0[(size_t)t + 1] += sc0[(size_t)t];
-      parallel_chunks(S, 256, [&](int64_t s0, int64_t s1, int t) { int32_t sc = (int32_t)sc0[(size_t)t];
-          for (int64_t s2 = s0; s2 < s1; ++s2) for (int64_t j = so[(size_t)s2]; j < so[(size_t)s2 + 1]; ++j) { const int v = sv[(size_t)j];
-              sn_of[v] = (int32_t)s2; vpos[v] = (int32_t)j; gidx[v] = sc; sc += B.dim(v); } });
+      parallel_chunks(nvv, 16384, [&](int64_t b0, int64_t e0, int t) { int32_t sc = (int32_t)sc0[(size_t)t];
+          int64_t s2 = (std::upper_bound(so.begin(), so.end(), b0) - so.begin()) - 1;      // the supernode position b0 lies in
+          for (int64_t j = b0; j < e0; ++j) { while (j >= so[(size_t)s2 + 1]) ++s2;
+              const int v = sv[(size_t)j]; sn_of[v] = (int32_t)s2; vpos[v] = (int32_t)j; gidx[v] = sc; sc += B.dim(v); } });
       std::vector<uint8_t> twice(host_threads() + 1, 0);                // (nv entries for nv vertices: a vertex emitted twice leaves another one out — and one of its two places disagrees)
       parallel_chunks(B.nv, 65536, [&](int64_t b0, int64_t e0, int t) { for (int64_t j = b0; j < e0; ++j) if (vpos[sv[(size_t)j]] != (int32_t)j) twice[t] = 1; });
       for (uint8_t b : twice) if (b) { err = "vertex emitted twice"; return false; }
@@ -649,13 +656,15 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     if (B.by_window) {
         // by windows: what another rank's window touches outside itself are the cones its poses see that it does not own (the masks) and the
         // first poses of windows that see one of its own cones or follow / precede it on the odometry chain — no walk over its edges
-        std::vector<int32_t> own(B.nfl, -1);
-        for (int s = 0; s < S; ++s) if (is_opaque(s)) { const int w = B.opaque_of_pose[B.sn[s][0]]; auto &bd = bndv[s];
+        // (a cone is "its own" iff it sits in the supernode: sn_of says so; the opaque supernodes one task each)
+        std::vector<int32_t> ops; for (int s = 0; s < S; ++s) if (is_opaque(s)) ops.push_back(s);
+        parallel_chunks((int64_t)ops.size(), 1, [&](int64_t o0, int64_t o1, int) { for (int64_t o = o0; o < o1; ++o) { const int s = ops[(size_t)o];
+            const int w = B.opaque_of_pose[B.sn[s][0]]; auto &bd = bndv[s];
             uint64_t firsts = B.pp_touch[w];
-            for (int v : B.sn[s]) if (v >= B.nfp) { own[v - B.nfp] = s; firsts |= B.seen_b[v - B.nfp]; }
+            for (int v : B.sn[s]) if (v >= B.nfp) firsts |= B.seen_b[v - B.nfp];
             for (int x = 1; x < opt.world; ++x) if ((firsts >> x) & 1) { const int m = B.wf[x]; if (sn_of[m] > s) bd.push_back(m); }
             const uint64_t bit = 1ull << w;
-            for (int l = 0; l < B.nfl; ++l) if ((B.seen_nb[l] & bit) && own[l] != s && sn_of[B.nfp + l] > s) bd.push_back(B.nfp + l); }
+            for (int l = 0; l < B.nfl; ++l) if ((B.seen_nb[l] & bit) && sn_of[B.nfp + l] > s) bd.push_back(B.nfp + l); } });
     } else
     for (int s = 0; s < S; ++s) if (is_opaque(s)) {
         const auto vs = B.sn[s]; const int C = chunk_count((int64_t)vs.size(), 8192);
@@ -802,13 +811,13 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         const int W = plan.world;
         auto window = [&](int fpos) { return (int)((int64_t)fpos * W / std::max(1, B.nfp)); };
         std::vector<int32_t> wmin(S, INT32_MAX), wmax(S, -1);
-        for (int s = 0; s < S; ++s) {
+        parallel_chunks(S, 512, [&](int64_t s0, int64_t s1, int) { for (int s = (int)s0; s < (int)s1; ++s) {      // a supernode's own poses ...
             if (B.by_window && is_opaque(s)) wmin[s] = wmax[s] = B.opaque_of_pose[B.sn[s][0]];      // (another rank's window: no walk over its ~100k poses)
             else for (int v : B.sn[s]) if (v < B.nfp) {
                 const int w = B.by_window ? (int)(std::upper_bound(B.wf.begin(), B.wf.end(), v) - B.wf.begin()) - 1 : window(v);      // (the table of window starts instead of a 64-bit division per pose)
-                wmin[s] = std::min(wmin[s], w); wmax[s] = std::max(wmax[s], w); }
+                wmin[s] = std::min(wmin[s], w); wmax[s] = std::max(wmax[s], w); } } });
+        for (int s = 0; s < S; ++s)                                   // ... and its children's, bottom-up
             for (int c : kids[s]) { wmin[s] = std::min(wmin[s], wmin[c]); wmax[s] = std::max(wmax[s], wmax[c]); }
-        }
         for (int s = S - 1; s >= 0; --s) {
             Front &F = plan.fronts[s];
             if (wmax[s] < 0) F.owner = parent[s] >= 0 ? plan.fronts[parent[s]].owner : -1;      // no pose below: follow the parent
