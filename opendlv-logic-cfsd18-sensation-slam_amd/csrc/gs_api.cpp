@@ -473,7 +473,7 @@ struct RawUpload {
     std::thread th; int rc = GS_OK; std::string err;
     ~RawUpload() { if (th.joinable()) th.join(); }                  // an exception (bad_alloc in the plan build) must not meet a joinable thread: std::terminate
     int32_t *pl_l = nullptr; double *pl_z = nullptr, *pl_info = nullptr;
-    std::vector<double> zinv;
+    std::vector<double> zinv; size_t pp_lo = 0, pp_hi = 0;         // the odometry edges whose records went up: [pp_lo, pp_hi) (all of them on a single GPU)
     uvec<int32_t> ell_l; uvec<double> ell_z, ell_w;               // pose-window shards: the ELL streams, filled on the host (they must outlive the copies: upload_graph ends with a sync)
 };
 static int upload_raw_begin(gs_graph *g, RawUpload &R) {
@@ -503,11 +503,27 @@ static int upload_raw_begin(gs_graph *g, RawUpload &R) {
         cp(d.pose_fixed, h.pose_fixed.data(), N); cp(d.lm_fixed, h.lm_fixed.data(), M);
         if (raw_pl) { cp(R.pl_l, h.pl_l.data(), Epl * sizeof(int32_t)); cp(R.pl_z, h.pl_z.data(), Epl * 2 * sizeof(double));
             cp(R.pl_info, h.pl_info.data(), Epl * 3 * sizeof(double)); }
-        cp(d.pp_info, h.pp_info.data(), Epp * 6 * sizeof(double));            // odometry edges keep their insertion order on the device
-        R.zinv.resize(Epp * 5);
-        for (size_t k = 0; k < Epp; ++k) { double inv[3]; se2_inverse_host(&h.pp_z[3 * k], inv);
-            double *o = &R.zinv[5 * k]; o[0] = inv[0]; o[1] = inv[1]; o[2] = inv[2]; o[3] = std::cos(inv[2]); o[4] = std::sin(inv[2]); }
-        cp(d.pp_zinv, R.zinv.data(), Epp * 5 * sizeof(double));
+        // odometry edges keep their insertion order on the device.  A pose-window shard evaluates an odometry edge only if one of its poses lies in
+        // the shard's window (gs_plan.cpp, rank_of_pp: the owner of an interior endpoint, else the window of the pose; an edge between two fixed
+        // poses is rank 0's): the records of the first to the last such edge go up — an eighth of 0.8 M inverses, cosines, sines and of 70 MB at
+        // world 8 (this thread took longer than the plan build).  upload_graph checks the plan's assignment against the range and sends what is missing.
+        size_t k0 = 0, k1 = Epp;
+        if (g->world > 1 && Epp > 0) {
+            size_t nfree = 0; for (size_t p = 0; p < N; ++p) nfree += !h.pose_fixed[p];
+            const size_t W = (size_t)g->world, r = (size_t)g->rank, f_lo = (r * nfree + W - 1) / W, f_hi = ((r + 1) * nfree + W - 1) / W;
+            size_t p_lo = N, p_hi = N, f = 0;                        // insertion indices of the window's first free pose and of the next window's
+            for (size_t p = 0; p < N; ++p) if (!h.pose_fixed[p]) { if (f == f_lo) p_lo = p; if (f == f_hi) { p_hi = p; break; } ++f; }
+            auto in = [&](int32_t p) { return (size_t)p >= p_lo && (size_t)p < p_hi; };
+            k0 = Epp; k1 = 0;
+            for (size_t k = 0; k < Epp; ++k) { const int32_t i = h.pp_i[k], j = h.pp_j[k];
+                if (in(i) || in(j) || (r == 0 && h.pose_fixed[i] && h.pose_fixed[j])) { k0 = std::min(k0, k); k1 = std::max(k1, k + 1); } }
+            if (k1 <= k0) k0 = k1 = 0; }
+        R.pp_lo = k0; R.pp_hi = k1;
+        cp(d.pp_info + 6 * k0, h.pp_info.data() + 6 * k0, (k1 - k0) * 6 * sizeof(double));
+        R.zinv.resize((k1 - k0) * 5);
+        for (size_t k = k0; k < k1; ++k) { double inv[3]; se2_inverse_host(&h.pp_z[3 * k], inv);
+            double *o = &R.zinv[5 * (k - k0)]; o[0] = inv[0]; o[1] = inv[1]; o[2] = inv[2]; o[3] = std::cos(inv[2]); o[4] = std::sin(inv[2]); }
+        cp(d.pp_zinv + 5 * k0, R.zinv.data(), (k1 - k0) * 5 * sizeof(double));
     });
     return GS_OK;
 }
@@ -565,7 +581,18 @@ static int upload_graph(gs_graph *g, RawUpload &raw) {
       std::vector<int32_t> inc(2 * Q);                                    // holds the record is known to the kernel; an edge another rank evaluates: edge = -1
       for (size_t q = 0; q < Q; ++q) { const int32_t k = P.ppinc[4 * q], role = P.ppinc[4 * q + 1], other = role ? P.ppinc[4 * q + 2] : P.ppinc[4 * q + 3];
           inc[2 * q] = (P.world > 1 && P.pp_rank[k] != P.rank) ? -1 : k; inc[2 * q + 1] = (int32_t)((uint32_t)other | ((uint32_t)role << 31)); }
-      UP(ppinc, inc); }
+      UP(ppinc, inc);
+      // a shard's helper thread sent the records of the odometry edges [pp_lo, pp_hi) — the ones that touch its window; an edge the plan gives
+      // this rank outside that range (none, by the assignment rule: kept as a check that cannot go wrong silently) is sent now
+      std::vector<int32_t> miss;
+      for (size_t q = 0; q < Q; ++q) { const int32_t k = inc[2 * q]; if (k >= 0 && ((size_t)k < raw.pp_lo || (size_t)k >= raw.pp_hi)) miss.push_back(k); }
+      std::sort(miss.begin(), miss.end()); miss.erase(std::unique(miss.begin(), miss.end()), miss.end());
+      for (int32_t k : miss) { double inv[3], o[5]; se2_inverse_host(&h.pp_z[3 * (size_t)k], inv);
+          o[0] = inv[0]; o[1] = inv[1]; o[2] = inv[2]; o[3] = std::cos(inv[2]); o[4] = std::sin(inv[2]);
+          HIP_TRY(hipMemcpy(d.pp_zinv + 5 * (size_t)k, o, sizeof(o), hipMemcpyHostToDevice));
+          HIP_TRY(hipMemcpy(d.pp_info + 6 * (size_t)k, &h.pp_info[6 * (size_t)k], 6 * sizeof(double), hipMemcpyHostToDevice)); }
+      g->pp_records_late = (int)miss.size();
+      if (ut_on && !miss.empty()) std::fprintf(stderr, "upload: %d odometry edge records sent after the plan\n", (int)miss.size()); }
 #define AL(dst, cnt) if ((rc = dev_alloc(g, &d.dst, (size_t)(cnt))) != GS_OK) return rc
 #define ZERO(dst, cnt) HIP_TRY(hipMemsetAsync(d.dst, 0, std::max<size_t>((size_t)(cnt), 1) * sizeof(*d.dst), g->stream))
     d.n_wtiles = 0; d.n_groups = 0; d.wt_lo = 0; d.wt_hi = 0; d.rank = P.rank;

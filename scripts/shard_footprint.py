@@ -11,8 +11,11 @@ def build(N, M, rank=None):
     t = pkg.track.generate(N, M); fe = pkg.Graph(); g = pkg.track.bench_graph(t, fe); fe.close()
     G = pkg.Graph(); G.load_bench_graph(g)
     if rank is not None: G.dist_configure(rank, world)
-    G.initialize_optimization(); time.sleep(0.2); G.initialize_optimization()      # second call: warm host threads / page cache, as in a running service (the pause: the first build's scratch is freed on a short-lived thread)
-    st = G.stats(); G.close(); return st
+    G.initialize_optimization(); time.sleep(0.2)                   # first call: cold (pages, device chunks); then, as in a running service, ...
+    sts = []
+    for _ in range(3): G.initialize_optimization(); sts.append(G.stats())      # ... three more: the median structure phase
+    G.close(); return sorted(sts, key=lambda q: q.ms_structure)[1]
+build(Nw * world, Mw * world, 1)                                   # (unreported: the process's first 800k-pose handle pays for the device allocator's first big chunks)
 s1 = build(Nw, Mw)
 print("single GPU %s: structure %.1f ms (plan %.1f), device %.1f MB, fronts %d" % (name, s1.ms_structure, s1.ms_plan_host, s1.device_bytes / 1e6, s1.n_fronts))
 out = {"single": dict(ms_structure=s1.ms_structure, ms_plan_host=s1.ms_plan_host, device_mb=s1.device_bytes / 1e6, fronts=s1.n_fronts), "ranks": []}
