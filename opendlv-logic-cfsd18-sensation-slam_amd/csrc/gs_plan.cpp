@@ -840,7 +840,8 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         if (B.by_window) {                                            // the edges of the poses this rank's plan is built from: every edge it evaluates is among them
             parallel_chunks((int64_t)ing.size(), 4096, [&](int64_t b0, int64_t e0, int) { for (int64_t u = b0; u < e0; ++u) { const int p = ing[(size_t)u];
                 for (int q = plan.pl_start[p]; q < plan.pl_start[p + 1]; ++q) plan.pl_rank[(size_t)q] = rank_of_pl(q);
-                for (int q = plan.ppadj_start[p]; q < plan.ppadj_start[p + 1]; ++q) { const int k = plan.ppadj[q] >> 1; plan.pp_rank[(size_t)k] = rank_of_pp(k); } } });
+                for (int q = plan.ppadj_start[p]; q < plan.ppadj_start[p + 1]; ++q) { const int code = plan.ppadj[q], k = code >> 1;
+                    if (!(code & 1) || !ing_flag[g.pp_i[k]]) plan.pp_rank[(size_t)k] = rank_of_pp(k); } } });      // (an edge between two such poses: written from its first one — one writer per entry)
         } else {
         parallel_chunks(Epl, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t k = b0; k < e0; ++k) plan.pl_rank[(size_t)k] = rank_of_pl(k); });
         parallel_chunks(Epp, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t k = b0; k < e0; ++k) plan.pp_rank[(size_t)k] = rank_of_pp(k); });
