@@ -224,14 +224,22 @@ def main():
     # (gs_debug_options.force_shared_top), so that the exchange buffer the group of one all-reduces is not empty
     dbg = dict(force_shared_top=3) if (dist_mode and world == 1) else None
     G = pkg.Graph(device=local, debug=dbg)
-    G.load_bench_graph(g)
+    # N > 1: rank-local ingestion — a rank is given every vertex and odometry edge, the observation edges of its own pose window, of the windows'
+    # first poses and of the fixed poses, and the whole graph's landmark windows (gs_dist_set_landmark_windows); GS_BENCH_FULL_INGEST=1: every
+    # rank holds the whole graph and finds the windows out itself (the default of the library, rounds 2-3)
+    local_ingest = dist_mode and world > 1 and os.environ.get("GS_BENCH_FULL_INGEST", "0") != "1"
+    ingest_frac = 1.0
+    if local_ingest:
+        ingest_frac = float(G.load_bench_graph_shard(g, rank, world).mean())
+    else:
+        G.load_bench_graph(g)
     def library_communicator(H):
         # RCCL INSIDE the library (north_star: the host side stays C++): rank 0 makes the unique id (ncclGetUniqueId through the C-ABI),
         # torch.distributed only carries its 128 bytes to the other ranks, every rank calls ncclCommInitRank through the C-ABI
         box = [pkg.binding.dist_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         H.dist_comm_init(box[0], rank, world)
-    if dist_mode:
+    if dist_mode and not local_ingest:
         G.dist_configure(rank, world)
     G.initialize_optimization()                    # structure phase (iteration-0 work): plan + upload to HBM
     plan = G.stats()
@@ -347,6 +355,8 @@ def main():
         ts = torch.tensor([plan.ms_structure], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
         dist.all_reduce(ts, op=dist.ReduceOp.MAX)
         out["structure_ms_slowest_rank"] = float(ts.item())
+        out["ingestion"] = ("rank-local: %.3f of the observation edges per rank (own window + the windows' first poses + fixed poses), landmark windows handed over" % ingest_frac
+                            if local_ingest else "every rank holds the whole graph")
     if dist_mode and world == 1:
         out["config"]["parallelism"] = ("single GPU through the multi-GPU code path (GS_BENCH_FORCE_DIST): RCCL group of 1 created inside the library, top 3 levels forced shared "
                                         "(%d doubles all-reduced per iteration), gs_dist_iterate" % G.dist_exchange_doubles())

@@ -319,6 +319,21 @@ int  gs_frame_frontend(gs_graph *g, const double pose_xytheta[3], const double *
  * assembly tree into a dense exchange buffer (device memory), the caller all-reduces that
  * buffer (RCCL sum, fp64), and every rank finishes the top of the tree redundantly. */
 int  gs_dist_configure(gs_graph *g, int32_t rank, int32_t world_size);   /* before gs_initialize_optimization */
+/* Rank-local ingestion (optional).  By default every rank is given the WHOLE graph and finds out in one pass over all observation edges which
+ * windows see which landmark.  A rank that is told so need not hold the other windows' observation edges at all: its plan is built from the edges
+ * of its own window's poses, of every window's FIRST pose (the separators of the shared top) and of the fixed poses; everything else of the other
+ * windows enters through two 64-bit masks per landmark — bit w set: an interior pose / the first pose of window w observes it.  Vertices and
+ * odometry edges are still added on every rank (they carry the global indices the exchange slots are agreed on), observation edges grouped by pose.
+ *   gs_dist_window_starts           insertion index of the first free pose of each window, world + 1 entries (the last: n_poses): which poses are whose
+ *   gs_dist_local_landmark_windows  this rank's OWN bits, from the edges it holds (the ranks' bits are disjoint: an all-reduce SUM over the ranks —
+ *                                   or an OR in a single process — gives the masks of the whole graph)
+ *   gs_dist_set_landmark_windows    hands the whole-graph masks to the handle (n_landmarks = 0: back to the default); the next structure phase
+ *                                   uses them and fails if an edge it holds contradicts them, or if the graph cannot be planned by windows
+ *                                   (more than 64 ranks, fewer than 4 free poses per window, odometry edges between two windows' interiors).
+ * The reference has no counterpart (one process, one optimiser: src/slam.cpp:53-65); SURVEY 8e's pose windows, without "every rank ingests everything". */
+int  gs_dist_window_starts(gs_graph *g, int32_t *out_first_pose, int32_t capacity);
+int  gs_dist_local_landmark_windows(gs_graph *g, uint64_t *seen_interior, uint64_t *seen_first, int32_t n_landmarks);
+int  gs_dist_set_landmark_windows(gs_graph *g, const uint64_t *seen_interior, const uint64_t *seen_first, int32_t n_landmarks);
 int64_t gs_dist_exchange_doubles(gs_graph *g);         /* length of the exchange buffer (after initialize)   */
 int  gs_dist_set_exchange_buffer(gs_graph *g, void *device_ptr);   /* NULL: the library allocates its own   */
 int  gs_dist_iterate_local(gs_graph *g);               /* linearise own edges + own subtrees + contribution  */

@@ -133,6 +133,9 @@ def lib():
     L.gs_set_stream.argtypes = [vp, vp]
     L.gs_dist_set_exchange_buffer.argtypes = [vp, vp]
     L.gs_dist_configure.argtypes = [vp, C.c_int32, C.c_int32]
+    L.gs_dist_window_starts.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32]
+    L.gs_dist_local_landmark_windows.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]
+    L.gs_dist_set_landmark_windows.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]
     L.gs_add_pose.argtypes = [vp, C.c_int32, _dp]
     L.gs_add_landmark.argtypes = [vp, C.c_int32, _dp]
     L.gs_add_odometry_edge.argtypes = [vp, C.c_int32, C.c_int32, _dp, _dp]
@@ -564,6 +567,44 @@ class Graph:
     def dist_configure(self, rank, world):
         self._check(self.L.gs_dist_configure(self.h, int(rank), int(world)))
 
+    # rank-local ingestion (include/graphslam.h, gs_dist_set_landmark_windows)
+    def dist_window_starts(self, world):
+        out = np.zeros(world + 1, dtype=np.int32)
+        self._check(self.L.gs_dist_window_starts(self.h, out.ctypes.data_as(C.POINTER(C.c_int32)), len(out)))
+        return out
+
+    def dist_local_landmark_windows(self, n_landmarks):
+        a = np.zeros(n_landmarks, dtype=np.uint64); b = np.zeros(n_landmarks, dtype=np.uint64); u = C.POINTER(C.c_uint64)
+        self._check(self.L.gs_dist_local_landmark_windows(self.h, a.ctypes.data_as(u), b.ctypes.data_as(u), n_landmarks))
+        return a, b
+
+    def dist_set_landmark_windows(self, seen_interior, seen_first):
+        a = np.ascontiguousarray(seen_interior, dtype=np.uint64); b = np.ascontiguousarray(seen_first, dtype=np.uint64); u = C.POINTER(C.c_uint64)
+        assert len(a) == len(b)
+        self._check(self.L.gs_dist_set_landmark_windows(self.h, a.ctypes.data_as(u), b.ctypes.data_as(u), len(a)))
+
+    def load_bench_graph_shard(self, g, rank, world, masks=None):
+        """Rank-local ingestion of the arrays bench_graph makes: every vertex and odometry edge, the observation edges of this rank's window, of the
+        windows' first poses and of the fixed poses only, and the whole-graph landmark windows (`masks`, default: landmark_windows(g, world)).
+        Returns the boolean selection of g's observation edges that went in (the handle's edge k is g's edge flatnonzero(keep)[k])."""
+        N, M = len(g["pose_est"]), len(g["lm_est"])
+        self.add_poses(np.arange(N), g["pose_est"]); self.add_landmarks(np.arange(M), g["lm_est"])
+        self.add_odometry_edges(g["pp_i"], g["pp_j"], g["pp_z"], g["pp_info"])
+        fixed = np.zeros(N, dtype=bool)
+        for i in g["fixed_poses"]:
+            self.set_fixed_pose(int(i)); fixed[int(i)] = True
+        for l in g["fixed_landmarks"]:
+            self.set_fixed_landmark(int(l))
+        self.dist_configure(rank, world)
+        first = self.dist_window_starts(world)
+        p = np.asarray(g["pl_p"])
+        keep = ((p >= first[rank]) & (p < first[rank + 1])) | np.isin(p, first[1:world]) | fixed[p]
+        self.add_observation_edges(p[keep], np.asarray(g["pl_l"])[keep], np.asarray(g["pl_z"])[keep], np.asarray(g["pl_info"])[keep])
+        if masks is None:
+            masks = landmark_windows(g, world)
+        self.dist_set_landmark_windows(*masks)
+        return keep
+
     def dist_exchange_doubles(self):
         return int(self.L.gs_dist_exchange_doubles(self.h))
 
@@ -625,6 +666,26 @@ class Graph:
             self.set_fixed_pose(int(i))
         for l in g["fixed_landmarks"]:
             self.set_fixed_landmark(int(l))
+
+
+def landmark_windows(g, world):
+    """The whole-graph landmark windows of gs_dist_set_landmark_windows, from bench_graph arrays in numpy: (seen_interior, seen_first), uint64 per landmark,
+    bit w = an interior pose / the first pose of window w observes it (windows = contiguous runs of the FREE poses, ceil(w * n_free / world) first)."""
+    N, M = len(g["pose_est"]), len(g["lm_est"])
+    fixed_p = np.zeros(N, dtype=bool); fixed_p[np.asarray(g["fixed_poses"], dtype=np.int64)] = True
+    fixed_l = np.zeros(M, dtype=bool); fixed_l[np.asarray(g["fixed_landmarks"], dtype=np.int64)] = True
+    fp = np.cumsum(~fixed_p) - 1; nfree = int((~fixed_p).sum())
+    wf = np.array([(w * nfree + world - 1) // world for w in range(world + 1)], dtype=np.int64)
+    p = np.asarray(g["pl_p"]); l = np.asarray(g["pl_l"]); ok = ~fixed_p[p] & ~fixed_l[l]
+    fpe = fp[p[ok]]; le = l[ok]
+    w = np.minimum(np.searchsorted(wf, fpe, side="right") - 1, world - 1)
+    first = (w >= 1) & (fpe == wf[w])
+    seen_interior = np.zeros(M, dtype=np.uint64); seen_first = np.zeros(M, dtype=np.uint64)
+    for x in range(world):
+        sel = w == x
+        seen_interior[np.unique(le[sel & ~first])] |= np.uint64(1 << x)
+        seen_first[np.unique(le[sel & first])] |= np.uint64(1 << x)
+    return seen_interior, seen_first
 
 
 class Slam:

@@ -940,6 +940,9 @@ static int build_plan_host(gs_graph *g) {
     o.timing = t.plan_timing > 0;
     o.by_window = t.shard_by_window != 0;
     o.force_shared_top = g->world <= 1 ? std::max(t.force_shared_top, 0) : 0;
+    if (g->world > 1 && !g->lm_seen_interior.empty()) {
+        if ((int)g->lm_seen_interior.size() != g->h.n_lms()) return fail(GS_ERR_INVALID, "gs_dist_set_landmark_windows: the masks cover another number of landmarks than the graph holds");
+        o.lm_seen_interior = g->lm_seen_interior.data(); o.lm_seen_first = g->lm_seen_first.data(); }
     std::string err;
     if (!build_plan(g->h, o, g->plan, err, &g->plan_ws)) { g->plan_version = ~0ull; return fail(GS_ERR_EMPTY, "plan: " + err); }
     g->plan_version = g->h.structure_version;
@@ -1783,6 +1786,44 @@ extern "C" int gs_frame_frontend(gs_graph *g, const double pose[3], const double
 extern "C" int gs_dist_configure(gs_graph *g, int32_t rank, int32_t world) {
     if (!g || world < 1 || rank < 0 || rank >= world) return fail(GS_ERR_INVALID, "bad rank/world");
     g->rank = rank; g->world = world; ++g->h.structure_version; ++g->h.reshape_version;
+    return GS_OK;
+}
+// ---- rank-local ingestion (round 4): a rank need not hold the observation edges of the other windows' interiors
+static void window_starts_of(const gs_graph *g, std::vector<int32_t> &first_pose, std::vector<int32_t> *fp_of_pose = nullptr) {
+    const HostGraph &h = g->h; const int N = h.n_poses(), W = std::max(1, g->world);
+    int nfree = 0; for (int p = 0; p < N; ++p) nfree += !h.pose_fixed[p];
+    first_pose.assign((size_t)W + 1, N);
+    if (fp_of_pose) fp_of_pose->assign((size_t)N, -1);
+    int f = 0, w = 0;
+    for (int p = 0; p < N; ++p) if (!h.pose_fixed[p]) {
+        while (w <= W && (int)(((int64_t)w * nfree + W - 1) / W) == f) first_pose[(size_t)w++] = p;     // (empty windows share a start)
+        if (fp_of_pose) (*fp_of_pose)[(size_t)p] = f;
+        ++f; }
+}
+extern "C" int gs_dist_window_starts(gs_graph *g, int32_t *out_first_pose, int32_t capacity) {
+    if (!g || !out_first_pose) return fail(GS_ERR_INVALID, "null argument");
+    if (capacity < g->world + 1) return fail(GS_ERR_CAPACITY, "gs_dist_window_starts: world + 1 entries are written");
+    std::vector<int32_t> fp; window_starts_of(g, fp);
+    std::memcpy(out_first_pose, fp.data(), fp.size() * sizeof(int32_t));
+    return GS_OK;
+}
+extern "C" int gs_dist_local_landmark_windows(gs_graph *g, uint64_t *seen_interior, uint64_t *seen_first, int32_t n_landmarks) {
+    if (!g || !seen_interior || !seen_first) return fail(GS_ERR_INVALID, "null argument");
+    const HostGraph &h = g->h;
+    if (n_landmarks != h.n_lms()) return fail(GS_ERR_INVALID, "gs_dist_local_landmark_windows: one entry per landmark of the graph");
+    if (g->world > 64) return fail(GS_ERR_INVALID, "landmark windows are 64-bit masks: at most 64 ranks");
+    std::vector<int32_t> first; window_starts_of(g, first);
+    const int r = g->rank; const uint64_t bit = 1ull << r;
+    std::fill(seen_interior, seen_interior + n_landmarks, 0ull); std::fill(seen_first, seen_first + n_landmarks, 0ull);
+    for (size_t k = 0; k < h.pl_p.size(); ++k) { const int p = h.pl_p[k], l = h.pl_l[k];
+        if (h.pose_fixed[p] || h.lm_fixed[l] || p < first[(size_t)r] || p >= first[(size_t)r + 1]) continue;      // this rank's own window only: the ranks' bits are disjoint, their sum is the union
+        if (r >= 1 && p == first[(size_t)r]) seen_first[l] |= bit; else seen_interior[l] |= bit; }
+    return GS_OK;
+}
+extern "C" int gs_dist_set_landmark_windows(gs_graph *g, const uint64_t *seen_interior, const uint64_t *seen_first, int32_t n_landmarks) {
+    if (!g || n_landmarks < 0 || (n_landmarks > 0 && (!seen_interior || !seen_first))) return fail(GS_ERR_INVALID, "bad argument");
+    g->lm_seen_interior.assign(seen_interior, seen_interior + n_landmarks); g->lm_seen_first.assign(seen_first, seen_first + n_landmarks);
+    ++g->h.structure_version; ++g->h.reshape_version;
     return GS_OK;
 }
 extern "C" int64_t gs_dist_exchange_doubles(gs_graph *g) { return (g && g->plan.valid) ? g->plan.exchange_doubles : 0; }

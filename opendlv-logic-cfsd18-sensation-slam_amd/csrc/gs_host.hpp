@@ -154,6 +154,10 @@ struct PlanOptions { int leaf_poses = 8; int world = 1; int rank = 0; int ell_la
                                                        // cones per frame, off below (there binary splits of wave fronts beat a workgroup front: lap-sized graphs 1.1 vs 1.9-2.6 ms per optimize(10))
                      int grow_headroom = 6;            // scalars a cluster front stays below the 63 of a wave: room for the boundary rows of two appended poses (grow_plan)
                      int grow_spine_headroom = 18;     // the same for the cluster front that holds the LAST pose: appended keyframes continue the track there (six poses)
+                     // rank-local ingestion (gs_dist_set_landmark_windows): per landmark (insertion index), the windows whose INTERIOR poses / whose FIRST pose see it,
+                     // handed over by the caller — the graph then needs the observation edges of this rank's own window, of the windows' first poses and of the
+                     // fixed poses only; nullptr: computed here in one pass over all observation edges (every rank holds the whole graph)
+                     const uint64_t *lm_seen_interior = nullptr, *lm_seen_first = nullptr;
                      bool timing = false;              // per-phase wall times on stderr (gs_debug_options.plan_timing)
                      int force_shared_top = 0; };      // world 1: treat the top k levels as the shared top of a sharded graph (gs_debug_options.force_shared_top)
 

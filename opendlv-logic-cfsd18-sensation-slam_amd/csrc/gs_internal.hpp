@@ -21,6 +21,7 @@ struct gs_graph {
     bool host_only = false;                 // cfg.device == -2: no HIP calls, no arithmetic
     gs::HostGraph h;
     gs::Plan plan;
+    std::vector<uint64_t> lm_seen_interior, lm_seen_first;        // rank-local ingestion: which windows see a landmark (gs_dist_set_landmark_windows); empty: the plan build walks all edges
     int pp_records_late = 0;                                       // odometry edges whose records a shard had to send after the plan (expected: 0)
     std::shared_ptr<void> plan_ws;          // scratch of gs::build_plan, kept between the plan builds of this handle
     uint64_t plan_version = ~0ull;          // h.structure_version the plan was built for

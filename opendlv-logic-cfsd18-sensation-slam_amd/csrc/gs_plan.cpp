@@ -483,6 +483,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     const bool want_win = opt.world > 1 && opt.world <= 64 && B.nfp >= 4 * opt.world && opt.by_window;
     std::vector<uint8_t> win_of;
     bool chain_ok = false;
+    const bool given = opt.lm_seen_interior != nullptr && opt.lm_seen_first != nullptr;      // rank-local ingestion: the masks come with the graph
     auto is_first = [&](int fp, int w) { return w >= 1 && fp == B.wf[w]; };
     if (want_win) {
         const int W = opt.world;
@@ -503,9 +504,11 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
                 if (bj && !bi) tt[wi] |= 1ull << wj; } });
         chain_ok = true; for (uint8_t v : bad) chain_ok = chain_ok && !v;
         if (chain_ok) { for (auto &tt : touch_t) for (int w = 0; w < W; ++w) B.pp_touch[w] |= tt[w];
-            B.seen_nb.assign(B.nfl, 0); B.seen_b.assign(B.nfl, 0); } }
+            B.seen_nb.assign(B.nfl, 0); B.seen_b.assign(B.nfl, 0);
+            if (given) for (int fl = 0; fl < B.nfl; ++fl) { B.seen_nb[fl] = opt.lm_seen_interior[B.lm_of_fl[fl]]; B.seen_b[fl] = opt.lm_seen_first[B.lm_of_fl[fl]]; } } }
+    if (given && !(want_win && chain_ok)) { err = "landmark windows were handed over (gs_dist_set_landmark_windows), but the graph cannot be planned by windows: more than 64 ranks, fewer than 4 free poses per window, or odometry edges between the interiors of two windows"; return false; }
     bool by_pose = true;
-    { std::vector<uint8_t> bad(host_threads() + 1, 0);
+    { std::vector<uint8_t> bad(host_threads() + 1, 0), miss(host_threads() + 1, 0);
       parallel_chunks(Epl, 65536, [&](int64_t b0, int64_t e0, int t) {
           int32_t prev = b0 > 0 ? g.pl_p[(size_t)b0 - 1] : -1;
           for (int64_t k = b0; k < e0; ++k) { const int32_t p = g.pl_p[(size_t)k];
@@ -516,8 +519,11 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
               if (chain_ok) { const int fp = B.fp_of_pose[(size_t)p]; if (fp < 0) continue;
                   const int fl = B.fl_of_lm[g.pl_l[(size_t)k]]; if (fl < 0) continue;
                   const int w = win_of[fp]; uint64_t *tgt = is_first(fp, w) ? &B.seen_b[fl] : &B.seen_nb[fl]; const uint64_t bit = 1ull << w;
-                  if (!(__atomic_load_n(tgt, __ATOMIC_RELAXED) & bit)) __atomic_fetch_or(tgt, bit, __ATOMIC_RELAXED); } } });
-      for (uint8_t b : bad) by_pose = by_pose && !b; }
+                  if (given) { if (!(*tgt & bit)) miss[t] = 1; }      // (handed over: the edges that ARE here must agree with them)
+                  else if (!(__atomic_load_n(tgt, __ATOMIC_RELAXED) & bit)) __atomic_fetch_or(tgt, bit, __ATOMIC_RELAXED); } } });
+      for (uint8_t b : bad) by_pose = by_pose && !b;
+      for (uint8_t b : miss) if (b) { err = "an observation edge of this graph is missing from the landmark windows handed over (gs_dist_set_landmark_windows)"; return false; } }
+    if (given && !by_pose) { err = "landmark windows were handed over, but the observation edges do not arrive grouped by pose"; return false; }
     if (by_pose) { for (int32_t q = (Epl > 0 ? g.pl_p[(size_t)Epl - 1] + 1 : 0); q <= N; ++q) plan.pl_start[(size_t)q] = Epl; }
     else {
         std::fill(plan.pl_start.begin(), plan.pl_start.end(), 0);
@@ -536,7 +542,11 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         parallel_chunks(N, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t p = b0; p < e0; ++p) { const int fp = B.fp_of_pose[(size_t)p];
             ing_flag[(size_t)p] = fp < 0 || (fp >= B.wf[opt.rank] && fp < B.wf[opt.rank + 1]); } });
         for (int x = 1; x < W; ++x) if (B.wf[x] < B.nfp) ing_flag[B.pose_of_fp[B.wf[x]]] = 1;
-        for (int p = 0; p < N; ++p) if (ing_flag[p]) ing.push_back(p); }
+        { const int T = chunk_count(N, 65536); std::vector<int32_t> cnt((size_t)T + 1, 0);      // (flags -> ascending list: counts per part, then every part writes its own)
+          parallel_chunks(N, 65536, [&](int64_t b0, int64_t e0, int t) { int32_t c = 0; for (int64_t p = b0; p < e0; ++p) c += ing_flag[(size_t)p]; cnt[(size_t)t + 1] = c; });
+          for (int t = 0; t < T; ++t) cnt[(size_t)t + 1] += cnt[(size_t)t];
+          ing.resize((size_t)cnt[(size_t)T]);
+          parallel_chunks(N, 65536, [&](int64_t b0, int64_t e0, int t) { int32_t c = cnt[(size_t)t]; for (int64_t p = b0; p < e0; ++p) if (ing_flag[(size_t)p]) ing[(size_t)c++] = (int32_t)p; }); } }
     GS_PT(2);
     // landmark -> its edges (insertion indices, pose order); turned into ELL indices at the end (lm_edges, single GPU only).  A stable
     // counting sort by landmark over the pose-grouped sequence, in chunks: per chunk a histogram, offsets per (chunk, landmark), scatter.

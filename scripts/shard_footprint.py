@@ -7,10 +7,13 @@ pkg = importlib.import_module("opendlv-logic-cfsd18-sensation-slam_amd")
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 name = sys.argv[2] if len(sys.argv) > 2 else "cfg4"
 Nw, Mw = pkg.track.CONFIGS[name]
-def build(N, M, rank=None):
+def build(N, M, rank=None, local=False):
     t = pkg.track.generate(N, M); fe = pkg.Graph(); g = pkg.track.bench_graph(t, fe); fe.close()
-    G = pkg.Graph(); G.load_bench_graph(g)
-    if rank is not None: G.dist_configure(rank, world)
+    G = pkg.Graph()
+    if local: G.load_bench_graph_shard(g, rank, world)              # rank-local ingestion (gs_dist_set_landmark_windows)
+    else:
+        G.load_bench_graph(g)
+        if rank is not None: G.dist_configure(rank, world)
     G.initialize_optimization(); time.sleep(0.2)                   # first call: cold (pages, device chunks); then, as in a running service, ...
     sts = []
     for _ in range(3): G.initialize_optimization(); sts.append(G.stats())      # ... three more: the median structure phase
@@ -25,4 +28,9 @@ for r in (0, world // 2, world - 1):
           % (r, world, world, name, sr.ms_structure, sr.ms_plan_host, sr.ms_structure / s1.ms_structure, sr.device_bytes / 1e6, sr.device_bytes / s1.device_bytes,
              sr.n_own_fronts, sr.n_shared_fronts, sr.n_fronts))
     out["ranks"].append(dict(rank=r, ms_structure=sr.ms_structure, ms_plan_host=sr.ms_plan_host, device_mb=sr.device_bytes / 1e6, own=sr.n_own_fronts, shared=sr.n_shared_fronts))
+for r in (0, world // 2, world - 1):
+    sr = build(Nw * world, Mw * world, r, local=True)
+    print("rank %d of %d, rank-local ingestion (own window's observation edges + landmark windows handed over): structure %.1f ms (plan %.1f) = %.2fx, device %.1f MB = %.2fx"
+          % (r, world, sr.ms_structure, sr.ms_plan_host, sr.ms_structure / s1.ms_structure, sr.device_bytes / 1e6, sr.device_bytes / s1.device_bytes))
+    out["ranks"].append(dict(rank=r, ingestion="rank-local", ms_structure=sr.ms_structure, ms_plan_host=sr.ms_plan_host, device_mb=sr.device_bytes / 1e6))
 os.makedirs("gpurun_out", exist_ok=True); json.dump(out, open("gpurun_out/shard_footprint_%dx%s.json" % (world, name), "w"), indent=1)

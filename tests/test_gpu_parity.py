@@ -673,18 +673,24 @@ def test_loop_closing_frame_runs_the_localizer_too_like_the_reference(pkg, front
 
 # ---------------------------------------------------------------- pose-window shards through the HIP kernels
 @pytest.mark.parametrize("world,N,M,more_fixed,by_window", [(2, 1000, 200, 0, 1), (4, 10000, 2000, 0, 1), (8, 10000, 2000, 0, 1),
-                                                            (3, 1000, 200, 1, 1), (5, 10000, 2000, 1, 1), (5, 10000, 2000, 1, 0), (8, 10000, 2000, 0, 0)])
+                                                            (3, 1000, 200, 1, 1), (5, 10000, 2000, 1, 1), (5, 10000, 2000, 1, 0), (8, 10000, 2000, 0, 0),
+                                                            (3, 1000, 200, 1, 2), (8, 10000, 2000, 0, 2), (5, 10000, 2000, 1, 2)])
 def test_sharded_iterations_match_oracle(pkg, po, bench_graphs, world, N, M, more_fixed, by_window):
     """`world` rank handles share this one GPU; the exchange buffers are summed in-process exactly where the
     multi-GPU run all-reduces them over RCCL.  After 5 Gauss-Newton iterations the merged estimates must match
     the oracle's (and the single-GPU path's).  Worlds that are no power of two, with fixed poses sprinkled through the lap (a window is a
     count of FREE poses); the plan of a rank by windows (round 4: per-landmark window masks, lists from its own window's edges) and by the
-    general recursion."""
+    general recursion; by_window = 2: rank-local ingestion — a rank holds the observation edges of its own window, of the windows' first poses and
+    of the fixed poses only, and is handed the whole graph's landmark windows (gs_dist_set_landmark_windows)."""
     _, g0 = bench_graphs(N, M)
     g = dict(g0)
     if more_fixed: g["fixed_poses"] = np.array(sorted(set([0, 1] + list(range(N // 11, N, N // 10 - 3)))), dtype=np.int32)
     ranks = []
+    masks = pkg.binding.landmark_windows(g, world) if by_window == 2 else None
     for r in range(world):
+        if by_window == 2:
+            G = pkg.Graph(); keep = G.load_bench_graph_shard(g, r, world, masks); assert keep.mean() < 1.0 / world + 0.08
+            G.initialize_optimization(); ranks.append(G); continue
         G = fresh(pkg, g, debug=dict(shard_by_window=by_window)); G.dist_configure(r, world); G.initialize_optimization(); ranks.append(G)
     assert ranks[0].dist_exchange_doubles() > 0
     for _ in range(5):

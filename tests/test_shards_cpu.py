@@ -133,6 +133,61 @@ def test_odd_worlds_and_fixed_poses_in_one_process(pkg, po, bench_graphs, world,
     assert np.abs(dp - dp_o).max() / scale < 1e-8 and np.abs(dl - dl_o).max() / scale < 1e-8
 
 
+@pytest.mark.parametrize("world", [2, 5, 8])
+def test_rank_local_ingestion_gives_the_plan_of_the_whole_graph(pkg, po, bench_graphs, world):
+    """gs_dist_set_landmark_windows (round 4): a rank that is told which windows see which landmark holds the observation edges of its own window,
+    of the windows' first poses and of the fixed poses only — a fraction 1 / world + a few of them.  Its plan must be the plan it builds from the
+    WHOLE graph: same fronts (pivots, boundaries, parents, levels, owners), same boundary rows, same exchange slots, same scalar numbering; and the
+    numbers must come out: every rank's part replayed from ITS edges only, exchange buffers summed, the merged increment against the oracle's
+    joint solve.  The masks: numpy over the whole graph here, and (checked equal) the OR of the ranks' own bits from gs_dist_local_landmark_windows."""
+    from conftest import make_oracle_graph
+    from plan_exec import Plan
+    _, g0 = bench_graphs(1000, 200)
+    g = dict(g0); g["fixed_poses"] = np.array(sorted(set([0, 1] + list(range(90, 1000, 97)))), dtype=np.int32)
+    og = make_oracle_graph(po, g); og.build_system(); og.apply_update(og.solve_ldlt(1)); dp_o, dl_o = og.delta()
+    scale = max(np.abs(dp_o).max(), np.abs(dl_o).max())
+    masks = pkg.binding.landmark_windows(g, world)
+    n_pl, n_pp, M = len(g["pl_p"]), len(g["pp_i"]), len(g["lm_est"])
+    seen_pl, seen_pp = np.zeros(n_pl, int), np.zeros(n_pp, int)
+    own_a, own_b = np.zeros(M, np.uint64), np.zeros(M, np.uint64)
+    plans, locals_, prim, kept = [], [], [], []
+    for rank in range(world):
+        F = pkg.Graph(device=-2); F.load_bench_graph(g); F.dist_configure(rank, world); F.plan_build_host(); PF = Plan(F.plan_export()); F.close()
+        G = pkg.Graph(device=-2); keep = G.load_bench_graph_shard(g, rank, world, masks); G.plan_build_host()
+        P = Plan(G.plan_export()); P.check_invariants()
+        a, b = G.dist_local_landmark_windows(M); own_a |= a; own_b |= b
+        kept.append(keep.mean())
+        for name in ("npiv", "nbnd", "parent", "level", "owner", "piv0", "bnd_rows", "pose_gidx", "lm_gidx", "x_off", "level_start", "pp_rank"):
+            assert np.array_equal(getattr(P, name), getattr(PF, name)), (rank, name)
+        assert P.exchange_doubles == PF.exchange_doubles and P.n_shared == PF.n_shared and P.n_scalar == PF.n_scalar
+        idx = np.flatnonzero(keep)                                   # the handle's observation edge k is g's edge idx[k]
+        assert np.array_equal(P.pl_rank == rank, (PF.pl_rank == rank)[idx]) and not (PF.pl_rank == rank)[~keep].any()      # everything it evaluates is among the edges it holds
+        kp = P.pp_rank == rank; kl = np.zeros(n_pl, bool); kl[idx[P.pl_rank == rank]] = True
+        seen_pl += kl; seen_pp += kp
+        sub = dict(g)
+        for k in ("pp_i", "pp_j", "pp_z", "pp_info"): sub[k] = g[k][kp]
+        for k in ("pl_p", "pl_l", "pl_z", "pl_info"): sub[k] = g[k][kl]
+        blk_sub = make_oracle_graph(po, sub).linearize_blocks()
+        blocks = dict(blk_sub)
+        blocks["Hpp_off"] = np.zeros((n_pp, 9)); blocks["Hpp_off"][kp] = blk_sub["Hpp_off"]
+        blocks["Hpl"] = np.zeros((len(idx), 6)); blocks["Hpl"][(P.pl_rank == rank)] = blk_sub["Hpl"]     # indexed by the handle's OWN edge numbers
+        X, ok = P.shard_local(blocks); assert ok
+        plans.append(P); locals_.append(X); prim.append(G.dist_known()); G.close()
+    assert np.array_equal(own_a, masks[0]) and np.array_equal(own_b, masks[1])       # the ranks' own bits add up to the whole graph's masks
+    assert (seen_pl == 1).all() and (seen_pp == 1).all() and max(kept) < 1.0 / world + 0.08
+    Xsum = np.sum(locals_, axis=0)
+    dp = np.zeros_like(dp_o); dl = np.zeros_like(dl_o)
+    for P, (pk, lk, pprim, lprim) in zip(plans, prim):
+        a, b, ok = P.shard_finish(Xsum.copy()); assert ok
+        dp += a * pprim[:, None]; dl += b * lprim[:, None]
+    assert np.abs(dp - dp_o).max() / scale < 1e-8 and np.abs(dl - dl_o).max() / scale < 1e-8
+    # masks that leave an edge out are refused, and so is a graph that cannot be planned by windows
+    G = pkg.Graph(device=-2); G.load_bench_graph_shard(g, 0, world, (np.zeros(M, np.uint64), np.zeros(M, np.uint64)))
+    with pytest.raises(pkg.GsError, match="missing from the landmark windows"):
+        G.plan_build_host()
+    G.close()
+
+
 @pytest.mark.parametrize("seed", [31, 33, 36, 37, 5, 12])
 def test_windows_that_fall_apart_still_give_every_rank_the_same_shared_top(pkg, po, seed):
     """Irregular graphs (random observations: every cone is seen from everywhere and sits in a separator) with poses fixed in the middle of the
