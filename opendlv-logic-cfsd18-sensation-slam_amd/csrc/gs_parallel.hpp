@@ -65,7 +65,7 @@ class WorkerPool {
         cur_.store(&job, std::memory_order_seq_cst);
         { std::lock_guard<std::mutex> lk(m_); gen_.fetch_add(1, std::memory_order_release); }
         if (sleepers_.load(std::memory_order_acquire) != 0) cv_.notify_all();
-        work(&job);
+        work(&job, 0);
         while (job.left.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
         cur_.store(nullptr, std::memory_order_seq_cst);
         while (active_.load(std::memory_order_seq_cst) != 0) __builtin_ia32_pause();
@@ -73,13 +73,21 @@ class WorkerPool {
         return true;
     }
   private:
-    struct Job { void (*fn)(void *, int) = nullptr; void *ctx = nullptr; int parts = 0; std::atomic<int> next{0}, left{0}; };
-    explicit WorkerPool(int n) { for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); }); for (auto &t : workers_) t.detach(); }
-    static void work(Job *j) {
-        for (;;) { const int t = j->next.fetch_add(1, std::memory_order_acq_rel); if (t >= j->parts) return;
-            j->fn(j->ctx, t); j->left.fetch_sub(1, std::memory_order_acq_rel); }
+    struct Job { void (*fn)(void *, int) = nullptr; void *ctx = nullptr; int parts = 0; std::atomic<int> next{0}, left{0}; std::atomic<uint64_t> taken{0}; };
+    explicit WorkerPool(int n) { for (int i = 0; i < n; ++i) workers_.emplace_back([this, i] { loop(i + 1); }); for (auto &t : workers_) t.detach(); }
+    // Part t goes to thread t when that thread is there to take it (the caller is thread 0, worker i thread i + 1): the same thread then walks the same
+    // slice of the arrays in one region after the other — and in one plan build after the other —, which keeps a slice in ONE core's caches; whoever
+    // is done with its own part takes what is left (a worker that sleeps does not hold its part back).  More than 64 parts: a plain counter.
+    static void work(Job *j, int me) {
+        if (j->parts > 64) {
+            for (;;) { const int t = j->next.fetch_add(1, std::memory_order_acq_rel); if (t >= j->parts) return;
+                j->fn(j->ctx, t); j->left.fetch_sub(1, std::memory_order_acq_rel); } }
+        auto take = [&](int t) { const uint64_t bit = 1ull << t; return !(j->taken.fetch_or(bit, std::memory_order_acq_rel) & bit); };
+        if (me < j->parts && take(me)) { j->fn(j->ctx, me); j->left.fetch_sub(1, std::memory_order_acq_rel); }
+        for (int t = 0; t < j->parts; ++t)
+            if (!(j->taken.load(std::memory_order_acquire) & (1ull << t)) && take(t)) { j->fn(j->ctx, t); j->left.fetch_sub(1, std::memory_order_acq_rel); }
     }
-    void loop() {
+    void loop(int me) {
         in_worker() = true;
         uint64_t seen = gen_.load(std::memory_order_acquire);
         for (;;) {
@@ -91,7 +99,7 @@ class WorkerPool {
                 cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; }); sleepers_.fetch_sub(1, std::memory_order_acq_rel); }
             seen = gen_.load(std::memory_order_acquire);
             active_.fetch_add(1, std::memory_order_seq_cst);
-            if (Job *j = cur_.load(std::memory_order_seq_cst)) work(j);
+            if (Job *j = cur_.load(std::memory_order_seq_cst)) work(j, me);
             active_.fetch_sub(1, std::memory_order_seq_cst);
         }
     }
