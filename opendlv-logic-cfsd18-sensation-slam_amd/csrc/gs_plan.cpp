@@ -52,13 +52,13 @@ template <class V, class T> void big_assign(V &v, size_t n, T value) { if (v.cap
 // counts -> inclusive running sums in place, v[i] += v[i - 1] for i = 1 .. n (v has n + 1 entries), on the host threads: a pose-window shard of
 // 8 x 100k poses has half a dozen of these over 0.8 M entries
 inline void parallel_prefix(int32_t *v, int64_t n) {
-    const int T = chunk_count(n, 65536);
+    const int T = chunk_count(n, 16384);
     if (T <= 1) { for (int64_t i = 1; i <= n; ++i) v[i] += v[i - 1]; return; }
     std::vector<int64_t> part((size_t)T + 1, 0);
-    parallel_chunks(n, 65536, [&](int64_t b0, int64_t e0, int t) { int64_t a = 0; for (int64_t i = b0 + 1; i <= e0; ++i) a += v[i]; part[(size_t)t + 1] = a; });
+    parallel_chunks(n, 16384, [&](int64_t b0, int64_t e0, int t) { int64_t a = 0; for (int64_t i = b0 + 1; i <= e0; ++i) a += v[i]; part[(size_t)t + 1] = a; });
     part[0] = v[0];
     for (int t = 0; t < T; ++t) part[(size_t)t + 1] += part[(size_t)t];
-    parallel_chunks(n, 65536, [&](int64_t b0, int64_t e0, int t) { int32_t run = (int32_t)part[(size_t)t]; for (int64_t i = b0 + 1; i <= e0; ++i) { run += v[i]; v[i] = run; } });
+    parallel_chunks(n, 16384, [&](int64_t b0, int64_t e0, int t) { int32_t run = (int32_t)part[(size_t)t]; for (int64_t i = b0 + 1; i <= e0; ++i) { run += v[i]; v[i] = run; } });
 }
 
 struct Builder {
@@ -95,11 +95,11 @@ struct Builder {
         auto index = [](const std::vector<uint8_t> &fixed, std::vector<int32_t> &free_of, std::vector<int32_t> &of_free) {
             const int64_t n = (int64_t)fixed.size();
             if (free_of.size() != (size_t)n) { free_of.clear(); free_of.resize((size_t)n); }
-            std::vector<int32_t> cnt((size_t)chunk_count(n, 65536) + 1, 0);
-            parallel_chunks(n, 65536, [&](int64_t b0, int64_t e0, int t) { int32_t c = 0; for (int64_t i = b0; i < e0; ++i) c += !fixed[(size_t)i]; cnt[(size_t)t + 1] = c; });
+            std::vector<int32_t> cnt((size_t)chunk_count(n, 16384) + 1, 0);
+            parallel_chunks(n, 16384, [&](int64_t b0, int64_t e0, int t) { int32_t c = 0; for (int64_t i = b0; i < e0; ++i) c += !fixed[(size_t)i]; cnt[(size_t)t + 1] = c; });
             for (size_t t = 1; t < cnt.size(); ++t) cnt[t] += cnt[t - 1];
             if (of_free.size() != (size_t)cnt.back()) { of_free.clear(); of_free.resize((size_t)cnt.back()); }
-            parallel_chunks(n, 65536, [&](int64_t b0, int64_t e0, int t) { int32_t c = cnt[(size_t)t];
+            parallel_chunks(n, 16384, [&](int64_t b0, int64_t e0, int t) { int32_t c = cnt[(size_t)t];
                 for (int64_t i = b0; i < e0; ++i) { if (fixed[(size_t)i]) free_of[(size_t)i] = -1; else { free_of[(size_t)i] = c; of_free[(size_t)c++] = (int32_t)i; } } });
             return (int)cnt.back(); };
         nfp = index(g.pose_fixed, fp_of_pose, pose_of_fp); nfl = index(g.lm_fixed, fl_of_lm, lm_of_fl);
@@ -490,12 +490,12 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
         B.wf.assign(W + 1, 0);
         for (int w = 0; w <= W; ++w) B.wf[w] = (int32_t)(((int64_t)w * B.nfp + W - 1) / W);
         win_of.resize(B.nfp);
-        parallel_chunks(B.nfp, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t i = b0; i < e0; ++i) win_of[(size_t)i] = (uint8_t)B.window((int)i); });
+        parallel_chunks(B.nfp, 16384, [&](int64_t b0, int64_t e0, int) { for (int64_t i = b0; i < e0; ++i) win_of[(size_t)i] = (uint8_t)B.window((int)i); });
         // odometry edges between windows must end in the later window's first pose
         std::vector<uint8_t> bad(host_threads() + 1, 0);
         B.pp_touch.assign(W, 0);
         std::vector<std::vector<uint64_t>> touch_t(host_threads() + 1, std::vector<uint64_t>(W, 0));
-        parallel_chunks(Epp, 65536, [&](int64_t b0, int64_t e0, int t) { auto &tt = touch_t[t];
+        parallel_chunks(Epp, 16384, [&](int64_t b0, int64_t e0, int t) { auto &tt = touch_t[t];
             for (int64_t k = b0; k < e0; ++k) { const int fi = B.fp_of_pose[g.pp_i[(size_t)k]], fj = B.fp_of_pose[g.pp_j[(size_t)k]];
                 if (fi < 0 || fj < 0) continue;
                 const int wi = win_of[fi], wj = win_of[fj]; const bool bi = is_first(fi, wi), bj = is_first(fj, wj);
@@ -509,7 +509,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     if (given && !(want_win && chain_ok)) { err = "landmark windows were handed over (gs_dist_set_landmark_windows), but the graph cannot be planned by windows: more than 64 ranks, fewer than 4 free poses per window, or odometry edges between the interiors of two windows"; return false; }
     bool by_pose = true;
     { std::vector<uint8_t> bad(host_threads() + 1, 0), miss(host_threads() + 1, 0);
-      parallel_chunks(Epl, 65536, [&](int64_t b0, int64_t e0, int t) {
+      parallel_chunks(Epl, 16384, [&](int64_t b0, int64_t e0, int t) {
           int32_t prev = b0 > 0 ? g.pl_p[(size_t)b0 - 1] : -1;
           for (int64_t k = b0; k < e0; ++k) { const int32_t p = g.pl_p[(size_t)k];
               plan.pl_order[(size_t)k] = (int32_t)k;
@@ -539,14 +539,14 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     std::vector<uint8_t> ing_flag;
     if (B.by_window) { const int W = opt.world;
         ing_flag.assign(N, 0);
-        parallel_chunks(N, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t p = b0; p < e0; ++p) { const int fp = B.fp_of_pose[(size_t)p];
+        parallel_chunks(N, 16384, [&](int64_t b0, int64_t e0, int) { for (int64_t p = b0; p < e0; ++p) { const int fp = B.fp_of_pose[(size_t)p];
             ing_flag[(size_t)p] = fp < 0 || (fp >= B.wf[opt.rank] && fp < B.wf[opt.rank + 1]); } });
         for (int x = 1; x < W; ++x) if (B.wf[x] < B.nfp) ing_flag[B.pose_of_fp[B.wf[x]]] = 1;
-        { const int T = chunk_count(N, 65536); std::vector<int32_t> cnt((size_t)T + 1, 0);      // (flags -> ascending list: counts per part, then every part writes its own)
-          parallel_chunks(N, 65536, [&](int64_t b0, int64_t e0, int t) { int32_t c = 0; for (int64_t p = b0; p < e0; ++p) c += ing_flag[(size_t)p]; cnt[(size_t)t + 1] = c; });
+        { const int T = chunk_count(N, 16384); std::vector<int32_t> cnt((size_t)T + 1, 0);      // (flags -> ascending list: counts per part, then every part writes its own)
+          parallel_chunks(N, 16384, [&](int64_t b0, int64_t e0, int t) { int32_t c = 0; for (int64_t p = b0; p < e0; ++p) c += ing_flag[(size_t)p]; cnt[(size_t)t + 1] = c; });
           for (int t = 0; t < T; ++t) cnt[(size_t)t + 1] += cnt[(size_t)t];
           ing.resize((size_t)cnt[(size_t)T]);
-          parallel_chunks(N, 65536, [&](int64_t b0, int64_t e0, int t) { int32_t c = cnt[(size_t)t]; for (int64_t p = b0; p < e0; ++p) if (ing_flag[(size_t)p]) ing[(size_t)c++] = (int32_t)p; }); } }
+          parallel_chunks(N, 16384, [&](int64_t b0, int64_t e0, int t) { int32_t c = cnt[(size_t)t]; for (int64_t p = b0; p < e0; ++p) if (ing_flag[(size_t)p]) ing[(size_t)c++] = (int32_t)p; }); } }
     GS_PT(2);
     // landmark -> its edges (insertion indices, pose order); turned into ELL indices at the end (lm_edges, single GPU only).  A stable
     // counting sort by landmark over the pose-grouped sequence, in chunks: per chunk a histogram, offsets per (chunk, landmark), scatter.
@@ -586,7 +586,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     pfill(plan.ppadj_start, (size_t)N + 1, (int32_t)0);
     if (B.by_window) {                                                // incidences of the poses in `ing` only: the edges that touch one, picked on the host threads
         const int T = host_threads() + 1; std::vector<std::vector<int32_t>> pick(T);
-        parallel_chunks(Epp, 65536, [&](int64_t b0, int64_t e0, int t) { for (int64_t k = b0; k < e0; ++k) if (ing_flag[g.pp_i[(size_t)k]] | ing_flag[g.pp_j[(size_t)k]]) pick[t].push_back((int32_t)k); });
+        parallel_chunks(Epp, 16384, [&](int64_t b0, int64_t e0, int t) { for (int64_t k = b0; k < e0; ++k) if (ing_flag[g.pp_i[(size_t)k]] | ing_flag[g.pp_j[(size_t)k]]) pick[t].push_back((int32_t)k); });
         for (auto &v : pick) for (int k : v) { if (ing_flag[g.pp_i[k]]) plan.ppadj_start[g.pp_i[k] + 1]++; if (ing_flag[g.pp_j[k]]) plan.ppadj_start[g.pp_j[k] + 1]++; }
         parallel_prefix(plan.ppadj_start.data(), N);
         plan.ppadj.resize((size_t)plan.ppadj_start[N]);
@@ -600,7 +600,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
       for (int k = 0; k < Epp; ++k) { plan.ppadj[fill[g.pp_i[k]]++] = 2 * k; plan.ppadj[fill[g.pp_j[k]]++] = 2 * k + 1; } }
     }
     big_resize(plan.ppinc, plan.ppadj.size() * 4);
-    parallel_chunks((int64_t)plan.ppadj.size(), 65536, [&](int64_t b0, int64_t e0, int) {
+    parallel_chunks((int64_t)plan.ppadj.size(), 16384, [&](int64_t b0, int64_t e0, int) {
         for (size_t q = (size_t)b0; q < (size_t)e0; ++q) { const int code = plan.ppadj[q], k = code >> 1;
             plan.ppinc[4 * q] = k; plan.ppinc[4 * q + 1] = code & 1; plan.ppinc[4 * q + 2] = g.pp_i[k]; plan.ppinc[4 * q + 3] = g.pp_j[k]; } });
 
@@ -609,7 +609,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     // fronts, such a plan cannot grow, and keeping them below 57 would only cost fronts (K = 16: 26 571 instead of 21 026, -5 % it/s)
     int kmax_all = 0;                                                 // most observation edges at one pose
     { std::vector<int> kt(host_threads() + 1, 0);
-      parallel_chunks(N, 65536, [&](int64_t b0, int64_t e0, int t) { int m = 0; for (int64_t p = b0; p < e0; ++p) m = std::max(m, plan.pl_start[(size_t)p + 1] - plan.pl_start[(size_t)p]); kt[t] = m; });
+      parallel_chunks(N, 16384, [&](int64_t b0, int64_t e0, int t) { int m = 0; for (int64_t p = b0; p < e0; ++p) m = std::max(m, plan.pl_start[(size_t)p + 1] - plan.pl_start[(size_t)p]); kt[t] = m; });
       for (int m : kt) kmax_all = std::max(kmax_all, m); }
     { const int kmax0 = kmax_all;
       if (kmax0 > 10 && leaf_auto) B.opt.leaf_poses = 8;           // (wide views keep leaves of 8 poses)
@@ -637,13 +637,13 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
           for (int64_t j = b0; j < e0; ++j) { while (j >= so[(size_t)s2 + 1]) ++s2;
               const int v = sv[(size_t)j]; sn_of[v] = (int32_t)s2; vpos[v] = (int32_t)j; gidx[v] = sc; sc += B.dim(v); } });
       std::vector<uint8_t> twice(host_threads() + 1, 0);                // (nv entries for nv vertices: a vertex emitted twice leaves another one out — and one of its two places disagrees)
-      parallel_chunks(B.nv, 65536, [&](int64_t b0, int64_t e0, int t) { for (int64_t j = b0; j < e0; ++j) if (vpos[sv[(size_t)j]] != (int32_t)j) twice[t] = 1; });
+      parallel_chunks(B.nv, 16384, [&](int64_t b0, int64_t e0, int t) { for (int64_t j = b0; j < e0; ++j) if (vpos[sv[(size_t)j]] != (int32_t)j) twice[t] = 1; });
       for (uint8_t b : twice) if (b) { err = "vertex emitted twice"; return false; }
       plan.n_scalar = (int32_t)sc0[(size_t)T]; }
     plan.pose_gidx.reserve((size_t)N + TAIL_POSES); plan.lm_gidx.reserve((size_t)M + TAIL_LMS);
     pfill(plan.pose_gidx, (size_t)N, (int32_t)-1); pfill(plan.lm_gidx, (size_t)M, (int32_t)-1);
-    parallel_chunks(B.nfp, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t i = b0; i < e0; ++i) plan.pose_gidx[B.pose_of_fp[(size_t)i]] = gidx[(size_t)i]; });
-    parallel_chunks(B.nfl, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t l = b0; l < e0; ++l) plan.lm_gidx[B.lm_of_fl[(size_t)l]] = gidx[(size_t)B.nfp + (size_t)l]; });
+    parallel_chunks(B.nfp, 16384, [&](int64_t b0, int64_t e0, int) { for (int64_t i = b0; i < e0; ++i) plan.pose_gidx[B.pose_of_fp[(size_t)i]] = gidx[(size_t)i]; });
+    parallel_chunks(B.nfl, 16384, [&](int64_t b0, int64_t e0, int) { for (int64_t l = b0; l < e0; ++l) plan.lm_gidx[B.lm_of_fl[(size_t)l]] = gidx[(size_t)B.nfp + (size_t)l]; });
 
     GS_PT(3);
     // ---- symbolic factorisation over supernodes ----
@@ -853,11 +853,11 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
                 for (int q = plan.ppadj_start[p]; q < plan.ppadj_start[p + 1]; ++q) { const int code = plan.ppadj[q], k = code >> 1;
                     if (!(code & 1) || !ing_flag[g.pp_i[k]]) plan.pp_rank[(size_t)k] = rank_of_pp(k); } } });      // (an edge between two such poses: written from its first one — one writer per entry)
         } else {
-        parallel_chunks(Epl, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t k = b0; k < e0; ++k) plan.pl_rank[(size_t)k] = rank_of_pl(k); });
-        parallel_chunks(Epp, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t k = b0; k < e0; ++k) plan.pp_rank[(size_t)k] = rank_of_pp(k); });
+        parallel_chunks(Epl, 16384, [&](int64_t b0, int64_t e0, int) { for (int64_t k = b0; k < e0; ++k) plan.pl_rank[(size_t)k] = rank_of_pl(k); });
+        parallel_chunks(Epp, 16384, [&](int64_t b0, int64_t e0, int) { for (int64_t k = b0; k < e0; ++k) plan.pp_rank[(size_t)k] = rank_of_pp(k); });
         }
-        parallel_chunks(B.nfp, 65536, [&](int64_t b0, int64_t e0, int) { for (int i = (int)b0; i < (int)e0; ++i) { const int o = vowner(i); plan.pose_known[B.pose_of_fp[i]] = (o < 0 || o == plan.rank); } });
-        parallel_chunks(B.nfl, 65536, [&](int64_t b0, int64_t e0, int) { for (int l = (int)b0; l < (int)e0; ++l) { const int o = vowner(B.nfp + l); plan.lm_known[B.lm_of_fl[l]] = (o < 0 || o == plan.rank); } });
+        parallel_chunks(B.nfp, 16384, [&](int64_t b0, int64_t e0, int) { for (int i = (int)b0; i < (int)e0; ++i) { const int o = vowner(i); plan.pose_known[B.pose_of_fp[i]] = (o < 0 || o == plan.rank); } });
+        parallel_chunks(B.nfl, 16384, [&](int64_t b0, int64_t e0, int) { for (int l = (int)b0; l < (int)e0; ++l) { const int o = vowner(B.nfp + l); plan.lm_known[B.lm_of_fl[l]] = (o < 0 || o == plan.rank); } });
         // per-rank level lists: owned fronts, then the shared top; exchange slots of the shared fronts
         plan.level_start_owned.assign(nlev + 1, 0); plan.level_fronts_owned.clear(); plan.level_fronts_shared.clear();
         for (int l = 0; l < nlev; ++l) {
@@ -917,7 +917,7 @@ bool build_plan(const HostGraph &g, const PlanOptions &opt_in, Plan &plan, std::
     int plo = 0, phi = N;
     if (plan.world > 1) { plo = N; phi = 0;
         std::vector<int> lo_t(host_threads() + 1, N), hi_t(host_threads() + 1, 0);
-        parallel_chunks(N, 65536, [&](int64_t b0, int64_t e0, int t) { int lo2 = N, hi2 = 0;
+        parallel_chunks(N, 16384, [&](int64_t b0, int64_t e0, int t) { int lo2 = N, hi2 = 0;
             for (int p = (int)b0; p < (int)e0; ++p) { bool any = false;
                 if (B.by_window && !ing_flag[p]) continue;
                 for (int s2 = plan.pl_start[p]; s2 < plan.pl_start[p + 1] && !any; ++s2) any = plan.pl_rank[plan.pl_order[s2]] == plan.rank;
@@ -955,14 +955,14 @@ GS_PT(70);
 GS_PT(71);
     // the assembly records named observation edges by insertion index so far
     { const int32_t zero_slot = (int32_t)(plan.ell_len - 1);
-      parallel_chunks((int64_t)plan.asm_recs.size(), 65536, [&](int64_t b0, int64_t e0, int) {
+      parallel_chunks((int64_t)plan.asm_recs.size(), 16384, [&](int64_t b0, int64_t e0, int) {
           for (int64_t t = b0; t < e0; ++t) { AsmRec &r = plan.asm_recs[(size_t)t];
               if (r.kind == ASM_PL || r.kind == ASM_PL_T) { const int32_t e = plan.ell_of_ins[r.src]; r.src = e >= 0 ? e : zero_slot; } } }); }
 GS_PT(72);
     // landmark -> ELL indices of its edges (the gather kernels: single GPU only)
     plan.lm_edges.clear();
     if (plan.world == 1) { plan.lm_edges.resize(Epl);
-        parallel_chunks(Epl, 65536, [&](int64_t b0, int64_t e0, int) { for (int64_t q = b0; q < e0; ++q) plan.lm_edges[(size_t)q] = plan.ell_of_ins[lm_k[(size_t)q]]; }); }
+        parallel_chunks(Epl, 16384, [&](int64_t b0, int64_t e0, int) { for (int64_t q = b0; q < e0; ++q) plan.lm_edges[(size_t)q] = plan.ell_of_ins[lm_k[(size_t)q]]; }); }
     else plan.lm_edges.assign(1, 0);
 GS_PT(73);
     // ---- wave tiles of the fused A5-A7 kernel: one wave = 64/T consecutive poses.  Per wave tile the distinct
