@@ -7,7 +7,11 @@
 //   3. handle B: gs_dist_configure(0, 1) + a shared top forced on the single rank (include/graphslam_debug.h: the only way to put a
 //      NON-EMPTY exchange buffer through RCCL on one GPU), gs_dist_unique_id -> gs_dist_comm_init -> gs_dist_optimize(10): local
 //      half -> ncclAllReduce(sum, fp64) -> shared top, all enqueued by the library;
-//   4. both must agree (1e-9 relative to the track's size) and report 10 iterations.
+//   4. both must agree (1e-9 relative to the track's size) and report 10 iterations;
+//   5. two more handles as the replicas of a world of 2 with RANK-LOCAL INGESTION: every vertex and odometry edge on both, a keyframe's observation
+//      edges only on the replica that owns its pose (and, on both, those of the second window's first pose and of the fixed poses), the landmark
+//      windows from gs_dist_local_landmark_windows OR-ed over the two and handed back with gs_dist_set_landmark_windows; 10 iterations through
+//      the two halves with the exchange buffers summed on the host; the merged poses against handle A's.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -26,9 +30,32 @@ static void se2_between(const double *a, const double *b, double *z) {      // z
     z[0] = c * dx + s * dy; z[1] = -s * dx + c * dy; z[2] = std::atan2(std::sin(b[2] - a[2]), std::cos(b[2] - a[2]));
 }
 
+// rank >= 0: rank-local ingestion — the observation edges of this replica's poses, of the windows' first poses and of the fixed poses only
 static int build(gs_graph *g, int N, int M, int K, const std::vector<double> &odom, const std::vector<double> &cxy,
-                 const std::vector<double> &obs, const std::vector<int32_t> &ocone, const std::vector<double> &zxy) {
+                 const std::vector<double> &obs, const std::vector<int32_t> &ocone, const std::vector<double> &zxy, int rank = -1, int world = 1) {
     std::vector<char> seen(M, 0);
+    std::vector<int32_t> first((size_t)world + 1, 0);
+    if (rank >= 0) {                                                // the vertices first: the windows are counted in FREE poses
+        for (int k = 0; k < N; ++k) {
+            CHECK(gs_add_pose(g, 1000 + k, &odom[3 * k]));
+            if (k > 0) { double z[3]; se2_between(&odom[3 * (k - 1)], &odom[3 * k], z);
+                const double info[9] = {5, 0, 0, 0, 5, 0, 0, 0, 5};
+                CHECK(gs_add_odometry_edge(g, 1000 + k - 1, 1000 + k, z, info)); } }
+        CHECK(gs_set_fixed_pose(g, 1000, 1)); CHECK(gs_set_fixed_pose(g, 1001, 1));
+        CHECK(gs_dist_configure(g, rank, world));
+        CHECK(gs_dist_window_starts(g, first.data(), world + 1));
+        int nobs = 0;
+        for (int k = 0; k < N; ++k) {
+            bool mine = k < 2 || (k >= first[(size_t)rank] && k < first[(size_t)rank + 1]);
+            for (int w = 1; w < world; ++w) mine = mine || k == first[(size_t)w];
+            for (int i = 0; i < K; ++i) { const int l = ocone[(size_t)k * K + i];
+                if (!seen[l]) { seen[l] = 1; const double e[2] = {cxy[2 * l] + 0.3, cxy[2 * l + 1] - 0.2}; CHECK(gs_add_landmark(g, l, e)); }      // every cone on every replica, in the same order
+                if (!mine) continue;
+                const double info[4] = {0.01, 0, 0, 0.01};
+                CHECK(gs_add_observation_edge(g, 1000 + k, l, &zxy[2 * ((size_t)k * K + i)], info)); ++nobs; } }
+        int fixed = 0; for (int l = 0; l < M && fixed < 2; ++l) if (seen[l]) { CHECK(gs_set_fixed_landmark(g, l, 1)); ++fixed; }
+        return nobs;
+    }
     for (int k = 0; k < N; ++k) {
         CHECK(gs_add_pose(g, 1000 + k, &odom[3 * k]));
         if (k > 0) { double z[3]; se2_between(&odom[3 * (k - 1)], &odom[3 * k], z);
@@ -71,7 +98,31 @@ int main() {
     std::printf("iterations %d %d  shared fronts %d  exchange doubles %lld  max |pose diff| / rms %.3g  chi2 %.6g -> %.6g\n", da, db, sb.n_shared_fronts,
                 (long long)gs_dist_exchange_doubles(B), worst / rms, sa.chi2_initial, sa.chi2_final);
     const bool ok = da == 10 && db == 10 && sb.n_shared_fronts > 0 && gs_dist_exchange_doubles(B) > 2 && worst / rms < 1e-9 && sa.chi2_final < sa.chi2_initial;
+    // ---- two replicas, rank-local ingestion
+    bool ok2 = false;
+    { const int world = 2; gs_graph *R[2] = {nullptr, nullptr}; int held[2] = {0, 0};
+      for (int r = 0; r < world; ++r) { CHECK(gs_create(nullptr, &R[r])); held[r] = build(R[r], N, M, K, odom, cxy, obs, ocone, zxy, r, world); if (held[r] <= 0) return 1; }
+      const int Mg = gs_num_landmarks(R[0]);
+      std::vector<uint64_t> a((size_t)Mg, 0), b((size_t)Mg, 0), a1((size_t)Mg), b1((size_t)Mg);
+      for (int r = 0; r < world; ++r) { CHECK(gs_dist_local_landmark_windows(R[r], a1.data(), b1.data(), Mg)); for (int l = 0; l < Mg; ++l) { a[l] |= a1[l]; b[l] |= b1[l]; } }
+      for (int r = 0; r < world; ++r) { CHECK(gs_dist_set_landmark_windows(R[r], a.data(), b.data(), Mg)); CHECK(gs_initialize_optimization(R[r])); }
+      const long long X = gs_dist_exchange_doubles(R[0]);
+      if (X != gs_dist_exchange_doubles(R[1]) || X <= 2) { std::fprintf(stderr, "exchange layouts differ\n"); return 1; }
+      std::vector<double> x0((size_t)X), x1((size_t)X);
+      for (int it = 0; it < 10; ++it) {
+          CHECK(gs_dist_iterate_local(R[0])); CHECK(gs_dist_iterate_local(R[1]));
+          CHECK(gs_dist_read_exchange(R[0], x0.data())); CHECK(gs_dist_read_exchange(R[1], x1.data()));
+          for (long long i = 0; i < X; ++i) x0[(size_t)i] += x1[(size_t)i];                       // (the all-reduce)
+          CHECK(gs_dist_write_exchange(R[0], x0.data())); CHECK(gs_dist_write_exchange(R[1], x0.data()));
+          CHECK(gs_dist_iterate_finish(R[0])); CHECK(gs_dist_iterate_finish(R[1])); }
+      std::vector<double> pm(3 * (size_t)N, 0.0), pr(3 * (size_t)N); std::vector<uint8_t> pk((size_t)N), lk((size_t)Mg), pp((size_t)N), lp((size_t)Mg);
+      for (int r = 0; r < world; ++r) { CHECK(gs_sync_estimates(R[r])); CHECK(gs_get_poses(R[r], N, nullptr, pr.data())); CHECK(gs_dist_known(R[r], pk.data(), lk.data(), pp.data(), lp.data()));
+          for (int k = 0; k < N; ++k) if (pp[(size_t)k]) for (int t = 0; t < 3; ++t) pm[3 * (size_t)k + t] = pr[3 * (size_t)k + t]; }
+      double worst2 = 0; for (int i = 0; i < 3 * N; ++i) worst2 = std::fmax(worst2, std::fabs(pa[i] - pm[(size_t)i]));
+      std::printf("rank-local ingestion, world 2: %d + %d of %d observation edges held, %lld exchange doubles, max |pose diff| / rms %.3g\n", held[0], held[1], K * N, X, worst2 / rms);
+      ok2 = worst2 / rms < 1e-7 && held[0] + held[1] < K * N + 4 * K * world;
+      gs_destroy(R[0]); gs_destroy(R[1]); }
     gs_destroy(A); gs_destroy(B);
-    std::puts(ok ? "OK" : "MISMATCH");
-    return ok ? 0 : 2;
+    std::puts(ok && ok2 ? "OK" : "MISMATCH");
+    return ok && ok2 ? 0 : 2;
 }
