@@ -427,7 +427,9 @@ class Graph:
     def initialize_optimization(self):
         self._check(self.L.gs_initialize_optimization(self.h))
 
-    def optimize(self, iterations=10):
+    def optimize(self, iterations=10, stats=True):
+        if not stats:                                       # the way Slam calls it (csrc/gs_slam.cpp: no statistics asked for, no chi2 pass behind the iterations)
+            return self._check(self.L.gs_optimize(self.h, int(iterations), None)), None
         st = Stats(); st.struct_size = C.sizeof(Stats)
         done = self._check(self.L.gs_optimize(self.h, int(iterations), C.byref(st)))
         return done, st

@@ -18,14 +18,15 @@ fe = pkg.Graph()                                   # front-end arithmetic for th
 print("%-14s | %-42s | %-30s" % ("poses:cones", "HIP: first call (structure) / second call / landmarks back [ms]", "CPU path: one call [ms] (symbolic)"))
 for N, M in sizes:
     t = pkg.track.generate(N, M); g = pkg.track.bench_graph(t, fe)
-    first, second, back, struct, first_r, struct_r = [], [], [], [], [], []
+    first, second, back, struct, first_r, struct_r, plain = [], [], [], [], [], [], []
     for rep in range(6):
         G = pkg.Graph(); G.load_bench_graph(g)
         t0 = time.perf_counter(); G.optimize(10); t1 = time.perf_counter()
         G.optimize(10); t2 = time.perf_counter()
         G.landmarks(); t3 = time.perf_counter()
+        G.optimize(10, stats=False); t4 = time.perf_counter()      # as Slam::optimizeGraph calls it: no statistics (no chi2 pass behind the iterations)
         if rep:                                     # the first repeat pays code-object loading
-            first.append(t1 - t0); second.append(t2 - t1); back.append(t3 - t2); struct.append(G.stats().ms_structure)
+            first.append(t1 - t0); second.append(t2 - t1); back.append(t3 - t2); struct.append(G.stats().ms_structure); plain.append(t4 - t3)
         G.close()
         G = pkg.Graph(); G.reserve_device(24 << 20); G.load_bench_graph(g)      # device memory taken at start-up (gs_reserve_device; gs_slam_create does it)
         t0 = time.perf_counter(); G.optimize(10); t1 = time.perf_counter()
@@ -43,5 +44,5 @@ for N, M in sizes:
         t0 = time.perf_counter(); og.optimize(10, ordering=1, solver=solver); t1 = time.perf_counter()
         if rep: cpu.append(t1 - t0); sym.append(float(solver.timings()[0]) if solver is not None else 0.0)
     med = lambda v: 1e3 * float(np.median(v))
-    print("%6d:%-7d | first %8.3f (structure %6.3f)  with memory reserved at start-up %8.3f (%6.3f)  second %8.3f  landmarks %6.3f | %9.3f (%.3f)   -> first call %.1fx (%.1fx), repeated call %.1fx"
-          % (N, M, med(first), float(np.median(struct)), med(first_r), float(np.median(struct_r)), med(second), med(back), med(cpu), float(np.median(sym)), med(cpu) / med(first), med(cpu) / med(first_r), med(cpu) / med(second)))
+    print("%6d:%-7d | first %8.3f (structure %6.3f)  with memory reserved at start-up %8.3f (%6.3f)  second %8.3f  without statistics %8.3f  landmarks %6.3f | %9.3f (%.3f)   -> first call %.1fx (%.1fx), repeated call %.1fx (%.1fx)"
+          % (N, M, med(first), float(np.median(struct)), med(first_r), float(np.median(struct_r)), med(second), med(plain), med(back), med(cpu), float(np.median(sym)), med(cpu) / med(first), med(cpu) / med(first_r), med(cpu) / med(second), med(cpu) / med(plain)))
