@@ -133,9 +133,10 @@ def lib():
     L.gs_set_stream.argtypes = [vp, vp]
     L.gs_dist_set_exchange_buffer.argtypes = [vp, vp]
     L.gs_dist_configure.argtypes = [vp, C.c_int32, C.c_int32]
-    L.gs_dist_window_starts.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32]
-    L.gs_dist_local_landmark_windows.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]
-    L.gs_dist_set_landmark_windows.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]
+    if hasattr(L, "gs_dist_window_starts"):               # (a tuning build of an older tree loaded through GS_LIB may predate rank-local ingestion)
+        L.gs_dist_window_starts.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32]
+        L.gs_dist_local_landmark_windows.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]
+        L.gs_dist_set_landmark_windows.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]
     L.gs_add_pose.argtypes = [vp, C.c_int32, _dp]
     L.gs_add_landmark.argtypes = [vp, C.c_int32, _dp]
     L.gs_add_odometry_edge.argtypes = [vp, C.c_int32, C.c_int32, _dp, _dp]
