@@ -375,7 +375,7 @@ static int pull_estimates_if_needed(gs_graph *g) {
     return GS_OK;
 }
 // The device-side failure state: fail[0] = code (1 zero pivot, 2 a whole-tree launch gave up on a front's flag, 3 a
-// failure another rank reported), fail[1] = updates applied since the last reset.  k_update applies nothing once the
+// zero pivot another rank reported, 4 a flag timeout another rank reported), fail[1] = updates applied since the last reset.  k_update applies nothing once the
 // code is non-zero, so the estimates in HBM are those of the last good iterate, as in g2o after a failed solve.
 static int read_failure(gs_graph *g, int32_t out[2]) {
     out[0] = out[1] = 0;
@@ -400,6 +400,8 @@ static int surface_failure(gs_graph *g) {
     if (st[0] == 2) { g->d.tree = 0; g->fell_back = true;
         return fail(GS_ERR_TIMEOUT, "whole-tree launch: a front's completion flag did not arrive in time; no update was applied from that "
                                     "iteration on (estimates = last good iterate); the handle now uses one launch per level"); }
+    if (st[0] == 4) return fail(GS_ERR_TIMEOUT, "a whole-tree launch of ANOTHER rank gave up on a front's flag (that rank now uses one launch per level); no update was applied from that "
+                                                "iteration on (estimates = last good iterate): the iteration can be run again");
     return fail(GS_ERR_NUMERIC, st[0] == 3 ? "another rank met a zero pivot: no update applied from that iteration on (estimates = last good iterate)"
                                            : "zero pivot: H is singular; no update applied from that iteration on (estimates = last good iterate)");
 }
@@ -1976,28 +1978,41 @@ extern "C" int gs_dist_optimize(gs_graph *g, int32_t iterations, gs_stats *stats
     g->d.conv_tol = -1.0;
     hipEventRecord(g->ev[5], g->stream);
     const int nh = std::min(iterations, 64);
-    for (int it = 0; it < iterations; ++it) {
-        g->d.hist_slot = it < nh ? it : -1;
-        enqueue_local(g, false);
-        if ((rc = enqueue_allreduce(g)) != GS_OK) { g->d.hist_slot = -1; return rc; }
-        enqueue_finish(g, false);
+    // A flag timeout on ANY rank (code 2 where it happened, 4 on the others: the same all-reduce tells everybody) is not a property of H: the rank it
+    // happened on switches to one launch per level, every rank runs the iterations that were not applied again — the repair gs_optimize makes on one GPU,
+    // decided identically on every rank (the count of applied updates is the same everywhere).  At most twice per call.
+    int32_t ff[4] = {0, 0, 0, 0}; double hist[80]; int from = 0, first_failure = 0;
+    for (int repair = 0; ; ++repair) {
+        for (int it = from; it < iterations; ++it) {
+            g->d.hist_slot = it < nh ? it : -1;
+            enqueue_local(g, false);
+            if ((rc = enqueue_allreduce(g)) != GS_OK) { g->d.hist_slot = -1; return rc; }
+            enqueue_finish(g, false);
+        }
+        g->d.hist_slot = -1;
+        hipEventRecord(g->ev[6], g->stream);
+        HIP_TRY(hipMemcpyAsync(ff, g->d.fail, sizeof(ff), hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(hipMemcpyAsync(hist, g->d.chi2, sizeof(hist), hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        if (ff[0] != 0 && first_failure == 0) first_failure = ff[0];
+        if ((ff[0] != 2 && ff[0] != 4) || repair >= 2) break;
+        if (ff[0] == 2) { g->d.tree = 0; g->fell_back = true; g->fallback_calls = 0; }
+        g->d.inject_iter = 0;
+        HIP_TRY(hipMemsetAsync(g->d.fail, 0, sizeof(int32_t), g->stream));      // the code only: the update count goes on
+        if (g->d.tickets) { HIP_TRY(hipMemsetAsync(g->d.tickets, 0, 2 * sizeof(uint32_t), g->stream)); g->d.ticket_base = 0; }
+        from = ff[1]; ff[0] = 0;
     }
-    g->d.hist_slot = -1;
-    hipEventRecord(g->ev[6], g->stream);
-    int32_t ff[4] = {0, 0, 0, 0}; double hist[80];
-    HIP_TRY(hipMemcpyAsync(ff, g->d.fail, sizeof(ff), hipMemcpyDeviceToHost, g->stream));
-    HIP_TRY(hipMemcpyAsync(hist, g->d.chi2, sizeof(hist), hipMemcpyDeviceToHost, g->stream));
-    HIP_TRY(hipStreamSynchronize(g->stream));
     rc = pull_estimates_if_needed(g); if (rc != GS_OK) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { reset_failure(g); return fail(GS_ERR_HIP, std::string("iteration: ") + hipGetErrorString(e)); }      // (a launch that never ran: the ticket counter and its running sum start again)
     float ms = 0; hipEventElapsedTime(&ms, g->ev[5], g->ev[6]);
     if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->struct_size = (int32_t)sizeof(*stats);
-        fill_plan_stats(g, stats); stats->iterations = ff[1]; stats->numeric_failure = ff[0]; stats->first_failure = ff[0];
+        fill_plan_stats(g, stats); stats->iterations = ff[1]; stats->numeric_failure = ff[0]; stats->first_failure = first_failure;
         stats->chi2_initial = iterations > 0 ? hist[1] : 0.0; stats->chi2_final = iterations > 0 ? hist[std::min(iterations, nh)] : 0.0;     // THIS rank's edges only (the ranks' sums add up to the graph's)
         stats->ms_total = ms; }
     if (ff[0]) { rc = reset_failure(g); if (rc != GS_OK) return rc;
         if (ff[0] == 2) { g->d.tree = 0; g->fell_back = true; g_last_error = "a front's completion flag did not arrive in time: the handle now uses one launch per level"; }
+        else if (ff[0] == 4) g_last_error = "another rank's whole-tree launch gave up on a front's flag, twice in this call";
         else g_last_error = ff[0] == 3 ? "another rank met a zero pivot (g2o: optimize() returns 0, the vertices keep the last good iterate)" : "zero pivot: H is singular (g2o: optimize() returns 0, the vertices keep the last good iterate)";
         return 0; }
     return ff[1];

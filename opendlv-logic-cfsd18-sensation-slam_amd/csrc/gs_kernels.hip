@@ -956,7 +956,9 @@ enum { FRONT_OWN = 0, FRONT_CONTRIB = 1, FRONT_TOP = 2 };
 // zero pivot — g2o stops the whole optimisation at that iteration and keeps the previous iterate.  The local phase
 // (linearise, own subtrees) has completed on this stream when the contribution launch starts.
 __device__ __forceinline__ void contrib_publish_fail(const DevGraph &d) {
-    if (d.xfail_off >= 0) d.exchange[d.xfail_off] = (d.fail[0] != 0) ? 1.0 : 0.0;
+    // two slots at the tail of the exchange buffer, summed over the ranks by the same all-reduce: [0] a zero pivot (or a failure heard of earlier) somewhere,
+    // [1] a whole-tree launch that gave up on a flag — not a property of H: the ranks can run the iteration again (gs_dist_optimize does)
+    if (d.xfail_off >= 0) { const int c = d.fail[0]; d.exchange[d.xfail_off] = (c != 0 && c != 2 && c != 4) ? 1.0 : 0.0; d.exchange[d.xfail_off + 1] = (c == 2 || c == 4) ? 1.0 : 0.0; }
 }
 template <bool USE_LDS>
 __global__ void __launch_bounds__(256) k_factor_level(DevGraph d, int level_off, int mode) {
@@ -2808,13 +2810,16 @@ __global__ void __launch_bounds__(256) k_update(DevGraph d) {
     // src/slam.cpp:481).  The iterations of a gs_optimize call are all enqueued up front, so the rule lives here: once
     // the failure flag is up (zero pivot, a whole-tree launch that gave up on a flag, or — pose-window shards — a
     // failure any rank reported with its contribution) no update is applied any more.  fail[1] counts applied updates.
-    const bool peer_failed = d.xfail_off >= 0 && d.exchange[d.xfail_off] != 0.0;
+    const bool peer_numeric = d.xfail_off >= 0 && d.exchange[d.xfail_off] != 0.0, peer_timeout = d.xfail_off >= 0 && d.exchange[d.xfail_off + 1] != 0.0;
+    const bool peer_failed = peer_numeric || peer_timeout;
     // fail[2]: the iteration in which gs_optimize_until's stop rule fired (0: not yet).  Only an EARLIER iteration's verdict
     // gates this launch: the block that evaluates the rule below writes it while other blocks of the same launch may still
     // be reading — with the iteration number in the flag they all see "not before this iteration" whatever the timing.
     const int conv_it = d.fail[2];
     const bool stop = d.fail[0] != 0 || peer_failed || (conv_it != 0 && conv_it < d.iter);
-    if (t == 0) { if (stop) { if (peer_failed) atomicMax(d.fail, 3); } else atomicAdd(d.fail + 1, 1); }
+    if (t == 0) { if (stop) { if (peer_failed) atomicCAS(d.fail, 0, peer_numeric ? 3 : 4); }      // 3: a zero pivot on another rank, 4: a flag timeout on another rank      // (3 only where nothing failed locally: the rank a flag timeout happened on must keep its 2 — it is the one that has to fall back to one launch per level;
+                                                                                 // with atomicMax every rank, the origin included, read "another rank failed" and the timeout came back with every later call)
+                  else atomicAdd(d.fail + 1, 1); }
     // pose-window shards: a rank only tracks the vertices of its own subtrees and of the shared top.
     // One thread per SCALAR of the estimates (3 N pose scalars, then 2 M landmark scalars): the estimate, the increment record and
     // the solution vector are read and written as fully coalesced 8-byte streams (a thread per vertex touched them with a 24-byte

@@ -779,6 +779,43 @@ def test_sharded_failure_on_one_rank_stops_every_rank(pkg, po, bench_graphs):
         G.close()
 
 
+def test_sharded_flag_timeout_is_reported_where_it_happened_and_the_run_goes_on(pkg, po, bench_graphs):
+    """A whole-tree launch of ONE rank gives up on a front's flag (injected: code 2).  Every rank skips that iteration's update — the code rides in the
+    exchange buffer —, but only the rank it happened on may read "timeout": it is the one that has to switch to one launch per level.  (Until the last
+    day of round 4 the merged flag overwrote the local code with "another rank failed" on EVERY rank, the origin included: nobody fell back, and where the
+    timeout was systematic — four rank processes time-sliced on one GPU in a rehearsal of bench.py --gpus 4 — it came back with every later iteration.)
+    After the report both ranks carry on from the last good iterate: 1 applied + 3 more iterations = the oracle's 4."""
+    world, (N, M) = 2, (1000, 200)
+    _, g = bench_graphs(N, M)
+    ranks = []
+    for r in range(world):
+        G = fresh(pkg, g); G.dist_configure(r, world); G.initialize_optimization(); ranks.append(G)
+    def iterate(n):
+        for _ in range(n):
+            for G in ranks: G.dist_iterate_local()
+            total = sum(G.dist_read_exchange() for G in ranks)
+            for G in ranks: G.dist_write_exchange(total); G.dist_iterate_finish()
+    ranks[1].debug_fail_at_iteration(2, 2)
+    iterate(3)                                                   # iteration 1 applied, 2 reports the timeout, 3 is skipped as well
+    codes = []
+    for G in ranks:
+        with pytest.raises(pkg.GsError) as e:
+            G.synchronize()
+        codes.append(e.value.code)
+    assert codes == [-10, -10] and "now uses one launch per level" in str(e.value), (codes, str(e.value))      # both: a timeout (rank 0: ANOTHER rank's); rank 1: its own
+    assert ranks[1].stats().fell_back == 1 and ranks[0].stats().fell_back == 0
+    iterate(3)
+    P = np.zeros((N, 3)); L = np.zeros((len(g["lm_est"]), 2))
+    for G in ranks:
+        G.sync_estimates()
+        pk, lk, pprim, lprim = G.dist_known()
+        P += G.poses() * pprim[:, None]; L += G.landmarks() * lprim[:, None]
+    og = make_oracle_graph(po, g); og.optimize(4, ordering=1)
+    assert rel(P, og.poses()) < 1e-9 and rel(L, og.landmarks()) < 1e-9
+    for G in ranks:
+        G.close()
+
+
 def test_sharded_handle_refuses_the_single_gpu_entry_points(pkg, bench_graphs):
     _, g = bench_graphs(50, 30)
     G = fresh(pkg, g); G.dist_configure(0, 2); G.initialize_optimization()
@@ -1086,7 +1123,14 @@ def test_rccl_all_reduce_inside_the_library_on_a_forced_shared_top(pkg, po, benc
     assert done == 0 and stf.iterations == 1 and stf.numeric_failure in (1, 3)      # (3: the flag came back through the all-reduce as well)
     og1 = make_oracle_graph(po, g); og1.optimize(1, ordering=1)
     assert rel(F.poses(), og1.poses()) < 1e-8                    # one iteration = one increment: the increment tolerance of this file's header
-    A.close(); G.close(); H.close(); F.close()
+    # a flag timeout is no property of H: gs_dist_optimize repairs it inside the call, as gs_optimize does on one GPU — the rank falls back to one
+    # launch per level and the iterations that were not applied run again: 4 of 4 come back, bit for bit the undisturbed handle's
+    T = fresh(pkg, g, debug=dict(force_shared_top=3)); T.dist_comm_init(pkg.binding.dist_unique_id(), 0, 1)
+    T.initialize_optimization(); T.debug_fail_at_iteration(2, 2)
+    done, stt = T.dist_optimize(4)
+    assert done == 4 and stt.numeric_failure == 0 and stt.first_failure == 2 and T.stats().fell_back == 1
+    assert np.array_equal(T.poses(), H.poses()) and np.array_equal(T.landmarks(), H.landmarks())
+    A.close(); G.close(); H.close(); F.close(); T.close()
 
 
 def test_cpp_consumer_runs_the_sharded_optimize_through_rccl(pkg):
