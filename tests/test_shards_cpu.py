@@ -18,7 +18,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, N, M, out_dir):
+def _worker(rank, world, port, N, M, out_dir, local=False):
     import importlib
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -32,8 +32,21 @@ def _worker(rank, world, port, N, M, out_dir):
     t = pkg.track.generate(N, M)
     g = pkg.track.bench_graph(t, po.OracleFrontend())
     G = pkg.Graph(device=-2)                          # host-only handle: plan logic, no arithmetic
-    G.load_bench_graph(g)
-    G.dist_configure(rank, world)
+    if local:
+        # rank-local ingestion the way separate processes do it: every rank holds its own window's observation edges (+ the windows' first poses, the
+        # fixed poses), computes its OWN bits of the landmark windows from them, the ranks SUM the two uint64 arrays (disjoint bits: the sum is the union)
+        M_all = len(g["lm_est"]); zero = np.zeros(M_all, np.uint64)
+        keep = G.load_bench_graph_shard(g, rank, world, (zero, zero))
+        a, b = G.dist_local_landmark_windows(M_all)
+        ta = torch.from_numpy(a.view(np.int64).copy()); tb = torch.from_numpy(b.view(np.int64).copy())
+        dist.all_reduce(ta, op=dist.ReduceOp.SUM); dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        G.dist_set_landmark_windows(ta.numpy().view(np.uint64), tb.numpy().view(np.uint64))
+        g = dict(g)                                   # from here on "the graph" is what this rank holds
+        for k in ("pl_p", "pl_l", "pl_z", "pl_info"):
+            g[k] = g[k][keep]
+    else:
+        G.load_bench_graph(g)
+        G.dist_configure(rank, world)
     G.plan_build_host()
     P = Plan(G.plan_export()); P.check_invariants()
     assert P.world == world and P.rank == rank and P.n_shared >= 1
@@ -64,12 +77,13 @@ def _worker(rank, world, port, N, M, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,N,M", [(2, 50, 30), (2, 1000, 200), (4, 1000, 200)])
-def test_sharded_increment_over_gloo_equals_joint_solve(po, bench_graphs, tmp_path, world, N, M):
+@pytest.mark.parametrize("world,N,M,local", [(2, 50, 30, False), (2, 1000, 200, False), (4, 1000, 200, False), (4, 1000, 200, True), (2, 1000, 200, True)])
+def test_sharded_increment_over_gloo_equals_joint_solve(po, bench_graphs, tmp_path, world, N, M, local):
+    """(local: rank-local ingestion — the ranks hold their own windows' observation edges only and agree on the landmark windows by an all-reduce)"""
     import torch.multiprocessing as mp
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, M, str(tmp_path))) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, M, str(tmp_path), local)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -85,7 +99,7 @@ def test_sharded_increment_over_gloo_equals_joint_solve(po, bench_graphs, tmp_pa
         assert np.array_equal(o["cnt"], np.ones_like(o["cnt"]))            # every vertex primary exactly once
         assert np.abs(o["dp"] - dp_o).max() / scale < 1e-8 and np.abs(o["dl"] - dl_o).max() / scale < 1e-8
     # the edges are partitioned, the work is spread, the exchange is small
-    assert sum(int(o["my_pl"]) for o in outs) == len(g["pl_p"]) and sum(int(o["my_pp"]) for o in outs) == len(g["pp_i"])
+    assert sum(int(o["my_pl"]) for o in outs) == len(g["pl_p"]) and sum(int(o["my_pp"]) for o in outs) == len(g["pp_i"])      # (rank-local ingestion too: every edge of the whole graph is evaluated by exactly one rank)
     assert all(int(o["owned"]) > 0 for o in outs)
     assert int(outs[0]["exchange"]) * 8 < 2_000_000
 
