@@ -327,6 +327,8 @@ int  gs_dist_configure(gs_graph *g, int32_t rank, int32_t world_size);   /* befo
  *   gs_dist_window_starts           insertion index of the first free pose of each window, world + 1 entries (the last: n_poses): which poses are whose
  *   gs_dist_local_landmark_windows  this rank's OWN bits, from the edges it holds (the ranks' bits are disjoint: an all-reduce SUM over the ranks —
  *                                   or an OR in a single process — gives the masks of the whole graph)
+ *   gs_dist_share_landmark_windows  the two steps around the exchange in one call, over the handle's own RCCL communicator (gs_dist_comm_init first): own bits ->
+ *                                   ncclAllReduce(uint64, sum) -> gs_dist_set_landmark_windows.  Collective: every rank calls it.
  *   gs_dist_set_landmark_windows    hands the whole-graph masks to the handle (n_landmarks = 0: back to the default); the next structure phase
  *                                   uses them and fails if an edge it holds contradicts them, or if the graph cannot be planned by windows
  *                                   (more than 64 ranks, fewer than 4 free poses per window, odometry edges between two windows' interiors).
@@ -334,6 +336,7 @@ int  gs_dist_configure(gs_graph *g, int32_t rank, int32_t world_size);   /* befo
 int  gs_dist_window_starts(gs_graph *g, int32_t *out_first_pose, int32_t capacity);
 int  gs_dist_local_landmark_windows(gs_graph *g, uint64_t *seen_interior, uint64_t *seen_first, int32_t n_landmarks);
 int  gs_dist_set_landmark_windows(gs_graph *g, const uint64_t *seen_interior, const uint64_t *seen_first, int32_t n_landmarks);
+int  gs_dist_share_landmark_windows(gs_graph *g);
 int64_t gs_dist_exchange_doubles(gs_graph *g);         /* length of the exchange buffer (after initialize)   */
 int  gs_dist_set_exchange_buffer(gs_graph *g, void *device_ptr);   /* NULL: the library allocates its own   */
 int  gs_dist_iterate_local(gs_graph *g);               /* linearise own edges + own subtrees + contribution  */

@@ -137,6 +137,7 @@ def lib():
         L.gs_dist_window_starts.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32]
         L.gs_dist_local_landmark_windows.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]
         L.gs_dist_set_landmark_windows.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]
+        L.gs_dist_share_landmark_windows.argtypes = [vp]
     L.gs_add_pose.argtypes = [vp, C.c_int32, _dp]
     L.gs_add_landmark.argtypes = [vp, C.c_int32, _dp]
     L.gs_add_odometry_edge.argtypes = [vp, C.c_int32, C.c_int32, _dp, _dp]
@@ -580,6 +581,9 @@ class Graph:
         a = np.zeros(n_landmarks, dtype=np.uint64); b = np.zeros(n_landmarks, dtype=np.uint64); u = C.POINTER(C.c_uint64)
         self._check(self.L.gs_dist_local_landmark_windows(self.h, a.ctypes.data_as(u), b.ctypes.data_as(u), n_landmarks))
         return a, b
+
+    def dist_share_landmark_windows(self):
+        self._check(self.L.gs_dist_share_landmark_windows(self.h))
 
     def dist_set_landmark_windows(self, seen_interior, seen_first):
         a = np.ascontiguousarray(seen_interior, dtype=np.uint64); b = np.ascontiguousarray(seen_first, dtype=np.uint64); u = C.POINTER(C.c_uint64)

@@ -1941,6 +1941,29 @@ static int enqueue_allreduce(gs_graph *g) {
     ncclResult_t nr = R->AllReduce(g->d.exchange, g->d.exchange, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)g->comm, g->stream);
     return nr == ncclSuccess ? GS_OK : rccl_fail(R, nr, "ncclAllReduce");
 }
+// rank-local ingestion without any other channel between the replicas than the library's own communicator: this rank's bits of the landmark windows
+// (from the edges it holds), ncclAllReduce(uint64, sum) — the ranks' bits are disjoint, the sum is the union —, the result handed to the handle
+extern "C" int gs_dist_share_landmark_windows(gs_graph *g) {
+    if (!g) return fail(GS_ERR_INVALID, "null graph");
+    if (!g->comm) return fail(GS_ERR_NOT_INITIALIZED, "no RCCL communicator: gs_dist_comm_init or gs_dist_set_communicator first");
+    if (g->comm_world > 0 && g->comm_world != g->world) return fail(GS_ERR_INVALID, "the communicator's size differs from gs_dist_configure's world");
+    int rc = ensure_device(g); if (rc != GS_OK) return rc;
+    std::string err; RcclApi *R = rccl_api(err); if (!R) return fail(GS_ERR_NO_DEVICE, err);
+    const int M = g->h.n_lms();
+    std::vector<uint64_t> m(2 * (size_t)M);
+    if ((rc = gs_dist_local_landmark_windows(g, m.data(), m.data() + M, M)) != GS_OK) return rc;
+    if (M == 0) return gs_dist_set_landmark_windows(g, nullptr, nullptr, 0);
+    uint64_t *dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, m.size() * sizeof(uint64_t)));
+    hipError_t e = hipMemcpyAsync(dev, m.data(), m.size() * sizeof(uint64_t), hipMemcpyHostToDevice, g->stream);
+    ncclResult_t nr = e == hipSuccess ? R->AllReduce(dev, dev, m.size(), ncclUint64, ncclSum, (ncclComm_t)g->comm, g->stream) : ncclSuccess;
+    if (e == hipSuccess && nr == ncclSuccess) e = hipMemcpyAsync(m.data(), dev, m.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    hipFree(dev);
+    if (nr != ncclSuccess) return rccl_fail(R, nr, "ncclAllReduce (landmark windows)");
+    if (e != hipSuccess) return fail(GS_ERR_HIP, std::string("landmark windows: ") + hipGetErrorString(e));
+    return gs_dist_set_landmark_windows(g, m.data(), m.data() + M, M);
+}
 extern "C" int gs_dist_iterate(gs_graph *g) {
     int rc = dist_ready(g); if (rc != GS_OK) return rc;
     if (!g->plan.dist) return fail(GS_ERR_INVALID, "not a sharded graph: gs_iterate");

@@ -88,6 +88,7 @@ int main() {
     CHECK(gs_dist_configure(B, 0, 1));
     char id[128]; CHECK(gs_dist_unique_id(id));                     // (rank 0 makes it; the other ranks would receive these 128 bytes)
     CHECK(gs_dist_comm_init(B, id, 0, 1));
+    CHECK(gs_dist_share_landmark_windows(B));                       // (a group of one: own bits -> ncclAllReduce(uint64, sum) -> back; what replicas without another channel call)
     const int db = gs_dist_optimize(B, 10, &sb); if (db < 0) { std::fprintf(stderr, "gs_dist_optimize: %s\n", gs_last_error()); return 1; }
     std::vector<double> pa(3 * N), pb(3 * N);
     CHECK(gs_get_poses(A, N, nullptr, pa.data())); CHECK(gs_get_poses(B, N, nullptr, pb.data()));
