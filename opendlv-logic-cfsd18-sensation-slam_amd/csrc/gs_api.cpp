@@ -2020,6 +2020,22 @@ extern "C" int gs_dist_optimize(gs_graph *g, int32_t iterations, gs_stats *stats
         if (ff[0] != 0 && first_failure == 0) first_failure = ff[0];
         if ((ff[0] != 2 && ff[0] != 4) || repair >= 2) break;
         if (ff[0] == 2) { g->d.tree = 0; g->fell_back = true; g->fallback_calls = 0; }
+        // Every rank is here (the code came with the same all-reduce).  A launch that gave up BEHIND the exchange — the shared top, a backward solve — is only
+        // heard of with the NEXT contribution: by then the other ranks have applied an update the rank it happened on has not.  The ranks compare their counts
+        // (one more all-reduce, only in this branch); if they differ the estimates have parted and no re-run can mend that: every rank says so, nobody goes on.
+        { std::string err; RcclApi *R = rccl_api(err); if (!R) return fail(GS_ERR_NO_DEVICE, err);
+          double v[2] = {(double)ff[1], -(double)ff[1]}, *dv = nullptr;
+          HIP_TRY(hipMalloc(&dv, sizeof(v)));
+          hipError_t e2 = hipMemcpyAsync(dv, v, sizeof(v), hipMemcpyHostToDevice, g->stream);
+          ncclResult_t nr = e2 == hipSuccess ? R->AllReduce(dv, dv, 2, ncclDouble, ncclMax, (ncclComm_t)g->comm, g->stream) : ncclSuccess;
+          if (e2 == hipSuccess && nr == ncclSuccess) e2 = hipMemcpyAsync(v, dv, sizeof(v), hipMemcpyDeviceToHost, g->stream);
+          if (e2 == hipSuccess) e2 = hipStreamSynchronize(g->stream);
+          hipFree(dv);
+          if (nr != ncclSuccess) return rccl_fail(R, nr, "ncclAllReduce (applied updates)");
+          if (e2 != hipSuccess) return fail(GS_ERR_HIP, std::string("applied updates: ") + hipGetErrorString(e2));
+          if (v[0] != -v[1]) { reset_failure(g);
+              return fail(GS_ERR_TIMEOUT, "a launch behind the exchange gave up on one rank after the others had applied that iteration's update: the ranks' estimates have parted "
+                                          "(updates applied: " + std::to_string((long long)-v[1]) + " .. " + std::to_string((long long)v[0]) + "); set the estimates again on every rank"); } }
         g->d.inject_iter = 0;
         HIP_TRY(hipMemsetAsync(g->d.fail, 0, sizeof(int32_t), g->stream));      // the code only: the update count goes on
         if (g->d.tickets) { HIP_TRY(hipMemsetAsync(g->d.tickets, 0, 2 * sizeof(uint32_t), g->stream)); g->d.ticket_base = 0; }
