@@ -352,7 +352,8 @@ int  gs_dist_iterate_finish(gs_graph *g);              /* after the all-reduce: 
  * gs_dist_optimize         Slam's optimize(10) (src/slam.cpp:481) on a sharded graph: `iterations` x gs_dist_iterate, g2o's failure rule
  *                          across ranks; returns the updates applied (0: a factorisation failed on some rank).  A whole-tree launch that gives up on a
  *                          front's flag on some rank (no property of H) is repaired inside the call: that rank switches to one launch per level, every rank
- *                          runs the iterations that were not applied again; gs_stats.first_failure = 2 / 4 says it happened (here / on another rank). */
+ *                          runs the iterations that were not applied again; gs_stats.first_failure = 2 / 4 says it happened (here / on another rank).  If the
+ *                          launch gave up BEHIND the exchange the ranks have applied different numbers of updates: all return GS_ERR_TIMEOUT (estimates to be set again). */
 int  gs_dist_unique_id(void *out_128_bytes);
 int  gs_dist_comm_init(gs_graph *g, const void *unique_id_128_bytes, int32_t rank, int32_t world_size);
 int  gs_dist_set_communicator(gs_graph *g, void *nccl_comm);
