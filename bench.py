@@ -294,7 +294,7 @@ def main():
 
     # A sharded run whose whole-tree launch gives up on a front's flag (the bounded polls: ranks that SHARE one GPU in a rehearsal are time-sliced against
     # each other, a profiler can do it too) reports that on every rank with the same all-reduce — the failure code rides in the exchange buffer —, the rank it
-    # happened on switches to one launch per level, nobody applied the update: the measurement starts again (at most 3 times).  One GPU: as before, no retry.
+    # happened on switches to one launch per level, nobody applied the update: the measurement starts again (at most world + 2 times).  One GPU: as before, no retry.
     attempts = 0
     while True:
         try:
@@ -309,7 +309,7 @@ def main():
             break
         except pkg.GsError as e:
             attempts += 1
-            if not dist_mode or world == 1 or attempts > 3:
+            if not dist_mode or world == 1 or attempts > world + 2:      # (each report moves ONE rank to one launch per level for good: at most `world` of them can come)
                 raise
             sys.stderr.write("bench: rank %d: %s -- measuring again (attempt %d)\n" % (rank, e, attempts + 1))
             dist.barrier()
