@@ -11,7 +11,7 @@ from plan_exec import Plan
 from conftest import make_oracle_graph
 pkg = importlib.import_module("opendlv-logic-cfsd18-sensation-slam_amd")
 from oracle import pyoracle as po
-fe=po.OracleFrontend(); bad=0; total=0; eng=0
+fe=po.OracleFrontend(); bad=0; total=0; eng=0; nloc=0
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0; count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 for seed in range(first, first + count):
     rng=np.random.default_rng(6000+seed)
@@ -51,6 +51,16 @@ for seed in range(first, first + count):
                     X,ok=P.shard_local(blocks); assert ok
                     plans.append(P); locs.append(X); prim.append(G.dist_known()); G.close()
                 eng+=e
+                if bw == 1 and e:                                # rank-local ingestion (gs_dist_set_landmark_windows) must give the same plans, field by field
+                    masks = pkg.binding.landmark_windows(g, world)
+                    for rank in range(world):
+                        L = pkg.Graph(device=-2); keep = L.load_bench_graph_shard(g, rank, world, masks); L.plan_build_host(); PL = Plan(L.plan_export()); L.close()
+                        PF = plans[rank]
+                        for name in ("npiv", "nbnd", "parent", "level", "owner", "piv0", "bnd_rows", "pose_gidx", "lm_gidx", "x_off", "pp_rank"):
+                            assert np.array_equal(getattr(PL, name), getattr(PF, name)), ("rank-local plan differs", rank, name)
+                        idx = np.flatnonzero(keep)
+                        assert np.array_equal(PL.pl_rank == rank, (PF.pl_rank == rank)[idx]) and not (PF.pl_rank == rank)[~keep].any(), ("rank-local edges", rank)
+                    nloc += 1
                 assert (spl==1).all() and (spp==1).all(), "edge owners"
                 assert len({len(x) for x in locs})==1, ("exchange sizes",[len(x) for x in locs])
                 Xs=np.sum(locs,axis=0); dp=np.zeros_like(dp_o); dl=np.zeros_like(dl_o)
@@ -61,5 +71,5 @@ for seed in range(first, first + count):
                 assert err<1e-7, ("err",err)
             except Exception as ex:
                 bad+=1; print("BAD seed",seed,"N",N,"world",world,"bw",bw,repr(ex)[:200], flush=True)
-print("seeds %d..%d: cases %d, by-window engaged %d, bad %d" % (first, first + count - 1, total, eng, bad))
+print("seeds %d..%d: cases %d, by-window engaged %d (rank-local ingestion compared in %d), bad %d" % (first, first + count - 1, total, eng, nloc, bad))
 sys.exit(1 if bad else 0)
