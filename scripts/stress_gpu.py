@@ -11,7 +11,7 @@ pkg = importlib.import_module("opendlv-logic-cfsd18-sensation-slam_amd")
 pkg.binding.DEFAULT_DEBUG["grow_min_poses"] = 0
 from oracle import pyoracle as po
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0; count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-bad = skipped = single = sharded = 0
+bad = skipped = single = sharded = local_steps = not_by_window = 0
 variants = {}
 for seed in range(first, first + count):
     rng = np.random.default_rng(7000 + seed)
@@ -30,10 +30,21 @@ for seed in range(first, first + count):
     variants[st.factor_variant] = variants.get(st.factor_variant, 0) + 1; single += 1
     err = max(np.abs(dp - dp_o).max(), np.abs(dl - dl_o).max()) / scale
     if done != 1 or err > 1e-8: bad += 1; print("BAD single seed", seed, kw, "done", done, "err %.2e" % err, "max front", st.max_front, "variant", st.factor_variant, flush=True)
-    for world in (2, 3, 5):
+    for world, local in ((2, 0), (3, 0), (5, 0), (2, 1), (4, 1)):
         if kw["n_poses"] < 8 * world: continue
         ranks = []
-        for r in range(world):
+        if local:                                                    # rank-local ingestion: only graphs that can be planned by windows (edges grouped by pose, odometry along the chain)
+            try:
+                masks = pkg.binding.landmark_windows(g, world)
+                for r in range(world):
+                    H = pkg.Graph(); ranks.append(H); H.load_bench_graph_shard(g, r, world, masks); H.initialize_optimization()
+            except pkg.GsError as ex:
+                [H.close() for H in ranks]
+                if "landmark windows" in str(ex): not_by_window += 1; continue
+                raise
+            local_steps += 1
+        else:
+          for r in range(world):
             H = pkg.Graph(); H.load_bench_graph(g); H.dist_configure(r, world); H.initialize_optimization(); ranks.append(H)
         lens = {H.dist_exchange_doubles() for H in ranks}
         if len(lens) != 1: bad += 1; print("BAD exchange sizes seed", seed, kw, world, sorted(lens), flush=True); [H.close() for H in ranks]; continue
@@ -47,5 +58,5 @@ for seed in range(first, first + count):
         e2 = max(np.abs(P - og.poses()).max(), np.abs(L - og.landmarks()).max()) / max(scale, 1e-300)
         sharded += 1
         if not (np.all(cp == 1) and np.all(cl == 1)) or e2 > 1e-7: bad += 1; print("BAD sharded seed", seed, kw, "world", world, "err %.2e" % e2, flush=True)
-print("seeds %d..%d: %d single-handle steps (factor variants %s), %d sharded steps, %d singular graphs skipped, %d BAD" % (first, first + count - 1, single, variants, sharded, skipped, bad))
+print("seeds %d..%d: %d single-handle steps (factor variants %s), %d sharded steps (%d of them with rank-local ingestion; %d graphs refused it: not plannable by windows), %d singular graphs skipped, %d BAD" % (first, first + count - 1, single, variants, sharded, local_steps, not_by_window, skipped, bad))
 sys.exit(1 if bad else 0)
